@@ -1,0 +1,282 @@
+"""ctypes front-end of the CPU oracle (oracle/ed_oracle.c) -- TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's ``cpu_baseline`` leg may
+import this module.  The product package never does.
+
+The Lanczos routines here restate SciFortran's ``sp_lanc_eigh`` /
+``sp_lanc_tridiag`` (github aamaricci/SciFortran, module SF_SP_LINALG; version
+un-pinned by the reference, CMakeLists.txt:92, and absent from
+/root/reference), anchored on the reference call sites ED_DIAG.f90:177-185
+and ED_GF_NORMAL.f90:232-237,638-640.  Iteration counts are NOT a parity
+quantity (the library's random start vector is compiler specific); energies
+and Lanczos coefficients for a *given* start vector are.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SRC = os.path.join(_HERE, "ed_oracle.c")
+_LIB = os.path.join(_HERE, "_build", "libed_oracle.so")
+
+BATH_TYPES = {"normal": 0, "hybrid": 1, "replica": 2}
+
+
+def build(force=False):
+    """gcc the C restatement into oracle/_build/libed_oracle.so."""
+    if (not force) and os.path.exists(_LIB) and os.path.getmtime(_LIB) >= os.path.getmtime(_SRC):
+        return _LIB
+    os.makedirs(os.path.dirname(_LIB), exist_ok=True)
+    subprocess.check_call(["gcc", "-O2", "-fPIC", "-shared", "-std=c99", "-o", _LIB, _SRC, "-lm"])
+    return _LIB
+
+
+class _Params(C.Structure):
+    _fields_ = [
+        ("Norb", C.c_int), ("Nspin", C.c_int), ("Nbath", C.c_int), ("Nph", C.c_int),
+        ("bath_type", C.c_int), ("ed_total_ud", C.c_int), ("hfmode", C.c_int), ("Nfoo", C.c_int),
+        ("Uloc", C.c_double * 5), ("Ust", C.c_double), ("Jh", C.c_double), ("Jx", C.c_double),
+        ("Jp", C.c_double), ("xmu", C.c_double), ("w0_ph", C.c_double), ("g_ph", C.c_double * 5),
+        ("impHloc", C.c_void_p), ("diag_hybr", C.c_void_p), ("bath_diag", C.c_void_p), ("hbath", C.c_void_p),
+    ]
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        L = C.CDLL(build())
+        L.orc_sector_open.restype = C.c_void_p
+        L.orc_sector_open.argtypes = [C.POINTER(_Params), C.c_int]
+        L.orc_sector_close.argtypes = [C.c_void_p]
+        L.orc_buildh.argtypes = [C.c_void_p]
+        L.orc_sp_nnz.restype = C.c_int64
+        L.orc_sp_nnz.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int64)]
+        L.orc_sp_export.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_spmatvec.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_directmatvec.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_hmat.argtypes = [C.c_void_p, C.c_void_p]
+        L.orc_sector_map.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        L.orc_sector_info.argtypes = [C.c_void_p] + [C.POINTER(C.c_int)] * 5 + [C.c_void_p, C.c_void_p, C.POINTER(C.c_int64)]
+        L.orc_binomial.restype = C.c_int
+        L.orc_get_sector.restype = C.c_int
+        L.orc_get_sector.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        L.orc_binary_search.restype = C.c_int
+        L.orc_binary_search.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        L.orc_c.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_double)]
+        L.orc_cdg.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_double)]
+        _lib = L
+    return _lib
+
+
+def get_sector(QN, N):
+    """ED_SETUP.f90:446-457"""
+    q = np.ascontiguousarray(QN, dtype=np.int32)
+    return int(lib().orc_get_sector(q.ctypes.data, len(q), int(N)))
+
+
+def binomial(n, k):
+    return int(lib().orc_binomial(int(n), int(k)))
+
+
+def c_op(pos, state):
+    out, sg = C.c_int(0), C.c_double(0)
+    lib().orc_c(pos, state, C.byref(out), C.byref(sg))
+    return out.value, sg.value
+
+
+def cdg_op(pos, state):
+    out, sg = C.c_int(0), C.c_double(0)
+    lib().orc_cdg(pos, state, C.byref(out), C.byref(sg))
+    return out.value, sg.value
+
+
+def binary_search(a, value):
+    a = np.ascontiguousarray(a, dtype=np.int32)
+    return int(lib().orc_binary_search(a.ctypes.data, len(a), int(value)))
+
+
+WHICH = {"d": 0, "nd": 1, "up": 2, "dw": 3, "ph": 4, "e_eph": 5, "ph_eph": 6}
+
+
+class Sector:
+    """One (Nup,Ndw) sector of the reference: build_Hv_sector .. delete_Hv_sector
+    (ED_HAMILTONIAN.f90:43-222) in serial mode."""
+
+    def __init__(self, model, nups, ndws):
+        m = model
+        self.model = m
+        f64 = lambda a: np.asfortranarray(np.asarray(a, dtype=np.float64))
+        self._imp = f64(m["impHloc"]); self._dh = f64(m["diag_hybr"]); self._bd = f64(m["bath_diag"])
+        self._hb = f64(m["hbath"]) if m.get("hbath") is not None else None
+        P = _Params()
+        P.Norb, P.Nspin, P.Nbath, P.Nph = m["Norb"], m["Nspin"], m["Nbath"], m.get("Nph", 0)
+        P.bath_type = BATH_TYPES[m.get("bath_type", "normal")]
+        P.ed_total_ud = 1 if m.get("ed_total_ud", True) else 0
+        P.hfmode = 1 if m.get("hfmode", True) else 0
+        P.Nfoo = self._bd.shape[1]
+        for i in range(5):
+            P.Uloc[i] = float(m["Uloc"][i]) if i < len(m["Uloc"]) else 0.0
+            P.g_ph[i] = float(m.get("g_ph", [0] * 5)[i]) if i < len(m.get("g_ph", [0] * 5)) else 0.0
+        P.Ust, P.Jh, P.Jx, P.Jp = m.get("Ust", 0.0), m.get("Jh", 0.0), m.get("Jx", 0.0), m.get("Jp", 0.0)
+        P.xmu, P.w0_ph = m.get("xmu", 0.0), m.get("w0_ph", 0.0)
+        assert self._imp.shape == (P.Nspin, P.Nspin, P.Norb, P.Norb)
+        assert self._dh.shape == (P.Nspin, P.Norb, P.Nbath)
+        assert self._bd.shape[0] == P.Nspin and self._bd.shape[2] == P.Nbath
+        P.impHloc, P.diag_hybr, P.bath_diag = self._imp.ctypes.data, self._dh.ctypes.data, self._bd.ctypes.data
+        if P.bath_type == 2:
+            assert self._hb is not None and self._hb.shape == (P.Nspin, P.Nspin, P.Norb, P.Norb, P.Nbath)
+        P.hbath = self._hb.ctypes.data if self._hb is not None else None
+        self._P = P
+        nups = list(np.atleast_1d(nups)); ndws = list(np.atleast_1d(ndws))
+        if P.ed_total_ud:
+            ns_orb = (P.Nbath + P.Norb) if P.bath_type == 1 else (P.Nbath + 1) * P.Norb
+        else:
+            ns_orb = P.Nbath + 1
+        self.isector = get_sector(nups + ndws, ns_orb)
+        self._h = lib().orc_sector_open(C.byref(P), self.isector)
+        v = [C.c_int() for _ in range(5)]
+        dups = np.zeros(5, np.int32); ddws = np.zeros(5, np.int32); dim = C.c_int64()
+        lib().orc_sector_info(self._h, *[C.byref(x) for x in v], dups.ctypes.data, ddws.ctypes.data, C.byref(dim))
+        self.Ns, self.Ns_Orb, self.Ns_Ud, self.DimPh, self.Nsectors = [x.value for x in v]
+        self.DimUps = dups[: self.Ns_Ud].copy(); self.DimDws = ddws[: self.Ns_Ud].copy()
+        self.DimUp = int(np.prod(self.DimUps, dtype=np.int64)); self.DimDw = int(np.prod(self.DimDws, dtype=np.int64))
+        self.Dim = dim.value
+        self._built = False
+
+    def close(self):
+        if self._h:
+            lib().orc_sector_close(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def map(self, k):
+        """Hs(k+1)%map (0-based k over [ups..., dws...])."""
+        n = int(self.DimUps[k]) if k < self.Ns_Ud else int(self.DimDws[k - self.Ns_Ud])
+        out = np.zeros(n, np.int32)
+        lib().orc_sector_map(self._h, k, out.ctypes.data)
+        return out
+
+    def buildh(self):
+        lib().orc_buildh(self._h)
+        self._built = True
+        return self
+
+    def sp(self, which, iud=0):
+        """(rowptr, cols[1-based], vals) of spH0d / spH0nd / spH0ups(iud+1) / ..."""
+        if not self._built:
+            self.buildh()
+        nrow = C.c_int64()
+        nnz = lib().orc_sp_nnz(self._h, WHICH[which], iud, C.byref(nrow))
+        rp = np.zeros(nrow.value + 1, np.int64); cols = np.zeros(nnz, np.int64); vals = np.zeros(nnz, np.float64)
+        if nrow.value:
+            lib().orc_sp_export(self._h, WHICH[which], iud, rp.ctypes.data, cols.ctypes.data, vals.ctypes.data)
+        return rp, cols, vals
+
+    def spmatvec(self, v):
+        """spMatVec_main / spMatVec_orbs (ED_HAMILTONIAN_SPARSE_HxV.f90:391-564)."""
+        if not self._built:
+            self.buildh()
+        v = np.ascontiguousarray(v, np.float64); assert v.shape == (self.Dim,)
+        hv = np.empty_like(v)
+        lib().orc_spmatvec(self._h, v.ctypes.data, hv.ctypes.data)
+        return hv
+
+    def directmatvec(self, v):
+        """directMatVec_main / _orbs (ED_HAMILTONIAN_DIRECT_HxV.f90:21-171)."""
+        v = np.ascontiguousarray(v, np.float64); assert v.shape == (self.Dim,)
+        hv = np.empty_like(v)
+        lib().orc_directmatvec(self._h, v.ctypes.data, hv.ctypes.data)
+        return hv
+
+    def hmat(self):
+        """dense Hmat of build_Hv_sector(isector,Hmat)."""
+        if not self._built:
+            self.buildh()
+        assert self.Dim <= 20000
+        H = np.zeros((self.Dim, self.Dim), np.float64, order="F")
+        lib().orc_hmat(self._h, H.ctypes.data)
+        return H
+
+
+# --------------------------------------------------------------------------
+# SciFortran SF_SP_LINALG restatement (see module docstring)
+# --------------------------------------------------------------------------
+def _lanczos_iteration(matvec, it, vin, vout, beta_prev):
+    """lanczos_iteration_d: iter 1 normalises vin; else rotates (vin,vout)."""
+    if it == 1:
+        nrm = np.sqrt(np.dot(vin, vin))
+        if nrm == 0.0:
+            raise ValueError("LANCZOS_ITERATION: norm =0!!")
+        vin = vin / nrm
+    else:
+        tmp = vin
+        vin = vout / beta_prev
+        vout = -beta_prev * tmp
+    tmp = matvec(vin)
+    vout = vout + tmp
+    alfa = float(np.dot(vin, vout))
+    vout = vout - alfa * vin
+    beta = float(np.sqrt(np.dot(vout, vout)))
+    return vin, vout, alfa, beta
+
+
+def sp_lanc_tridiag(matvec, vin, nlanc, threshold=1e-12):
+    """alanc(1:n), blanc(1:n) with blanc(1)=0 unused (ED_GF_NORMAL.f90:638-640)."""
+    from numpy import zeros
+    alanc = zeros(nlanc); blanc = zeros(nlanc)
+    vin = np.array(vin, np.float64); vout = np.zeros_like(vin); b = 0.0
+    nused = 0
+    for it in range(1, nlanc + 1):
+        vin, vout, a, b = _lanczos_iteration(matvec, it, vin, vout, b)
+        alanc[it - 1] = a; nused = it
+        if abs(b) < threshold:
+            break
+        if it < nlanc:
+            blanc[it] = b
+    return alanc, blanc, nused
+
+
+def sp_lanc_eigh(matvec, vect, nitermax, threshold=1e-12, ncheck=10):
+    """Plain two-pass Lanczos ground state.  Returns (egs, vect, nlanc)."""
+    from scipy.linalg import eigh_tridiagonal
+    vect = np.array(vect, np.float64)
+    if np.dot(vect, vect) == 0.0:
+        raise ValueError("oracle needs an explicit start vector (the library's RNG is compiler specific)")
+    vin = vect.copy(); vout = np.zeros_like(vin)
+    alanc = []; blanc = [0.0]; b = 0.0; esave = 0.0; nlanc = 0
+    for it in range(1, nitermax + 1):
+        vin, vout, a, b = _lanczos_iteration(matvec, it, vin, vout, b)
+        if abs(b) < threshold:
+            alanc.append(a); nlanc += 1
+            break
+        nlanc += 1
+        alanc.append(a); blanc.append(b)
+        w = eigh_tridiagonal(np.array(alanc), np.array(blanc[1:nlanc]), eigvals_only=True) if nlanc > 1 else np.array(alanc)
+        if nlanc >= ncheck:
+            diff = abs(w[0] - esave)
+            if diff <= threshold:
+                esave = w[0]
+                break
+        esave = w[0]
+    al = np.array(alanc[:nlanc]); bl = np.array(blanc[1:nlanc])
+    if nlanc > 1:
+        w, Z = eigh_tridiagonal(al, bl)
+    else:
+        w, Z = al.copy(), np.ones((1, 1))
+    egs = float(w[0])
+    vin = vect.copy(); vout = np.zeros_like(vin); out = np.zeros_like(vin); b = 0.0
+    for it in range(1, nlanc + 1):
+        vin, vout, a, b = _lanczos_iteration(matvec, it, vin, vout, b)
+        out = out + vin * Z[it - 1, 0]
+    out = out / np.sqrt(np.dot(out, out))
+    return egs, out, nlanc
