@@ -1,0 +1,929 @@
+// edgpu.hip -- libedgpu.so: sector operator + Lanczos loop on MI355X behind the C ABI of
+// include/edgpu.h.  Host orchestration here, device code in kernels.hpp, sector/factor
+// construction in sector_host.hpp.  gfx950 only; no CPU compute path.
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/edgpu.h"
+#include "sector_host.hpp"
+#include "kernels.hpp"
+
+namespace edgpu {
+
+static thread_local std::string g_err;
+static int fail(int code, const std::string &msg) { g_err = msg; return code; }
+
+#define HIPCHK(expr)                                                                                   \
+    do {                                                                                               \
+        hipError_t e_ = (expr);                                                                        \
+        if (e_ != hipSuccess) {                                                                        \
+            int c_ = (e_ == hipErrorNoDevice || e_ == hipErrorInvalidDevice) ? EDGPU_ENODEVICE         \
+                     : (e_ == hipErrorOutOfMemory ? EDGPU_ENOMEM : EDGPU_EHIP);                        \
+            return fail(c_, std::string(#expr) + ": " + hipGetErrorString(e_));                       \
+        }                                                                                              \
+    } while (0)
+#define CHK(expr) do { int r_ = (expr); if (r_ != EDGPU_OK) return r_; } while (0)
+
+static int require_device()
+{
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n < 1) return fail(EDGPU_ENODEVICE, "edgpu: no HIP device visible (this library has no CPU fallback)");
+    return EDGPU_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// RCCL, resolved at run time so that the library loads on hosts without it and shares the
+// copy an embedding process (e.g. PyTorch) may already have loaded.
+// ------------------------------------------------------------------------------------------
+struct NcclUid { char b[128]; };
+struct Rccl {
+    int (*GetUniqueId)(NcclUid *) = nullptr;
+    int (*CommInitRank)(void **, int, NcclUid, int) = nullptr;
+    int (*CommDestroy)(void *) = nullptr;
+    int (*Send)(const void *, size_t, int, int, void *, hipStream_t) = nullptr;
+    int (*Recv)(void *, size_t, int, int, void *, hipStream_t) = nullptr;
+    int (*AllReduce)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    const char *(*GetErrorString)(int) = nullptr;
+    bool ok = false;
+    bool load()
+    {
+        if (ok) return true;
+        void *h = RTLD_DEFAULT;
+        if (!dlsym(h, "ncclCommInitRank")) {
+            h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+            if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+            if (!h) return false;
+        }
+#define L(name) *(void **)(&name) = dlsym(h, "nccl" #name); if (!name) return false
+        L(GetUniqueId); L(CommInitRank); L(CommDestroy); L(Send); L(Recv); L(AllReduce); L(GroupStart); L(GroupEnd); L(GetErrorString);
+#undef L
+        ok = true;
+        return true;
+    }
+};
+static Rccl g_rccl;
+constexpr int kNcclDouble = 8, kNcclSum = 0;
+
+struct Comm {
+    enum Kind { NONE, RCCL, CALLBACK } kind = NONE;
+    int rank = 0, size = 1;
+    void *nccl = nullptr;
+    edgpu_allgatherv_fn ag = nullptr; edgpu_allreduce_fn ar = nullptr; void *ctx = nullptr;
+};
+
+template <class T> struct DevBuf {
+    T *p = nullptr; size_t n = 0;
+    int alloc(size_t count) { release(); n = count; if (!count) return EDGPU_OK; HIPCHK(hipMalloc((void **)&p, count * sizeof(T))); return EDGPU_OK; }
+    int upload(const std::vector<T> &h) { CHK(alloc(h.size())); if (h.size()) HIPCHK(hipMemcpy(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice)); return EDGPU_OK; }
+    void release() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
+    ~DevBuf() { release(); }
+};
+
+struct DevFactor {
+    DevBuf<int32_t> map, rank, rowptr, cols, ellc, talpha, tbeta;
+    DevBuf<double> vals, ellv, E, tval, lin;
+    int32_t width = 0;
+};
+
+}  // namespace edgpu
+
+using namespace edgpu;
+
+struct edgpu_sector_s {
+    SectorHost H;
+    Comm comm;
+    int device = 0;
+    hipStream_t stream = nullptr, cstream = nullptr;
+    hipEvent_t ev_a = nullptr, ev_b = nullptr, ev_gather = nullptr, ev_ready = nullptr;
+    std::vector<std::unique_ptr<DevFactor>> fac;
+    DevBuf<double> diag, cross, gup, gdw, bd_up, bd_dw;
+    DevBuf<int32_t> stride;
+    // explicit CSR
+    DevBuf<int64_t> csr_rowptr, uppre, dwpre; DevBuf<int32_t> csr_cols; DevBuf<double> csr_vals;
+    int64_t csr_nnz = 0; int32_t csr_rpb = 0, csr_bpr = 0, csr_tile = 4;
+    // work vectors
+    DevBuf<double> vfull, tmp_in, tmp_out, lz[5], scal, alphas, betas, zvec, partial;
+    int64_t nloc = 0, nloc_el = 0, vecdim = 0;
+    int32_t nmax = 0;
+    bool use_lds = false; int kron_threads = 256; size_t kron_lds = 0;
+    bool two_factor = false, extra = false;
+    int64_t nnz_total = 0, bytes_stored = 0;
+    int64_t npartial = 0;
+};
+
+namespace edgpu {
+using S = edgpu_sector_s;
+
+static int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// ---------------------------------------------------------------------------------------
+// device-side construction
+// ---------------------------------------------------------------------------------------
+static int upload_factor(S *s, int k)
+{
+    const Factor &f = s->H.fac[k];
+    auto df = std::make_unique<DevFactor>();
+    CHK(df->map.upload(f.map)); CHK(df->rank.upload(f.rank));
+    std::vector<int32_t> rp32(f.rowptr.begin(), f.rowptr.end());
+    CHK(df->rowptr.upload(rp32)); CHK(df->cols.upload(f.cols)); CHK(df->vals.upload(f.vals));
+    CHK(df->E.upload(f.E));
+    df->width = std::max(f.width, 1);
+    if (df->width > 64) return fail(EDGPU_EUNSUPPORTED, "edgpu: more than 64 hops per spin configuration");
+    if ((int)f.terms.size() > kMaxTerms) return fail(EDGPU_EUNSUPPORTED, "edgpu: too many one-body hop terms");
+    // ELL image: up factors transposed [width][dim] (lanes run over rows), dw factors [dim][width]
+    const bool transposed = k < s->H.Ns_Ud;
+    std::vector<int32_t> ec((size_t)df->width * f.dim); std::vector<double> ev((size_t)df->width * f.dim);
+    for (int32_t i = 0; i < f.dim; i++)
+        for (int32_t q = 0; q < df->width; q++) {
+            int64_t p = f.rowptr[i] + q; bool has = p < f.rowptr[i + 1];
+            size_t o = transposed ? (size_t)q * f.dim + i : (size_t)i * df->width + q;
+            ec[o] = has ? f.cols[p] : i; ev[o] = has ? f.vals[p] : 0.0;
+        }
+    CHK(df->ellc.upload(ec)); CHK(df->ellv.upload(ev));
+    std::vector<int32_t> ta, tb; std::vector<double> tv;
+    for (auto &t : f.terms) { ta.push_back(t.alpha); tb.push_back(t.beta); tv.push_back(t.t); }
+    if (ta.empty()) { ta.push_back(1); tb.push_back(1); tv.push_back(0.0); }
+    CHK(df->talpha.upload(ta)); CHK(df->tbeta.upload(tb)); CHK(df->tval.upload(tv));
+    // per-level one-body coefficients for the on-the-fly energy table
+    {
+        const edgpu_desc &d = s->H.desc; const SectorHost &H = s->H;
+        int spin = k < H.Ns_Ud ? 1 : d.Nspin;
+        std::vector<double> lin(f.nbits, 0.0);
+        auto hf = [&](int a) { return d.hfmode ? -0.5 * d.Uloc[a - 1] - (d.Norb - 1) * (0.5 * d.Ust + 0.5 * (d.Ust - d.Jh)) : 0.0; };
+        if (d.ed_total_ud) {
+            for (int a = 1; a <= d.Norb; a++) lin[a - 1] += H.imp(spin, spin, a, a) - d.xmu + hf(a);
+            for (int a = 1; a <= d.Nfoo; a++) for (int kp = 1; kp <= d.Nbath; kp++) lin[H.stride[a - 1][kp - 1] - 1] += H.bdiag(spin, a, kp);
+        } else {
+            int a = (k % H.Ns_Ud) + 1;
+            lin[0] += H.imp(spin, spin, a, a) - d.xmu + hf(a);
+            for (int kp = 1; kp <= d.Nbath; kp++) lin[kp] += H.bdiag(spin, a, kp);
+        }
+        CHK(df->lin.upload(lin));
+    }
+    s->fac.push_back(std::move(df));
+    return EDGPU_OK;
+}
+
+static int build_diag(S *s)
+{
+    const SectorHost &H = s->H; const edgpu_desc &d = H.desc;
+    DiagArgs A{};
+    A.Norb = d.Norb; A.Nspin = d.Nspin; A.Nbath = d.Nbath; A.Nfoo = d.Nfoo; A.hfmode = d.hfmode; A.total_ud = d.ed_total_ud; A.Ns_Ud = H.Ns_Ud;
+    for (int k = 0; k < 2 * H.Ns_Ud; k++) { A.dims[k] = H.fac[k].dim; A.maps[k] = s->fac[k]->map.p; }
+    A.nloc = s->nloc_el; A.shift = H.dw0 * H.DimUp;
+    for (int a = 0; a < EDGPU_MAX_ORB; a++) { A.Uloc[a] = d.Uloc[a]; A.imp_up[a] = A.imp_dw[a] = 0.0; }
+    for (int a = 1; a <= d.Norb; a++) { A.imp_up[a - 1] = H.imp(1, 1, a, a); A.imp_dw[a - 1] = H.imp(d.Nspin, d.Nspin, a, a); }
+    A.Ust = d.Ust; A.Jh = d.Jh; A.xmu = d.xmu;
+    A.bd_up = s->bd_up.p; A.bd_dw = s->bd_dw.p; A.stride = s->stride.p;
+    CHK(s->diag.alloc((size_t)s->nloc_el));
+    hipLaunchKernelGGL(k_build_diag, dim3((unsigned)cdiv(s->nloc_el, 256)), dim3(256), 0, s->stream, A, s->diag.p);
+    HIPCHK(hipGetLastError());
+    return EDGPU_OK;
+}
+
+static int build_csr(S *s)
+{
+    const SectorHost &H = s->H;
+    if (!s->two_factor || H.DimPh > 1 || H.Jhflag) return fail(EDGPU_EUNSUPPORTED, "edgpu: storage=CSR supports ed_total_ud=T without phonons and Jx/Jp");
+    if (H.DimUp * H.DimDw >= ((int64_t)1 << 31)) return fail(EDGPU_EUNSUPPORTED, "edgpu: storage=CSR needs DimUp*DimDw < 2^31 (int32 columns)");
+    const Factor &up = H.fac[0], &dw = H.fac[1];
+    std::vector<int64_t> uppre(up.dim + 1, 0), dwpre(H.Qdw + 1, 0);
+    for (int i = 0; i < up.dim; i++) uppre[i + 1] = uppre[i] + 1 + (up.rowptr[i + 1] - up.rowptr[i]);
+    int64_t maxrow = 0; int upmax = 0;
+    for (int i = 0; i < up.dim; i++) upmax = std::max<int>(upmax, (int)(up.rowptr[i + 1] - up.rowptr[i]));
+    for (int64_t q = 0; q < H.Qdw; q++) {
+        int64_t nd = dw.rowptr[H.dw0 + q + 1] - dw.rowptr[H.dw0 + q];
+        dwpre[q + 1] = dwpre[q] + uppre[up.dim] + nd * up.dim;
+        maxrow = std::max<int64_t>(maxrow, 1 + upmax + nd);
+    }
+    s->csr_nnz = dwpre[H.Qdw];
+    CHK(s->uppre.upload(uppre)); CHK(s->dwpre.upload(dwpre));
+    CHK(s->csr_rowptr.alloc((size_t)s->nloc_el + 1)); CHK(s->csr_cols.alloc((size_t)s->csr_nnz)); CHK(s->csr_vals.alloc((size_t)s->csr_nnz));
+    CsrBuildArgs A{};
+    A.DimUp = (int32_t)H.DimUp; A.DimDw = (int32_t)H.DimDw; A.Qdw = H.Qdw; A.dw0 = H.dw0;
+    A.uprp = s->fac[0]->rowptr.p; A.upc = s->fac[0]->cols.p; A.upv = s->fac[0]->vals.p;
+    A.dwrp = s->fac[1]->rowptr.p; A.dwc = s->fac[1]->cols.p; A.dwv = s->fac[1]->vals.p;
+    A.uppre = s->uppre.p; A.dwpre = s->dwpre.p; A.diag = s->diag.p;
+    A.rowptr = s->csr_rowptr.p; A.cols = s->csr_cols.p; A.vals = s->csr_vals.p;
+    hipLaunchKernelGGL(k_csr_build, dim3((unsigned)cdiv(s->nloc_el + 1, 256)), dim3(256), 0, s->stream, A);
+    HIPCHK(hipGetLastError());
+    constexpr int CAP = 4608;
+    s->csr_rpb = (int32_t)std::min<int64_t>(256, CAP / std::max<int64_t>(maxrow, 1));
+    if (s->csr_rpb < 1) return fail(EDGPU_EUNSUPPORTED, "edgpu: a CSR row exceeds the LDS product tile");
+    s->csr_bpr = (int32_t)cdiv(H.DimUp, s->csr_rpb);
+    s->csr_tile = std::min(4, s->csr_bpr);
+    return EDGPU_OK;
+}
+
+static int64_t max_partials(const S *s)
+{
+    int64_t n = std::max<int64_t>(s->H.Qdw * s->H.DimPh, 4096);
+    if (s->csr_bpr) n = std::max<int64_t>(n, (int64_t)s->csr_bpr * s->H.Qdw);
+    return n;
+}
+
+static int create(const edgpu_desc *desc, S **out)
+{
+    CHK(require_device());
+    auto s = std::unique_ptr<S>(new S());
+    std::string e = s->H.init(*desc);
+    if (!e.empty()) return fail(EDGPU_EINVAL, e);
+    if (desc->storage < EDGPU_STORE_KRON || desc->storage > EDGPU_STORE_DIRECT) return fail(EDGPU_EINVAL, "edgpu: bad storage");
+    if (desc->device >= 0) HIPCHK(hipSetDevice(desc->device));
+    HIPCHK(hipGetDevice(&s->device));
+    HIPCHK(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
+    HIPCHK(hipStreamCreateWithFlags(&s->cstream, hipStreamNonBlocking));
+    HIPCHK(hipEventCreate(&s->ev_a)); HIPCHK(hipEventCreate(&s->ev_b));
+    HIPCHK(hipEventCreateWithFlags(&s->ev_gather, hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&s->ev_ready, hipEventDisableTiming));
+    SectorHost &H = s->H;
+    s->comm.rank = desc->mpi_rank; s->comm.size = desc->mpi_size;
+    s->two_factor = desc->ed_total_ud != 0;
+    s->extra = H.DimPh > 1 || H.Jhflag;
+    s->nloc_el = H.DimUp * H.Qdw; s->nloc = s->nloc_el * H.DimPh; s->vecdim = s->nloc;
+    for (int k = 0; k < 2 * H.Ns_Ud; k++) CHK(upload_factor(s.get(), k));
+    CHK(s->cross.upload(H.cross)); CHK(s->gup.upload(H.gph_up)); CHK(s->gdw.upload(H.gph_dw));
+    {
+        std::vector<double> bu((size_t)desc->Nfoo * desc->Nbath), bd((size_t)desc->Nfoo * desc->Nbath);
+        for (int a = 1; a <= desc->Nfoo; a++) for (int k = 1; k <= desc->Nbath; k++) { bu[(a - 1) + desc->Nfoo * (k - 1)] = H.bdiag(1, a, k); bd[(a - 1) + desc->Nfoo * (k - 1)] = H.bdiag(desc->Nspin, a, k); }
+        std::vector<int32_t> st((size_t)desc->Norb * desc->Nbath);
+        for (int a = 1; a <= desc->Norb; a++) for (int k = 1; k <= desc->Nbath; k++) st[(a - 1) + desc->Norb * (k - 1)] = H.stride[a - 1][k - 1];
+        CHK(s->bd_up.upload(bu)); CHK(s->bd_dw.upload(bd)); CHK(s->stride.upload(st));
+    }
+    // launch geometry of the fused two-factor kernel
+    if (s->two_factor) {
+        size_t rowbytes = (size_t)H.DimUp * sizeof(double);
+        s->use_lds = rowbytes + 128 <= 150 * 1024;
+        s->kron_threads = H.DimUp >= 4096 ? 1024 : (H.DimUp >= 1024 ? 512 : 256);
+        s->kron_lds = (s->use_lds ? rowbytes : 0) + 16 * sizeof(double);
+    }
+    // operator storage
+    int64_t nnz_fac = 0;
+    if (s->two_factor) {
+        const Factor &up = H.fac[0], &dw = H.fac[1];
+        int64_t nd = dw.rowptr[H.dw0 + H.Qdw] - dw.rowptr[H.dw0];
+        nnz_fac = (int64_t)up.cols.size() * H.Qdw + nd * H.DimUp;
+    } else {
+        for (int k = 0; k < 2 * H.Ns_Ud; k++) nnz_fac += (int64_t)H.fac[k].cols.size() * (s->nloc_el / H.fac[k].dim);
+    }
+    s->nnz_total = (s->nloc_el + nnz_fac) * H.DimPh;
+    if (desc->storage != EDGPU_STORE_DIRECT) { CHK(build_diag(s.get())); s->bytes_stored = s->nloc_el * 8; }
+    if (desc->storage == EDGPU_STORE_CSR) {
+        CHK(build_csr(s.get()));
+        s->bytes_stored = s->csr_nnz * 12 + (s->nloc_el + 1) * 8;
+    }
+    if (desc->mpi_size > 1) CHK(s->vfull.alloc((size_t)(H.DimUp * H.DimDw * H.DimPh)));
+    s->npartial = max_partials(s.get());
+    CHK(s->partial.alloc((size_t)s->npartial));
+    CHK(s->scal.alloc(SC_COUNT));
+    HIPCHK(hipMemsetAsync(s->scal.p, 0, SC_COUNT * sizeof(double), s->stream));
+    HIPCHK(hipStreamSynchronize(s->stream));
+    *out = s.release();
+    return EDGPU_OK;
+}
+
+static void destroy(S *s)
+{
+    if (!s) return;
+    (void)hipSetDevice(s->device);
+    (void)hipDeviceSynchronize();
+    if (s->comm.kind == Comm::RCCL && s->comm.nccl && g_rccl.ok) g_rccl.CommDestroy(s->comm.nccl);
+    if (s->ev_a) (void)hipEventDestroy(s->ev_a);
+    if (s->ev_b) (void)hipEventDestroy(s->ev_b);
+    if (s->ev_gather) (void)hipEventDestroy(s->ev_gather);
+    if (s->ev_ready) (void)hipEventDestroy(s->ev_ready);
+    if (s->stream) (void)hipStreamDestroy(s->stream);
+    if (s->cstream) (void)hipStreamDestroy(s->cstream);
+    delete s;
+}
+
+// ---------------------------------------------------------------------------------------
+// exchange step: gather the input vector of every rank (phonon block by phonon block)
+// ---------------------------------------------------------------------------------------
+static int gather_vector(S *s, const double *v_local, hipStream_t st)
+{
+    const SectorHost &H = s->H; Comm &c = s->comm;
+    const int P = c.size;
+    std::vector<int64_t> counts(P), displs(P);
+    for (int r = 0; r < P; r++) {
+        int64_t q = H.DimDw / P, rem = H.DimDw % P;
+        int64_t qd = r < rem ? q + 1 : q, d0 = r < rem ? r * (q + 1) : r * q + rem;
+        counts[r] = qd * H.DimUp; displs[r] = d0 * H.DimUp;
+    }
+    const int64_t nel_loc = s->nloc_el, nel = H.DimUp * H.DimDw;
+    for (int iph = 0; iph < H.DimPh; iph++) {
+        const double *send = v_local + (int64_t)iph * nel_loc;
+        double *recv = s->vfull.p + (int64_t)iph * nel;
+        if (c.kind == Comm::RCCL) {
+            HIPCHK(hipMemcpyAsync(recv + displs[c.rank], send, (size_t)nel_loc * 8, hipMemcpyDeviceToDevice, st));
+            int rc = g_rccl.GroupStart();
+            for (int r = 0; r < P && rc == 0; r++) {
+                if (r == c.rank) continue;
+                rc = g_rccl.Send(send, (size_t)nel_loc, kNcclDouble, r, c.nccl, st);
+                if (rc == 0) rc = g_rccl.Recv(recv + displs[r], (size_t)counts[r], kNcclDouble, r, c.nccl, st);
+            }
+            int rc2 = g_rccl.GroupEnd();
+            if (rc || rc2) return fail(EDGPU_ECOMM, std::string("edgpu: RCCL send/recv failed: ") + g_rccl.GetErrorString(rc ? rc : rc2));
+        } else if (c.kind == Comm::CALLBACK) {
+            HIPCHK(hipStreamSynchronize(st));
+            if (c.ag(c.ctx, send, nel_loc, recv, counts.data(), displs.data(), P)) return fail(EDGPU_ECOMM, "edgpu: allgatherv callback failed");
+        } else
+            return fail(EDGPU_ECOMM, "edgpu: mpi_size>1 but no communicator attached (edgpu_comm_init_*)");
+    }
+    return EDGPU_OK;
+}
+
+// sum scal[SC_TMP] over ranks
+static int allreduce_tmp(S *s)
+{
+    Comm &c = s->comm;
+    if (c.size == 1) return EDGPU_OK;
+    double *p = s->scal.p + SC_TMP;
+    if (c.kind == Comm::RCCL) {
+        int rc = g_rccl.AllReduce(p, p, 1, kNcclDouble, kNcclSum, c.nccl, s->stream);
+        if (rc) return fail(EDGPU_ECOMM, std::string("edgpu: RCCL allreduce failed: ") + g_rccl.GetErrorString(rc));
+    } else if (c.kind == Comm::CALLBACK) {
+        double h;
+        HIPCHK(hipMemcpyAsync(&h, p, 8, hipMemcpyDeviceToHost, s->stream)); HIPCHK(hipStreamSynchronize(s->stream));
+        if (c.ar(c.ctx, &h, 1)) return fail(EDGPU_ECOMM, "edgpu: allreduce callback failed");
+        HIPCHK(hipMemcpyAsync(p, &h, 8, hipMemcpyHostToDevice, s->stream)); HIPCHK(hipStreamSynchronize(s->stream));
+    } else
+        return fail(EDGPU_ECOMM, "edgpu: mpi_size>1 but no communicator attached");
+    return EDGPU_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// one product  out = H*v  (epi=false)   or the Lanczos-fused form (epi=true):
+//   out = s_cur*H*u - beta*s_prev*u_prev ;  scal[TMP] = (s_cur*u) . out
+// ---------------------------------------------------------------------------------------
+template <int F> static void launch_kron2(S *s, const Kron2Args &A, int64_t rows)
+{
+    size_t lds = (F & KF_LDS) ? s->kron_lds : 16 * sizeof(double);
+    static bool attr_set = false;
+    if (!attr_set && lds > 64 * 1024) { (void)hipFuncSetAttribute((const void *)k_kron2<F>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; }
+    hipLaunchKernelGGL(k_kron2<F>, dim3((unsigned)rows), dim3(s->kron_threads), lds, s->stream, A);
+}
+
+static int dispatch_kron2(S *s, int flags, const Kron2Args &A, int64_t rows)
+{
+#define CASE(f) case (f): launch_kron2<(f)>(s, A, rows); break;
+#define CASE4(b) CASE(b) CASE((b) | KF_DIRECT) CASE((b) | KF_EPI) CASE((b) | KF_DIRECT | KF_EPI)
+#define CASE8(b) CASE4(b) CASE4((b) | KF_PH | KF_ND)
+    switch (flags) {
+        CASE8(0) CASE8(KF_LDS) CASE8(KF_NODW) CASE8(KF_NODW | KF_LDS) CASE8(KF_NOLOCAL)
+    default: return fail(EDGPU_EINVAL, "edgpu: internal kernel variant missing");
+    }
+#undef CASE8
+#undef CASE4
+#undef CASE
+    HIPCHK(hipGetLastError());
+    return EDGPU_OK;
+}
+
+static int direct_tables(S *s)
+{
+    const SectorHost &H = s->H; const edgpu_desc &d = H.desc;
+    for (int k = 0; k < 2 * H.Ns_Ud; k++) {
+        DevFactor &f = *s->fac[k];
+        TabArgs T{};
+        T.dim = H.fac[k].dim; T.nterms = (int32_t)H.fac[k].terms.size(); T.width = f.width; T.transposed = k < H.Ns_Ud;
+        T.map = f.map.p; T.rank = f.rank.p; T.talpha = f.talpha.p; T.tbeta = f.tbeta.p; T.tval = f.tval.p;
+        T.ellc = f.ellc.p; T.ellv = f.ellv.p; T.lin = f.lin.p; T.nlev = H.fac[k].nbits;
+        T.impmask = d.ed_total_ud ? (1 << d.Norb) - 1 : 0; T.pair = d.ed_total_ud ? d.Ust - d.Jh : 0.0; T.E = f.E.p;
+        hipLaunchKernelGGL(k_direct_tables, dim3((unsigned)cdiv(T.dim, 256)), dim3(256), 0, s->stream, T);
+    }
+    HIPCHK(hipGetLastError());
+    return EDGPU_OK;
+}
+
+static int hxv(S *s, const double *v, double *out, bool epi, const double *uprev)
+{
+    const SectorHost &H = s->H; const edgpu_desc &d = H.desc;
+    const bool multi = s->comm.size > 1;
+    const bool direct = d.storage == EDGPU_STORE_DIRECT;
+    if (direct) CHK(direct_tables(s));
+    if (multi) {  // start the exchange on the comm stream; local work overlaps it
+        HIPCHK(hipEventRecord(s->ev_ready, s->stream));
+        HIPCHK(hipStreamWaitEvent(s->cstream, s->ev_ready, 0));
+        CHK(gather_vector(s, v, s->cstream));
+        HIPCHK(hipEventRecord(s->ev_gather, s->cstream));
+    }
+    int64_t nblocks = 0;
+    if (d.storage == EDGPU_STORE_CSR) {
+        if (multi) HIPCHK(hipStreamWaitEvent(s->stream, s->ev_gather, 0));
+        CsrArgs A{};
+        A.nrows = s->nloc_el; A.rows_per_block = s->csr_rpb; A.DimUp = (int32_t)H.DimUp; A.blocks_per_row = s->csr_bpr; A.Qdw = H.Qdw; A.tile = s->csr_tile;
+        A.rowptr = s->csr_rowptr.p; A.cols = s->csr_cols.p; A.vals = s->csr_vals.p;
+        A.x = multi ? s->vfull.p : v; A.y = out; A.v_local = v; A.uprev = uprev; A.scal = s->scal.p; A.partial = s->partial.p; A.epi = epi;
+        // the column index is global; on one GPU local == global
+        nblocks = (int64_t)s->csr_bpr * H.Qdw;
+        hipLaunchKernelGGL(k_csr_spmv<4608>, dim3((unsigned)nblocks), dim3(256), 0, s->stream, A);
+        HIPCHK(hipGetLastError());
+    } else if (s->two_factor) {
+        Kron2Args A{};
+        A.DimUp = (int32_t)H.DimUp; A.DimDw = (int32_t)H.DimDw; A.DimPh = H.DimPh; A.Norb = d.Norb; A.Qdw = H.Qdw; A.dw0 = H.dw0;
+        A.upc = s->fac[0]->ellc.p; A.upv = s->fac[0]->ellv.p; A.upw = s->fac[0]->width;
+        A.dwc = s->fac[1]->ellc.p; A.dwv = s->fac[1]->ellv.p; A.dww = s->fac[1]->width;
+        A.diag = s->diag.p; A.Eup = s->fac[0]->E.p; A.Edw = s->fac[1]->E.p; A.cross = s->cross.p;
+        A.mapup = s->fac[0]->map.p; A.mapdw = s->fac[1]->map.p; A.rankup = s->fac[0]->rank.p; A.rankdw = s->fac[1]->rank.p;
+        A.impmask = (1 << d.Norb) - 1; A.nI = 1 << d.Norb; A.econst = H.econst; A.w0 = d.w0_ph; A.gsum = H.gph_sum; A.Jx = d.Jx; A.Jp = d.Jp;
+        A.gup = s->gup.p; A.gdw = s->gdw.p;
+        A.v = v; A.vfull = multi ? s->vfull.p : v; A.out = out; A.uprev = uprev; A.scal = s->scal.p; A.partial = s->partial.p;
+        int base = (direct ? KF_DIRECT : 0) | (epi ? KF_EPI : 0) | (s->extra ? (KF_PH | KF_ND) : 0);
+        nblocks = H.Qdw * H.DimPh;
+        if (!multi) CHK(dispatch_kron2(s, base | (s->use_lds ? KF_LDS : 0), A, nblocks));
+        else {
+            CHK(dispatch_kron2(s, base | KF_NODW | (s->use_lds ? KF_LDS : 0), A, nblocks));
+            HIPCHK(hipStreamWaitEvent(s->stream, s->ev_gather, 0));
+            CHK(dispatch_kron2(s, base | KF_NOLOCAL, A, nblocks));
+        }
+    } else {
+        GenArgs A{};
+        A.nfac = 2 * H.Ns_Ud; A.DimPh = H.DimPh; A.Norb = d.Norb; A.direct = direct;
+        int64_t st = 1;
+        for (int k = 0; k < A.nfac; k++) {
+            A.dims[k] = H.fac[k].dim; A.strides[k] = st; st *= H.fac[k].dim;
+            A.rowptr[k] = s->fac[k]->rowptr.p; A.cols[k] = s->fac[k]->cols.p; A.vals[k] = s->fac[k]->vals.p; A.E[k] = s->fac[k]->E.p; A.maps[k] = s->fac[k]->map.p;
+        }
+        A.diag = s->diag.p; A.cross = s->cross.p; A.gup = s->gup.p; A.gdw = s->gdw.p; A.nI = 1 << d.Norb; A.total_ud = d.ed_total_ud; A.impmask = (1 << d.Norb) - 1;
+        A.econst = H.econst; A.w0 = d.w0_ph; A.gsum = H.gph_sum; A.Nel = s->nloc_el;
+        A.v = v; A.out = out; A.uprev = uprev; A.scal = s->scal.p; A.partial = s->partial.p; A.epi = epi;
+        nblocks = std::min<int64_t>(cdiv(s->nloc, 256), 4096);
+        hipLaunchKernelGGL(k_generic, dim3((unsigned)nblocks), dim3(256), 0, s->stream, A);
+        HIPCHK(hipGetLastError());
+    }
+    if (epi) {
+        hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(1024), 0, s->stream, s->partial.p, nblocks, s->scal.p + SC_TMP);
+        HIPCHK(hipGetLastError());
+        CHK(allreduce_tmp(s));
+    }
+    return EDGPU_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// symmetric tridiagonal eigen-solver (implicit QL with Wilkinson shifts), host, n <= ~1000.
+// d: diagonal (n), e: sub-diagonal e[1..n-1] (e[0] unused).  On exit d = eigenvalues
+// (unsorted); if z != nullptr (n*n, row-major z[i*n+j], identity on entry) columns = vectors.
+// ---------------------------------------------------------------------------------------
+static bool tqli(std::vector<double> &d, std::vector<double> &e, int n, double *z)
+{
+    for (int i = 1; i < n; i++) e[i - 1] = e[i];
+    if (n > 0) e[n - 1] = 0.0;
+    for (int l = 0; l < n; l++) {
+        int iter = 0, m;
+        do {
+            for (m = l; m < n - 1; m++) {
+                double dd = std::fabs(d[m]) + std::fabs(d[m + 1]);
+                if (std::fabs(e[m]) <= 2.3e-16 * dd) break;
+            }
+            if (m != l) {
+                if (iter++ == 120) return false;
+                double g = (d[l + 1] - d[l]) / (2.0 * e[l]);
+                double r = std::hypot(g, 1.0);
+                g = d[m] - d[l] + e[l] / (g + (g >= 0.0 ? std::fabs(r) : -std::fabs(r)));
+                double sn = 1.0, c = 1.0, p = 0.0;
+                int i;
+                for (i = m - 1; i >= l; i--) {
+                    double f = sn * e[i], b = c * e[i];
+                    e[i + 1] = (r = std::hypot(f, g));
+                    if (r == 0.0) { d[i + 1] -= p; e[m] = 0.0; break; }
+                    sn = f / r; c = g / r;
+                    g = d[i + 1] - p;
+                    r = (d[i] - g) * sn + 2.0 * c * b;
+                    d[i + 1] = g + (p = sn * r);
+                    g = c * r - b;
+                    if (z)
+                        for (int k = 0; k < n; k++) {
+                            double f2 = z[(size_t)k * n + i + 1];
+                            z[(size_t)k * n + i + 1] = sn * z[(size_t)k * n + i] + c * f2;
+                            z[(size_t)k * n + i] = c * z[(size_t)k * n + i] - sn * f2;
+                        }
+                }
+                if (r == 0.0 && i >= l) continue;
+                d[l] -= p; e[l] = g; e[m] = 0.0;
+            }
+        } while (m != l);
+    }
+    return true;
+}
+
+// lowest eigenvalue (and optionally its eigenvector) of T_k = tridiag(alphas[0..k), betas[1..k))
+static bool tridiag_lowest(const double *al, const double *be, int k, double *e0, std::vector<double> *zcol)
+{
+    std::vector<double> d(al, al + k), e(k, 0.0);
+    for (int i = 1; i < k; i++) e[i] = be[i];
+    std::vector<double> z;
+    if (zcol) { z.assign((size_t)k * k, 0.0); for (int i = 0; i < k; i++) z[(size_t)i * k + i] = 1.0; }
+    if (!tqli(d, e, k, zcol ? z.data() : nullptr)) return false;
+    int im = 0;
+    for (int i = 1; i < k; i++) if (d[i] < d[im]) im = i;
+    *e0 = d[im];
+    if (zcol) { zcol->resize(k); for (int i = 0; i < k; i++) (*zcol)[i] = z[(size_t)i * k + im]; }
+    return true;
+}
+
+// ---------------------------------------------------------------------------------------
+// Lanczos loop, device resident.  Restates SciFortran's lanczos_iteration / sp_lanc_eigh /
+// sp_lanc_tridiag (module SF_SP_LINALG, not part of the reference tree; call sites
+// ED_DIAG.f90:177-185, ED_GF_NORMAL.f90:232-237) with vectors kept unnormalised in HBM and the
+// 1/beta scale carried in a device scalar, so one iteration is: fused product+alpha, one
+// axpy+norm pass, two single-workgroup reductions -- and no host synchronisation.
+// ---------------------------------------------------------------------------------------
+static int lz_prepare(S *s, int nmax)
+{
+    for (int i = 0; i < 3; i++) if (s->lz[i].n != (size_t)s->nloc) CHK(s->lz[i].alloc((size_t)s->nloc));
+    if (s->nmax < nmax) {
+        CHK(s->alphas.alloc((size_t)nmax + 2)); CHK(s->betas.alloc((size_t)nmax + 2)); CHK(s->zvec.alloc((size_t)nmax + 2));
+        s->nmax = nmax;
+    }
+    HIPCHK(hipMemsetAsync(s->alphas.p, 0, ((size_t)nmax + 2) * 8, s->stream));
+    HIPCHK(hipMemsetAsync(s->betas.p, 0, ((size_t)nmax + 2) * 8, s->stream));
+    return EDGPU_OK;
+}
+
+static int reduce_dot(S *s, const double *a, const double *b)
+{
+    int nb = (int)std::min<int64_t>(cdiv(s->nloc, 256 * 8), 2048);
+    nb = std::max(nb, 1);
+    hipLaunchKernelGGL(k_dot_partial, dim3(nb), dim3(256), 0, s->stream, a, b, s->nloc, s->partial.p);
+    hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(1024), 0, s->stream, s->partial.p, (int64_t)nb, s->scal.p + SC_TMP);
+    HIPCHK(hipGetLastError());
+    return allreduce_tmp(s);
+}
+
+struct LzVecs { double *uprev, *ucur, *w; };
+
+// start: ucur holds the (unnormalised) start vector
+static int lz_start(S *s, LzVecs &V)
+{
+    HIPCHK(hipMemsetAsync(V.uprev, 0, (size_t)s->nloc * 8, s->stream));
+    CHK(reduce_dot(s, V.ucur, V.ucur));
+    hipLaunchKernelGGL(k_scalar_step, dim3(1), dim3(1), 0, s->stream, s->scal.p, s->alphas.p, s->betas.p, (const double *)nullptr, 0, 2);
+    HIPCHK(hipGetLastError());
+    return EDGPU_OK;
+}
+
+// iteration k (0-based): fills alphas[k], betas[k+1]; optional eigenvector accumulation
+static int lz_iter(S *s, LzVecs &V, int k, double *acc)
+{
+    CHK(hxv(s, V.ucur, V.w, true, V.uprev));
+    hipLaunchKernelGGL(k_scalar_step, dim3(1), dim3(1), 0, s->stream, s->scal.p, s->alphas.p, s->betas.p, (const double *)nullptr, k, 0);
+    if (acc) hipLaunchKernelGGL(k_scalar_step, dim3(1), dim3(1), 0, s->stream, s->scal.p, s->alphas.p, s->betas.p, (const double *)s->zvec.p, k, 3);
+    int nb = (int)std::max<int64_t>(1, std::min<int64_t>(cdiv(s->nloc, 256 * 4), 4096));
+    hipLaunchKernelGGL(k_axpy_norm, dim3(nb), dim3(256), 0, s->stream, V.w, V.ucur, acc, s->scal.p, s->nloc, s->partial.p);
+    hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(1024), 0, s->stream, s->partial.p, (int64_t)nb, s->scal.p + SC_TMP);
+    HIPCHK(hipGetLastError());
+    CHK(allreduce_tmp(s));
+    hipLaunchKernelGGL(k_scalar_step, dim3(1), dim3(1), 0, s->stream, s->scal.p, s->alphas.p, s->betas.p, (const double *)nullptr, k, 1);
+    HIPCHK(hipGetLastError());
+    double *t = V.uprev; V.uprev = V.ucur; V.ucur = V.w; V.w = t;
+    return EDGPU_OK;
+}
+
+static int fetch_coeffs(S *s, int k, std::vector<double> &al, std::vector<double> &be)
+{
+    al.resize(k + 1); be.resize(k + 2);
+    HIPCHK(hipMemcpyAsync(al.data(), s->alphas.p, (size_t)(k + 1) * 8, hipMemcpyDeviceToHost, s->stream));
+    HIPCHK(hipMemcpyAsync(be.data(), s->betas.p, (size_t)(k + 2) * 8, hipMemcpyDeviceToHost, s->stream));
+    HIPCHK(hipStreamSynchronize(s->stream));
+    return EDGPU_OK;
+}
+
+static int lanczos_gs(S *s, int nitermax, double threshold, int ncheck, double *egs, double *vect_dev, int *nlanc_out)
+{
+    if (nitermax < 1) return fail(EDGPU_EINVAL, "edgpu_lanczos_gs: nitermax < 1");
+    if (ncheck < 1) ncheck = 10;
+    if ((int64_t)nitermax > s->H.Dim) nitermax = (int)s->H.Dim;   // ED_DIAG.f90:100 Nitermax=min(dim,lanc_niter)
+    CHK(lz_prepare(s, nitermax));
+    for (int i = 3; i < 5; i++) if (s->lz[i].n != (size_t)s->nloc) CHK(s->lz[i].alloc((size_t)s->nloc));
+    double *start = s->lz[3].p, *acc = s->lz[4].p;
+    // zero input => library-generated start vector (ED_DIAG.f90:147 passes eig_basis=0)
+    HIPCHK(hipMemcpyAsync(start, vect_dev, (size_t)s->nloc * 8, hipMemcpyDeviceToDevice, s->stream));
+    CHK(reduce_dot(s, start, start));
+    double nrm2;
+    HIPCHK(hipMemcpyAsync(&nrm2, s->scal.p + SC_TMP, 8, hipMemcpyDeviceToHost, s->stream)); HIPCHK(hipStreamSynchronize(s->stream));
+    if (nrm2 == 0.0) {
+        const SectorHost &H = s->H;
+        hipLaunchKernelGGL(k_random_start, dim3(2048), dim3(256), 0, s->stream, start, H.DimUp, H.Qdw, H.dw0, H.DimDw, H.DimPh, (uint64_t)1234567);
+        HIPCHK(hipGetLastError());
+    }
+    LzVecs V{s->lz[0].p, s->lz[1].p, s->lz[2].p};
+    HIPCHK(hipMemcpyAsync(V.ucur, start, (size_t)s->nloc * 8, hipMemcpyDeviceToDevice, s->stream));
+    CHK(lz_start(s, V));
+    std::vector<double> al, be;
+    int nlanc = 0; double esave = 0.0, e0 = 0.0;
+    for (int k = 0; k < nitermax; k++) {
+        CHK(lz_iter(s, V, k, nullptr));
+        CHK(fetch_coeffs(s, k, al, be));
+        nlanc = k + 1;
+        if (std::fabs(be[k + 1]) < threshold) break;       // invariant subspace reached
+        if (!tridiag_lowest(al.data(), be.data(), nlanc, &e0, nullptr)) return fail(EDGPU_ENOTCONVERGED, "edgpu: tridiagonal QL did not converge");
+        if (nlanc >= ncheck && std::fabs(e0 - esave) <= threshold) break;
+        esave = e0;
+    }
+    std::vector<double> z;
+    if (!tridiag_lowest(al.data(), be.data(), nlanc, &e0, &z)) return fail(EDGPU_ENOTCONVERGED, "edgpu: tridiagonal QL did not converge");
+    *egs = e0; *nlanc_out = nlanc;
+    // second pass: regenerate the Krylov vectors and accumulate vect = sum_k Z(k,1) v_k
+    HIPCHK(hipMemcpyAsync(s->zvec.p, z.data(), (size_t)nlanc * 8, hipMemcpyHostToDevice, s->stream));
+    HIPCHK(hipMemsetAsync(acc, 0, (size_t)s->nloc * 8, s->stream));
+    V = LzVecs{s->lz[0].p, s->lz[1].p, s->lz[2].p};
+    HIPCHK(hipMemcpyAsync(V.ucur, start, (size_t)s->nloc * 8, hipMemcpyDeviceToDevice, s->stream));
+    CHK(lz_start(s, V));
+    for (int k = 0; k < nlanc; k++) CHK(lz_iter(s, V, k, acc));
+    CHK(reduce_dot(s, acc, acc));
+    hipLaunchKernelGGL(k_scalar_step, dim3(1), dim3(1), 0, s->stream, s->scal.p, s->alphas.p, s->betas.p, (const double *)nullptr, 0, 2);
+    int nb = (int)std::max<int64_t>(1, std::min<int64_t>(cdiv(s->nloc, 256 * 4), 4096));
+    hipLaunchKernelGGL(k_scale, dim3(nb), dim3(256), 0, s->stream, acc, s->scal.p, (int)SC_SCUR, s->nloc);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(vect_dev, acc, (size_t)s->nloc * 8, hipMemcpyDeviceToDevice, s->stream));
+    HIPCHK(hipStreamSynchronize(s->stream));
+    return EDGPU_OK;
+}
+
+static int lanczos_tridiag(S *s, const double *vin_dev, int nlanc, double threshold, double *alanc, double *blanc, int *nused)
+{
+    if (nlanc < 1) return fail(EDGPU_EINVAL, "edgpu_lanczos_tridiag: nlanc < 1");
+    CHK(lz_prepare(s, nlanc));
+    LzVecs V{s->lz[0].p, s->lz[1].p, s->lz[2].p};
+    HIPCHK(hipMemcpyAsync(V.ucur, vin_dev, (size_t)s->nloc * 8, hipMemcpyDeviceToDevice, s->stream));
+    CHK(lz_start(s, V));
+    for (int i = 0; i < nlanc; i++) { alanc[i] = 0.0; blanc[i] = 0.0; }
+    std::vector<double> al, be;
+    int used = 0;
+    const int chunk = 8;  // look at beta on the host every `chunk` iterations
+    for (int k = 0; k < nlanc;) {
+        int kend = std::min(nlanc, k + chunk);
+        for (; k < kend; k++) CHK(lz_iter(s, V, k, nullptr));
+        CHK(fetch_coeffs(s, k - 1, al, be));
+        bool stop = false;
+        for (int i = used; i < k; i++) {
+            alanc[i] = al[i]; used = i + 1;
+            if (std::fabs(be[i + 1]) < threshold) { stop = true; break; }
+            if (i + 1 < nlanc) blanc[i + 1] = be[i + 1];
+        }
+        if (stop) break;
+    }
+    *nused = used;
+    return EDGPU_OK;
+}
+
+}  // namespace edgpu
+
+// =========================================================================================
+// C ABI
+// =========================================================================================
+extern "C" {
+
+int edgpu_abi_version(void) { return EDGPU_ABI_VERSION; }
+const char *edgpu_last_error(void) { return g_err.c_str(); }
+
+int edgpu_sector_create(const edgpu_desc *desc, edgpu_handle *out)
+{
+    if (!desc || !out) return fail(EDGPU_EINVAL, "edgpu_sector_create: null argument");
+    *out = nullptr;
+    return create(desc, out);
+}
+int edgpu_sector_destroy(edgpu_handle h) { destroy(h); return EDGPU_OK; }
+int64_t edgpu_sector_vecdim(edgpu_handle h) { return h ? h->vecdim : -1; }
+
+int edgpu_sector_info(edgpu_handle h, edgpu_info *o)
+{
+    if (!h || !o) return fail(EDGPU_EINVAL, "edgpu_sector_info: null argument");
+    const SectorHost &H = h->H;
+    memset(o, 0, sizeof(*o));
+    o->isector = H.isector; o->Ns = H.Ns; o->Ns_Orb = H.Ns_Orb; o->Ns_Ud = H.Ns_Ud; o->DimPh = H.DimPh; o->Jhflag = H.Jhflag;
+    for (int k = 0; k < H.Ns_Ud; k++) { o->DimUps[k] = H.fac[k].dim; o->DimDws[k] = H.fac[k + H.Ns_Ud].dim; }
+    o->DimUp = H.DimUp; o->DimDw = H.DimDw; o->Dim = H.Dim; o->mpiQdw = H.Qdw; o->mpiIshift = H.dw0 * H.DimUp; o->vecDim = h->vecdim;
+    o->nnz_total = h->nnz_total; o->bytes_stored = h->bytes_stored;
+    return EDGPU_OK;
+}
+
+int edgpu_sector_map(edgpu_handle h, int32_t k, int32_t *out)
+{
+    if (!h || !out || k < 0 || k >= 2 * h->H.Ns_Ud) return fail(EDGPU_EINVAL, "edgpu_sector_map: bad argument");
+    // read back from the device copy the kernels use
+    HIPCHK(hipMemcpy(out, h->fac[k]->map.p, (size_t)h->H.fac[k].dim * 4, hipMemcpyDeviceToHost));
+    return EDGPU_OK;
+}
+
+int edgpu_factor_size(edgpu_handle h, int32_t which, int32_t iud, int64_t *nrow, int64_t *nnz)
+{
+    if (!h || !nrow || !nnz) return fail(EDGPU_EINVAL, "edgpu_factor_size: null argument");
+    const SectorHost &H = h->H;
+    if (which == EDGPU_SP_UP || which == EDGPU_SP_DW) {
+        if (iud < 0 || iud >= H.Ns_Ud) return fail(EDGPU_EINVAL, "edgpu_factor_size: bad iud");
+        const Factor &f = H.fac[which == EDGPU_SP_UP ? iud : iud + H.Ns_Ud];
+        *nrow = f.dim; *nnz = (int64_t)f.cols.size();
+        return EDGPU_OK;
+    }
+    if (which == EDGPU_SP_ND) {
+        if (!H.Jhflag) { *nrow = 0; *nnz = 0; return EDGPU_OK; }
+        if (H.DimUp * H.DimDw > 50000000) return fail(EDGPU_EUNSUPPORTED, "edgpu_factor_size: spH0nd export is an inspection aid for small sectors");
+        std::vector<int64_t> c; std::vector<double> v; int64_t n = 0;
+        for (int64_t q = 0; q < H.Qdw; q++) for (int64_t iup = 0; iup < H.DimUp; iup++) { H.nonlocal_row(iup, H.dw0 + q, c, v); n += (int64_t)c.size(); }
+        *nrow = h->nloc_el; *nnz = n;
+        return EDGPU_OK;
+    }
+    return fail(EDGPU_EINVAL, "edgpu_factor_size: bad which");
+}
+
+int edgpu_factor_export(edgpu_handle h, int32_t which, int32_t iud, int64_t *row_ptr, int64_t *cols, double *vals)
+{
+    if (!h || !row_ptr) return fail(EDGPU_EINVAL, "edgpu_factor_export: null argument");
+    const SectorHost &H = h->H;
+    if (which == EDGPU_SP_UP || which == EDGPU_SP_DW) {
+        if (iud < 0 || iud >= H.Ns_Ud) return fail(EDGPU_EINVAL, "edgpu_factor_export: bad iud");
+        const Factor &f = H.fac[which == EDGPU_SP_UP ? iud : iud + H.Ns_Ud];
+        DevFactor &df = *h->fac[which == EDGPU_SP_UP ? iud : iud + H.Ns_Ud];
+        // values and columns come back from the device copy (what the kernels actually read)
+        std::vector<int32_t> c(f.cols.size()), rp(f.dim + 1);
+        HIPCHK(hipMemcpy(rp.data(), df.rowptr.p, rp.size() * 4, hipMemcpyDeviceToHost));
+        if (!c.empty()) { HIPCHK(hipMemcpy(c.data(), df.cols.p, c.size() * 4, hipMemcpyDeviceToHost)); HIPCHK(hipMemcpy(vals, df.vals.p, c.size() * 8, hipMemcpyDeviceToHost)); }
+        for (size_t i = 0; i < rp.size(); i++) row_ptr[i] = rp[i];
+        for (size_t i = 0; i < c.size(); i++) cols[i] = (int64_t)c[i] + 1;
+        return EDGPU_OK;
+    }
+    if (which == EDGPU_SP_ND) {
+        std::vector<int64_t> c; std::vector<double> v; int64_t n = 0, r = 0;
+        row_ptr[0] = 0;
+        for (int64_t q = 0; q < H.Qdw; q++)
+            for (int64_t iup = 0; iup < H.DimUp; iup++) {
+                H.nonlocal_row(iup, H.dw0 + q, c, v);
+                for (size_t k = 0; k < c.size(); k++) { cols[n] = c[k] + 1; vals[n] = v[k]; n++; }
+                row_ptr[++r] = n;
+            }
+        return EDGPU_OK;
+    }
+    return fail(EDGPU_EINVAL, "edgpu_factor_export: bad which");
+}
+
+int edgpu_diag_export(edgpu_handle h, double *d_host)
+{
+    if (!h || !d_host) return fail(EDGPU_EINVAL, "edgpu_diag_export: null argument");
+    if (!h->diag.p) { CHK(build_diag(h)); }
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipMemcpy(d_host, h->diag.p, (size_t)h->nloc_el * 8, hipMemcpyDeviceToHost));
+    return EDGPU_OK;
+}
+
+int edgpu_csr_rows(edgpu_handle h, int64_t row0, int64_t nrows, int64_t *row_ptr, int32_t *cols, double *vals, int64_t cap)
+{
+    if (!h || !row_ptr) return fail(EDGPU_EINVAL, "edgpu_csr_rows: null argument");
+    if (!h->csr_rowptr.p) return fail(EDGPU_EINVAL, "edgpu_csr_rows: sector was not created with storage=CSR");
+    if (row0 < 0 || nrows < 0 || row0 + nrows > h->nloc_el) return fail(EDGPU_EINVAL, "edgpu_csr_rows: row window out of range");
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipMemcpy(row_ptr, h->csr_rowptr.p + row0, (size_t)(nrows + 1) * 8, hipMemcpyDeviceToHost));
+    int64_t n = row_ptr[nrows] - row_ptr[0];
+    if (n > cap) return fail(EDGPU_EINVAL, "edgpu_csr_rows: capacity too small");
+    if (n && cols && vals) {
+        HIPCHK(hipMemcpy(cols, h->csr_cols.p + row_ptr[0], (size_t)n * 4, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(vals, h->csr_vals.p + row_ptr[0], (size_t)n * 8, hipMemcpyDeviceToHost));
+    }
+    return EDGPU_OK;
+}
+
+int edgpu_hxv_device(edgpu_handle h, const double *v_dev, double *hv_dev)
+{
+    if (!h || !v_dev || !hv_dev) return fail(EDGPU_EINVAL, "edgpu_hxv_device: null argument");
+    HIPCHK(hipSetDevice(h->device));
+    CHK(hxv(h, v_dev, hv_dev, false, nullptr));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return EDGPU_OK;
+}
+
+int edgpu_hxv64(edgpu_handle h, int64_t nloc, const double *v, double *hv)
+{
+    if (!h || !v || !hv) return fail(EDGPU_EINVAL, "edgpu_hxv: null argument");
+    if (nloc != h->vecdim) return fail(EDGPU_EINVAL, "directMatVec_cc ERROR: Nloc != dim(isector)");  // ED_HAMILTONIAN_DIRECT_HxV.f90:35
+    HIPCHK(hipSetDevice(h->device));
+    if (h->tmp_in.n != (size_t)nloc) { CHK(h->tmp_in.alloc((size_t)nloc)); CHK(h->tmp_out.alloc((size_t)nloc)); }
+    HIPCHK(hipMemcpyAsync(h->tmp_in.p, v, (size_t)nloc * 8, hipMemcpyHostToDevice, h->stream));
+    CHK(hxv(h, h->tmp_in.p, h->tmp_out.p, false, nullptr));
+    HIPCHK(hipMemcpyAsync(hv, h->tmp_out.p, (size_t)nloc * 8, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return EDGPU_OK;
+}
+int edgpu_hxv(edgpu_handle h, const int32_t *nloc, const double *v, double *hv)
+{
+    if (!nloc) return fail(EDGPU_EINVAL, "edgpu_hxv: null Nloc");
+    return edgpu_hxv64(h, (int64_t)*nloc, v, hv);
+}
+
+int edgpu_hxv_time(edgpu_handle h, const double *v_dev, double *hv_dev, int32_t nwarm, int32_t nrep, float *ms_mean)
+{
+    if (!h || !v_dev || !hv_dev || !ms_mean || nrep < 1) return fail(EDGPU_EINVAL, "edgpu_hxv_time: bad argument");
+    HIPCHK(hipSetDevice(h->device));
+    for (int i = 0; i < nwarm; i++) CHK(hxv(h, v_dev, hv_dev, false, nullptr));
+    HIPCHK(hipEventRecord(h->ev_a, h->stream));
+    for (int i = 0; i < nrep; i++) CHK(hxv(h, v_dev, hv_dev, false, nullptr));
+    HIPCHK(hipEventRecord(h->ev_b, h->stream));
+    HIPCHK(hipEventSynchronize(h->ev_b));
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, h->ev_a, h->ev_b));
+    *ms_mean = ms / nrep;
+    return EDGPU_OK;
+}
+
+int edgpu_lanczos_gs_device(edgpu_handle h, int32_t nitermax, double threshold, int32_t ncheck, double *egs, double *vect_dev, int32_t *nlanc)
+{
+    if (!h || !egs || !vect_dev || !nlanc) return fail(EDGPU_EINVAL, "edgpu_lanczos_gs: null argument");
+    HIPCHK(hipSetDevice(h->device));
+    return lanczos_gs(h, nitermax, threshold, ncheck, egs, vect_dev, nlanc);
+}
+int edgpu_lanczos_gs(edgpu_handle h, int32_t nitermax, double threshold, int32_t ncheck, double *egs, double *vect, int32_t *nlanc)
+{
+    if (!h || !egs || !vect || !nlanc) return fail(EDGPU_EINVAL, "edgpu_lanczos_gs: null argument");
+    HIPCHK(hipSetDevice(h->device));
+    if (h->tmp_in.n != (size_t)h->nloc) { CHK(h->tmp_in.alloc((size_t)h->nloc)); CHK(h->tmp_out.alloc((size_t)h->nloc)); }
+    HIPCHK(hipMemcpy(h->tmp_in.p, vect, (size_t)h->nloc * 8, hipMemcpyHostToDevice));
+    CHK(lanczos_gs(h, nitermax, threshold, ncheck, egs, h->tmp_in.p, nlanc));
+    HIPCHK(hipMemcpy(vect, h->tmp_in.p, (size_t)h->nloc * 8, hipMemcpyDeviceToHost));
+    return EDGPU_OK;
+}
+int edgpu_lanczos_tridiag_device(edgpu_handle h, const double *vin_dev, int32_t nlanc, double threshold, double *alanc, double *blanc, int32_t *nused)
+{
+    if (!h || !vin_dev || !alanc || !blanc || !nused) return fail(EDGPU_EINVAL, "edgpu_lanczos_tridiag: null argument");
+    HIPCHK(hipSetDevice(h->device));
+    return lanczos_tridiag(h, vin_dev, nlanc, threshold, alanc, blanc, nused);
+}
+int edgpu_lanczos_tridiag(edgpu_handle h, const double *vin, int32_t nlanc, double threshold, double *alanc, double *blanc, int32_t *nused)
+{
+    if (!h || !vin || !alanc || !blanc || !nused) return fail(EDGPU_EINVAL, "edgpu_lanczos_tridiag: null argument");
+    HIPCHK(hipSetDevice(h->device));
+    if (h->tmp_in.n != (size_t)h->nloc) { CHK(h->tmp_in.alloc((size_t)h->nloc)); CHK(h->tmp_out.alloc((size_t)h->nloc)); }
+    HIPCHK(hipMemcpy(h->tmp_in.p, vin, (size_t)h->nloc * 8, hipMemcpyHostToDevice));
+    return lanczos_tridiag(h, h->tmp_in.p, nlanc, threshold, alanc, blanc, nused);
+}
+
+int edgpu_lanczos_time(edgpu_handle h, int32_t nwarm, int32_t niter, float *ms_per_iter)
+{
+    if (!h || !ms_per_iter || niter < 1) return fail(EDGPU_EINVAL, "edgpu_lanczos_time: bad argument");
+    HIPCHK(hipSetDevice(h->device));
+    CHK(lz_prepare(h, nwarm + niter + 1));
+    LzVecs V{h->lz[0].p, h->lz[1].p, h->lz[2].p};
+    const SectorHost &H = h->H;
+    hipLaunchKernelGGL(k_random_start, dim3(2048), dim3(256), 0, h->stream, V.ucur, H.DimUp, H.Qdw, H.dw0, H.DimDw, H.DimPh, (uint64_t)1234567);
+    HIPCHK(hipGetLastError());
+    CHK(lz_start(h, V));
+    int k = 0;
+    for (; k < nwarm; k++) CHK(lz_iter(h, V, k, nullptr));
+    HIPCHK(hipEventRecord(h->ev_a, h->stream));
+    for (; k < nwarm + niter; k++) CHK(lz_iter(h, V, k, nullptr));
+    HIPCHK(hipEventRecord(h->ev_b, h->stream));
+    HIPCHK(hipEventSynchronize(h->ev_b));
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, h->ev_a, h->ev_b));
+    *ms_per_iter = ms / niter;
+    return EDGPU_OK;
+}
+
+int edgpu_comm_unique_id(void *id128)
+{
+    if (!id128) return fail(EDGPU_EINVAL, "edgpu_comm_unique_id: null argument");
+    if (!g_rccl.load()) return fail(EDGPU_ECOMM, "edgpu: RCCL (librccl.so) could not be loaded");
+    int rc = g_rccl.GetUniqueId((NcclUid *)id128);
+    if (rc) return fail(EDGPU_ECOMM, std::string("ncclGetUniqueId: ") + g_rccl.GetErrorString(rc));
+    return EDGPU_OK;
+}
+int edgpu_comm_init_rccl(edgpu_handle h, const void *id128)
+{
+    if (!h || !id128) return fail(EDGPU_EINVAL, "edgpu_comm_init_rccl: null argument");
+    if (!g_rccl.load()) return fail(EDGPU_ECOMM, "edgpu: RCCL (librccl.so) could not be loaded");
+    HIPCHK(hipSetDevice(h->device));
+    NcclUid uid; memcpy(&uid, id128, sizeof(uid));
+    int rc = g_rccl.CommInitRank(&h->comm.nccl, h->comm.size, uid, h->comm.rank);
+    if (rc) return fail(EDGPU_ECOMM, std::string("ncclCommInitRank: ") + g_rccl.GetErrorString(rc));
+    h->comm.kind = Comm::RCCL;
+    return EDGPU_OK;
+}
+int edgpu_comm_init_callbacks(edgpu_handle h, edgpu_allgatherv_fn ag, edgpu_allreduce_fn ar, void *ctx)
+{
+    if (!h || !ag || !ar) return fail(EDGPU_EINVAL, "edgpu_comm_init_callbacks: null argument");
+    h->comm.kind = Comm::CALLBACK; h->comm.ag = ag; h->comm.ar = ar; h->comm.ctx = ctx;
+    return EDGPU_OK;
+}
+
+int edgpu_device_count(int32_t *n)
+{
+    if (!n) return fail(EDGPU_EINVAL, "edgpu_device_count: null argument");
+    int c = 0;
+    if (hipGetDeviceCount(&c) != hipSuccess) c = 0;
+    *n = c;
+    return EDGPU_OK;
+}
+int edgpu_malloc(void **dev, size_t bytes) { if (!dev) return fail(EDGPU_EINVAL, "edgpu_malloc: null"); CHK(require_device()); HIPCHK(hipMalloc(dev, bytes)); return EDGPU_OK; }
+int edgpu_free(void *dev) { if (dev) HIPCHK(hipFree(dev)); return EDGPU_OK; }
+int edgpu_memcpy_h2d(void *dev, const void *host, size_t bytes) { HIPCHK(hipMemcpy(dev, host, bytes, hipMemcpyHostToDevice)); return EDGPU_OK; }
+int edgpu_memcpy_d2h(void *host, const void *dev, size_t bytes) { HIPCHK(hipMemcpy(host, dev, bytes, hipMemcpyDeviceToHost)); return EDGPU_OK; }
+int edgpu_device_synchronize(void) { HIPCHK(hipDeviceSynchronize()); return EDGPU_OK; }
+
+}  // extern "C"

@@ -1,0 +1,496 @@
+// kernels.hpp -- gfx950 device kernels of the sector operator and the Lanczos vector updates.
+//
+// Layout in HBM (all fp64 vectors): v(iup, idw, iph) with iup fastest,
+//   i = iup + idw*DimUp + iph*DimUp*Qdw        (ED_HAMILTONIAN_SPARSE_HxV.f90:417, 0-based here)
+// A rank owns the dw columns [dw0, dw0+Qdw) (ED_HAMILTONIAN.f90:96-110).
+//
+// No MFMA anywhere: these are HBM-bound gather/stream kernels; what matters is coalescing
+// along iup, LDS staging of the row that the up-hops gather from, and keeping the per-spin
+// factor tables (KBs..MBs) cache resident.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace edgpu {
+
+constexpr int kMaxTerms = 256;
+
+// scalars of the Lanczos recurrence, resident in HBM so the loop needs no host round trip
+enum { SC_SCUR = 0, SC_SPREV = 1, SC_BETA = 2, SC_ALPHA = 3, SC_TMP = 4, SC_ZK = 5, SC_COUNT = 8 };
+
+struct DiagArgs {  // bit-exact diagonal (stored/H_local.f90:13-71, stored/Orbs/H_local.f90:1-80)
+    int32_t Norb, Nspin, Nbath, Nfoo, hfmode, total_ud, Ns_Ud;
+    int32_t dims[2 * EDGPU_MAX_ORB];
+    const int32_t *maps[2 * EDGPU_MAX_ORB];
+    int64_t nloc, shift;  // local electronic rows, global offset of the first one
+    double Uloc[EDGPU_MAX_ORB], Ust, Jh, xmu;
+    double imp_up[EDGPU_MAX_ORB], imp_dw[EDGPU_MAX_ORB];
+    const double *bd_up, *bd_dw;  // [Nfoo*Nbath]: bath_diag(1,a,k), bath_diag(Nspin,a,k), index (a-1)+Nfoo*(k-1)
+    const int32_t *stride;        // [Norb*Nbath]: getBathStride(a,k), index (a-1)+Norb*(k-1)
+};
+
+// HIP's __dadd_rn/__dmul_rn are plain + and * which the compiler contracts to FMA; the
+// reference's CPU path rounds after every multiply and every add, so pin the instructions.
+__device__ __forceinline__ double mul_rn(double a, double b) { double r; asm volatile("v_mul_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ double add_rn(double a, double b) { double r; asm volatile("v_add_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ double sub_rn(double a, double b) { double r; asm volatile("v_add_f64 %0, %1, -%2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+
+__global__ void __launch_bounds__(256) k_build_diag(DiagArgs A, double *__restrict__ d)
+{
+    int64_t il = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (il >= A.nloc) return;
+    int64_t ig = il + A.shift;  // 0-based global electronic index
+    uint32_t mu[EDGPU_MAX_ORB], md[EDGPU_MAX_ORB];
+    {
+        int64_t c = ig;
+        for (int k = 0; k < A.Ns_Ud; k++) { mu[k] = (uint32_t)A.maps[k][c % A.dims[k]]; c /= A.dims[k]; }
+        for (int k = 0; k < A.Ns_Ud; k++) { md[k] = (uint32_t)A.maps[k + A.Ns_Ud][c % A.dims[k + A.Ns_Ud]]; c /= A.dims[k + A.Ns_Ud]; }
+    }
+    auto nimp = [&](const uint32_t *m, int a) -> int { return A.total_ud ? (int)((m[0] >> (a - 1)) & 1u) : (int)(m[a - 1] & 1u); };
+    auto nbath = [&](const uint32_t *m, int a, int kp) -> int {
+        return A.total_ud ? (int)((m[0] >> (A.stride[(a - 1) + A.Norb * (kp - 1)] - 1)) & 1u) : (int)((m[a - 1] >> kp) & 1u);
+    };
+    // Non-fused IEEE ops in the reference's statement order => same bits as the CPU path.
+    double h = 0.0;
+    for (int a = 1; a <= A.Norb; a++) {
+        int nu = nimp(mu, a), nd = nimp(md, a);
+        h = add_rn(h, mul_rn(A.imp_up[a - 1], (double)nu));
+        h = add_rn(h, mul_rn(A.imp_dw[a - 1], (double)nd));
+        h = sub_rn(h, mul_rn(A.xmu, (double)(nu + nd)));
+    }
+    for (int a = 1; a <= A.Norb; a++)
+        h = add_rn(h, mul_rn(mul_rn(A.Uloc[a - 1], (double)nimp(mu, a)), (double)nimp(md, a)));
+    if (A.Norb > 1) {
+        for (int a = 1; a <= A.Norb; a++)
+            for (int b = a + 1; b <= A.Norb; b++)
+                h = add_rn(h, mul_rn(A.Ust, (double)(nimp(mu, a) * nimp(md, b) + nimp(mu, b) * nimp(md, a))));
+        double ustjh = sub_rn(A.Ust, A.Jh);
+        for (int a = 1; a <= A.Norb; a++)
+            for (int b = a + 1; b <= A.Norb; b++)
+                h = add_rn(h, mul_rn(ustjh, (double)(nimp(mu, a) * nimp(mu, b) + nimp(md, a) * nimp(md, b))));
+    }
+    if (A.hfmode) {
+        for (int a = 1; a <= A.Norb; a++) {
+            double t1 = mul_rn(mul_rn(0.5, A.Uloc[a - 1]), (double)(nimp(mu, a) + nimp(md, a)));
+            h = add_rn(sub_rn(h, t1), mul_rn(0.25, A.Uloc[a - 1]));
+        }
+        if (A.Norb > 1) {
+            double ustjh = sub_rn(A.Ust, A.Jh);
+            for (int a = 1; a <= A.Norb; a++)
+                for (int b = a + 1; b <= A.Norb; b++) {
+                    double n4 = (double)(nimp(mu, a) + nimp(md, a) + nimp(mu, b) + nimp(md, b));
+                    h = add_rn(sub_rn(h, mul_rn(mul_rn(0.5, A.Ust), n4)), mul_rn(0.25, A.Ust));
+                    h = add_rn(sub_rn(h, mul_rn(mul_rn(0.5, ustjh), n4)), mul_rn(0.25, ustjh));
+                }
+        }
+    }
+    for (int a = 1; a <= A.Nfoo; a++)
+        for (int kp = 1; kp <= A.Nbath; kp++) {
+            int ix = (a - 1) + A.Nfoo * (kp - 1);
+            h = add_rn(h, mul_rn(A.bd_up[ix], (double)nbath(mu, a, kp)));
+            h = add_rn(h, mul_rn(A.bd_dw[ix], (double)nbath(md, a, kp)));
+        }
+    d[il] = h;
+}
+
+// ---------------------------------------------------------------------------------------------
+// block-wide deterministic sum (fixed shuffle tree, then fixed order over waves)
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ double wave_sum(double x)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
+    return x;
+}
+__device__ __forceinline__ double block_sum(double x, double *scratch /* >= blockDim/64 doubles */)
+{
+    x = wave_sum(x);
+    int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    __syncthreads();
+    if (lane == 0) scratch[w] = x;
+    __syncthreads();
+    double r = 0.0;
+    if (threadIdx.x == 0) for (int i = 0; i < nw; i++) r += scratch[i];
+    return r;  // valid on thread 0
+}
+
+// ---------------------------------------------------------------------------------------------
+// The fused two-factor operator (ed_total_ud=T):
+//   Hv(iup,idw) = d*v + sum_k Hdw[idw,k] v(iup,jdw_k) + sum_k Hup[iup,k] v(jup_k,idw) [+ph] [+Jx/Jp]
+// replaces the five sweeps of spMatVec_main (ED_HAMILTONIAN_SPARSE_HxV.f90:391-485) and the
+// scatter loops of directMatVec_main (ED_HAMILTONIAN_DIRECT_HxV.f90:21-95) by one gather pass.
+// One workgroup per (idw, iph) row of DimUp contiguous doubles; the row is staged in LDS
+// because every up-hop gathers from it; dw-hops read whole neighbour rows, coalesced in iup.
+// ---------------------------------------------------------------------------------------------
+struct Kron2Args {
+    int32_t DimUp, DimDw, DimPh, Norb;
+    int64_t Qdw, dw0;
+    const int32_t *upc; const double *upv; int32_t upw;  // ELL, [upw][DimUp]
+    const int32_t *dwc; const double *dwv; int32_t dww;  // ELL, [DimDw][dww]
+    const double *diag;                                   // [Qdw*DimUp] (KRON) or nullptr (DIRECT)
+    const double *Eup, *Edw, *cross;                     // DIRECT: per-spin tables + impurity coupling
+    const int32_t *mapup, *mapdw, *rankup, *rankdw;
+    int32_t impmask, nI;
+    double econst, w0, gsum, Jx, Jp;
+    const double *gup, *gdw;
+    const double *v, *vfull;  // local shard / gathered vector (same pointer on one GPU)
+    double *out;
+    const double *uprev; const double *scal; double *partial;  // Lanczos epilogue
+    int32_t rows_per_tile;    // blockIdx -> row remap granularity (0 = identity)
+};
+
+enum { KF_DIRECT = 1, KF_LDS = 2, KF_EPI = 4, KF_PH = 8, KF_ND = 16, KF_NOLOCAL = 32, KF_NODW = 64 };
+
+template <int F>
+__global__ void __launch_bounds__(1024) k_kron2(Kron2Args A)
+{
+    extern __shared__ double lds[];
+    const int DimUp = A.DimUp;
+    double *red = lds + ((F & KF_LDS) ? DimUp : 0);
+    const int64_t row = blockIdx.x;
+    const int iph = (int)(row / A.Qdw);
+    const int64_t idwl = row - (int64_t)iph * A.Qdw, idw = A.dw0 + idwl;
+    const int64_t rbase = ((int64_t)iph * A.Qdw + idwl) * DimUp;       // local row base
+    const int64_t fbase = (int64_t)iph * A.DimDw * DimUp;              // phonon block base in vfull
+    const double *vrow = A.v + rbase;
+    if (F & KF_LDS) {
+        for (int i = threadIdx.x; i < DimUp; i += blockDim.x) lds[i] = vrow[i];
+        __syncthreads();
+    }
+    const int dww = (F & KF_NODW) ? 0 : A.dww;
+    const int32_t *dwc = A.dwc + idw * A.dww;
+    const double *dwv = A.dwv + idw * A.dww;
+    uint32_t mdw = 0; double edw = 0.0;
+    if (F & (KF_DIRECT | KF_PH | KF_ND)) mdw = (uint32_t)A.mapdw[idw];
+    if (F & KF_DIRECT) edw = A.Edw[idw] + A.econst;
+    double s_cur = 1.0, c_prev = 0.0, asum = 0.0;
+    if (F & KF_EPI) { s_cur = A.scal[SC_SCUR]; c_prev = A.scal[SC_BETA] * A.scal[SC_SPREV]; }
+
+    for (int iup = threadIdx.x; iup < DimUp; iup += blockDim.x) {
+        const double x = (F & KF_LDS) ? lds[iup] : vrow[iup];
+        double acc = 0.0;
+        uint32_t mup = 0;
+        if (F & (KF_DIRECT | KF_PH | KF_ND)) mup = (uint32_t)A.mapup[iup];
+        if (!(F & KF_NOLOCAL)) {
+            double dval;
+            if (F & KF_DIRECT) dval = edw + A.Eup[iup] + A.cross[(mup & A.impmask) * A.nI + (mdw & A.impmask)];
+            else dval = A.diag[idwl * DimUp + iup];
+            if (F & KF_PH) dval += A.w0 * iph;
+            acc = dval * x;
+            // up hops: gather inside the staged row
+            for (int k = 0; k < A.upw; k++) {
+                int32_t j = A.upc[(int64_t)k * DimUp + iup];
+                double t = A.upv[(int64_t)k * DimUp + iup];
+                acc += t * ((F & KF_LDS) ? lds[j] : vrow[j]);
+            }
+            if (F & KF_PH) {  // stored/H_e_ph.f90:12-39 : g(n-1) (x) (b + b^+)
+                double g = A.gup[mup & A.impmask] + A.gdw[mdw & A.impmask] - A.gsum;
+                const int64_t pstride = A.Qdw * DimUp;
+                if (iph + 1 < A.DimPh) acc += g * sqrt((double)(iph + 1)) * A.v[rbase + pstride + iup];
+                if (iph > 0) acc += g * sqrt((double)iph) * A.v[rbase - pstride + iup];
+            }
+        }
+        // dw hops: neighbour rows, coalesced in iup
+        for (int k = 0; k < dww; k++) acc += dwv[k] * A.vfull[fbase + (int64_t)dwc[k] * DimUp + iup];
+        if ((F & KF_ND) && !(F & KF_NODW)) {  // stored/H_non_local.f90:21-83 evaluated on the fly
+            for (int a = 0; a < A.Norb; a++)
+                for (int b = 0; b < A.Norb; b++) {
+                    const uint32_t ba = 1u << a, bb = 1u << b;
+                    if (A.Jx != 0.0 && a != b && (mup & bb) && (mdw & ba) && !(mdw & bb) && !(mup & ba)) {
+                        uint32_t k1 = mdw & ~ba, k2 = k1 | bb, k3 = mup & ~bb, k4 = k3 | ba;
+                        int sg = __popc(mdw & (ba - 1)) + __popc(k1 & (bb - 1)) + __popc(mup & (bb - 1)) + __popc(k3 & (ba - 1));
+                        double t = (sg & 1) ? -A.Jx : A.Jx;
+                        acc += t * A.vfull[fbase + (int64_t)A.rankdw[k2] * DimUp + A.rankup[k4]];
+                    }
+                    if (A.Jp != 0.0 && (mup & bb) && (mdw & bb) && !(mdw & ba) && !(mup & ba)) {
+                        uint32_t k1 = mdw & ~bb, k2 = k1 | ba, k3 = mup & ~bb, k4 = k3 | ba;
+                        int sg = __popc(mdw & (bb - 1)) + __popc(k1 & (ba - 1)) + __popc(mup & (bb - 1)) + __popc(k3 & (ba - 1));
+                        double t = (sg & 1) ? -A.Jp : A.Jp;
+                        acc += t * A.vfull[fbase + (int64_t)A.rankdw[k2] * DimUp + A.rankup[k4]];
+                    }
+                }
+        }
+        if (F & KF_EPI) {
+            double w;
+            if (F & KF_NOLOCAL) w = A.out[rbase + iup] + s_cur * acc;        // second half of a split product
+            else w = s_cur * acc - c_prev * A.uprev[rbase + iup];
+            A.out[rbase + iup] = w;
+            if (!(F & KF_NODW)) asum += (s_cur * x) * w;
+        } else {
+            if (F & KF_NOLOCAL) A.out[rbase + iup] += acc; else A.out[rbase + iup] = acc;
+        }
+    }
+    if ((F & KF_EPI) && !(F & KF_NODW)) {
+        double r = block_sum(asum, red);
+        if (threadIdx.x == 0) A.partial[blockIdx.x] = r;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Generic multi-factor operator (ed_total_ud=F: spMatVec_orbs / directMatVec_orbs,
+// ED_HAMILTONIAN_SPARSE_HxV.f90:487-564, ED_HAMILTONIAN_DIRECT_HxV.f90:100-171).
+// State index is the mixed-radix number over [DimUps..., DimDws...]; factor k acts on digit k.
+// ---------------------------------------------------------------------------------------------
+struct GenArgs {
+    int32_t nfac, DimPh, Norb, direct;
+    int32_t dims[2 * EDGPU_MAX_ORB];
+    int64_t strides[2 * EDGPU_MAX_ORB];
+    const int32_t *rowptr[2 * EDGPU_MAX_ORB];
+    const int32_t *cols[2 * EDGPU_MAX_ORB];
+    const double *vals[2 * EDGPU_MAX_ORB];
+    const double *E[2 * EDGPU_MAX_ORB];
+    const int32_t *maps[2 * EDGPU_MAX_ORB];
+    const double *diag, *cross, *gup, *gdw;
+    int32_t nI, total_ud, impmask;
+    double econst, w0, gsum;
+    int64_t Nel;
+    const double *v; double *out;
+    const double *uprev; const double *scal; double *partial; int32_t epi;
+};
+
+__global__ void __launch_bounds__(256) k_generic(GenArgs A)
+{
+    __shared__ double red[8];
+    const int64_t N = A.Nel * A.DimPh;
+    double s_cur = 1.0, c_prev = 0.0, asum = 0.0;
+    if (A.epi) { s_cur = A.scal[SC_SCUR]; c_prev = A.scal[SC_BETA] * A.scal[SC_SPREV]; }
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += (int64_t)gridDim.x * blockDim.x) {
+        const int iph = (int)(i / A.Nel);
+        const int64_t iel = i - (int64_t)iph * A.Nel;
+        int32_t dig[2 * EDGPU_MAX_ORB];
+        { int64_t c = iel; for (int k = 0; k < A.nfac; k++) { dig[k] = (int32_t)(c % A.dims[k]); c /= A.dims[k]; } }
+        const double x = A.v[i];
+        double dval;
+        uint32_t mu = 0, md = 0;
+        if (A.direct || A.DimPh > 1) {  // impurity-bit words of both spins
+            const int nud = A.nfac / 2;
+            if (A.total_ud) { mu = (uint32_t)A.maps[0][dig[0]] & A.impmask; md = (uint32_t)A.maps[1][dig[1]] & A.impmask; }
+            else for (int a = 0; a < nud; a++) { mu |= ((uint32_t)A.maps[a][dig[a]] & 1u) << a; md |= ((uint32_t)A.maps[a + nud][dig[a + nud]] & 1u) << a; }
+        }
+        if (A.direct) {
+            dval = A.econst + A.cross[mu * A.nI + md];
+            for (int k = 0; k < A.nfac; k++) dval += A.E[k][dig[k]];
+        } else dval = A.diag[iel];
+        if (A.DimPh > 1) dval += A.w0 * iph;
+        double acc = dval * x;
+        for (int k = 0; k < A.nfac; k++) {
+            const int32_t r0 = A.rowptr[k][dig[k]], r1 = A.rowptr[k][dig[k] + 1];
+            for (int32_t p = r0; p < r1; p++) acc += A.vals[k][p] * A.v[i + (int64_t)(A.cols[k][p] - dig[k]) * A.strides[k]];
+        }
+        if (A.DimPh > 1) {
+            double g = A.gup[mu] + A.gdw[md] - A.gsum;
+            if (iph + 1 < A.DimPh) acc += g * sqrt((double)(iph + 1)) * A.v[i + A.Nel];
+            if (iph > 0) acc += g * sqrt((double)iph) * A.v[i - A.Nel];
+        }
+        if (A.epi) { double w = s_cur * acc - c_prev * A.uprev[i]; A.out[i] = w; asum += (s_cur * x) * w; }
+        else A.out[i] = acc;
+    }
+    if (A.epi) { double r = block_sum(asum, red); if (threadIdx.x == 0) A.partial[blockIdx.x] = r; }
+}
+
+// ---------------------------------------------------------------------------------------------
+// On-the-fly rebuild of the per-spin tables from the bit patterns (DIRECT storage): every
+// matrix element of H_sigma is recomputed at each product, as directMatVec does -- but once per
+// spin configuration (O(Dim_sigma) work) instead of once per state (O(N)).
+// ---------------------------------------------------------------------------------------------
+struct TabArgs {
+    int32_t dim, nterms, width, transposed;  // transposed: ELL [width][dim] (up) else [dim][width] (dw)
+    const int32_t *map, *rank;
+    const int32_t *talpha, *tbeta; const double *tval;
+    int32_t *ellc; double *ellv;
+    const double *lin; int32_t nlev; int32_t impmask; double pair;  // E[i] = sum lin[l] n_l + pair * C(#imp,2)
+    double *E;
+};
+
+__global__ void __launch_bounds__(256) k_direct_tables(TabArgs A)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= A.dim) return;
+    const uint32_t mi = (uint32_t)A.map[i];
+    int32_t cj[64]; double cv[64]; int n = 0;
+    for (int t = 0; t < A.nterms; t++) {
+        const uint32_t ba = 1u << (A.talpha[t] - 1), bb = 1u << (A.tbeta[t] - 1);
+        if (!(mi & ba) || (mi & bb)) continue;
+        const uint32_t k1 = mi & ~ba, mj = k1 | bb;
+        int sg = __popc(mj & (bb - 1)) + __popc(k1 & (ba - 1));   // c_beta on source, c^+_alpha on k1
+        double val = (sg & 1) ? -A.tval[t] : A.tval[t];
+        int32_t j = A.rank[mj];
+        int p = n;
+        bool dup = false;
+        for (int q = 0; q < n; q++) if (cj[q] == j) { cv[q] += val; dup = true; break; }
+        if (dup) continue;
+        while (p > 0 && cj[p - 1] > j) { cj[p] = cj[p - 1]; cv[p] = cv[p - 1]; p--; }   // keep cols ascending
+        cj[p] = j; cv[p] = val; n++;
+    }
+    for (int k = 0; k < A.width; k++) {
+        int32_t j = k < n ? cj[k] : i; double val = k < n ? cv[k] : 0.0;
+        int64_t o = A.transposed ? (int64_t)k * A.dim + i : (int64_t)i * A.width + k;
+        A.ellc[o] = j; A.ellv[o] = val;
+    }
+    double e = 0.0;
+    for (int l = 0; l < A.nlev; l++) if (mi & (1u << l)) e += A.lin[l];
+    int ni = __popc(mi & A.impmask);
+    e += A.pair * (double)(ni * (ni - 1) / 2);
+    A.E[i] = e;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Explicit CSR (storage=CSR): expansion of the Kronecker sum, then a row-block streaming SpMV.
+// ---------------------------------------------------------------------------------------------
+struct CsrBuildArgs {
+    int32_t DimUp, DimDw; int64_t Qdw, dw0;
+    const int32_t *uprp, *upc; const double *upv;   // CSR of H_up (rowptr32)
+    const int32_t *dwrp, *dwc; const double *dwv;   // CSR of H_dw
+    const int64_t *uppre;                           // prefix over iup of (1 + nnz_up(iup)), [DimUp+1]
+    const int64_t *dwpre;                           // prefix over local idw of row-block nnz, [Qdw+1]
+    const double *diag;
+    int64_t *rowptr; int32_t *cols; double *vals;
+};
+
+// row (iup, idw) holds, in ascending column order: dw hops to jdw<idw, up hops jup<iup, the
+// diagonal, up hops jup>iup, dw hops jdw>idw.  Columns index the gathered vector (global idw).
+__global__ void __launch_bounds__(256) k_csr_build(CsrBuildArgs A)
+{
+    const int64_t il = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t nloc = A.Qdw * A.DimUp;
+    if (il > nloc) return;
+    if (il == nloc) { A.rowptr[nloc] = A.dwpre[A.Qdw]; return; }
+    const int64_t idwl = il / A.DimUp; const int iup = (int)(il - idwl * A.DimUp); const int64_t idw = A.dw0 + idwl;
+    const int ndw = A.dwrp[idw + 1] - A.dwrp[idw];
+    int64_t p = A.dwpre[idwl] + (int64_t)iup * ndw + A.uppre[iup];
+    A.rowptr[il] = p;
+    const int32_t d0 = A.dwrp[idw], d1 = A.dwrp[idw + 1], u0 = A.uprp[iup], u1 = A.uprp[iup + 1];
+    int32_t q = d0;
+    for (; q < d1 && A.dwc[q] < idw; q++) { A.cols[p] = (int32_t)((int64_t)A.dwc[q] * A.DimUp + iup); A.vals[p] = A.dwv[q]; p++; }
+    int32_t r = u0;
+    for (; r < u1 && A.upc[r] < iup; r++) { A.cols[p] = (int32_t)(idw * A.DimUp + A.upc[r]); A.vals[p] = A.upv[r]; p++; }
+    A.cols[p] = (int32_t)(idw * A.DimUp + iup); A.vals[p] = A.diag[il]; p++;
+    for (; r < u1; r++) { A.cols[p] = (int32_t)(idw * A.DimUp + A.upc[r]); A.vals[p] = A.upv[r]; p++; }
+    for (; q < d1; q++) { A.cols[p] = (int32_t)((int64_t)A.dwc[q] * A.DimUp + iup); A.vals[p] = A.dwv[q]; p++; }
+}
+
+struct CsrArgs {
+    int64_t nrows; int32_t rows_per_block; int32_t DimUp; int32_t blocks_per_row; int64_t Qdw; int32_t tile;
+    const int64_t *rowptr; const int32_t *cols; const double *vals;
+    const double *x; double *y;
+    const double *v_local;  // x restricted to the local rows (== x on one GPU), for the alpha dot
+    const double *uprev; const double *scal; double *partial; int32_t epi;
+};
+
+// "CSR-stream": a workgroup owns `rows_per_block` consecutive rows of one idw row, streams their
+// contiguous nnz range coalesced (value*x[col] -> LDS), then one thread per row sums its segment.
+template <int CAP>
+__global__ void __launch_bounds__(256) k_csr_spmv(CsrArgs A)
+{
+    __shared__ double prod[CAP];
+    __shared__ double red[4];
+    // blockIdx -> (idw, jb): tiles of `tile` row-blocks sweep all idw before moving on in iup,
+    // so the dw-hop gathers of one sweep stay inside a DimDw x (tile*rows_per_block) slab of x.
+    int64_t idwl; int jb;
+    {
+        const int64_t b = blockIdx.x, per_tile = (int64_t)A.tile * A.Qdw;
+        const int nt_full = A.blocks_per_row / A.tile;
+        int64_t t, r; int tw;
+        if (b < (int64_t)nt_full * per_tile) { t = b / per_tile; r = b - t * per_tile; tw = A.tile; }
+        else { t = nt_full; r = b - (int64_t)nt_full * per_tile; tw = A.blocks_per_row - nt_full * A.tile; }
+        idwl = r / tw; jb = (int)(t * A.tile + (r - idwl * tw));
+    }
+    const int iup0 = jb * A.rows_per_block;
+    int nr = A.DimUp - iup0; if (nr > A.rows_per_block) nr = A.rows_per_block;
+    const int64_t row0 = idwl * A.DimUp + iup0;
+    const int64_t p0 = A.rowptr[row0], p1 = A.rowptr[row0 + nr];
+    const int n = (int)(p1 - p0);
+    for (int k = threadIdx.x; k < n; k += blockDim.x) prod[k] = A.vals[p0 + k] * A.x[A.cols[p0 + k]];
+    __syncthreads();
+    double s_cur = 1.0, c_prev = 0.0, asum = 0.0;
+    if (A.epi) { s_cur = A.scal[SC_SCUR]; c_prev = A.scal[SC_BETA] * A.scal[SC_SPREV]; }
+    if ((int)threadIdx.x < nr) {
+        const int64_t row = row0 + threadIdx.x;
+        const int a = (int)(A.rowptr[row] - p0), e = (int)(A.rowptr[row + 1] - p0);
+        double acc = 0.0;
+        for (int k = a; k < e; k++) acc += prod[k];
+        if (A.epi) { double w = s_cur * acc - c_prev * A.uprev[row]; A.y[row] = w; asum = (s_cur * A.v_local[row]) * w; }
+        else A.y[row] = acc;
+    }
+    if (A.epi) { double r = block_sum(asum, red); if (threadIdx.x == 0) A.partial[blockIdx.x] = r; }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Lanczos vector kernels (SciFortran lanczos_iteration semantics, see lanczos.hpp)
+// ---------------------------------------------------------------------------------------------
+// out[0] = sum(in[0..n)) in a fixed order; single workgroup
+__global__ void __launch_bounds__(1024) k_reduce_final(const double *__restrict__ in, int64_t n, double *__restrict__ out)
+{
+    __shared__ double red[16];
+    double s = 0.0;
+    for (int64_t i = threadIdx.x; i < n; i += blockDim.x) s += in[i];
+    double r = block_sum(s, red);
+    if (threadIdx.x == 0) *out = r;
+}
+
+// partial[b] = sum over the block's grid-stride elements of a[i]*b[i]
+__global__ void __launch_bounds__(256) k_dot_partial(const double *__restrict__ a, const double *__restrict__ b, int64_t n, double *__restrict__ partial)
+{
+    __shared__ double red[4];
+    double s = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) s += a[i] * b[i];
+    double r = block_sum(s, red);
+    if (threadIdx.x == 0) partial[blockIdx.x] = r;
+}
+
+// w -= alpha*(s_cur*u) ; partial beta^2 ; optionally acc += zk*s_cur*u (eigenvector pass)
+__global__ void __launch_bounds__(256) k_axpy_norm(double *__restrict__ w, const double *__restrict__ u, double *__restrict__ acc,
+                                                   const double *__restrict__ scal, int64_t n, double *__restrict__ partial)
+{
+    __shared__ double red[4];
+    const double s_cur = scal[SC_SCUR], alpha = scal[SC_ALPHA], zk = scal[SC_ZK];
+    double s = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const double vi = s_cur * u[i];
+        const double wi = w[i] - alpha * vi;
+        w[i] = wi; s += wi * wi;
+        if (acc) acc[i] += zk * vi;
+    }
+    double r = block_sum(s, red);
+    if (threadIdx.x == 0) partial[blockIdx.x] = r;
+}
+
+// scalar bookkeeping, one thread.  mode 0: alpha = TMP ; store alphas[k].
+// mode 1: beta = sqrt(TMP) ; store betas[k+1] ; rotate scales (s_prev=s_cur, s_cur=1/beta).
+// mode 2: start: s_cur = 1/sqrt(TMP), s_prev = 0, beta = 0.   mode 3: ZK = zvec[k].
+__global__ void k_scalar_step(double *scal, double *alphas, double *betas, const double *zvec, int k, int mode)
+{
+    if (threadIdx.x | blockIdx.x) return;
+    if (mode == 0) { scal[SC_ALPHA] = scal[SC_TMP]; alphas[k] = scal[SC_TMP]; }
+    else if (mode == 1) {
+        double b = sqrt(scal[SC_TMP]);
+        betas[k + 1] = b; scal[SC_BETA] = b; scal[SC_SPREV] = scal[SC_SCUR]; scal[SC_SCUR] = b > 0.0 ? 1.0 / b : 0.0;
+    } else if (mode == 2) { scal[SC_SCUR] = 1.0 / sqrt(scal[SC_TMP]); scal[SC_SPREV] = 0.0; scal[SC_BETA] = 0.0; scal[SC_ALPHA] = 0.0; scal[SC_ZK] = 0.0; }
+    else if (mode == 3) { scal[SC_ZK] = zvec ? zvec[k] : 0.0; }
+}
+
+// x[i] *= scal[idx]
+__global__ void __launch_bounds__(256) k_scale(double *__restrict__ x, const double *__restrict__ scal, int idx, int64_t n)
+{
+    const double s = scal[idx];
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) x[i] *= s;
+}
+
+// deterministic pseudo-random start vector in (0,1): counter-based hash of the GLOBAL index,
+// so the same vector is produced for any rank count (the library seeds a fixed-seed RNG,
+// SciFortran lanczos_eigh; the stream itself is compiler specific and not a parity quantity)
+__device__ __forceinline__ uint64_t splitmix64(uint64_t z)
+{
+    z += 0x9E3779B97F4A7C15ull; z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; return z ^ (z >> 31);
+}
+__global__ void __launch_bounds__(256) k_random_start(double *__restrict__ x, int64_t DimUp, int64_t Qdw, int64_t dw0, int64_t DimDw, int DimPh, uint64_t seed)
+{
+    const int64_t n = DimUp * Qdw * DimPh;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t iph = i / (DimUp * Qdw), r = i - iph * DimUp * Qdw;
+        const int64_t g = r + dw0 * DimUp + iph * DimUp * DimDw;
+        x[i] = ((double)(splitmix64((uint64_t)g + seed) >> 11) + 0.5) * (1.0 / 9007199254740992.0);
+    }
+}
+
+}  // namespace edgpu

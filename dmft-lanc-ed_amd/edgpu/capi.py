@@ -1,0 +1,112 @@
+"""ctypes binding of libedgpu.so (include/edgpu.h).  No torch types cross this boundary."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libedgpu.so")
+
+EDGPU_ABI_VERSION = 1
+MAX_ORB = 5
+STORE_KRON, STORE_CSR, STORE_DIRECT = 0, 1, 2
+STORAGE = {"kron": STORE_KRON, "csr": STORE_CSR, "direct": STORE_DIRECT}
+BATH = {"normal": 0, "hybrid": 1, "replica": 2}
+SP_ND, SP_UP, SP_DW = 1, 2, 3
+ENODEVICE = -2
+
+# every symbol include/edgpu.h declares
+SYMBOLS = [
+    "edgpu_sector_create", "edgpu_sector_destroy", "edgpu_sector_vecdim", "edgpu_sector_info",
+    "edgpu_sector_map", "edgpu_factor_size", "edgpu_factor_export", "edgpu_diag_export", "edgpu_csr_rows",
+    "edgpu_hxv", "edgpu_hxv64", "edgpu_hxv_device", "edgpu_hxv_time",
+    "edgpu_lanczos_gs", "edgpu_lanczos_gs_device", "edgpu_lanczos_tridiag", "edgpu_lanczos_tridiag_device",
+    "edgpu_lanczos_time", "edgpu_comm_unique_id", "edgpu_comm_init_rccl", "edgpu_comm_init_callbacks",
+    "edgpu_device_count", "edgpu_malloc", "edgpu_free", "edgpu_memcpy_h2d", "edgpu_memcpy_d2h",
+    "edgpu_device_synchronize", "edgpu_last_error", "edgpu_abi_version",
+]
+
+
+class Desc(C.Structure):
+    _fields_ = [
+        ("abi_version", C.c_int32), ("Norb", C.c_int32), ("Nspin", C.c_int32), ("Nbath", C.c_int32),
+        ("Nph", C.c_int32), ("bath_type", C.c_int32), ("ed_total_ud", C.c_int32), ("storage", C.c_int32),
+        ("hfmode", C.c_int32), ("Nfoo", C.c_int32), ("nups", C.c_int32 * MAX_ORB), ("ndws", C.c_int32 * MAX_ORB),
+        ("mpi_rank", C.c_int32), ("mpi_size", C.c_int32), ("device", C.c_int32), ("reserved", C.c_int32),
+        ("Uloc", C.c_double * MAX_ORB), ("Ust", C.c_double), ("Jh", C.c_double), ("Jx", C.c_double),
+        ("Jp", C.c_double), ("xmu", C.c_double), ("w0_ph", C.c_double), ("g_ph", C.c_double * MAX_ORB),
+        ("impHloc", C.c_void_p), ("diag_hybr", C.c_void_p), ("bath_diag", C.c_void_p), ("hbath", C.c_void_p),
+    ]
+
+
+class Info(C.Structure):
+    _fields_ = [
+        ("isector", C.c_int32), ("Ns", C.c_int32), ("Ns_Orb", C.c_int32), ("Ns_Ud", C.c_int32), ("DimPh", C.c_int32),
+        ("Jhflag", C.c_int32), ("DimUps", C.c_int32 * MAX_ORB), ("DimDws", C.c_int32 * MAX_ORB),
+        ("DimUp", C.c_int64), ("DimDw", C.c_int64), ("Dim", C.c_int64), ("mpiQdw", C.c_int64),
+        ("mpiIshift", C.c_int64), ("vecDim", C.c_int64), ("nnz_total", C.c_int64), ("bytes_stored", C.c_int64),
+    ]
+
+
+ALLGATHERV_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.c_int32)
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_int32)
+
+_lib = None
+
+
+class EdgpuError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("edgpu error %d: %s" % (code, msg))
+        self.code = code
+
+
+def lib():
+    """Load libedgpu.so; fails loudly when the HIP extension has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError("libedgpu.so is missing (%s): build it with __graft_entry__.build(); there is no fallback path" % LIB_PATH)
+    L = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    vp, i32, i64, dbl = C.c_void_p, C.c_int32, C.c_int64, C.c_double
+    P = C.POINTER
+    sig = {
+        "edgpu_sector_create": (C.c_int, [P(Desc), P(vp)]),
+        "edgpu_sector_destroy": (C.c_int, [vp]),
+        "edgpu_sector_vecdim": (i64, [vp]),
+        "edgpu_sector_info": (C.c_int, [vp, P(Info)]),
+        "edgpu_sector_map": (C.c_int, [vp, i32, vp]),
+        "edgpu_factor_size": (C.c_int, [vp, i32, i32, P(i64), P(i64)]),
+        "edgpu_factor_export": (C.c_int, [vp, i32, i32, vp, vp, vp]),
+        "edgpu_diag_export": (C.c_int, [vp, vp]),
+        "edgpu_csr_rows": (C.c_int, [vp, i64, i64, vp, vp, vp, i64]),
+        "edgpu_hxv": (C.c_int, [vp, P(i32), vp, vp]),
+        "edgpu_hxv64": (C.c_int, [vp, i64, vp, vp]),
+        "edgpu_hxv_device": (C.c_int, [vp, vp, vp]),
+        "edgpu_hxv_time": (C.c_int, [vp, vp, vp, i32, i32, P(C.c_float)]),
+        "edgpu_lanczos_gs": (C.c_int, [vp, i32, dbl, i32, P(dbl), vp, P(i32)]),
+        "edgpu_lanczos_gs_device": (C.c_int, [vp, i32, dbl, i32, P(dbl), vp, P(i32)]),
+        "edgpu_lanczos_tridiag": (C.c_int, [vp, vp, i32, dbl, vp, vp, P(i32)]),
+        "edgpu_lanczos_tridiag_device": (C.c_int, [vp, vp, i32, dbl, vp, vp, P(i32)]),
+        "edgpu_lanczos_time": (C.c_int, [vp, i32, i32, P(C.c_float)]),
+        "edgpu_comm_unique_id": (C.c_int, [vp]),
+        "edgpu_comm_init_rccl": (C.c_int, [vp, vp]),
+        "edgpu_comm_init_callbacks": (C.c_int, [vp, ALLGATHERV_FN, ALLREDUCE_FN, vp]),
+        "edgpu_device_count": (C.c_int, [P(i32)]),
+        "edgpu_malloc": (C.c_int, [P(vp), C.c_size_t]),
+        "edgpu_free": (C.c_int, [vp]),
+        "edgpu_memcpy_h2d": (C.c_int, [vp, vp, C.c_size_t]),
+        "edgpu_memcpy_d2h": (C.c_int, [vp, vp, C.c_size_t]),
+        "edgpu_device_synchronize": (C.c_int, []),
+        "edgpu_last_error": (C.c_char_p, []),
+        "edgpu_abi_version": (C.c_int, []),
+    }
+    for name, (res, args) in sig.items():
+        f = getattr(L, name)
+        f.restype = res
+        f.argtypes = args
+    _lib = L
+    return L
+
+
+def check(rc):
+    if rc != 0:
+        raise EdgpuError(rc, lib().edgpu_last_error().decode())

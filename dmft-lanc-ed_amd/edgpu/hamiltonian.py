@@ -1,0 +1,229 @@
+"""Host-side mirror of the reference operator interface over the C ABI.
+
+Names follow the reference (ED_HAMILTONIAN.f90:10-13, ED_VARS_GLOBAL.f90:75-81,148):
+``build_Hv_sector`` / ``delete_Hv_sector`` / ``vecDim_Hv_sector`` / ``spHtimesV_p`` and the
+SciFortran entry points the reference calls with that operator, ``sp_lanc_eigh`` and
+``sp_lanc_tridiag`` (ED_DIAG.f90:177-185, ED_GF_NORMAL.f90:232-237).  Everything computes in
+libedgpu.so on the GPU; numpy arrays only carry inputs and results.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import capi
+from .capi import check
+
+
+class DeviceVector:
+    """fp64 vector in HBM owned through edgpu_malloc/edgpu_free."""
+
+    def __init__(self, n):
+        self.n = int(n)
+        p = C.c_void_p()
+        check(capi.lib().edgpu_malloc(C.byref(p), self.n * 8))
+        self.ptr = p.value
+
+    def upload(self, a):
+        a = np.ascontiguousarray(a, np.float64)
+        assert a.size == self.n
+        check(capi.lib().edgpu_memcpy_h2d(self.ptr, a.ctypes.data, self.n * 8))
+        return self
+
+    def download(self):
+        out = np.empty(self.n, np.float64)
+        check(capi.lib().edgpu_memcpy_d2h(out.ctypes.data, self.ptr, self.n * 8))
+        return out
+
+    def free(self):
+        if self.ptr:
+            capi.lib().edgpu_free(self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def _f64(a):
+    return np.asfortranarray(np.asarray(a, dtype=np.float64))
+
+
+class HvSector:
+    """One live sector operator: build_Hv_sector(isector) ... delete_Hv_sector()."""
+
+    def __init__(self, model, nups, ndws, ed_sparse_H=True, storage=None, rank=0, size=1, device=-1):
+        m = model
+        if storage is None:
+            storage = "kron" if ed_sparse_H else "direct"
+        self.storage = storage
+        d = capi.Desc()
+        d.abi_version = capi.EDGPU_ABI_VERSION
+        d.Norb, d.Nspin, d.Nbath, d.Nph = m["Norb"], m["Nspin"], m["Nbath"], m.get("Nph", 0)
+        d.bath_type = capi.BATH[m.get("bath_type", "normal")]
+        d.ed_total_ud = 1 if m.get("ed_total_ud", True) else 0
+        d.storage = capi.STORAGE[storage]
+        d.hfmode = 1 if m.get("hfmode", True) else 0
+        self._imp, self._dh, self._bd = _f64(m["impHloc"]), _f64(m["diag_hybr"]), _f64(m["bath_diag"])
+        self._hb = _f64(m["hbath"]) if m.get("hbath") is not None else None
+        d.Nfoo = self._bd.shape[1]
+        nups = list(np.atleast_1d(nups)); ndws = list(np.atleast_1d(ndws))
+        for i in range(capi.MAX_ORB):
+            d.nups[i] = int(nups[i]) if i < len(nups) else 0
+            d.ndws[i] = int(ndws[i]) if i < len(ndws) else 0
+            d.Uloc[i] = float(m["Uloc"][i]) if i < len(m["Uloc"]) else 0.0
+            g = m.get("g_ph", ())
+            d.g_ph[i] = float(g[i]) if i < len(g) else 0.0
+        d.mpi_rank, d.mpi_size, d.device = rank, size, device
+        d.Ust, d.Jh, d.Jx, d.Jp = m.get("Ust", 0.0), m.get("Jh", 0.0), m.get("Jx", 0.0), m.get("Jp", 0.0)
+        d.xmu, d.w0_ph = m.get("xmu", 0.0), m.get("w0_ph", 0.0)
+        d.impHloc, d.diag_hybr, d.bath_diag = self._imp.ctypes.data, self._dh.ctypes.data, self._bd.ctypes.data
+        d.hbath = self._hb.ctypes.data if self._hb is not None else None
+        self._desc = d
+        h = C.c_void_p()
+        check(capi.lib().edgpu_sector_create(C.byref(d), C.byref(h)))
+        self._h = h
+        info = capi.Info()
+        check(capi.lib().edgpu_sector_info(self._h, C.byref(info)))
+        self.info = info
+        self.isector, self.Dim, self.vecDim = info.isector, info.Dim, info.vecDim
+        self.DimUp, self.DimDw, self.DimPh, self.Ns_Ud = info.DimUp, info.DimDw, info.DimPh, info.Ns_Ud
+        self.mpiQdw, self.mpiIshift = info.mpiQdw, info.mpiIshift
+        self._cb = None
+
+    # ---- lifecycle ------------------------------------------------------------------
+    def delete_Hv_sector(self):
+        if self._h:
+            capi.lib().edgpu_sector_destroy(self._h)
+            self._h = None
+
+    close = delete_Hv_sector
+
+    def __del__(self):
+        try:
+            self.delete_Hv_sector()
+        except Exception:
+            pass
+
+    def vecDim_Hv_sector(self):
+        return int(capi.lib().edgpu_sector_vecdim(self._h))
+
+    # ---- inspection -----------------------------------------------------------------
+    def map(self, k):
+        n = int(self.info.DimUps[k]) if k < self.Ns_Ud else int(self.info.DimDws[k - self.Ns_Ud])
+        out = np.zeros(n, np.int32)
+        check(capi.lib().edgpu_sector_map(self._h, k, out.ctypes.data))
+        return out
+
+    def sp(self, which, iud=0):
+        w = {"nd": capi.SP_ND, "up": capi.SP_UP, "dw": capi.SP_DW}[which]
+        nrow, nnz = C.c_int64(), C.c_int64()
+        check(capi.lib().edgpu_factor_size(self._h, w, iud, C.byref(nrow), C.byref(nnz)))
+        rp = np.zeros(nrow.value + 1, np.int64); cols = np.zeros(nnz.value, np.int64); vals = np.zeros(nnz.value, np.float64)
+        if nrow.value:
+            check(capi.lib().edgpu_factor_export(self._h, w, iud, rp.ctypes.data, cols.ctypes.data, vals.ctypes.data))
+        return rp, cols, vals
+
+    def diag(self):
+        out = np.zeros(self.vecDim // self.DimPh, np.float64)
+        check(capi.lib().edgpu_diag_export(self._h, out.ctypes.data))
+        return out
+
+    def csr_rows(self, row0, nrows, cap=None):
+        cap = cap or nrows * 256
+        rp = np.zeros(nrows + 1, np.int64); cols = np.zeros(cap, np.int32); vals = np.zeros(cap, np.float64)
+        check(capi.lib().edgpu_csr_rows(self._h, row0, nrows, rp.ctypes.data, cols.ctypes.data, vals.ctypes.data, cap))
+        n = int(rp[-1] - rp[0])
+        return rp, cols[:n], vals[:n]
+
+    # ---- the operator ---------------------------------------------------------------
+    def spHtimesV(self, v):
+        """dd_sparse_HxV(Nloc,v,Hv) with host arrays (ED_VARS_GLOBAL.f90:75-81)."""
+        v = np.ascontiguousarray(v, np.float64)
+        hv = np.empty_like(v)
+        check(capi.lib().edgpu_hxv64(self._h, v.size, v.ctypes.data, hv.ctypes.data))
+        return hv
+
+    def spHtimesV_i32(self, v):
+        """Same through the int32 Nloc-by-reference entry the Fortran pointer binds."""
+        v = np.ascontiguousarray(v, np.float64)
+        hv = np.empty_like(v)
+        n = C.c_int32(v.size)
+        check(capi.lib().edgpu_hxv(self._h, C.byref(n), v.ctypes.data, hv.ctypes.data))
+        return hv
+
+    def spHtimesV_device(self, v_dev, hv_dev):
+        check(capi.lib().edgpu_hxv_device(self._h, v_dev.ptr, hv_dev.ptr))
+
+    def hxv_time(self, v_dev, hv_dev, nwarm=3, nrep=20):
+        ms = C.c_float()
+        check(capi.lib().edgpu_hxv_time(self._h, v_dev.ptr, hv_dev.ptr, nwarm, nrep, C.byref(ms)))
+        return ms.value
+
+    # ---- Lanczos --------------------------------------------------------------------
+    def sp_lanc_eigh(self, vect=None, nitermax=512, threshold=1e-12, ncheck=10):
+        """(egs, vect, nlanc); vect=None/zeros -> library start vector."""
+        v = np.zeros(self.vecDim, np.float64) if vect is None else np.array(vect, np.float64)
+        e, n = C.c_double(), C.c_int32()
+        check(capi.lib().edgpu_lanczos_gs(self._h, nitermax, threshold, ncheck, C.byref(e), v.ctypes.data, C.byref(n)))
+        return e.value, v, n.value
+
+    def sp_lanc_eigh_device(self, vect_dev, nitermax=512, threshold=1e-12, ncheck=10):
+        e, n = C.c_double(), C.c_int32()
+        check(capi.lib().edgpu_lanczos_gs_device(self._h, nitermax, threshold, ncheck, C.byref(e), vect_dev.ptr, C.byref(n)))
+        return e.value, n.value
+
+    def sp_lanc_tridiag(self, vin, nlanc, threshold=1e-12):
+        vin = np.ascontiguousarray(vin, np.float64)
+        a = np.zeros(nlanc); b = np.zeros(nlanc); n = C.c_int32()
+        check(capi.lib().edgpu_lanczos_tridiag(self._h, vin.ctypes.data, nlanc, threshold, a.ctypes.data, b.ctypes.data, C.byref(n)))
+        return a, b, n.value
+
+    def lanczos_time(self, nwarm=2, niter=10):
+        ms = C.c_float()
+        check(capi.lib().edgpu_lanczos_time(self._h, nwarm, niter, C.byref(ms)))
+        return ms.value
+
+    # ---- exchange -------------------------------------------------------------------
+    def comm_init_rccl(self, uid_bytes):
+        buf = C.create_string_buffer(bytes(uid_bytes), 128)
+        check(capi.lib().edgpu_comm_init_rccl(self._h, buf))
+
+    def comm_init_callbacks(self, allgatherv, allreduce):
+        """allgatherv(send_ptr, nsend, recv_ptr, counts, displs) / allreduce(np_array) in Python."""
+        def _ag(ctx, send, nsend, recv, counts, displs, nr):
+            try:
+                allgatherv(send, nsend, recv, [counts[i] for i in range(nr)], [displs[i] for i in range(nr)])
+                return 0
+            except Exception as e:  # pragma: no cover
+                print("allgatherv callback failed:", e)
+                return 1
+
+        def _ar(ctx, buf, n):
+            try:
+                a = np.ctypeslib.as_array(buf, shape=(n,))
+                allreduce(a)
+                return 0
+            except Exception as e:  # pragma: no cover
+                print("allreduce callback failed:", e)
+                return 1
+
+        self._cb = (capi.ALLGATHERV_FN(_ag), capi.ALLREDUCE_FN(_ar))
+        check(capi.lib().edgpu_comm_init_callbacks(self._h, self._cb[0], self._cb[1], None))
+
+
+def rccl_unique_id():
+    buf = C.create_string_buffer(128)
+    check(capi.lib().edgpu_comm_unique_id(buf))
+    return buf.raw
+
+
+def build_Hv_sector(model, nups, ndws, **kw):
+    return HvSector(model, nups, ndws, **kw)
+
+
+def device_count():
+    n = C.c_int32()
+    check(capi.lib().edgpu_device_count(C.byref(n)))
+    return n.value

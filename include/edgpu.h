@@ -1,0 +1,162 @@
+/*
+ * edgpu.h -- C ABI of libedgpu.so, the MI355X (gfx950) implementation of the
+ * Lanczos-ED hot path of lcrippa/dmft-lanc-ed.
+ *
+ * Every entry point names the reference interface it replaces (file:line in
+ * /root/reference).  Plain pointers and sizes only; arrays are column-major
+ * with the reference's index order so the unchanged Fortran host can pass
+ * them as they are (see INTEGRATION.md for the ISO_C_BINDING stubs).
+ *
+ * Error convention: the reference aborts with `stop "<msg>"`; here every
+ * function returns 0 on success or a negative EDGPU_E* code, and
+ * edgpu_last_error() returns the message the Fortran shim prints before
+ * `stop`.  There is no CPU fallback: without a HIP device calls that compute
+ * fail with EDGPU_ENODEVICE.
+ *
+ * Threading: one host thread per rank/GPU, one sector live per handle
+ * (the reference keeps one sector in module globals, ED_HAMILTONIAN_COMMON.f90:11-43).
+ */
+#ifndef EDGPU_H
+#define EDGPU_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EDGPU_ABI_VERSION 1
+#define EDGPU_MAX_ORB 5 /* ED_SETUP.f90:66 "Norb > 5 is currently not supported" */
+
+enum { EDGPU_OK = 0, EDGPU_EINVAL = -1, EDGPU_ENODEVICE = -2, EDGPU_EHIP = -3, EDGPU_ENOMEM = -4,
+       EDGPU_EUNSUPPORTED = -5, EDGPU_ECOMM = -6, EDGPU_ENOTCONVERGED = -7 };
+
+/* bath_type, ED_INPUT_VARS.f90:205 */
+enum { EDGPU_BATH_NORMAL = 0, EDGPU_BATH_HYBRID = 1, EDGPU_BATH_REPLICA = 2 };
+
+/* How the sector operator is held in HBM.
+ *  KRON   : the reference's stored format (ed_sparse_H=T): diagonal spH0d + per-spin
+ *           factors spH0ups/spH0dws (+ spH0nd, phonon blocks); ED_VARS_GLOBAL.f90:142-146.
+ *  CSR    : the same operator expanded to one explicit CSR (int64 row_ptr, int32 col, fp64 val).
+ *  DIRECT : nothing stored (ed_sparse_H=F): diagonal and hop tables are recomputed from the
+ *           bit patterns at every product; ED_HAMILTONIAN_DIRECT_HxV.f90:21-95. */
+enum { EDGPU_STORE_KRON = 0, EDGPU_STORE_CSR = 1, EDGPU_STORE_DIRECT = 2 };
+
+/* Resolved inputs of build_Hv_sector (ED_HAMILTONIAN.f90:43-168) -- the values the
+ * Fortran side holds in ED_INPUT_VARS / ED_VARS_GLOBAL when it builds a sector. */
+typedef struct edgpu_desc {
+    int32_t abi_version;          /* EDGPU_ABI_VERSION */
+    int32_t Norb, Nspin, Nbath;   /* ED_INPUT_VARS.f90:129-131 */
+    int32_t Nph;                  /* DimPh = Nph+1, ED_SETUP.f90:133 */
+    int32_t bath_type;            /* EDGPU_BATH_* */
+    int32_t ed_total_ud;          /* logical, ED_INPUT_VARS.f90:152 */
+    int32_t storage;              /* EDGPU_STORE_*; ed_sparse_H=T -> KRON (or CSR), F -> DIRECT */
+    int32_t hfmode;               /* logical, ED_INPUT_VARS.f90:176 */
+    int32_t Nfoo;                 /* size(bath_diag,2): Norb (normal,replica) or 1 (hybrid) */
+    int32_t nups[EDGPU_MAX_ORB];  /* sector quantum numbers, Ns_Ud entries used */
+    int32_t ndws[EDGPU_MAX_ORB];
+    int32_t mpi_rank, mpi_size;   /* dw-column partition, ED_HAMILTONIAN.f90:96-110 */
+    int32_t device;               /* HIP device ordinal, -1 = current device */
+    int32_t reserved;
+    double Uloc[EDGPU_MAX_ORB], Ust, Jh, Jx, Jp, xmu;
+    double w0_ph, g_ph[EDGPU_MAX_ORB];
+    const double *impHloc;   /* (Nspin,Nspin,Norb,Norb)        ED_VARS_GLOBAL.f90:120 */
+    const double *diag_hybr; /* (Nspin,Norb,Nbath)             ED_HAMILTONIAN_COMMON.f90:41 */
+    const double *bath_diag; /* (Nspin,Nfoo,Nbath)             ED_HAMILTONIAN_COMMON.f90:42 */
+    const double *hbath;     /* (Nspin,Nspin,Norb,Norb,Nbath)  replica only, else NULL */
+} edgpu_desc;
+
+typedef struct edgpu_sector_s *edgpu_handle;
+
+typedef struct edgpu_info {
+    int32_t isector;              /* ED_SETUP.f90:446-457 */
+    int32_t Ns, Ns_Orb, Ns_Ud, DimPh;
+    int32_t Jhflag;               /* ED_SETUP.f90:147-148 */
+    int32_t DimUps[EDGPU_MAX_ORB], DimDws[EDGPU_MAX_ORB];
+    int64_t DimUp, DimDw;         /* products */
+    int64_t Dim;                  /* getDim(isector) = DimUp*DimDw*DimPh (64-bit: Ns=18 overflows int32) */
+    int64_t mpiQdw;               /* local dw columns */
+    int64_t mpiIshift;            /* global offset of the first local electronic row */
+    int64_t vecDim;               /* DimUp*mpiQdw*DimPh, ED_HAMILTONIAN.f90:251 */
+    int64_t nnz_total;            /* nnz of the expanded operator restricted to local rows */
+    int64_t bytes_stored;         /* HBM bytes held by the operator in the chosen storage */
+} edgpu_info;
+
+/* ---- lifecycle: build_Hv_sector / delete_Hv_sector / vecDim_Hv_sector -------------
+ * ED_HAMILTONIAN.f90:43-168, 174-222, 229-253 */
+int edgpu_sector_create(const edgpu_desc *desc, edgpu_handle *out);
+int edgpu_sector_destroy(edgpu_handle h);
+int64_t edgpu_sector_vecdim(edgpu_handle h);
+int edgpu_sector_info(edgpu_handle h, edgpu_info *out);
+
+/* ---- bit-exact inspection of what build_sector / ed_buildh_* produced ---------------
+ * Hs(k)%map, k=0..2*Ns_Ud-1 ordered [ups..., dws...]   (ED_SETUP.f90:745-780) */
+int edgpu_sector_map(edgpu_handle h, int32_t k, int32_t *out);
+/* spH0ups(iud)/spH0dws(iud)/spH0nd as (row_ptr[nrow+1], cols 1-based, vals), rows in the
+ * reference's storage order (ED_SPARSE_MATRIX.f90:255-323).  which: 1 nd, 2 up, 3 dw. */
+enum { EDGPU_SP_ND = 1, EDGPU_SP_UP = 2, EDGPU_SP_DW = 3 };
+int edgpu_factor_size(edgpu_handle h, int32_t which, int32_t iud, int64_t *nrow, int64_t *nnz);
+int edgpu_factor_export(edgpu_handle h, int32_t which, int32_t iud, int64_t *row_ptr, int64_t *cols, double *vals);
+/* spH0d: the local diagonal d(1:DimUp*mpiQdw) (stored/H_local.f90:13-71), computed on the device */
+int edgpu_diag_export(edgpu_handle h, double *d_host);
+/* explicit CSR (storage=CSR only): sizes and a window of rows [row0,row0+nrows) copied to the host */
+int edgpu_csr_rows(edgpu_handle h, int64_t row0, int64_t nrows, int64_t *row_ptr, int32_t *cols, double *vals, int64_t cap);
+
+/* ---- the operator: dd_sparse_HxV(Nloc,v,Hv), ED_VARS_GLOBAL.f90:75-81 ----------------
+ * Host-pointer form, callable through spHtimesV_p.  Overwrites Hv.  Copies v in and Hv
+ * out over PCIe on every call: correctness path, not the fast path. */
+int edgpu_hxv(edgpu_handle h, const int32_t *nloc, const double *v, double *hv);
+int edgpu_hxv64(edgpu_handle h, int64_t nloc, const double *v, double *hv);
+/* Device-pointer form: v and Hv already live in HBM (vecDim doubles each). */
+int edgpu_hxv_device(edgpu_handle h, const double *v_dev, double *hv_dev);
+/* Mean device time (ms) of one product over `nrep` launches after `nwarm`, measured with
+ * HIP events on the stream the kernels are launched on. */
+int edgpu_hxv_time(edgpu_handle h, const double *v_dev, double *hv_dev, int32_t nwarm, int32_t nrep, float *ms_mean);
+
+/* ---- the Lanczos loop the reference delegates to SciFortran ---------------------------
+ * sp_lanc_eigh(MatVec,egs,vect,Nitermax,iverbose,threshold)   ED_DIAG.f90:177-185
+ * vect (host, vecDim): in = start vector (all zero -> deterministic pseudo-random start,
+ * as the library does), out = normalised ground state.  The whole loop runs in HBM. */
+int edgpu_lanczos_gs(edgpu_handle h, int32_t nitermax, double threshold, int32_t ncheck,
+                     double *egs, double *vect, int32_t *nlanc);
+/* same with the vector resident on the device (no PCIe traffic) */
+int edgpu_lanczos_gs_device(edgpu_handle h, int32_t nitermax, double threshold, int32_t ncheck,
+                            double *egs, double *vect_dev, int32_t *nlanc);
+/* sp_lanc_tridiag(MatVec,vin,alanc,blanc)   ED_GF_NORMAL.f90:232-237 ; blanc(1) unused (638-640) */
+int edgpu_lanczos_tridiag(edgpu_handle h, const double *vin, int32_t nlanc, double threshold,
+                          double *alanc, double *blanc, int32_t *nused);
+int edgpu_lanczos_tridiag_device(edgpu_handle h, const double *vin_dev, int32_t nlanc, double threshold,
+                                 double *alanc, double *blanc, int32_t *nused);
+/* `niter` plain Lanczos iterations from a fixed start, no convergence test, no host sync
+ * inside the loop: the timed region of bench.py.  Returns mean ms/iteration (HIP events). */
+int edgpu_lanczos_time(edgpu_handle h, int32_t nwarm, int32_t niter, float *ms_per_iter);
+
+/* ---- multi-GPU exchange (replaces MPI_AllGatherv/MPI_AllReduce of the MPI matvecs,
+ * ED_SETUP.f90:689-733, ED_HAMILTONIAN_SPARSE_HxV.f90:674-692) --------------------------
+ * RCCL: every rank calls unique_id on rank 0, the host broadcasts the 128 bytes, then init. */
+int edgpu_comm_unique_id(void *id128);
+int edgpu_comm_init_rccl(edgpu_handle h, const void *id128);
+/* Host-supplied exchange (e.g. MPI or gloo), used when RCCL is not wanted.
+ * allgatherv: send_dev[nsend] -> recv_dev at displs[r] (counts[r] doubles) for every rank r.
+ * allreduce : in-place sum of n host doubles. */
+typedef int (*edgpu_allgatherv_fn)(void *ctx, const double *send_dev, int64_t nsend, double *recv_dev,
+                                   const int64_t *counts, const int64_t *displs, int32_t nranks);
+typedef int (*edgpu_allreduce_fn)(void *ctx, double *buf_host, int32_t n);
+int edgpu_comm_init_callbacks(edgpu_handle h, edgpu_allgatherv_fn ag, edgpu_allreduce_fn ar, void *ctx);
+
+/* ---- device memory helpers for hosts without a HIP binding (Fortran) ---------------------- */
+int edgpu_device_count(int32_t *n);
+int edgpu_malloc(void **dev, size_t bytes);
+int edgpu_free(void *dev);
+int edgpu_memcpy_h2d(void *dev, const void *host, size_t bytes);
+int edgpu_memcpy_d2h(void *host, const void *dev, size_t bytes);
+int edgpu_device_synchronize(void);
+
+const char *edgpu_last_error(void);
+int edgpu_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EDGPU_H */

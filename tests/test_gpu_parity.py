@@ -1,0 +1,168 @@
+"""GPU parity: libedgpu.so (through the C ABI) against the CPU oracle on the same inputs.
+
+Integer/index work is bit-exact; the fp64 products are compared with
+  max|Hv_gpu - Hv_oracle| <= 1e-12 * max|Hv_oracle|
+(the reference's own stored-vs-direct spread is 3e-15 at |Hv|~1e3; the GPU sums
+the same terms in a different order)."""
+import numpy as np
+import pytest
+
+import cases
+from oracle import oracle
+
+pytestmark = pytest.mark.gpu
+HXV_RTOL = 1e-12
+ZOO = cases.zoo()
+IDS = [z[0] for z in ZOO]
+
+
+def _storages(m):
+    st = ["kron", "direct"]
+    if m.get("ed_total_ud", True) and m.get("Nph", 0) == 0 and not (m["Norb"] > 1 and (m.get("Jx", 0) or m.get("Jp", 0))):
+        st.append("csr")
+    return st
+
+
+@pytest.mark.parametrize("name,m,nu,nd", ZOO, ids=IDS)
+def test_sector_maps_and_factors_bit_exact(edgpu_mod, name, m, nu, nd):
+    S = oracle.Sector(m, nu, nd).buildh()
+    G = edgpu_mod.HvSector(m, nu, nd)
+    assert G.isector == S.isector and G.Dim == S.Dim and G.vecDim_Hv_sector() == S.Dim
+    for k in range(2 * S.Ns_Ud):
+        np.testing.assert_array_equal(G.map(k), S.map(k))
+    for iud in range(S.Ns_Ud):
+        for which in ("up", "dw"):
+            rp, c, v = S.sp(which, iud); rp2, c2, v2 = G.sp(which, iud)
+            np.testing.assert_array_equal(rp2, rp); np.testing.assert_array_equal(c2, c)
+            np.testing.assert_array_equal(v2, v)   # values are +-t: bit-exact incl. sign
+    if m.get("ed_total_ud", True) and m["Norb"] > 1 and (m.get("Jx", 0) or m.get("Jp", 0)):
+        rp, c, v = S.sp("nd"); rp2, c2, v2 = G.sp("nd")
+        np.testing.assert_array_equal(rp2, rp); np.testing.assert_array_equal(c2, c); np.testing.assert_array_equal(v2, v)
+    # spH0d: the device evaluates the reference's statement order with unfused IEEE ops
+    d_ref = S.sp("d")[2]
+    np.testing.assert_array_equal(G.diag(), d_ref)
+    G.close()
+
+
+@pytest.mark.parametrize("name,m,nu,nd", ZOO, ids=IDS)
+def test_hxv_matches_oracle(edgpu_mod, name, m, nu, nd):
+    S = oracle.Sector(m, nu, nd)
+    for v in (cases.sinvec(S.Dim), np.random.RandomState(11).uniform(-0.5, 0.5, S.Dim)):
+        ref = S.spmatvec(v)
+        tol = HXV_RTOL * max(np.abs(ref).max(), 1e-300)
+        for st in _storages(m):
+            G = edgpu_mod.HvSector(m, nu, nd, storage=st)
+            hv = G.spHtimesV(v)
+            assert np.abs(hv - ref).max() <= tol, (st, np.abs(hv - ref).max(), tol)
+            if S.Dim < 2 ** 31:
+                np.testing.assert_array_equal(G.spHtimesV_i32(v), hv)
+            G.close()
+
+
+@pytest.mark.parametrize("g", cases.golden_cases(), ids=lambda g: g["name"])
+def test_hxv_against_reference_known_answers(edgpu_mod, g):
+    m = cases.model_from_golden(g)
+    for st in _storages(m):
+        G = edgpu_mod.HvSector(m, g["nups"], g["ndws"], storage=st)
+        assert G.isector == g["isector"] and G.Dim == g["N"]
+        v = cases.sinvec(G.Dim)
+        hv = G.spHtimesV(v)
+        scale = np.abs(hv).sum()
+        assert abs(hv.sum() - g["sum_Hv"]) <= 1e-12 * scale
+        if "v_Hv" in g:
+            assert abs(v @ hv - g["v_Hv"]) <= 1e-12 * scale
+        if "Hv_1_3" in g:
+            np.testing.assert_allclose(hv[:3], g["Hv_1_3"], rtol=1e-13)
+        G.close()
+
+
+def test_explicit_csr_rows_equal_dense(edgpu_mod):
+    from edgpu import model
+    m, nu, nd = model.half_filled_c(5)
+    S = oracle.Sector(m, nu, nd); H = S.hmat()
+    G = edgpu_mod.HvSector(m, nu, nd, storage="csr")
+    rp, cols, vals = G.csr_rows(0, S.Dim)
+    assert rp[0] == 0 and rp[-1] == G.info.nnz_total == np.count_nonzero(H) + np.count_nonzero(np.diag(H) == 0)
+    D = np.zeros_like(H)
+    for i in range(S.Dim):
+        c = cols[rp[i]:rp[i + 1]]
+        assert np.all(np.diff(c) > 0)          # canonical CSR: ascending columns
+        D[i, c] = vals[rp[i]:rp[i + 1]]
+    np.testing.assert_array_equal(D, H)
+    G.close()
+
+
+LANC = [z for z in ZOO if z[0] in ("c_nb5_half", "c_nb7_half", "norb2_normal_JxJp", "replica_sz_sx_JxJp", "orbs_norb2_nb3", "phonons_nb3_nph3", "nb6_even")]
+
+
+@pytest.mark.parametrize("name,m,nu,nd", LANC, ids=[z[0] for z in LANC])
+def test_lanczos_ground_state(edgpu_mod, name, m, nu, nd):
+    """E0 against dense diagonalisation of the oracle's Hmat: |dE0| <= 1e-10;
+    eigenvector: residual |H x - E0 x| small, unit norm."""
+    S = oracle.Sector(m, nu, nd)
+    w = np.linalg.eigvalsh(S.hmat())
+    for st in ("kron", "direct"):
+        G = edgpu_mod.HvSector(m, nu, nd, storage=st)
+        e0, x, nl = G.sp_lanc_eigh(nitermax=min(512, S.Dim), threshold=1e-14)
+        assert abs(e0 - w[0]) <= 1e-10, (st, e0, w[0], nl)
+        assert abs(np.linalg.norm(x) - 1.0) < 1e-12
+        assert np.linalg.norm(S.spmatvec(x) - e0 * x) < 1e-6
+        G.close()
+
+
+@pytest.mark.parametrize("name,m,nu,nd", LANC[:4], ids=[z[0] for z in LANC[:4]])
+def test_lanczos_same_start_same_coefficients(edgpu_mod, name, m, nu, nd):
+    """Same start vector => same alpha/beta as the oracle's restatement (k<=30: rel 1e-9)
+    and same E0 from sp_lanc_eigh."""
+    S = oracle.Sector(m, nu, nd)
+    v0 = np.random.RandomState(5).uniform(0, 1, S.Dim)
+    n = 30
+    a_ref, b_ref, used_ref = oracle.sp_lanc_tridiag(S.spmatvec, v0, n)
+    G = edgpu_mod.HvSector(m, nu, nd)
+    a, b, used = G.sp_lanc_tridiag(v0, n)
+    assert used == used_ref
+    np.testing.assert_allclose(a[:used], a_ref[:used], rtol=1e-9, atol=1e-9)
+    np.testing.assert_allclose(b[1:used], b_ref[1:used], rtol=1e-9, atol=1e-9)
+    assert b[0] == 0.0
+    e_ref, x_ref, _ = oracle.sp_lanc_eigh(S.spmatvec, v0, min(300, S.Dim), threshold=1e-14)
+    e, x, _ = G.sp_lanc_eigh(v0, nitermax=min(300, S.Dim), threshold=1e-14)
+    assert abs(e - e_ref) <= 1e-10
+    assert min(np.linalg.norm(x - x_ref), np.linalg.norm(x + x_ref)) < 1e-6
+    G.close()
+
+
+def test_c2_size_properties(edgpu_mod):
+    """BASELINE config 2 (Ns=12, N=853776): oracle parity on the full vector, plus
+    size-independent properties: symmetry <u,Hv>=<Hu,v> and linearity."""
+    from edgpu import model
+    m, nu, nd = model.half_filled_c(11)
+    S = oracle.Sector(m, nu, nd)
+    assert S.Dim == 853776
+    rng = np.random.RandomState(3)
+    u, v = rng.uniform(-0.5, 0.5, S.Dim), rng.uniform(-0.5, 0.5, S.Dim)
+    ref = S.spmatvec(v)
+    for st in ("kron", "direct", "csr"):
+        G = edgpu_mod.HvSector(m, nu, nd, storage=st)
+        hv, hu = G.spHtimesV(v), G.spHtimesV(u)
+        assert np.abs(hv - ref).max() <= HXV_RTOL * np.abs(ref).max()
+        assert abs(u @ hv - hu @ v) <= 1e-11 * (np.abs(u) @ np.abs(hv))
+        hl = G.spHtimesV(2.0 * u - 3.0 * v)
+        assert np.abs(hl - (2.0 * hu - 3.0 * hv)).max() <= 1e-12 * np.abs(hl).max()
+        G.close()
+
+
+def test_device_pointer_path_and_errors(edgpu_mod):
+    from edgpu import model, capi
+    m, nu, nd = model.half_filled_c(5)
+    G = edgpu_mod.HvSector(m, nu, nd)
+    v = cases.sinvec(G.Dim)
+    dv, dh = edgpu_mod.DeviceVector(G.Dim).upload(v), edgpu_mod.DeviceVector(G.Dim)
+    G.spHtimesV_device(dv, dh)
+    np.testing.assert_array_equal(dh.download(), G.spHtimesV(v))
+    with pytest.raises(capi.EdgpuError):          # wrong Nloc, reference: stop "Nloc != dim(isector)"
+        G.spHtimesV(v[:-1])
+    with pytest.raises(capi.EdgpuError):
+        edgpu_mod.HvSector(dict(m, Norb=6), nu, nd)
+    ms = G.hxv_time(dv, dh, 1, 3)
+    assert ms > 0
+    G.close()
