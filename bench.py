@@ -1,0 +1,173 @@
+#!/usr/bin/env python3
+"""bench.py -- Lanczos HxV throughput of the Ns=16 half-filled sector on N MI355X.
+
+A "step" is one full Lanczos iteration on the device-resident sector operator: the product
+w = H v (fused with the beta*v_prev subtraction and the alpha dot), the axpy+norm pass and the
+two single-workgroup reductions.  Default workload = BASELINE config 3: 1 orbital, Nbath=15
+(Ns=16), Nup=Ndw=8, N=165,636,900, operator held as an explicit CSR in HBM.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W]
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Rank 0 prints ONE JSON line.  `value` = equivalent-CSR bytes of one product (B_csr of the whole
+sector) divided by the wall time of one Lanczos step (max over ranks): GB/s of HxV
+sustained inside the Lanczos loop.  N>1 is strong scaling (same sector, dw columns split over
+the ranks, RCCL exchange of the input vector every product).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "dmft-lanc-ed_amd"))
+
+HBM_PEAK_GBPS = 8000.0  # MI355X spec, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def b_csr(N, nnz):
+    """explicit CSR algorithmic bytes of one product: 12*nnz + 8*(N+1) + 16*N  """
+    return 12 * nnz + 8 * (N + 1) + 16 * N
+
+
+def cpu_baseline(seconds_budget=20.0):
+    """The CPU oracle (a port: C restatement of spMatVec_main, single thread) on a bounded
+    sample of the same workload family: the Ns=12 half-filled sector."""
+    import numpy as np
+    from edgpu import model
+    from oracle import oracle
+    m, nu, nd = model.half_filled_c(11)
+    S = oracle.Sector(m, nu, nd)
+    t0 = time.perf_counter(); S.buildh(); tb = time.perf_counter() - t0
+    v = np.random.RandomState(0).uniform(-0.5, 0.5, S.Dim)
+    S.spmatvec(v)
+    n, t0 = 0, time.perf_counter()
+    while True:
+        S.spmatvec(v); n += 1
+        dt = time.perf_counter() - t0
+        if dt > seconds_budget or n >= 40:
+            break
+    N = S.Dim; nnz = N * (1 + m["Ns"])
+    return {"value": b_csr(N, nnz) / (dt / n) / 1e9, "unit": "GB/s", "cores": 1, "kind": "port",
+            "sample": "oracle spMatVec_main restatement, Ns=12 half-filled sector (N=%d), %d products in %.1f s (+%.1f s build); equivalent-CSR bytes / time" % (N, n, dt, tb),
+            "s_per_hxv": dt / n}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--nbath", type=int, default=15, help="Ns = nbath+1 (15 -> BASELINE config 3)")
+    ap.add_argument("--storage", default="csr", choices=["csr", "kron", "direct"])
+    ap.add_argument("--no-extra", action="store_true", help="skip the kron/direct side measurements")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    a = ap.parse_args()
+
+    import torch
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus and world > 1:
+        a.gpus = world
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (libedgpu.so has no CPU path)")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    import numpy as np
+    import edgpu
+    from edgpu import model
+
+    m, nu, nd = model.half_filled_c(a.nbath)
+    t_build = time.perf_counter()
+    G = edgpu.HvSector(m, nu, nd, storage=a.storage, rank=rank, size=world, device=local_rank)
+    if world > 1:
+        uid = torch.zeros(128, dtype=torch.uint8, device="cuda")
+        if rank == 0:
+            uid.copy_(torch.frombuffer(bytearray(edgpu.rccl_unique_id()), dtype=torch.uint8))
+        dist.broadcast(uid, 0)
+        G.comm_init_rccl(bytes(uid.cpu().numpy().tobytes()))
+    torch.cuda.synchronize()
+    t_build = time.perf_counter() - t_build
+
+    K, W = a.steps, a.warmup
+    G.bench_begin(W + K + 2)
+    G.bench_steps(W, timed=False)
+    torch.cuda.synchronize()
+    if dist: dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    G.bench_steps(K, timed=True)
+    torch.cuda.synchronize()
+    if dist: dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if dist:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    hxv_ms, alphas, betas = G.bench_result(K, ncoef=W + K)
+
+    N = int(G.Dim); Ns = m["Ns"]
+    nnz = N * (1 + Ns)                   # 1 diag + Ns/2 up + Ns/2 dw per row at half filling, all V != 0
+    Nloc = int(G.vecDim); nnz_loc = int(G.info.nnz_total)
+    ms_step = dt / K * 1e3
+    bytes_fmt = {"csr": b_csr(Nloc, nnz_loc), "kron": 24 * Nloc, "direct": 16 * Nloc}[a.storage]
+    out = {
+        "metric": "Lanczos HxV GB/s (equivalent-CSR bytes of one product / Lanczos-iteration time), Ns=%d half-filled sector" % Ns,
+        "value": b_csr(N, nnz) / (dt / K) / 1e9, "unit": "GB/s",
+        "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": ms_step, "higher_is_better": True,
+        "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "iters_per_sec": K / dt,
+        "config": {"workload": "1-orbital Anderson impurity, Nbath=%d (Ns=%d), sector Nup=Ndw=%d, N=%d, default initial bath, operator storage=%s, one Lanczos iteration per step"
+                               % (a.nbath, Ns, nu[0], N, a.storage),
+                   "storage": a.storage, "N": N, "nnz": nnz, "parallelism": "dw-column split x%d, RCCL exchange of v per product" % world if world > 1 else "single GPU"},
+        "roofline": {"bound": "hbm", "kernel": {"csr": "k_csr_spmv", "kron": "k_kron2", "direct": "k_kron2"}[a.storage],
+                     "achieved": bytes_fmt / (hxv_ms * 1e-3) / 1e9 if hxv_ms > 0 else None, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                     "frac": (bytes_fmt / (hxv_ms * 1e-3) / 1e9) / HBM_PEAK_GBPS if hxv_ms > 0 else None,
+                     "algorithmic_bytes_per_launch": bytes_fmt, "kernel_ms": hxv_ms, "traffic": None},
+        "build_s": t_build,
+        "lanczos_alpha_first_last": [float(alphas[0]), float(alphas[-1])] if len(alphas) else None,
+    }
+    pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(pmc):
+        try:
+            for rec in json.load(open(pmc)):
+                if rec.get("storage") == a.storage and rec.get("nbath") == a.nbath and rec.get("n_gpus") == world:
+                    out["roofline"]["traffic"] = rec["hbm_bytes_per_launch"]
+                    out["roofline"]["traffic_source"] = rec.get("source")
+        except Exception:
+            pass
+    if world == 1 and rank == 0 and not a.no_extra:
+        extra = {}
+        G.close()
+        for st in ("kron", "direct"):
+            if st == a.storage:
+                continue
+            g = edgpu.HvSector(m, nu, nd, storage=st, device=local_rank)
+            g.bench_begin(W + K + 2); g.bench_steps(W); torch.cuda.synchronize()
+            t0 = time.perf_counter(); g.bench_steps(K, timed=True); torch.cuda.synchronize(); d2 = time.perf_counter() - t0
+            ms, _, _ = g.bench_result(K)
+            fb = {"kron": 24 * N, "direct": 16 * N}[st]
+            extra[st] = {"ms_per_step": d2 / K * 1e3, "iters_per_sec": K / d2, "hxv_kernel_ms": ms,
+                         "format_GBps": fb / (ms * 1e-3) / 1e9, "equivalent_csr_GBps": b_csr(N, nnz) / (ms * 1e-3) / 1e9}
+            g.close()
+        out["other_formats"] = extra
+    if world == 1 and rank == 0 and not a.no_cpu:
+        out["cpu_baseline"] = cpu_baseline()
+    if rank == 0:
+        print(json.dumps(out))
+    if dist:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -109,13 +109,14 @@ struct edgpu_sector_s {
     DevBuf<int32_t> stride;
     // explicit CSR
     DevBuf<int64_t> csr_rowptr, uppre, dwpre; DevBuf<int32_t> csr_cols; DevBuf<double> csr_vals;
-    int64_t csr_nnz = 0; int32_t csr_rpb = 0, csr_bpr = 0, csr_tile = 4;
+    int64_t csr_nnz = 0; int32_t csr_rpb = 0, csr_bpr = 0, csr_tile = 1, csr_variant = 6;
     // work vectors
     DevBuf<double> vfull, tmp_in, tmp_out, lz[5], scal, alphas, betas, zvec, partial;
     int64_t nloc = 0, nloc_el = 0, vecdim = 0;
     int32_t nmax = 0;
-    bool use_lds = false; int kron_threads = 256; size_t kron_lds = 0;
-    bool two_factor = false, extra = false;
+    bool use_lds = false; int kron_threads = 256, kron_threads_override = 0; size_t kron_lds = 0;
+    bool two_factor = false, extra = false, multi = false;
+    std::vector<hipEvent_t> bench_ev; int bench_k = 0; double *bv[3] = {nullptr, nullptr, nullptr};
     int64_t nnz_total = 0, bytes_stored = 0;
     int64_t npartial = 0;
 };
@@ -124,6 +125,8 @@ namespace edgpu {
 using S = edgpu_sector_s;
 
 static int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+static int dbg_flags() { static int f = -1; if (f < 0) { const char *e = getenv("EDGPU_DEBUG"); f = e ? atoi(e) : 0; } return f; }
+static int dbg_int(const char *name, int dflt) { const char *e = getenv(name); return e ? atoi(e) : dflt; }
 
 // ---------------------------------------------------------------------------------------
 // device-side construction
@@ -216,11 +219,13 @@ static int build_csr(S *s)
     A.rowptr = s->csr_rowptr.p; A.cols = s->csr_cols.p; A.vals = s->csr_vals.p;
     hipLaunchKernelGGL(k_csr_build, dim3((unsigned)cdiv(s->nloc_el + 1, 256)), dim3(256), 0, s->stream, A);
     HIPCHK(hipGetLastError());
-    constexpr int CAP = 4608;
-    s->csr_rpb = (int32_t)std::min<int64_t>(256, CAP / std::max<int64_t>(maxrow, 1));
+    s->csr_variant = dbg_int("EDGPU_CSR_VARIANT", 6);
+    const int v_ = s->csr_variant;
+    const int CAP = (v_ == 3 || v_ == 4) ? 2304 : ((v_ == 5 || v_ == 6) ? 1152 : 4608), RMAX = (v_ == 3 || v_ == 4) ? 128 : ((v_ == 5 || v_ == 6) ? 64 : 256);
+    s->csr_rpb = (int32_t)std::min<int64_t>(RMAX, CAP / std::max<int64_t>(maxrow, 1));
     if (s->csr_rpb < 1) return fail(EDGPU_EUNSUPPORTED, "edgpu: a CSR row exceeds the LDS product tile");
     s->csr_bpr = (int32_t)cdiv(H.DimUp, s->csr_rpb);
-    s->csr_tile = std::min(4, s->csr_bpr);
+    s->csr_tile = std::max(1, std::min(dbg_int("EDGPU_CSR_TILE", 1 << 20), s->csr_bpr));
     return EDGPU_OK;
 }
 
@@ -261,8 +266,10 @@ static int create(const edgpu_desc *desc, S **out)
     // launch geometry of the fused two-factor kernel
     if (s->two_factor) {
         size_t rowbytes = (size_t)H.DimUp * sizeof(double);
-        s->use_lds = rowbytes + 128 <= 150 * 1024;
+        s->use_lds = rowbytes + 128 <= 150 * 1024 && !(dbg_flags() & 4);
+        if (dbg_int("EDGPU_KRON_THREADS", 0)) s->kron_threads_override = dbg_int("EDGPU_KRON_THREADS", 0);
         s->kron_threads = H.DimUp >= 4096 ? 1024 : (H.DimUp >= 1024 ? 512 : 256);
+        if (s->kron_threads_override) s->kron_threads = s->kron_threads_override;
         s->kron_lds = (s->use_lds ? rowbytes : 0) + 16 * sizeof(double);
     }
     // operator storage
@@ -280,7 +287,8 @@ static int create(const edgpu_desc *desc, S **out)
         CHK(build_csr(s.get()));
         s->bytes_stored = s->csr_nnz * 12 + (s->nloc_el + 1) * 8;
     }
-    if (desc->mpi_size > 1) CHK(s->vfull.alloc((size_t)(H.DimUp * H.DimDw * H.DimPh)));
+    s->multi = desc->mpi_size > 1 || (desc->reserved & 1);   // reserved bit 0: run the exchange path even on one rank (tests)
+    if (s->multi) CHK(s->vfull.alloc((size_t)(H.DimUp * H.DimDw * H.DimPh)));
     s->npartial = max_partials(s.get());
     CHK(s->partial.alloc((size_t)s->npartial));
     CHK(s->scal.alloc(SC_COUNT));
@@ -296,6 +304,7 @@ static void destroy(S *s)
     (void)hipSetDevice(s->device);
     (void)hipDeviceSynchronize();
     if (s->comm.kind == Comm::RCCL && s->comm.nccl && g_rccl.ok) g_rccl.CommDestroy(s->comm.nccl);
+    for (auto e : s->bench_ev) (void)hipEventDestroy(e);
     if (s->ev_a) (void)hipEventDestroy(s->ev_a);
     if (s->ev_b) (void)hipEventDestroy(s->ev_b);
     if (s->ev_gather) (void)hipEventDestroy(s->ev_gather);
@@ -345,7 +354,7 @@ static int gather_vector(S *s, const double *v_local, hipStream_t st)
 static int allreduce_tmp(S *s)
 {
     Comm &c = s->comm;
-    if (c.size == 1) return EDGPU_OK;
+    if (!s->multi) return EDGPU_OK;
     double *p = s->scal.p + SC_TMP;
     if (c.kind == Comm::RCCL) {
         int rc = g_rccl.AllReduce(p, p, 1, kNcclDouble, kNcclSum, c.nccl, s->stream);
@@ -407,7 +416,7 @@ static int direct_tables(S *s)
 static int hxv(S *s, const double *v, double *out, bool epi, const double *uprev)
 {
     const SectorHost &H = s->H; const edgpu_desc &d = H.desc;
-    const bool multi = s->comm.size > 1;
+    const bool multi = s->multi;
     const bool direct = d.storage == EDGPU_STORE_DIRECT;
     if (direct) CHK(direct_tables(s));
     if (multi) {  // start the exchange on the comm stream; local work overlaps it
@@ -422,10 +431,16 @@ static int hxv(S *s, const double *v, double *out, bool epi, const double *uprev
         CsrArgs A{};
         A.nrows = s->nloc_el; A.rows_per_block = s->csr_rpb; A.DimUp = (int32_t)H.DimUp; A.blocks_per_row = s->csr_bpr; A.Qdw = H.Qdw; A.tile = s->csr_tile;
         A.rowptr = s->csr_rowptr.p; A.cols = s->csr_cols.p; A.vals = s->csr_vals.p;
-        A.x = multi ? s->vfull.p : v; A.y = out; A.v_local = v; A.uprev = uprev; A.scal = s->scal.p; A.partial = s->partial.p; A.epi = epi;
+        A.x = multi ? s->vfull.p : v; A.y = out; A.v_local = v; A.uprev = uprev; A.scal = s->scal.p; A.partial = s->partial.p; A.epi = epi; A.xcd_rows = dbg_int("EDGPU_CSR_XCD", 0);
         // the column index is global; on one GPU local == global
         nblocks = (int64_t)s->csr_bpr * H.Qdw;
-        hipLaunchKernelGGL(k_csr_spmv<4608>, dim3((unsigned)nblocks), dim3(256), 0, s->stream, A);
+        if (s->csr_variant == 1) hipLaunchKernelGGL(k_csr_spmv<4608>, dim3((unsigned)nblocks), dim3(256), 0, s->stream, A);
+        else if (s->csr_variant == 2) hipLaunchKernelGGL((k_csr_spmv2<256, 4608, false>), dim3((unsigned)nblocks), dim3(256), 0, s->stream, A);
+        else if (s->csr_variant == 3) hipLaunchKernelGGL((k_csr_spmv2<128, 2304, false>), dim3((unsigned)nblocks), dim3(128), 0, s->stream, A);
+        else if (s->csr_variant == 4) hipLaunchKernelGGL((k_csr_spmv2<128, 2304, true>), dim3((unsigned)nblocks), dim3(128), 0, s->stream, A);
+        else if (s->csr_variant == 5) hipLaunchKernelGGL((k_csr_spmv2<64, 1152, true>), dim3((unsigned)nblocks), dim3(64), 0, s->stream, A);
+        else if (s->csr_variant == 6) hipLaunchKernelGGL((k_csr_spmv2<64, 1152, false>), dim3((unsigned)nblocks), dim3(64), 0, s->stream, A);
+        else hipLaunchKernelGGL((k_csr_spmv2<256, 4608, true>), dim3((unsigned)nblocks), dim3(256), 0, s->stream, A);
         HIPCHK(hipGetLastError());
     } else if (s->two_factor) {
         Kron2Args A{};
@@ -437,6 +452,8 @@ static int hxv(S *s, const double *v, double *out, bool epi, const double *uprev
         A.impmask = (1 << d.Norb) - 1; A.nI = 1 << d.Norb; A.econst = H.econst; A.w0 = d.w0_ph; A.gsum = H.gph_sum; A.Jx = d.Jx; A.Jp = d.Jp;
         A.gup = s->gup.p; A.gdw = s->gdw.p;
         A.v = v; A.vfull = multi ? s->vfull.p : v; A.out = out; A.uprev = uprev; A.scal = s->scal.p; A.partial = s->partial.p;
+        if (dbg_flags() & 1) A.upw = 0;
+        if (dbg_flags() & 2) A.dww = 0;
         int base = (direct ? KF_DIRECT : 0) | (epi ? KF_EPI : 0) | (s->extra ? (KF_PH | KF_ND) : 0);
         nblocks = H.Qdw * H.DimPh;
         if (!multi) CHK(dispatch_kron2(s, base | (s->use_lds ? KF_LDS : 0), A, nblocks));
@@ -572,9 +589,8 @@ static int lz_start(S *s, LzVecs &V)
 }
 
 // iteration k (0-based): fills alphas[k], betas[k+1]; optional eigenvector accumulation
-static int lz_iter(S *s, LzVecs &V, int k, double *acc)
+static int lz_iter_tail(S *s, LzVecs &V, int k, double *acc)
 {
-    CHK(hxv(s, V.ucur, V.w, true, V.uprev));
     hipLaunchKernelGGL(k_scalar_step, dim3(1), dim3(1), 0, s->stream, s->scal.p, s->alphas.p, s->betas.p, (const double *)nullptr, k, 0);
     if (acc) hipLaunchKernelGGL(k_scalar_step, dim3(1), dim3(1), 0, s->stream, s->scal.p, s->alphas.p, s->betas.p, (const double *)s->zvec.p, k, 3);
     int nb = (int)std::max<int64_t>(1, std::min<int64_t>(cdiv(s->nloc, 256 * 4), 4096));
@@ -586,6 +602,11 @@ static int lz_iter(S *s, LzVecs &V, int k, double *acc)
     HIPCHK(hipGetLastError());
     double *t = V.uprev; V.uprev = V.ucur; V.ucur = V.w; V.w = t;
     return EDGPU_OK;
+}
+static int lz_iter(S *s, LzVecs &V, int k, double *acc)
+{
+    CHK(hxv(s, V.ucur, V.w, true, V.uprev));
+    return lz_iter_tail(s, V, k, acc);
 }
 
 static int fetch_coeffs(S *s, int k, std::vector<double> &al, std::vector<double> &be)
@@ -883,6 +904,66 @@ int edgpu_lanczos_time(edgpu_handle h, int32_t nwarm, int32_t niter, float *ms_p
     float ms = 0.f;
     HIPCHK(hipEventElapsedTime(&ms, h->ev_a, h->ev_b));
     *ms_per_iter = ms / niter;
+    return EDGPU_OK;
+}
+
+// ---- step-wise Lanczos for external timing (bench.py): begin, then enqueue steps -----------
+int edgpu_lanczos_bench_begin(edgpu_handle h, int32_t max_steps)
+{
+    if (!h || max_steps < 1) return fail(EDGPU_EINVAL, "edgpu_lanczos_bench_begin: bad argument");
+    HIPCHK(hipSetDevice(h->device));
+    CHK(lz_prepare(h, max_steps + 1));
+    h->bv[0] = h->lz[0].p; h->bv[1] = h->lz[1].p; h->bv[2] = h->lz[2].p;
+    const SectorHost &H = h->H;
+    hipLaunchKernelGGL(k_random_start, dim3(2048), dim3(256), 0, h->stream, h->bv[1], H.DimUp, H.Qdw, H.dw0, H.DimDw, H.DimPh, (uint64_t)1234567);
+    HIPCHK(hipGetLastError());
+    LzVecs V{h->bv[0], h->bv[1], h->bv[2]};
+    CHK(lz_start(h, V));
+    h->bench_k = 0;
+    while ((int)h->bench_ev.size() < 2 * max_steps) { hipEvent_t e; HIPCHK(hipEventCreate(&e)); h->bench_ev.push_back(e); }
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return EDGPU_OK;
+}
+// enqueue `nsteps` iterations (asynchronous; caller synchronises the device).  When `timed`
+// the product kernel(s) of every step are bracketed by HIP events on the launch stream.
+int edgpu_lanczos_bench_steps(edgpu_handle h, int32_t nsteps, int32_t timed)
+{
+    if (!h || nsteps < 0) return fail(EDGPU_EINVAL, "edgpu_lanczos_bench_steps: bad argument");
+    if (!h->bv[0]) return fail(EDGPU_EINVAL, "edgpu_lanczos_bench_steps: call edgpu_lanczos_bench_begin first");
+    if (h->bench_k + nsteps > h->nmax - 1) return fail(EDGPU_EINVAL, "edgpu_lanczos_bench_steps: more steps than announced");
+    HIPCHK(hipSetDevice(h->device));
+    LzVecs V{h->bv[0], h->bv[1], h->bv[2]};
+    for (int i = 0; i < nsteps; i++) {
+        const int k = h->bench_k;
+        if (timed) {   // lz_iter with the product bracketed by events
+            HIPCHK(hipEventRecord(h->bench_ev[2 * i], h->stream));
+            CHK(hxv(h, V.ucur, V.w, true, V.uprev));
+            HIPCHK(hipEventRecord(h->bench_ev[2 * i + 1], h->stream));
+            CHK(lz_iter_tail(h, V, k, nullptr));
+        } else
+            CHK(lz_iter(h, V, k, nullptr));
+        h->bench_k++;
+    }
+    h->bv[0] = V.uprev; h->bv[1] = V.ucur; h->bv[2] = V.w;
+    return EDGPU_OK;
+}
+// after a device synchronise: mean duration (ms) of the product over the last timed batch, and
+// the Lanczos coefficients produced so far (for checks)
+int edgpu_lanczos_bench_result(edgpu_handle h, int32_t nsteps_timed, float *hxv_ms_mean, double *alphas, double *betas, int32_t ncoef)
+{
+    if (!h) return fail(EDGPU_EINVAL, "edgpu_lanczos_bench_result: null handle");
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    if (hxv_ms_mean) {
+        double tot = 0.0;
+        for (int i = 0; i < nsteps_timed; i++) { float ms = 0.f; HIPCHK(hipEventElapsedTime(&ms, h->bench_ev[2 * i], h->bench_ev[2 * i + 1])); tot += ms; }
+        *hxv_ms_mean = nsteps_timed > 0 ? (float)(tot / nsteps_timed) : 0.f;
+    }
+    if (alphas && betas && ncoef > 0) {
+        if (ncoef > h->bench_k) ncoef = h->bench_k;
+        HIPCHK(hipMemcpy(alphas, h->alphas.p, (size_t)ncoef * 8, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(betas, h->betas.p + 1, (size_t)ncoef * 8, hipMemcpyDeviceToHost));
+    }
     return EDGPU_OK;
 }
 

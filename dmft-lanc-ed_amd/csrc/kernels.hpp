@@ -374,7 +374,7 @@ struct CsrArgs {
     const int64_t *rowptr; const int32_t *cols; const double *vals;
     const double *x; double *y;
     const double *v_local;  // x restricted to the local rows (== x on one GPU), for the alpha dot
-    const double *uprev; const double *scal; double *partial; int32_t epi;
+    const double *uprev; const double *scal; double *partial; int32_t epi; int32_t xcd_rows;
 };
 
 // "CSR-stream": a workgroup owns `rows_per_block` consecutive rows of one idw row, streams their
@@ -413,6 +413,84 @@ __global__ void __launch_bounds__(256) k_csr_spmv(CsrArgs A)
         else A.y[row] = acc;
     }
     if (A.epi) { double r = block_sum(asum, red); if (threadIdx.x == 0) A.partial[blockIdx.x] = r; }
+}
+
+// Second form: the contiguous (value, column) range of the row block is copied to LDS with wide
+// coalesced loads (16 B per lane, all issued before the first use), then lane r walks row r out
+// of LDS.  For a fixed entry slot k the lanes of a wave then gather x at consecutive addresses
+// for the dw hops and the diagonal (9 of 17 entries at half filling) instead of 17 clusters per
+// instruction, and no product array / segmented sum is needed.
+typedef double dbl2_t __attribute__((ext_vector_type(2)));
+typedef int int4_t __attribute__((ext_vector_type(4)));
+
+template <int ROWS, int CAPN, bool NT>
+__global__ void __launch_bounds__(ROWS) k_csr_spmv2(CsrArgs A)
+{
+    // LDS image of the row block's (value, column) range, shifted by (p0 & 3) so that 4-entry
+    // groups are 32-byte aligned both in HBM and in LDS (wide loads, wide conflict-free stores)
+    __shared__ __attribute__((aligned(32))) double sval[CAPN + 4];
+    __shared__ __attribute__((aligned(16))) int32_t scol[CAPN + 4];
+    __shared__ double red[4];
+    int64_t idwl; int jb;
+    {
+        const int64_t b = blockIdx.x, per_tile = (int64_t)A.tile * A.Qdw;
+        const int nt_full = A.blocks_per_row / A.tile;
+        int64_t t, r; int tw;
+        if (b < (int64_t)nt_full * per_tile) { t = b / per_tile; r = b - t * per_tile; tw = A.tile; }
+        else { t = nt_full; r = b - (int64_t)nt_full * per_tile; tw = A.blocks_per_row - nt_full * A.tile; }
+        if (A.xcd_rows) {
+            // workgroups are dealt round-robin over the 8 XCDs: keep all row blocks of one idw row on
+            // one XCD (its L2 then serves that row's up-hop gathers).  Speed only, never correctness.
+            const int64_t q8 = A.Qdw & ~(int64_t)7, body = q8 * tw;
+            if (r < body) { const int64_t g = r / (8 * (int64_t)tw), w = r - g * 8 * tw; idwl = g * 8 + (w & 7); jb = (int)(t * A.tile + (w >> 3)); }
+            else { const int64_t w = r - body; idwl = q8 + w / tw; jb = (int)(t * A.tile + (w - (w / tw) * tw)); }
+        } else { idwl = r / tw; jb = (int)(t * A.tile + (r - idwl * tw)); }
+    }
+    const int tid = threadIdx.x;
+    const int iup0 = jb * A.rows_per_block;
+    int nr = A.DimUp - iup0; if (nr > A.rows_per_block) nr = A.rows_per_block;
+    const int64_t row0 = idwl * A.DimUp + iup0;
+    const int64_t p0 = A.rowptr[row0], p1 = A.rowptr[row0 + nr];
+    const int n = (int)(p1 - p0);
+    const int sh = (int)(p0 & 3);
+    int ra = 0, re = 0;
+    if (tid < nr) { ra = (int)(A.rowptr[row0 + tid] - p0) + sh; re = (int)(A.rowptr[row0 + tid + 1] - p0) + sh; }
+    {
+        const double *gv = A.vals + (p0 - sh); const int32_t *gc = A.cols + (p0 - sh);   // 4-aligned base
+        const int end = sh + n;                       // entries [sh, end) are ours
+        const int g0 = sh ? 1 : 0, g1 = end >> 2;     // full 4-groups [g0, g1)
+        if (sh && tid >= sh && tid < 4 && tid < end) { sval[tid] = gv[tid]; scol[tid] = gc[tid]; }
+        const dbl2_t *pv = reinterpret_cast<const dbl2_t *>(gv);
+        const int4_t *pc = reinterpret_cast<const int4_t *>(gc);
+        dbl2_t *sv2 = reinterpret_cast<dbl2_t *>(sval);
+        int4_t *sc4 = reinterpret_cast<int4_t *>(scol);
+        for (int g = g0 + tid; g < g1; g += ROWS) {
+            dbl2_t a, b; int4_t c;
+            if (NT) { a = __builtin_nontemporal_load(pv + 2 * g); b = __builtin_nontemporal_load(pv + 2 * g + 1); c = __builtin_nontemporal_load(pc + g); }
+            else { a = pv[2 * g]; b = pv[2 * g + 1]; c = pc[g]; }
+            sv2[2 * g] = a; sv2[2 * g + 1] = b; sc4[g] = c;
+        }
+        int ts = g1 << 2; if (sh && ts < 4) ts = 4;        // tail: entries [ts, end) past the last full group
+        const int tt = ts + tid;
+        if (tt < end) { sval[tt] = gv[tt]; scol[tt] = gc[tt]; }
+    }
+    __syncthreads();
+    double s_cur = 1.0, c_prev = 0.0, asum = 0.0;
+    if (A.epi) { s_cur = A.scal[SC_SCUR]; c_prev = A.scal[SC_BETA] * A.scal[SC_SPREV]; }
+    if (tid < nr) {
+        const int64_t row = row0 + tid;
+        double acc0 = 0.0, acc1 = 0.0;
+        int k = ra;
+        for (; k + 4 <= re; k += 4) {
+            const double x0 = A.x[scol[k]], x1 = A.x[scol[k + 1]], x2 = A.x[scol[k + 2]], x3 = A.x[scol[k + 3]];
+            acc0 += sval[k] * x0; acc1 += sval[k + 1] * x1; acc0 += sval[k + 2] * x2; acc1 += sval[k + 3] * x3;
+        }
+        for (; k < re; k++) acc0 += sval[k] * A.x[scol[k]];
+        const double acc = acc0 + acc1;
+        if (A.epi) { double w = s_cur * acc - c_prev * A.uprev[row]; A.y[row] = w; asum = (s_cur * A.v_local[row]) * w; }
+        else A.y[row] = acc;
+    }
+    if (A.epi) { double r = block_sum(asum, red); if (tid == 0) A.partial[blockIdx.x] = r; }
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -53,7 +53,7 @@ def _f64(a):
 class HvSector:
     """One live sector operator: build_Hv_sector(isector) ... delete_Hv_sector()."""
 
-    def __init__(self, model, nups, ndws, ed_sparse_H=True, storage=None, rank=0, size=1, device=-1):
+    def __init__(self, model, nups, ndws, ed_sparse_H=True, storage=None, rank=0, size=1, device=-1, force_exchange=False):
         m = model
         if storage is None:
             storage = "kron" if ed_sparse_H else "direct"
@@ -76,6 +76,7 @@ class HvSector:
             g = m.get("g_ph", ())
             d.g_ph[i] = float(g[i]) if i < len(g) else 0.0
         d.mpi_rank, d.mpi_size, d.device = rank, size, device
+        d.reserved = 1 if force_exchange else 0
         d.Ust, d.Jh, d.Jx, d.Jp = m.get("Ust", 0.0), m.get("Jh", 0.0), m.get("Jx", 0.0), m.get("Jp", 0.0)
         d.xmu, d.w0_ph = m.get("xmu", 0.0), m.get("w0_ph", 0.0)
         d.impHloc, d.diag_hybr, d.bath_diag = self._imp.ctypes.data, self._dh.ctypes.data, self._bd.ctypes.data
@@ -184,6 +185,18 @@ class HvSector:
         ms = C.c_float()
         check(capi.lib().edgpu_lanczos_time(self._h, nwarm, niter, C.byref(ms)))
         return ms.value
+
+    def bench_begin(self, max_steps):
+        check(capi.lib().edgpu_lanczos_bench_begin(self._h, max_steps))
+
+    def bench_steps(self, n, timed=False):
+        check(capi.lib().edgpu_lanczos_bench_steps(self._h, n, 1 if timed else 0))
+
+    def bench_result(self, ntimed, ncoef=0):
+        ms = C.c_float()
+        a = np.zeros(max(ncoef, 1)); b = np.zeros(max(ncoef, 1))
+        check(capi.lib().edgpu_lanczos_bench_result(self._h, ntimed, C.byref(ms), a.ctypes.data, b.ctypes.data, ncoef))
+        return ms.value, a[:ncoef], b[:ncoef]
 
     # ---- exchange -------------------------------------------------------------------
     def comm_init_rccl(self, uid_bytes):

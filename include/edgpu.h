@@ -58,7 +58,7 @@ typedef struct edgpu_desc {
     int32_t ndws[EDGPU_MAX_ORB];
     int32_t mpi_rank, mpi_size;   /* dw-column partition, ED_HAMILTONIAN.f90:96-110 */
     int32_t device;               /* HIP device ordinal, -1 = current device */
-    int32_t reserved;
+    int32_t reserved;             /* bit 0: run the exchange code path even with mpi_size=1 (self-test) */
     double Uloc[EDGPU_MAX_ORB], Ust, Jh, Jx, Jp, xmu;
     double w0_ph, g_ph[EDGPU_MAX_ORB];
     const double *impHloc;   /* (Nspin,Nspin,Norb,Norb)        ED_VARS_GLOBAL.f90:120 */
@@ -131,6 +131,14 @@ int edgpu_lanczos_tridiag_device(edgpu_handle h, const double *vin_dev, int32_t 
 /* `niter` plain Lanczos iterations from a fixed start, no convergence test, no host sync
  * inside the loop: the timed region of bench.py.  Returns mean ms/iteration (HIP events). */
 int edgpu_lanczos_time(edgpu_handle h, int32_t nwarm, int32_t niter, float *ms_per_iter);
+
+/* Step-wise form of the same loop for an external clock (bench.py): `begin` sets up a fixed
+ * start vector, `steps` enqueues iterations asynchronously on the library's stream (the caller
+ * synchronises the device), `result` returns the mean product-kernel time measured with HIP
+ * events on that stream and the first `ncoef` Lanczos coefficients (alpha_k, beta_{k+1}). */
+int edgpu_lanczos_bench_begin(edgpu_handle h, int32_t max_steps);
+int edgpu_lanczos_bench_steps(edgpu_handle h, int32_t nsteps, int32_t timed);
+int edgpu_lanczos_bench_result(edgpu_handle h, int32_t nsteps_timed, float *hxv_ms_mean, double *alphas, double *betas, int32_t ncoef);
 
 /* ---- multi-GPU exchange (replaces MPI_AllGatherv/MPI_AllReduce of the MPI matvecs,
  * ED_SETUP.f90:689-733, ED_HAMILTONIAN_SPARSE_HxV.f90:674-692) --------------------------

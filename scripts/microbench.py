@@ -1,0 +1,18 @@
+"""Ad-hoc kernel timing sweep (development aid): python tools_microbench.py <nbath> <storage> [nrep]"""
+import sys, os
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "dmft-lanc-ed_amd"))
+import numpy as np
+import edgpu
+from edgpu import model
+nbath = int(sys.argv[1]); st = sys.argv[2]; nrep = int(sys.argv[3]) if len(sys.argv) > 3 else 10
+m, nu, nd = model.half_filled_c(nbath)
+G = edgpu.HvSector(m, nu, nd, storage=st)
+N = G.Dim
+v = edgpu.DeviceVector(N); h = edgpu.DeviceVector(N)
+v.upload(np.random.RandomState(0).uniform(-0.5, 0.5, N))
+ms = G.hxv_time(v, h, 2, nrep)
+nnz = N * (1 + m["Ns"])
+bcsr = 12 * nnz + 8 * (N + 1) + 16 * N
+fmt = {"csr": bcsr, "kron": 24 * N, "direct": 16 * N}[st]
+print("nbath=%d st=%s EDGPU_DEBUG=%s CSRV=%s TILE=%s THR=%s : %.4f ms  fmt %.0f GB/s  eqcsr %.0f GB/s" % (nbath, st, os.environ.get("EDGPU_DEBUG"), os.environ.get("EDGPU_CSR_VARIANT"), os.environ.get("EDGPU_CSR_TILE"), os.environ.get("EDGPU_KRON_THREADS"), ms, fmt / ms / 1e6, bcsr / ms / 1e6))
