@@ -1,0 +1,89 @@
+"""The N>1 path: dw-column partition + exchange.  CPU: world_size-2 gloo job over the host
+logic.  GPU: world_size-2 and -3 jobs sharing the one GPU through the callback exchange, and
+the RCCL code path on a single-rank communicator."""
+import json
+import os
+import socket
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _launch(mode, case, size, timeout=600):
+    port = _free_port()
+    with tempfile.TemporaryDirectory() as d:
+        procs = []
+        for r in range(size):
+            env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(size), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+            procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "mp_worker.py"), mode, case, d], env=env,
+                                          stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+        outs = []
+        for p in procs:
+            try:
+                o, _ = p.communicate(timeout=timeout)
+            except subprocess.TimeoutExpired:
+                for q in procs:
+                    q.kill()
+                raise
+            outs.append(o.decode())
+        for r, p in enumerate(procs):
+            assert p.returncode == 0, "rank %d failed:\n%s" % (r, outs[r][-3000:])
+        return [json.load(open(os.path.join(d, "rank%d.json" % r))) for r in range(size)]
+
+
+@pytest.mark.parametrize("case,size", [("c_nb5_half", 2), ("phonons_nb3_nph3", 2), ("nb5_offhalf_2_4", 3)])
+def test_partition_and_staged_exchange_gloo_cpu(case, size):
+    res = _launch("cpu", case, size)
+    assert all(r["ok"] for r in res)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case,size", [("c_nb5_half", 2), ("c_nb7_half", 3), ("norb2_normal_JxJp", 2), ("phonons_norb2_JxJp", 2), ("nb5_offhalf_2_4", 4)])
+def test_multirank_on_one_gpu_callback_exchange(edgpu_mod, case, size):
+    import cases
+    from oracle import oracle
+    res = _launch("gpu", case, size)
+    name, m, nu, nd = [z for z in cases.zoo() if z[0] == case][0]
+    S = oracle.Sector(m, nu, nd)
+    e_dense = np.linalg.eigvalsh(S.hmat())[0]
+    G = edgpu_mod.HvSector(m, nu, nd)
+    v0 = np.random.RandomState(5).uniform(0, 1, S.Dim)
+    a1, b1, _ = G.sp_lanc_tridiag(v0, 20)
+    G.close()
+    for r in res:
+        for k, v in r.items():
+            if k.startswith("e0_"):
+                assert abs(v - e_dense) < 1e-10, (k, v, e_dense)
+            if k.startswith("a_"):   # same coefficients on every rank and as the single-rank run
+                np.testing.assert_allclose(v, a1, rtol=1e-9, atol=1e-9)
+            if k.startswith("b_"):
+                np.testing.assert_allclose(v, b1, rtol=1e-9, atol=1e-9)
+
+
+@pytest.mark.gpu
+def test_rccl_code_path_single_rank(edgpu_mod):
+    """edgpu_comm_unique_id/init_rccl + the split (local | exchange | dw) product and the device
+    all-reduce, on a one-rank communicator: same numbers as the fused single-GPU path."""
+    import cases
+    from edgpu import model
+    m, nu, nd = model.half_filled_c(7)
+    v = cases.sinvec(4900)
+    for st in ("kron", "direct", "csr"):
+        A = edgpu_mod.HvSector(m, nu, nd, storage=st)
+        B = edgpu_mod.HvSector(m, nu, nd, storage=st, force_exchange=True)
+        B.comm_init_rccl(edgpu_mod.rccl_unique_id())
+        ha, hb = A.spHtimesV(v), B.spHtimesV(v)
+        assert np.abs(ha - hb).max() <= 1e-13 * np.abs(ha).max()
+        ea, _, _ = A.sp_lanc_eigh(v, nitermax=200, threshold=1e-14)
+        eb, _, _ = B.sp_lanc_eigh(v, nitermax=200, threshold=1e-14)
+        assert abs(ea - eb) < 1e-11
+        A.close(); B.close()
