@@ -111,7 +111,7 @@ struct edgpu_sector_s {
     DevBuf<int64_t> csr_rowptr, uppre, dwpre; DevBuf<int32_t> csr_cols; DevBuf<double> csr_vals;
     int64_t csr_nnz = 0; int32_t csr_rpb = 0, csr_bpr = 0, csr_tile = 1, csr_variant = 6;
     // work vectors
-    DevBuf<double> vfull, tmp_in, tmp_out, lz[5], scal, alphas, betas, zvec, partial;
+    DevBuf<double> vfull, tmp_in, tmp_out, lz[5], scal, alphas, betas, zvec, partial, partial2;
     int64_t nloc = 0, nloc_el = 0, vecdim = 0;
     int32_t nmax = 0;
     bool use_lds = false; int kron_threads = 256, kron_threads_override = 0; size_t kron_lds = 0;
@@ -291,6 +291,7 @@ static int create(const edgpu_desc *desc, S **out)
     if (s->multi) CHK(s->vfull.alloc((size_t)(H.DimUp * H.DimDw * H.DimPh)));
     s->npartial = max_partials(s.get());
     CHK(s->partial.alloc((size_t)s->npartial));
+    CHK(s->partial2.alloc(1024));
     CHK(s->scal.alloc(SC_COUNT));
     HIPCHK(hipMemsetAsync(s->scal.p, 0, SC_COUNT * sizeof(double), s->stream));
     HIPCHK(hipStreamSynchronize(s->stream));
@@ -373,6 +374,21 @@ static int allreduce_tmp(S *s)
 // one product  out = H*v  (epi=false)   or the Lanczos-fused form (epi=true):
 //   out = s_cur*H*u - beta*s_prev*u_prev ;  scal[TMP] = (s_cur*u) . out
 // ---------------------------------------------------------------------------------------
+// scal[TMP] = sum(partial[0..n)) : one pass for short arrays, two passes for long ones
+static int reduce_partials(S *s, int64_t n)
+{
+    const double *src = s->partial.p;
+    if (n > 16384) {
+        const int64_t chunk = cdiv(n, 1024);
+        const int nb = (int)cdiv(n, chunk);
+        hipLaunchKernelGGL(k_reduce_chunks, dim3(nb), dim3(256), 0, s->stream, src, n, chunk, s->partial2.p);
+        src = s->partial2.p; n = nb;
+    }
+    hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(1024), 0, s->stream, src, n, s->scal.p + SC_TMP);
+    HIPCHK(hipGetLastError());
+    return EDGPU_OK;
+}
+
 template <int F> static void launch_kron2(S *s, const Kron2Args &A, int64_t rows)
 {
     size_t lds = (F & KF_LDS) ? s->kron_lds : 16 * sizeof(double);
@@ -478,8 +494,7 @@ static int hxv(S *s, const double *v, double *out, bool epi, const double *uprev
         HIPCHK(hipGetLastError());
     }
     if (epi) {
-        hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(1024), 0, s->stream, s->partial.p, nblocks, s->scal.p + SC_TMP);
-        HIPCHK(hipGetLastError());
+        CHK(reduce_partials(s, nblocks));
         CHK(allreduce_tmp(s));
     }
     return EDGPU_OK;

@@ -454,7 +454,11 @@ __global__ void __launch_bounds__(ROWS) k_csr_spmv2(CsrArgs A)
     const int n = (int)(p1 - p0);
     const int sh = (int)(p0 & 3);
     int ra = 0, re = 0;
-    if (tid < nr) { ra = (int)(A.rowptr[row0 + tid] - p0) + sh; re = (int)(A.rowptr[row0 + tid + 1] - p0) + sh; }
+    double up_i = 0.0, xl_i = 0.0;   // epilogue operands, requested before the stream so their latency hides under it
+    if (tid < nr) {
+        ra = (int)(A.rowptr[row0 + tid] - p0) + sh; re = (int)(A.rowptr[row0 + tid + 1] - p0) + sh;
+        if (A.epi) { up_i = A.uprev[row0 + tid]; xl_i = A.v_local[row0 + tid]; }
+    }
     {
         const double *gv = A.vals + (p0 - sh); const int32_t *gc = A.cols + (p0 - sh);   // 4-aligned base
         const int end = sh + n;                       // entries [sh, end) are ours
@@ -487,7 +491,7 @@ __global__ void __launch_bounds__(ROWS) k_csr_spmv2(CsrArgs A)
         }
         for (; k < re; k++) acc0 += sval[k] * A.x[scol[k]];
         const double acc = acc0 + acc1;
-        if (A.epi) { double w = s_cur * acc - c_prev * A.uprev[row]; A.y[row] = w; asum = (s_cur * A.v_local[row]) * w; }
+        if (A.epi) { double w = s_cur * acc - c_prev * up_i; A.y[row] = w; asum = (s_cur * xl_i) * w; }
         else A.y[row] = acc;
     }
     if (A.epi) { double r = block_sum(asum, red); if (tid == 0) A.partial[blockIdx.x] = r; }
@@ -504,6 +508,18 @@ __global__ void __launch_bounds__(1024) k_reduce_final(const double *__restrict_
     for (int64_t i = threadIdx.x; i < n; i += blockDim.x) s += in[i];
     double r = block_sum(s, red);
     if (threadIdx.x == 0) *out = r;
+}
+
+// stage 1 of a large reduction: block b sums the contiguous chunk [b*chunk, (b+1)*chunk) in a
+// fixed order (deterministic for a given n), so the single-workgroup final pass stays short
+__global__ void __launch_bounds__(256) k_reduce_chunks(const double *__restrict__ in, int64_t n, int64_t chunk, double *__restrict__ out)
+{
+    __shared__ double red[4];
+    const int64_t lo = (int64_t)blockIdx.x * chunk, hi = lo + chunk < n ? lo + chunk : n;
+    double s = 0.0;
+    for (int64_t i = lo + threadIdx.x; i < hi; i += blockDim.x) s += in[i];
+    double r = block_sum(s, red);
+    if (threadIdx.x == 0) out[blockIdx.x] = r;
 }
 
 // partial[b] = sum over the block's grid-stride elements of a[i]*b[i]

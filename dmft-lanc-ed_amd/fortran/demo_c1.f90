@@ -1,0 +1,48 @@
+!> BASELINE config 1 from the Fortran side: 1 orbital, Nbath=5 (Ns=6), sector (3,3), default
+!  initial bath (ED_BATH/dmft_aux.f90:110-133).  Binds the GPU operator to a procedure pointer
+!  with the reference's abstract interface and prints the SURVEY 8c known-answer quantities.
+program demo_c1
+  use ED_HAMILTONIAN_GPU
+  implicit none
+  abstract interface
+     subroutine dd_sparse_HxV(Nloc, v, Hv)      ! ED_VARS_GLOBAL.f90:75-81
+       integer                 :: Nloc
+       real(8), dimension(Nloc) :: v
+       real(8), dimension(Nloc) :: Hv
+     end subroutine dd_sparse_HxV
+  end interface
+  procedure(dd_sparse_HxV), pointer :: spHtimesV_p => null()
+  integer, parameter :: Norb = 1, Nspin = 1, Nbath = 5
+  real(8) :: impHloc(Nspin,Nspin,Norb,Norb), diag_hybr(Nspin,Norb,Nbath), bath_diag(Nspin,Norb,Nbath)
+  real(8) :: Uloc(5), g_ph(5), egs
+  real(8), allocatable :: v(:), Hv(:), vect(:), alanc(:), blanc(:)
+  integer :: N, i, nlanc, isparse
+  logical :: sparse_H
+  impHloc = 0d0
+  bath_diag(1,1,:) = [-2d0, -1d0, 0d0, 1d0, 2d0]
+  diag_hybr = 1d0/sqrt(dble(Nbath))
+  Uloc = 0d0; Uloc(1) = 2d0; g_ph = 0d0
+  do isparse = 1, 2
+     sparse_H = (isparse == 1)
+     call build_Hv_sector_gpu(Norb, Nspin, Nbath, 0, "normal", .true., sparse_H, .true., [3], [3], &
+          Uloc, 0d0, 0d0, 0d0, 0d0, 0d0, 0d0, g_ph, impHloc, diag_hybr, bath_diag)
+     spHtimesV_p => spMatVec_gpu
+     N = vecDim_Hv_sector_gpu()
+     if (.not. allocated(v)) allocate(v(N), Hv(N), vect(N), alanc(20), blanc(20))
+     do i = 1, N
+        v(i) = sin(dble(i))
+     end do
+     call spHtimesV_p(N, v, Hv)
+     write(*,"(A,L1,A,I6)") "ed_sparse_H=", sparse_H, " N=", N
+     write(*,"(A,ES24.16)") "sum_Hv=", sum(Hv)
+     write(*,"(A,ES24.16)") "v_Hv=", dot_product(v, Hv)
+     write(*,"(A,3ES24.16)") "Hv_1_3=", Hv(1:3)
+     vect = 0d0
+     call sp_lanc_eigh_gpu(egs, vect, min(N, 512), threshold=1d-14, nlanc=nlanc)
+     write(*,"(A,F20.14,A,I4)") "E0=", egs, " nlanc=", nlanc
+     call sp_lanc_tridiag_gpu(v, alanc, blanc)
+     write(*,"(A,2ES24.16)") "alanc_1_2=", alanc(1:2)
+     spHtimesV_p => null()
+     call delete_Hv_sector_gpu()
+  end do
+end program demo_c1

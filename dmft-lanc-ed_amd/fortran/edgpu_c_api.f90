@@ -1,0 +1,142 @@
+!> ISO_C_BINDING view of include/edgpu.h -- the only place the Fortran host sees the C ABI.
+!  Field order and kinds mirror `edgpu_desc` / `edgpu_info` exactly.
+module EDGPU_C_API
+  use, intrinsic :: iso_c_binding
+  implicit none
+  public
+
+  integer(c_int32_t), parameter :: EDGPU_ABI_VERSION = 1
+  integer(c_int32_t), parameter :: EDGPU_MAX_ORB = 5
+  integer(c_int32_t), parameter :: EDGPU_BATH_NORMAL = 0, EDGPU_BATH_HYBRID = 1, EDGPU_BATH_REPLICA = 2
+  integer(c_int32_t), parameter :: EDGPU_STORE_KRON = 0, EDGPU_STORE_CSR = 1, EDGPU_STORE_DIRECT = 2
+
+  type, bind(C) :: edgpu_desc
+     integer(c_int32_t) :: abi_version
+     integer(c_int32_t) :: Norb, Nspin, Nbath
+     integer(c_int32_t) :: Nph
+     integer(c_int32_t) :: bath_type
+     integer(c_int32_t) :: ed_total_ud
+     integer(c_int32_t) :: storage
+     integer(c_int32_t) :: hfmode
+     integer(c_int32_t) :: Nfoo
+     integer(c_int32_t) :: nups(EDGPU_MAX_ORB)
+     integer(c_int32_t) :: ndws(EDGPU_MAX_ORB)
+     integer(c_int32_t) :: mpi_rank, mpi_size
+     integer(c_int32_t) :: device
+     integer(c_int32_t) :: reserved
+     real(c_double)     :: Uloc(EDGPU_MAX_ORB), Ust, Jh, Jx, Jp, xmu
+     real(c_double)     :: w0_ph, g_ph(EDGPU_MAX_ORB)
+     type(c_ptr)        :: impHloc, diag_hybr, bath_diag, hbath
+  end type edgpu_desc
+
+  type, bind(C) :: edgpu_info
+     integer(c_int32_t) :: isector
+     integer(c_int32_t) :: Ns, Ns_Orb, Ns_Ud, DimPh
+     integer(c_int32_t) :: Jhflag
+     integer(c_int32_t) :: DimUps(EDGPU_MAX_ORB), DimDws(EDGPU_MAX_ORB)
+     integer(c_int64_t) :: DimUp, DimDw
+     integer(c_int64_t) :: Dim
+     integer(c_int64_t) :: mpiQdw
+     integer(c_int64_t) :: mpiIshift
+     integer(c_int64_t) :: vecDim
+     integer(c_int64_t) :: nnz_total
+     integer(c_int64_t) :: bytes_stored
+  end type edgpu_info
+
+  interface
+     function edgpu_sector_create(desc, handle) bind(C, name="edgpu_sector_create") result(rc)
+       import :: c_int, c_ptr, edgpu_desc
+       type(edgpu_desc), intent(in) :: desc
+       type(c_ptr), intent(out)     :: handle
+       integer(c_int)               :: rc
+     end function edgpu_sector_create
+     function edgpu_sector_destroy(handle) bind(C, name="edgpu_sector_destroy") result(rc)
+       import :: c_int, c_ptr
+       type(c_ptr), value :: handle
+       integer(c_int)     :: rc
+     end function edgpu_sector_destroy
+     function edgpu_sector_vecdim(handle) bind(C, name="edgpu_sector_vecdim") result(n)
+       import :: c_int64_t, c_ptr
+       type(c_ptr), value :: handle
+       integer(c_int64_t) :: n
+     end function edgpu_sector_vecdim
+     function edgpu_sector_info(handle, info) bind(C, name="edgpu_sector_info") result(rc)
+       import :: c_int, c_ptr, edgpu_info
+       type(c_ptr), value            :: handle
+       type(edgpu_info), intent(out) :: info
+       integer(c_int)                :: rc
+     end function edgpu_sector_info
+     function edgpu_sector_map(handle, k, out) bind(C, name="edgpu_sector_map") result(rc)
+       import :: c_int, c_int32_t, c_ptr
+       type(c_ptr), value        :: handle
+       integer(c_int32_t), value :: k
+       integer(c_int32_t)        :: out(*)
+       integer(c_int)            :: rc
+     end function edgpu_sector_map
+     !> dd_sparse_HxV(Nloc,v,Hv), ED_VARS_GLOBAL.f90:75-81 : Nloc by reference, host arrays
+     function edgpu_hxv(handle, nloc, v, hv) bind(C, name="edgpu_hxv") result(rc)
+       import :: c_int, c_int32_t, c_double, c_ptr
+       type(c_ptr), value             :: handle
+       integer(c_int32_t), intent(in) :: nloc
+       real(c_double), intent(in)     :: v(*)
+       real(c_double)                 :: hv(*)
+       integer(c_int)                 :: rc
+     end function edgpu_hxv
+     function edgpu_lanczos_gs(handle, nitermax, threshold, ncheck, egs, vect, nlanc) bind(C, name="edgpu_lanczos_gs") result(rc)
+       import :: c_int, c_int32_t, c_double, c_ptr
+       type(c_ptr), value        :: handle
+       integer(c_int32_t), value :: nitermax, ncheck
+       real(c_double), value     :: threshold
+       real(c_double)            :: egs
+       real(c_double)            :: vect(*)
+       integer(c_int32_t)        :: nlanc
+       integer(c_int)            :: rc
+     end function edgpu_lanczos_gs
+     function edgpu_lanczos_tridiag(handle, vin, nlanc, threshold, alanc, blanc, nused) bind(C, name="edgpu_lanczos_tridiag") result(rc)
+       import :: c_int, c_int32_t, c_double, c_ptr
+       type(c_ptr), value         :: handle
+       real(c_double), intent(in) :: vin(*)
+       integer(c_int32_t), value  :: nlanc
+       real(c_double), value      :: threshold
+       real(c_double)             :: alanc(*), blanc(*)
+       integer(c_int32_t)         :: nused
+       integer(c_int)             :: rc
+     end function edgpu_lanczos_tridiag
+     function edgpu_last_error() bind(C, name="edgpu_last_error") result(msg)
+       import :: c_ptr
+       type(c_ptr) :: msg
+     end function edgpu_last_error
+     function edgpu_device_count(n) bind(C, name="edgpu_device_count") result(rc)
+       import :: c_int, c_int32_t
+       integer(c_int32_t) :: n
+       integer(c_int)     :: rc
+     end function edgpu_device_count
+  end interface
+
+contains
+
+  !> message of the last failed call as a Fortran string
+  function edgpu_error_message() result(s)
+    character(len=:), allocatable   :: s
+    type(c_ptr)                     :: p
+    character(kind=c_char), pointer :: cs(:)
+    integer                         :: n
+    p = edgpu_last_error()
+    s = ""
+    if (.not. c_associated(p)) return
+    call c_f_pointer(p, cs, [1024])
+    n = 0
+    do while (n < 1024)
+       if (cs(n+1) == c_null_char) exit
+       n = n + 1
+    end do
+    allocate(character(len=n) :: s)
+    block
+      integer :: i
+      do i = 1, n
+         s(i:i) = cs(i)
+      end do
+    end block
+  end function edgpu_error_message
+
+end module EDGPU_C_API

@@ -1,0 +1,38 @@
+"""The Fortran host side: amdflang-compiled ISO_C_BINDING shim + demo driver for config 1."""
+import os
+import re
+import subprocess
+
+import pytest
+
+import cases
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DEMO = os.path.join(ROOT, "dmft-lanc-ed_amd", "fortran", "_build", "demo_c1")
+
+
+def test_shim_sources_declare_the_c_abi_names():
+    src = open(os.path.join(ROOT, "dmft-lanc-ed_amd", "fortran", "edgpu_c_api.f90")).read()
+    hdr = open(os.path.join(ROOT, "include", "edgpu.h")).read()
+    names = re.findall(r'bind\(C, name="(edgpu_[a-z0-9_]+)"\)', src)
+    assert len(names) >= 9
+    for n in names:
+        assert re.search(r"\b%s\s*\(" % n, hdr), n
+
+
+@pytest.mark.gpu
+def test_fortran_driver_config1_matches_reference_known_answers():
+    if not os.path.exists(DEMO):
+        pytest.skip("Fortran demo not built (amdflang absent at build time)")
+    out = subprocess.run([DEMO], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300).stdout.decode()
+    g = [c for c in cases.golden_cases() if c["name"] == "c1_Nbath5"][0]
+    blocks = out.split("ed_sparse_H=")[1:]
+    assert len(blocks) == 2, out
+    for b in blocks:          # stored (T) and on-the-fly (F)
+        f = lambda key: [float(x) for x in re.findall(r"[-+]?\d+\.\d+(?:[eE][-+]?\d+)?", re.search(key + r"=\s*(.*)", b).group(1))[:3]]
+        assert "N=   400" in b
+        assert abs(f("sum_Hv")[0] - g["sum_Hv"]) < 1e-11
+        assert abs(f("v_Hv")[0] - g["v_Hv"]) < 1e-10
+        for x, y in zip(f("Hv_1_3"), g["Hv_1_3"]):
+            assert abs(x - y) < 1e-12
+        assert abs(f("E0")[0] - g["E0"]) < 1e-10
