@@ -90,6 +90,7 @@ template <class T> struct DevBuf {
 
 struct DevFactor {
     DevBuf<int32_t> map, rank, rowptr, cols, ellc, talpha, tbeta;
+    DevBuf<uint32_t> pcols, pcodes; DevBuf<double> ptval; bool packed = false; int32_t pterms = 0;
     DevBuf<double> vals, ellv, E, tval, lin;
     int32_t width = 0;
 };
@@ -115,7 +116,7 @@ struct edgpu_sector_s {
     int64_t nloc = 0, nloc_el = 0, vecdim = 0;
     int32_t nmax = 0;
     bool use_lds = false; int kron_threads = 256, kron_threads_override = 0; size_t kron_lds = 0;
-    bool two_factor = false, extra = false, multi = false;
+    bool two_factor = false, extra = false, multi = false, kron_split = false; int dw_w = 64, dw_variant = 2, dw_rows = 64; bool up_persistent = true; int up_grid = 256, up_threads = 1024;
     std::vector<hipEvent_t> bench_ev; int bench_k = 0; double *bv[3] = {nullptr, nullptr, nullptr};
     int64_t nnz_total = 0, bytes_stored = 0;
     int64_t npartial = 0;
@@ -152,6 +153,29 @@ static int upload_factor(S *s, int k)
             ec[o] = has ? f.cols[p] : i; ev[o] = has ? f.vals[p] : 0.0;
         }
     CHK(df->ellc.upload(ec)); CHK(df->ellv.upload(ev));
+    // packed image for the persistent local pass: 16-bit column + (sign | term index) byte per hop;
+    // padded slots use code 127 -> amplitude 0.  Only when every entry is a single hop term.
+    if (transposed && f.dim <= 65536 && f.terms.size() < 127) {
+        const int W = df->width, ncw = (W + 1) / 2, ndw = (W + 3) / 4;
+        std::vector<uint32_t> pc((size_t)ncw * f.dim, 0u), pd((size_t)ndw * f.dim, 0u);
+        std::vector<double> tvl(128, 0.0);
+        for (size_t t = 0; t < f.terms.size(); t++) tvl[t] = std::fabs(f.terms[t].t);
+        bool ok = true;
+        for (int32_t i = 0; i < f.dim && ok; i++)
+            for (int32_t q = 0; q < 4 * ndw; q++) {
+                int64_t p = f.rowptr[i] + q; bool has = q < W && p < f.rowptr[i + 1];
+                uint32_t col = has ? (uint32_t)f.cols[p] : (uint32_t)i, code = 127u;
+                if (has) {
+                    int tid = -1;
+                    for (size_t t = 0; t < f.terms.size(); t++) if (std::fabs(f.terms[t].t) == std::fabs(f.vals[p])) { tid = (int)t; break; }
+                    if (tid < 0) { ok = false; break; }     // summed duplicates: keep the wide image
+                    code = (uint32_t)tid | (f.vals[p] < 0.0 ? 0x80u : 0u);
+                }
+                if (q < 2 * ncw) pc[(size_t)(q / 2) * f.dim + i] |= col << (16 * (q & 1));
+                pd[(size_t)(q / 4) * f.dim + i] |= code << (8 * (q & 3));
+            }
+        if (ok) { CHK(df->pcols.upload(pc)); CHK(df->pcodes.upload(pd)); CHK(df->ptval.upload(tvl)); df->packed = true; df->pterms = 128; }
+    }
     std::vector<int32_t> ta, tb; std::vector<double> tv;
     for (auto &t : f.terms) { ta.push_back(t.alpha); tb.push_back(t.beta); tv.push_back(t.t); }
     if (ta.empty()) { ta.push_back(1); tb.push_back(1); tv.push_back(0.0); }
@@ -232,6 +256,10 @@ static int build_csr(S *s)
 static int64_t max_partials(const S *s)
 {
     int64_t n = std::max<int64_t>(s->H.Qdw * s->H.DimPh, 4096);
+    if (s->two_factor) {   // column-tiled dw pass: one partial per workgroup
+        const int w = s->dw_w, R = std::min(256 / w, s->dw_rows);
+        n = std::max<int64_t>(n, 8 * cdiv(cdiv(s->H.DimUp, w), 8) * cdiv(s->H.Qdw * s->H.DimPh, std::max(R, 1)));
+    }
     if (s->csr_bpr) n = std::max<int64_t>(n, (int64_t)s->csr_bpr * s->H.Qdw);
     return n;
 }
@@ -271,6 +299,15 @@ static int create(const edgpu_desc *desc, S **out)
         s->kron_threads = H.DimUp >= 4096 ? 1024 : (H.DimUp >= 1024 ? 512 : 256);
         if (s->kron_threads_override) s->kron_threads = s->kron_threads_override;
         s->kron_lds = (s->use_lds ? rowbytes : 0) + 16 * sizeof(double);
+        // two-pass product (local pass + column-tiled dw pass) once the vector no longer fits the caches
+        s->kron_split = dbg_int("EDGPU_KRON_SPLIT", (H.DimUp * H.DimDw * 8 > ((int64_t)48 << 20)) ? 1 : 0) != 0;
+        s->dw_w = dbg_int("EDGPU_DW_W", 64);
+        s->dw_variant = dbg_int("EDGPU_DW_VARIANT", 2);
+        s->up_persistent = dbg_int("EDGPU_UP_PERSISTENT", 1) != 0;
+        s->up_grid = dbg_int("EDGPU_UP_GRID", 256);
+        s->up_threads = dbg_int("EDGPU_UP_THREADS", 1024) == 512 ? 512 : 1024;
+        s->dw_rows = std::max(1, std::min(64, dbg_int("EDGPU_DW_ROWS", 64)));
+        if (s->dw_w != 8 && s->dw_w != 16 && s->dw_w != 32 && s->dw_w != 64 && s->dw_w != 128 && s->dw_w != 256) s->dw_w = 32;
     }
     // operator storage
     int64_t nnz_fac = 0;
@@ -413,6 +450,7 @@ static int dispatch_kron2(S *s, int flags, const Kron2Args &A, int64_t rows)
     return EDGPU_OK;
 }
 
+static bool direct_tables_dirty(S *) { return false; }
 static int direct_tables(S *s)
 {
     const SectorHost &H = s->H; const edgpu_desc &d = H.desc;
@@ -422,6 +460,7 @@ static int direct_tables(S *s)
         T.dim = H.fac[k].dim; T.nterms = (int32_t)H.fac[k].terms.size(); T.width = f.width; T.transposed = k < H.Ns_Ud;
         T.map = f.map.p; T.rank = f.rank.p; T.talpha = f.talpha.p; T.tbeta = f.tbeta.p; T.tval = f.tval.p;
         T.ellc = f.ellc.p; T.ellv = f.ellv.p; T.lin = f.lin.p; T.nlev = H.fac[k].nbits;
+        T.pcols = f.packed ? f.pcols.p : nullptr; T.pcodes = f.packed ? f.pcodes.p : nullptr;
         T.impmask = d.ed_total_ud ? (1 << d.Norb) - 1 : 0; T.pair = d.ed_total_ud ? d.Ust - d.Jh : 0.0; T.E = f.E.p;
         hipLaunchKernelGGL(k_direct_tables, dim3((unsigned)cdiv(T.dim, 256)), dim3(256), 0, s->stream, T);
     }
@@ -472,11 +511,60 @@ static int hxv(S *s, const double *v, double *out, bool epi, const double *uprev
         if (dbg_flags() & 2) A.dww = 0;
         int base = (direct ? KF_DIRECT : 0) | (epi ? KF_EPI : 0) | (s->extra ? (KF_PH | KF_ND) : 0);
         nblocks = H.Qdw * H.DimPh;
-        if (!multi) CHK(dispatch_kron2(s, base | (s->use_lds ? KF_LDS : 0), A, nblocks));
+        const bool split = multi || (s->kron_split && !s->extra);
+        if (!split) CHK(dispatch_kron2(s, base | (s->use_lds ? KF_LDS : 0), A, nblocks));
         else {
-            CHK(dispatch_kron2(s, base | KF_NODW | (s->use_lds ? KF_LDS : 0), A, nblocks));
-            HIPCHK(hipStreamWaitEvent(s->stream, s->ev_gather, 0));
-            CHK(dispatch_kron2(s, base | KF_NOLOCAL, A, nblocks));
+            const bool persistent = s->up_persistent && !s->extra && s->fac[0]->packed && s->fac[0]->width <= 16 && s->use_lds && H.DimUp <= 13312 && !direct_tables_dirty(s);
+            if (persistent) {
+                UpArgs U{};
+                U.DimUp = A.DimUp; U.DimPh = A.DimPh; U.Qdw = A.Qdw; U.dw0 = A.dw0; U.nrows = H.Qdw * H.DimPh;
+                U.pcols = s->fac[0]->pcols.p; U.pcodes = s->fac[0]->pcodes.p; U.upw = s->fac[0]->width; U.tval = s->fac[0]->ptval.p; U.nterms = s->fac[0]->pterms;
+                U.diag = A.diag; U.Eup = A.Eup; U.Edw = A.Edw; U.cross = A.cross; U.mapup = A.mapup; U.mapdw = A.mapdw; U.impmask = A.impmask; U.nI = A.nI; U.econst = A.econst;
+                U.v = v; U.out = out; U.uprev = uprev; U.scal = s->scal.p;
+                const size_t lds = (((size_t)H.DimUp + 1) & ~(size_t)1) * 8 + 128 * 8;
+                const int grid = (int)std::min<int64_t>(U.nrows, s->up_grid);
+#define UP_LAUNCH(D_, E_, T_)                                                                                                   \
+    do {                                                                                                                            \
+        static bool attr_ = false;                                                                                                  \
+        if (!attr_) { (void)hipFuncSetAttribute((const void *)k_uppass<D_, E_, T_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_ = true; } \
+        hipLaunchKernelGGL((k_uppass<D_, E_, T_>), dim3(grid), dim3(T_), lds, s->stream, U);                                        \
+    } while (0)
+                if (s->up_threads == 512) {
+                    if (direct) { if (epi) UP_LAUNCH(true, true, 512); else UP_LAUNCH(true, false, 512); }
+                    else { if (epi) UP_LAUNCH(false, true, 512); else UP_LAUNCH(false, false, 512); }
+                } else {
+                    if (direct) { if (epi) UP_LAUNCH(true, true, 1024); else UP_LAUNCH(true, false, 1024); }
+                    else { if (epi) UP_LAUNCH(false, true, 1024); else UP_LAUNCH(false, false, 1024); }
+                }
+#undef UP_LAUNCH
+                HIPCHK(hipGetLastError());
+            } else
+                CHK(dispatch_kron2(s, base | KF_NODW | (s->use_lds ? KF_LDS : 0), A, nblocks));
+            if (multi) HIPCHK(hipStreamWaitEvent(s->stream, s->ev_gather, 0));
+            if (s->extra) CHK(dispatch_kron2(s, base | KF_NOLOCAL, A, nblocks));   // Jx/Jp and phonon cases: row-wise dw pass
+            else {
+                DwArgs D{};
+                D.DimUp = A.DimUp; D.DimDw = A.DimDw; D.DimPh = A.DimPh; D.Qdw = A.Qdw; D.dw0 = A.dw0;
+                D.dwc = A.dwc; D.dwv = A.dwv; D.dww = A.dww; D.v = v; D.vfull = A.vfull; D.out = out; D.scal = s->scal.p; D.partial = s->partial.p;
+                D.w = s->dw_w; D.wshift = 0; while ((1 << D.wshift) < D.w) D.wshift++;
+                const int dv = s->dw_variant;
+                const bool vec2 = dv >= 2 && (H.DimUp % 2 == 0) && D.w >= 4 && D.dww <= 64;
+                D.ntiles = (int32_t)cdiv(H.DimUp, D.w);
+                D.R = vec2 ? std::min(64, s->dw_rows) : 256 / D.w;
+                D.chunks = (int32_t)cdiv(H.Qdw * H.DimPh, D.R);
+                nblocks = 8 * cdiv(D.ntiles, 8) * (int64_t)D.chunks;
+                if (!vec2) {
+                    if (epi) hipLaunchKernelGGL(k_dwpass<true>, dim3((unsigned)nblocks), dim3(256), 0, s->stream, D);
+                    else hipLaunchKernelGGL(k_dwpass<false>, dim3((unsigned)nblocks), dim3(256), 0, s->stream, D);
+                } else if (dv == 2) {
+                    if (epi) hipLaunchKernelGGL((k_dwpass2<true, false>), dim3((unsigned)nblocks), dim3(256), 0, s->stream, D);
+                    else hipLaunchKernelGGL((k_dwpass2<false, false>), dim3((unsigned)nblocks), dim3(256), 0, s->stream, D);
+                } else {
+                    if (epi) hipLaunchKernelGGL((k_dwpass2<true, true>), dim3((unsigned)nblocks), dim3(256), 0, s->stream, D);
+                    else hipLaunchKernelGGL((k_dwpass2<false, true>), dim3((unsigned)nblocks), dim3(256), 0, s->stream, D);
+                }
+                HIPCHK(hipGetLastError());
+            }
         }
     } else {
         GenArgs A{};

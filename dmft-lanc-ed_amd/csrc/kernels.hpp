@@ -227,6 +227,189 @@ __global__ void __launch_bounds__(1024) k_kron2(Kron2Args A)
 }
 
 // ---------------------------------------------------------------------------------------------
+// Local pass (diagonal + up hops) of the split product, persistent form: one 1024-thread
+// workgroup per CU walks rows b, b+grid, ...  The row is staged in LDS for the up-hop gathers;
+// the NEXT row is already on its way into registers while the current one is computed, so the
+// HBM stream never waits for the barrier.  H_up is read in a packed image (16-bit column +
+// 8-bit term code per hop: 3 B instead of 12 B per entry, amplitudes from a tiny LDS table)
+// because every workgroup re-reads the whole factor for every row it owns.
+// ---------------------------------------------------------------------------------------------
+struct UpArgs {
+    int32_t DimUp, DimPh; int64_t Qdw, dw0, nrows;
+    const uint32_t *pcols, *pcodes; int32_t upw;      // packed ELL: [ceil(upw/2)][DimUp], [ceil(upw/4)][DimUp]
+    const double *tval; int32_t nterms;
+    const double *diag, *Eup, *Edw, *cross; const int32_t *mapup, *mapdw; int32_t impmask, nI; double econst;
+    const double *v; double *out; const double *uprev; const double *scal;
+};
+
+template <bool DIRECT, bool EPI, int NT>
+__global__ void __launch_bounds__(NT) k_uppass(UpArgs A)
+{
+    extern __shared__ double lds[];
+    constexpr int MAXQ = 13312 / NT;               // DimUp <= 13312 (Ns <= 16 at half filling)
+    constexpr int MAXC = 4;                        // <= 16 hops per up configuration
+    const int DimUp = A.DimUp, tid = threadIdx.x;
+    double *tv = lds + ((DimUp + 1) & ~1);
+    for (int t = tid; t < A.nterms; t += NT) tv[t] = A.tval[t];
+    const int nq = (DimUp + NT - 1) / NT;
+    const int ncw = (A.upw + 1) >> 1, ndw = (A.upw + 3) >> 2;
+    // Two software pipelines.  Over rows: the NEXT row of v is requested into registers while
+    // the current row is computed out of LDS.  Inside a row: the operands of element q+1 (stored
+    // diagonal, u_prev, packed hops) are requested before element q is computed.
+    double xr[MAXQ];
+    int64_t row = blockIdx.x;
+    if (row < A.nrows) {
+#pragma unroll
+        for (int q = 0; q < MAXQ; q++) { const int i = tid + q * NT; xr[q] = (q < nq && i < DimUp) ? A.v[row * DimUp + i] : 0.0; }
+    }
+    double s_cur = 1.0, c_prev = 0.0;
+    if (EPI) { s_cur = A.scal[SC_SCUR]; c_prev = A.scal[SC_BETA] * A.scal[SC_SPREV]; }
+    struct Ops { double d, u; uint32_t codes[MAXC], cols[2 * MAXC]; };
+    while (row < A.nrows) {
+        const int64_t idwl = row % A.Qdw, idw = A.dw0 + idwl;
+        auto load_ops = [&](int i, Ops &o) {
+            if (!DIRECT) o.d = A.diag[idwl * DimUp + i];
+            if (EPI) o.u = A.uprev[row * DimUp + i];
+#pragma unroll
+            for (int c = 0; c < MAXC; c++) if (c < ndw) o.codes[c] = A.pcodes[(int64_t)c * DimUp + i];
+#pragma unroll
+            for (int c = 0; c < 2 * MAXC; c++) if (c < ncw) o.cols[c] = A.pcols[(int64_t)c * DimUp + i];
+        };
+        Ops cur, nxt;
+        if (tid < DimUp) load_ops(tid, cur);
+#pragma unroll
+        for (int q = 0; q < MAXQ; q++) { const int i = tid + q * NT; if (q < nq && i < DimUp) lds[i] = xr[q]; }
+        __syncthreads();
+        const int64_t next = row + gridDim.x;
+        if (next < A.nrows) {
+#pragma unroll
+            for (int q = 0; q < MAXQ; q++) { const int i = tid + q * NT; if (q < nq && i < DimUp) xr[q] = A.v[next * DimUp + i]; }
+        }
+        uint32_t mdw = 0; double edw = 0.0;
+        if (DIRECT) { mdw = (uint32_t)A.mapdw[idw] & A.impmask; edw = A.Edw[idw] + A.econst; }
+        for (int i = tid; i < DimUp; i += NT) {
+            if (i + NT < DimUp) load_ops(i + NT, nxt);
+            const double x = lds[i];
+            double dval;
+            if (DIRECT) dval = edw + A.Eup[i] + A.cross[((uint32_t)A.mapup[i] & A.impmask) * A.nI + mdw];
+            else dval = cur.d;
+            double acc = dval * x;
+#pragma unroll
+            for (int c = 0; c < MAXC; c++)
+                if (c < ndw) {
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        const uint32_t code = (cur.codes[c] >> (8 * e)) & 0xffu;
+                        const uint32_t col = (cur.cols[2 * c + (e >> 1)] >> (16 * (e & 1))) & 0xffffu;
+                        double t = tv[code & 0x7fu];
+                        t = (code & 0x80u) ? -t : t;
+                        acc += t * lds[col];
+                    }
+                }
+            if (EPI) A.out[row * DimUp + i] = s_cur * acc - c_prev * cur.u;
+            else A.out[row * DimUp + i] = acc;
+            cur = nxt;
+        }
+        __syncthreads();
+        row = next;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// dw-hop pass, column tiled: out(iup,idw) += sum_k Hdw[idw,k] * v(iup, jdw_k).
+// Every neighbour row jdw is needed by ~Ns/2 different idw rows that are spread over the whole
+// sector, so a row-major sweep re-fetches v about Ns/2 times from HBM.  Here the sweep is over
+// narrow iup tiles instead: the slab v(tile, all idw) (DimDw*w*8 bytes, 3.3 MB for w=32 at
+// Ns=16) stays in one XCD's 4 MB L2 while that XCD walks all idw rows of the tile, so the
+// gathers are L2 hits and HBM sees v once.  Tiles are dealt to XCDs by blockIdx % 8 (the
+// observed round-robin dispatch; speed only -- any placement gives the same result).
+// ---------------------------------------------------------------------------------------------
+struct DwArgs {
+    int32_t DimUp, DimDw, DimPh; int64_t Qdw, dw0;
+    const int32_t *dwc; const double *dwv; int32_t dww;
+    const double *v, *vfull; double *out;
+    const double *scal; double *partial;
+    int32_t w, wshift, ntiles, R, chunks;
+};
+
+template <bool EPI>
+__global__ void __launch_bounds__(256) k_dwpass(DwArgs A)
+{
+    __shared__ double red[4];
+    const int xcd = blockIdx.x & 7; const int64_t sidx = blockIdx.x >> 3;
+    const int64_t tl = sidx / A.chunks; const int chunk = (int)(sidx - tl * A.chunks);
+    const int tile = (int)(tl * 8 + xcd);
+    double asum = 0.0;
+    if (tile < A.ntiles) {
+        const int j = threadIdx.x & (A.w - 1), r = threadIdx.x >> A.wshift;
+        const int64_t row = (int64_t)chunk * A.R + r;
+        const int iup = tile * A.w + j;
+        if (row < A.Qdw * A.DimPh && iup < A.DimUp) {
+            const int iph = (int)(row / A.Qdw);
+            const int64_t idw = A.dw0 + (row - (int64_t)iph * A.Qdw);
+            const int64_t e = row * A.DimUp + iup, fbase = (int64_t)iph * A.DimDw * A.DimUp + iup;
+            const int32_t *dwc = A.dwc + idw * A.dww; const double *dwv = A.dwv + idw * A.dww;
+            double acc = 0.0;
+            for (int k = 0; k < A.dww; k++) acc += dwv[k] * A.vfull[fbase + (int64_t)dwc[k] * A.DimUp];
+            if (EPI) { const double s_cur = A.scal[SC_SCUR]; const double wv = A.out[e] + s_cur * acc; A.out[e] = wv; asum = (s_cur * A.v[e]) * wv; }
+            else A.out[e] += acc;
+        }
+    }
+    if (EPI) { double rr = block_sum(asum, red); if (threadIdx.x == 0) A.partial[blockIdx.x] = rr; }
+}
+
+// Same pass with two iup per lane (16-byte loads/stores; needs DimUp even) and the Hdw rows of
+// the block staged in LDS once, which removes the per-lane table loads: ~5x fewer vector-memory
+// instructions per element than k_dwpass.
+typedef double dbl2v __attribute__((ext_vector_type(2)));
+template <bool EPI, bool NT>
+__global__ void __launch_bounds__(256) k_dwpass2(DwArgs A)
+{
+    __shared__ double red[4];
+    __shared__ double tv[64 * 64];     // [row in block][k]  (<= 64 rows x <= 64 hops)
+    __shared__ int32_t tc[64 * 64];
+    const int xcd = blockIdx.x & 7; const int64_t sidx = blockIdx.x >> 3;
+    const int64_t tl = sidx / A.chunks; const int chunk = (int)(sidx - tl * A.chunks);
+    const int tile = (int)(tl * 8 + xcd);
+    double asum = 0.0;
+    if (tile < A.ntiles) {
+        const int64_t nrows = A.Qdw * A.DimPh, row0 = (int64_t)chunk * A.R;
+        const int rb = (int)((nrows - row0) < A.R ? (nrows - row0) : A.R);   // rows in this block
+        for (int t = threadIdx.x; t < rb * A.dww; t += 256) {
+            const int r = t / A.dww, k = t - r * A.dww;
+            const int64_t row = row0 + r; const int64_t idw = A.dw0 + (row % A.Qdw);
+            tv[t] = A.dwv[idw * A.dww + k]; tc[t] = A.dwc[idw * A.dww + k];
+        }
+        __syncthreads();
+        const int lpr = A.w >> 1;                    // lanes per row
+        const int j = threadIdx.x & (lpr - 1), r0 = threadIdx.x >> (A.wshift - 1), rstep = 256 >> (A.wshift - 1);
+        const int iup = tile * A.w + 2 * j;
+        const double s_cur = EPI ? A.scal[SC_SCUR] : 1.0;
+        if (iup < A.DimUp)
+            for (int r = r0; r < rb; r += rstep) {
+                const int64_t row = row0 + r;
+                const int iph = (int)(row / A.Qdw);
+                const int64_t e = row * A.DimUp + iup, fbase = (int64_t)iph * A.DimDw * A.DimUp + iup;
+                dbl2v acc = {0.0, 0.0};
+                const double *tvr = tv + r * A.dww; const int32_t *tcr = tc + r * A.dww;
+                for (int k = 0; k < A.dww; k++) {
+                    const dbl2v x = *reinterpret_cast<const dbl2v *>(A.vfull + fbase + (int64_t)tcr[k] * A.DimUp);
+                    acc += tvr[k] * x;
+                }
+                dbl2v *po = reinterpret_cast<dbl2v *>(A.out + e);
+                dbl2v o = NT ? __builtin_nontemporal_load(po) : *po;
+                if (EPI) {
+                    const dbl2v vl = *reinterpret_cast<const dbl2v *>(A.v + e);
+                    o += s_cur * acc;
+                    asum += (s_cur * vl.x) * o.x + (s_cur * vl.y) * o.y;
+                } else o += acc;
+                if (NT) __builtin_nontemporal_store(o, po); else *po = o;
+            }
+    }
+    if (EPI) { double rr = block_sum(asum, red); if (threadIdx.x == 0) A.partial[blockIdx.x] = rr; }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Generic multi-factor operator (ed_total_ud=F: spMatVec_orbs / directMatVec_orbs,
 // ED_HAMILTONIAN_SPARSE_HxV.f90:487-564, ED_HAMILTONIAN_DIRECT_HxV.f90:100-171).
 // State index is the mixed-radix number over [DimUps..., DimDws...]; factor k acts on digit k.
@@ -298,6 +481,7 @@ struct TabArgs {
     const int32_t *map, *rank;
     const int32_t *talpha, *tbeta; const double *tval;
     int32_t *ellc; double *ellv;
+    uint32_t *pcols, *pcodes;   // optional packed image (k_uppass), zeroed by the caller
     const double *lin; int32_t nlev; int32_t impmask; double pair;  // E[i] = sum lin[l] n_l + pair * C(#imp,2)
     double *E;
 };
@@ -307,7 +491,7 @@ __global__ void __launch_bounds__(256) k_direct_tables(TabArgs A)
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= A.dim) return;
     const uint32_t mi = (uint32_t)A.map[i];
-    int32_t cj[64]; double cv[64]; int n = 0;
+    int32_t cj[64]; double cv[64]; uint8_t ct[64]; int n = 0;
     for (int t = 0; t < A.nterms; t++) {
         const uint32_t ba = 1u << (A.talpha[t] - 1), bb = 1u << (A.tbeta[t] - 1);
         if (!(mi & ba) || (mi & bb)) continue;
@@ -319,8 +503,21 @@ __global__ void __launch_bounds__(256) k_direct_tables(TabArgs A)
         bool dup = false;
         for (int q = 0; q < n; q++) if (cj[q] == j) { cv[q] += val; dup = true; break; }
         if (dup) continue;
-        while (p > 0 && cj[p - 1] > j) { cj[p] = cj[p - 1]; cv[p] = cv[p - 1]; p--; }   // keep cols ascending
-        cj[p] = j; cv[p] = val; n++;
+        while (p > 0 && cj[p - 1] > j) { cj[p] = cj[p - 1]; cv[p] = cv[p - 1]; ct[p] = ct[p - 1]; p--; }   // keep cols ascending
+        cj[p] = j; cv[p] = val; ct[p] = (uint8_t)(t | ((sg & 1) ^ (A.tval[t] < 0.0 ? 1 : 0) ? 0x80 : 0)); n++;
+    }
+    if (A.pcols) {
+        const int ncw = (A.width + 1) >> 1, ndw = (A.width + 3) >> 2;
+        for (int c = 0; c < ncw; c++) {
+            uint32_t w = 0;
+            for (int e = 0; e < 2; e++) { const int q = 2 * c + e; w |= (uint32_t)(q < n ? cj[q] : i) << (16 * e); }
+            A.pcols[(int64_t)c * A.dim + i] = w;
+        }
+        for (int c = 0; c < ndw; c++) {
+            uint32_t w = 0;
+            for (int e = 0; e < 4; e++) { const int q = 4 * c + e; w |= (uint32_t)(q < n ? ct[q] : 127u) << (8 * e); }
+            A.pcodes[(int64_t)c * A.dim + i] = w;
+        }
     }
     for (int k = 0; k < A.width; k++) {
         int32_t j = k < n ? cj[k] : i; double val = k < n ? cv[k] : 0.0;
