@@ -1010,6 +1010,64 @@ int edgpu_lanczos_time(edgpu_handle h, int32_t nwarm, int32_t niter, float *ms_p
     return EDGPU_OK;
 }
 
+// ---- O|state> between two live sectors (GF builders, ED_GF_NORMAL.f90:190-213, 264-283) ------
+int edgpu_apply_op(edgpu_handle from, edgpu_handle to, int32_t iorb, int32_t ispin, int32_t dagger,
+                   const double *vin_dev, double *vout_dev, double *norm2)
+{
+    if (!from || !to || !vin_dev || !vout_dev || !norm2) return fail(EDGPU_EINVAL, "edgpu_apply_op: null argument");
+    const SectorHost &F = from->H, &T = to->H;
+    if (F.Ns_Ud != T.Ns_Ud || F.Ns_Orb != T.Ns_Orb || F.DimPh != T.DimPh || F.desc.Norb != T.desc.Norb)
+        return fail(EDGPU_EINVAL, "edgpu_apply_op: sectors belong to different models");
+    if (from->multi || to->multi) return fail(EDGPU_EUNSUPPORTED, "edgpu_apply_op: single rank only for now");
+    if (iorb < 1 || iorb > F.desc.Norb || ispin < 1 || ispin > 2) return fail(EDGPU_EINVAL, "edgpu_apply_op: bad iorb/ispin");
+    // ED_GF_NORMAL.f90:138-145: (ialfa,iorb1) = (1,iorb) for ed_total_ud else (iorb,1); ibeta = ialfa+(ispin-1)*Ns_Ud
+    const int ialfa = F.desc.ed_total_ud ? 1 : iorb, iorb1 = F.desc.ed_total_ud ? iorb : 1;
+    const int fb = (ialfa - 1) + (ispin - 1) * F.Ns_Ud;
+    for (int k = 0; k < 2 * F.Ns_Ud; k++) {
+        int want = F.fac[k].npart + ((k == fb) ? (dagger ? 1 : -1) : 0);
+        if (T.fac[k].npart != want) return fail(EDGPU_EINVAL, "edgpu_apply_op: target sector is not getCDGsector/getCsector of the source");
+    }
+    HIPCHK(hipSetDevice(to->device));
+    OpArgs A{};
+    A.nfac = 2 * F.Ns_Ud; A.fb = fb; A.bitpos = iorb1 - 1; A.dagger = dagger ? 1 : 0; A.DimPh = T.DimPh;
+    for (int k = 0; k < A.nfac; k++) { A.dims_to[k] = T.fac[k].dim; A.dims_from[k] = F.fac[k].dim; }
+    A.map_to_fb = to->fac[fb]->map.p; A.rank_from_fb = from->fac[fb]->rank.p;
+    A.nel_to = to->nloc_el; A.nel_from = from->nloc_el; A.vin = vin_dev; A.vout = vout_dev;
+    const int nb = (int)std::max<int64_t>(1, std::min<int64_t>(cdiv(to->nloc, 256), 8192));
+    HIPCHK(hipStreamSynchronize(from->stream));
+    hipLaunchKernelGGL(k_apply_op, dim3(nb), dim3(256), 0, to->stream, A);
+    HIPCHK(hipGetLastError());
+    CHK(reduce_dot(to, vout_dev, vout_dev));                 // norm2 = <v|v>, then v /= sqrt(norm2)
+    HIPCHK(hipMemcpyAsync(norm2, to->scal.p + SC_TMP, 8, hipMemcpyDeviceToHost, to->stream));
+    HIPCHK(hipStreamSynchronize(to->stream));
+    if (*norm2 > 0.0) {
+        hipLaunchKernelGGL(k_scalar_step, dim3(1), dim3(1), 0, to->stream, to->scal.p, to->alphas.p, to->betas.p, (const double *)nullptr, 0, 2);
+        hipLaunchKernelGGL(k_scale, dim3(nb), dim3(256), 0, to->stream, vout_dev, to->scal.p, (int)SC_SCUR, to->nloc);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(to->stream));
+    }
+    return EDGPU_OK;
+}
+
+// One Green's-function Lanczos leg entirely in HBM: O|state>, normalise, sp_lanc_tridiag.
+// state_host: vecdim(from) doubles on the host.  Returns norm2, alanc/blanc (nlanc) and nused.
+int edgpu_gf_lanczos(edgpu_handle from, edgpu_handle to, int32_t iorb, int32_t ispin, int32_t dagger,
+                     const double *state_host, int32_t nlanc, double threshold, double *norm2,
+                     double *alanc, double *blanc, int32_t *nused)
+{
+    if (!from || !to || !state_host || !alanc || !blanc || !nused || !norm2) return fail(EDGPU_EINVAL, "edgpu_gf_lanczos: null argument");
+    HIPCHK(hipSetDevice(to->device));
+    if (from->tmp_in.n != (size_t)from->nloc) { CHK(from->tmp_in.alloc((size_t)from->nloc)); CHK(from->tmp_out.alloc((size_t)from->nloc)); }
+    if (to->tmp_in.n != (size_t)to->nloc) { CHK(to->tmp_in.alloc((size_t)to->nloc)); CHK(to->tmp_out.alloc((size_t)to->nloc)); }
+    HIPCHK(hipMemcpy(from->tmp_in.p, state_host, (size_t)from->nloc * 8, hipMemcpyHostToDevice));
+    CHK(lz_prepare(to, nlanc));
+    CHK(edgpu_apply_op(from, to, iorb, ispin, dagger, from->tmp_in.p, to->tmp_in.p, norm2));
+    for (int i = 0; i < nlanc; i++) { alanc[i] = 0.0; blanc[i] = 0.0; }
+    *nused = 0;
+    if (*norm2 <= 0.0) return EDGPU_OK;
+    return lanczos_tridiag(to, to->tmp_in.p, nlanc, threshold, alanc, blanc, nused);
+}
+
 // ---- step-wise Lanczos for external timing (bench.py): begin, then enqueue steps -----------
 int edgpu_lanczos_bench_begin(edgpu_handle h, int32_t max_steps)
 {

@@ -695,6 +695,41 @@ __global__ void __launch_bounds__(ROWS) k_csr_spmv2(CsrArgs A)
 }
 
 // ---------------------------------------------------------------------------------------------
+// |out> = c^+_{orb,spin} |in>  or  c_{orb,spin} |in>  between two sectors, gather form over the
+// target index (ED_GF_NORMAL.f90:190-213 and 264-283 loop over the source and scatter).
+// The sign involves only the spin string that changes (cdg/c of ED_SETUP.f90:805-831).
+// ---------------------------------------------------------------------------------------------
+struct OpArgs {
+    int32_t nfac, fb, bitpos, dagger, DimPh;        // fb: factor (digit) that changes; bitpos: 0-based level
+    int32_t dims_to[2 * EDGPU_MAX_ORB], dims_from[2 * EDGPU_MAX_ORB];
+    const int32_t *map_to_fb, *rank_from_fb;
+    int64_t nel_to, nel_from;
+    const double *vin; double *vout;
+};
+
+__global__ void __launch_bounds__(256) k_apply_op(OpArgs A)
+{
+    const int64_t N = A.nel_to * A.DimPh;
+    for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < N; j += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t iph = j / A.nel_to; int64_t c = j - iph * A.nel_to;
+        int64_t isrc = 0, stride = 1; double val = 0.0; bool ok = true; double sgn = 1.0;
+        for (int k = 0; k < A.nfac; k++) {
+            int32_t dg = (int32_t)(c % A.dims_to[k]); c /= A.dims_to[k];
+            if (k == A.fb) {
+                const uint32_t r = (uint32_t)A.map_to_fb[dg], bit = 1u << A.bitpos;
+                if (A.dagger ? !(r & bit) : (r & bit)) ok = false;
+                const uint32_t m = A.dagger ? (r & ~bit) : (r | bit);
+                sgn = (__popc(m & (bit - 1u)) & 1) ? -1.0 : 1.0;
+                dg = ok ? A.rank_from_fb[m] : 0;
+            }
+            isrc += (int64_t)dg * stride; stride *= A.dims_from[k];
+        }
+        if (ok) val = sgn * A.vin[isrc + iph * A.nel_from];
+        A.vout[j] = val;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Lanczos vector kernels (SciFortran lanczos_iteration semantics, see lanczos.hpp)
 // ---------------------------------------------------------------------------------------------
 // out[0] = sum(in[0..n)) in a fixed order; single workgroup

@@ -226,6 +226,22 @@ class HvSector:
         check(capi.lib().edgpu_comm_init_callbacks(self._h, self._cb[0], self._cb[1], None))
 
 
+def apply_op(sec_from, sec_to, iorb, ispin, dagger, vin_dev, vout_dev):
+    """O|state> in HBM (ED_GF_NORMAL.f90:190-213, 264-283); returns norm2, vout normalised."""
+    n2 = C.c_double()
+    check(capi.lib().edgpu_apply_op(sec_from._h, sec_to._h, iorb, ispin, 1 if dagger else 0, vin_dev.ptr, vout_dev.ptr, C.byref(n2)))
+    return n2.value
+
+
+def gf_lanczos(sec_from, sec_to, iorb, ispin, dagger, state, nlanc, threshold=1e-12):
+    """One leg of lanc_build_gf_normal_main: (norm2, alanc, blanc, nused)."""
+    state = np.ascontiguousarray(state, np.float64)
+    a = np.zeros(nlanc); b = np.zeros(nlanc); n2 = C.c_double(); nu = C.c_int32()
+    check(capi.lib().edgpu_gf_lanczos(sec_from._h, sec_to._h, iorb, ispin, 1 if dagger else 0, state.ctypes.data, nlanc, threshold,
+                                      C.byref(n2), a.ctypes.data, b.ctypes.data, C.byref(nu)))
+    return n2.value, a, b, nu.value
+
+
 def rccl_unique_id():
     buf = C.create_string_buffer(128)
     check(capi.lib().edgpu_comm_unique_id(buf))

@@ -132,6 +132,18 @@ int edgpu_lanczos_tridiag_device(edgpu_handle h, const double *vin_dev, int32_t 
  * inside the loop: the timed region of bench.py.  Returns mean ms/iteration (HIP events). */
 int edgpu_lanczos_time(edgpu_handle h, int32_t nwarm, int32_t niter, float *ms_per_iter);
 
+/* ---- Green's-function leg: O|state> between two live sectors, in HBM ------
+ * vout(j) = sgn * vin(i) with |j> = c^+_{iorb,ispin}|i> (dagger=1) or c_{iorb,ispin}|i> (dagger=0),
+ * ED_GF_NORMAL.f90:190-213 / 264-283; `to` must be getCDGsector/getCsector of `from`
+ * (ED_SETUP.f90:377-418).  vout is returned normalised, norm2 = <vout|vout> before normalisation
+ * (the weight passed to add_to_lanczos_gf_normal, ED_GF_NORMAL.f90:239). */
+int edgpu_apply_op(edgpu_handle from, edgpu_handle to, int32_t iorb, int32_t ispin, int32_t dagger,
+                   const double *vin_dev, double *vout_dev, double *norm2);
+/* the whole leg: upload state, apply O, normalise, sp_lanc_tridiag in the target sector */
+int edgpu_gf_lanczos(edgpu_handle from, edgpu_handle to, int32_t iorb, int32_t ispin, int32_t dagger,
+                     const double *state_host, int32_t nlanc, double threshold, double *norm2,
+                     double *alanc, double *blanc, int32_t *nused);
+
 /* Step-wise form of the same loop for an external clock (bench.py): `begin` sets up a fixed
  * start vector, `steps` enqueues iterations asynchronously on the library's stream (the caller
  * synchronises the device), `result` returns the mean product-kernel time measured with HIP

@@ -280,3 +280,47 @@ def sp_lanc_eigh(matvec, vect, nitermax, threshold=1e-12, ncheck=10):
         out = out + vin * Z[it - 1, 0]
     out = out / np.sqrt(np.dot(out, out))
     return egs, out, nlanc
+
+
+# --------------------------------------------------------------------------
+# Green's-function leg (ED_GF_NORMAL.f90:124-334), small sectors only
+# --------------------------------------------------------------------------
+def apply_op(S_from, S_to, iorb, ispin, dagger, state):
+    """vvinit of lanc_build_gf_normal_main: loops over the SOURCE states i and scatters
+    vvinit(j) = sgn*state(i) (ED_GF_NORMAL.f90:190-213 for c^+, 264-283 for c).
+    Returns (vvinit normalised, norm2)."""
+    Ns_Ud, Ns_Orb = S_from.Ns_Ud, S_from.Ns_Orb
+    total_ud = S_from.model.get("ed_total_ud", True)
+    ialfa, iorb1 = (1, iorb) if total_ud else (iorb, 1)
+    ibeta = ialfa + (ispin - 1) * Ns_Ud
+    idims = [int(x) for x in list(S_from.DimUps) + list(S_from.DimDws)]
+    jdims = [int(x) for x in list(S_to.DimUps) + list(S_to.DimDws)]
+    HI = [S_from.map(k) for k in range(2 * Ns_Ud)]
+    HJ = [S_to.map(k) for k in range(2 * Ns_Ud)]
+    iel, jel = S_from.DimUp * S_from.DimDw, S_to.DimUp * S_to.DimDw
+    vv = np.zeros(S_to.Dim)
+    for i in range(1, S_from.Dim + 1):
+        iph = (i - 1) // iel + 1
+        i_el = (i - 1) % iel + 1
+        c = i_el - 1; ind = []
+        for d in idims:                       # state2indices
+            ind.append(c % d + 1); c //= d
+        m = int(HI[ibeta - 1][ind[ibeta - 1] - 1])
+        occ = (m >> (iorb1 - 1)) & 1
+        if dagger:
+            if occ != 0:
+                continue
+            r, sgn = cdg_op(iorb1, m)
+        else:
+            if occ != 1:
+                continue
+            r, sgn = c_op(iorb1, m)
+        jnd = list(ind)
+        jnd[ibeta - 1] = binary_search(HJ[ibeta - 1], r)
+        j = jnd[0]; prod = 1                  # indices2state
+        for k in range(1, len(jnd)):
+            prod *= jdims[k - 1]; j += (jnd[k] - 1) * prod
+        j += (iph - 1) * jel
+        vv[j - 1] = sgn * state[i - 1]
+    norm2 = float(vv @ vv)
+    return (vv / np.sqrt(norm2) if norm2 > 0 else vv), norm2

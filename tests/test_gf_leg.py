@@ -1,0 +1,57 @@
+"""Green's-function Lanczos leg on the device (O|gs>, normalise,
+sp_lanc_tridiag) against the oracle restatement and against dense resolvents."""
+import numpy as np
+import pytest
+
+import cases
+from oracle import oracle
+
+pytestmark = pytest.mark.gpu
+
+
+def _gf_from_lanczos(z, norm2, a, b, n, e0, sign):
+    """continued fraction  norm2 / (z -+ (a1-e0) - b2^2/(z -+ (a2-e0) - ...))  (ED_GF_NORMAL.f90:599-654 uses
+    the equivalent pole expansion of the same tridiagonal matrix)"""
+    g = 0.0
+    for k in range(n - 1, -1, -1):
+        bk2 = b[k + 1] ** 2 if k + 1 < n else 0.0
+        g = 1.0 / (z - sign * (a[k] - e0) - bk2 * g)
+    return norm2 * g
+
+
+CASES = [("c_nb5_half", 1, 1), ("c_nb5_half", 1, 2), ("norb2_normal_JxJp", 2, 1), ("orbs_norb2_nb3", 2, 2), ("phonons_nb3_nph3", 1, 1)]
+
+
+@pytest.mark.parametrize("case,iorb,ispin", CASES)
+def test_gf_leg_matches_oracle_and_dense(edgpu_mod, case, iorb, ispin):
+    name, m, nu, nd = [z for z in cases.zoo() if z[0] == case][0]
+    S = oracle.Sector(m, nu, nd)
+    H = S.hmat(); w, U = np.linalg.eigh(H); e0, gs = w[0], U[:, 0]
+    G0 = edgpu_mod.HvSector(m, nu, nd, storage="direct")
+    total_ud = m.get("ed_total_ud", True)
+    ia = 0 if total_ud else iorb - 1
+    for dagger in (True, False):
+        nu2, nd2 = list(nu), list(nd)
+        (nu2 if ispin == 1 else nd2)[ia] += 1 if dagger else -1
+        St = oracle.Sector(m, nu2, nd2)
+        vref, n2ref = oracle.apply_op(S, St, iorb, ispin, dagger, gs)
+        Gt = edgpu_mod.HvSector(m, nu2, nd2, storage="kron")
+        din, dout = edgpu_mod.DeviceVector(S.Dim).upload(gs), edgpu_mod.DeviceVector(St.Dim)
+        n2 = edgpu_mod.apply_op(G0, Gt, iorb, ispin, dagger, din, dout)
+        assert abs(n2 - n2ref) <= 1e-13
+        np.testing.assert_allclose(dout.download(), vref, rtol=0, atol=1e-14)   # a signed copy: exact up to the 1/sqrt scale
+        nl = min(St.Dim, 60)
+        n2b, a, b, used = edgpu_mod.gf_lanczos(G0, Gt, iorb, ispin, dagger, gs, nl)
+        a_ref, b_ref, used_ref = oracle.sp_lanc_tridiag(St.spmatvec, vref, nl)
+        assert used == used_ref and abs(n2b - n2ref) <= 1e-13
+        k = min(used, 25)
+        np.testing.assert_allclose(a[:k], a_ref[:k], rtol=1e-9, atol=1e-9)
+        np.testing.assert_allclose(b[1:k], b_ref[1:k], rtol=1e-9, atol=1e-9)
+        # G(i w_n) from the GPU coefficients vs the dense resolvent <v|(z -+ (H_t - e0))^-1|v>*norm2: 1e-8
+        Ht = St.hmat(); sign = 1.0 if dagger else -1.0
+        for wn in (0.3, 1.0, 3.0):
+            z = 1j * wn
+            dense = n2ref * (vref @ np.linalg.solve(z * np.eye(St.Dim) - sign * (Ht - e0 * np.eye(St.Dim)), vref))
+            assert abs(_gf_from_lanczos(z, n2b, a, b, used, e0, sign) - dense) <= 1e-8 * max(1.0, abs(dense))
+        Gt.close()
+    G0.close()
