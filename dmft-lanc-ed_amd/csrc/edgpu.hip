@@ -110,6 +110,8 @@ struct edgpu_sector_s {
     DevBuf<int32_t> stride;
     // explicit CSR
     DevBuf<int64_t> csr_rowptr, uppre, dwpre; DevBuf<int32_t> csr_cols; DevBuf<double> csr_vals;
+    DevBuf<int64_t> csrD_rowptr; DevBuf<int32_t> csrD_cols; DevBuf<double> csrD_vals;   // dw block of the split form
+    bool csr_split = false; int64_t csrL_nnz = 0, csrD_nnz = 0; int32_t csrD_rpb = 64, csrD_bpr = 0; int csrD_nt = 1; bool csrL_small = false, csrD_small = false, csr_persist = false; int csr_pgrid = 4096;
     int64_t csr_nnz = 0; int32_t csr_rpb = 0, csr_bpr = 0, csr_tile = 1, csr_variant = 6;
     // work vectors
     DevBuf<double> vfull, tmp_in, tmp_out, lz[5], scal, alphas, betas, zvec, partial, partial2;
@@ -234,16 +236,42 @@ static int build_csr(S *s)
     }
     s->csr_nnz = dwpre[H.Qdw];
     CHK(s->uppre.upload(uppre)); CHK(s->dwpre.upload(dwpre));
-    CHK(s->csr_rowptr.alloc((size_t)s->nloc_el + 1)); CHK(s->csr_cols.alloc((size_t)s->csr_nnz)); CHK(s->csr_vals.alloc((size_t)s->csr_nnz));
+    // Two storage forms of the same explicit matrix: one CSR, or (default for large sectors) two CSR
+    // blocks H = H_loc + H_dw so that each block can be streamed in the order that keeps ITS gathers
+    // cache resident (rows for the up hops, XCD-owned column tiles for the dw hops).
+    s->csr_split = dbg_int("EDGPU_CSR_SPLIT", (H.DimUp * H.DimDw * 8 > ((int64_t)48 << 20)) ? 1 : 0) != 0;
+    s->csrL_nnz = H.Qdw * uppre[up.dim]; s->csrD_nnz = s->csr_nnz - s->csrL_nnz;
     CsrBuildArgs A{};
     A.DimUp = (int32_t)H.DimUp; A.DimDw = (int32_t)H.DimDw; A.Qdw = H.Qdw; A.dw0 = H.dw0;
     A.uprp = s->fac[0]->rowptr.p; A.upc = s->fac[0]->cols.p; A.upv = s->fac[0]->vals.p;
     A.dwrp = s->fac[1]->rowptr.p; A.dwc = s->fac[1]->cols.p; A.dwv = s->fac[1]->vals.p;
     A.uppre = s->uppre.p; A.dwpre = s->dwpre.p; A.diag = s->diag.p;
-    A.rowptr = s->csr_rowptr.p; A.cols = s->csr_cols.p; A.vals = s->csr_vals.p;
-    hipLaunchKernelGGL(k_csr_build, dim3((unsigned)cdiv(s->nloc_el + 1, 256)), dim3(256), 0, s->stream, A);
+    const unsigned gb = (unsigned)cdiv(s->nloc_el + 1, 256);
+    if (!s->csr_split) {
+        CHK(s->csr_rowptr.alloc((size_t)s->nloc_el + 1)); CHK(s->csr_cols.alloc((size_t)s->csr_nnz)); CHK(s->csr_vals.alloc((size_t)s->csr_nnz));
+        A.rowptr = s->csr_rowptr.p; A.cols = s->csr_cols.p; A.vals = s->csr_vals.p;
+        hipLaunchKernelGGL(k_csr_build, dim3(gb), dim3(256), 0, s->stream, A, 0);
+    } else {
+        CHK(s->csr_rowptr.alloc((size_t)s->nloc_el + 1)); CHK(s->csr_cols.alloc((size_t)s->csrL_nnz)); CHK(s->csr_vals.alloc((size_t)s->csrL_nnz));
+        CHK(s->csrD_rowptr.alloc((size_t)s->nloc_el + 1)); CHK(s->csrD_cols.alloc((size_t)s->csrD_nnz)); CHK(s->csrD_vals.alloc((size_t)s->csrD_nnz));
+        A.rowptr = s->csr_rowptr.p; A.cols = s->csr_cols.p; A.vals = s->csr_vals.p;
+        hipLaunchKernelGGL(k_csr_build, dim3(gb), dim3(256), 0, s->stream, A, 1);
+        A.rowptr = s->csrD_rowptr.p; A.cols = s->csrD_cols.p; A.vals = s->csrD_vals.p;
+        hipLaunchKernelGGL(k_csr_build, dim3(gb), dim3(256), 0, s->stream, A, 2);
+        int64_t ndmax = 0;
+        for (int64_t q = 0; q < H.Qdw; q++) ndmax = std::max<int64_t>(ndmax, dw.rowptr[H.dw0 + q + 1] - dw.rowptr[H.dw0 + q]);
+        s->csrD_rpb = (int32_t)std::min<int64_t>(dbg_int("EDGPU_CSRD_ROWS", 64), 1152 / std::max<int64_t>(ndmax, 1));
+        if (s->csrD_rpb < 1) return fail(EDGPU_EUNSUPPORTED, "edgpu: a CSR row exceeds the LDS tile");
+        s->csrD_bpr = (int32_t)cdiv(H.DimUp, s->csrD_rpb);
+        s->csrD_nt = dbg_int("EDGPU_CSRD_NT", 1);
+        maxrow = 1 + upmax;
+        s->csrL_small = (1 + upmax) * 64 <= 640 && dbg_int("EDGPU_CSR_SMALL", 1);     // smaller LDS image -> more resident workgroups
+        s->csrD_small = ndmax * s->csrD_rpb <= 640 && dbg_int("EDGPU_CSR_SMALL", 1);
+    }
     HIPCHK(hipGetLastError());
     s->csr_variant = dbg_int("EDGPU_CSR_VARIANT", 6);
+    s->csr_persist = dbg_int("EDGPU_CSR_PERSIST", 0) != 0 && s->csr_variant == 6;   // measured: no faster than the plain form
+    s->csr_pgrid = std::max(8, dbg_int("EDGPU_CSR_PGRID", 4096));
     const int v_ = s->csr_variant;
     const int CAP = (v_ == 3 || v_ == 4) ? 2304 : ((v_ == 5 || v_ == 6) ? 1152 : 4608), RMAX = (v_ == 3 || v_ == 4) ? 128 : ((v_ == 5 || v_ == 6) ? 64 : 256);
     s->csr_rpb = (int32_t)std::min<int64_t>(RMAX, CAP / std::max<int64_t>(maxrow, 1));
@@ -261,6 +289,7 @@ static int64_t max_partials(const S *s)
         n = std::max<int64_t>(n, 8 * cdiv(cdiv(s->H.DimUp, w), 8) * cdiv(s->H.Qdw * s->H.DimPh, std::max(R, 1)));
     }
     if (s->csr_bpr) n = std::max<int64_t>(n, (int64_t)s->csr_bpr * s->H.Qdw);
+    if (s->csrD_bpr) n = std::max<int64_t>(n, 8 * cdiv(s->csrD_bpr, 8) * s->H.Qdw);
     return n;
 }
 
@@ -322,7 +351,7 @@ static int create(const edgpu_desc *desc, S **out)
     if (desc->storage != EDGPU_STORE_DIRECT) { CHK(build_diag(s.get())); s->bytes_stored = s->nloc_el * 8; }
     if (desc->storage == EDGPU_STORE_CSR) {
         CHK(build_csr(s.get()));
-        s->bytes_stored = s->csr_nnz * 12 + (s->nloc_el + 1) * 8;
+        s->bytes_stored = s->csr_nnz * 12 + (s->nloc_el + 1) * 8 * (s->csr_split ? 2 : 1);
     }
     s->multi = desc->mpi_size > 1 || (desc->reserved & 1);   // reserved bit 0: run the exchange path even on one rank (tests)
     if (s->multi) CHK(s->vfull.alloc((size_t)(H.DimUp * H.DimDw * H.DimPh)));
@@ -489,14 +518,35 @@ static int hxv(S *s, const double *v, double *out, bool epi, const double *uprev
         A.x = multi ? s->vfull.p : v; A.y = out; A.v_local = v; A.uprev = uprev; A.scal = s->scal.p; A.partial = s->partial.p; A.epi = epi; A.xcd_rows = dbg_int("EDGPU_CSR_XCD", 0);
         // the column index is global; on one GPU local == global
         nblocks = (int64_t)s->csr_bpr * H.Qdw;
-        if (s->csr_variant == 1) hipLaunchKernelGGL(k_csr_spmv<4608>, dim3((unsigned)nblocks), dim3(256), 0, s->stream, A);
+        A.pass = s->csr_split ? 1 : 0; A.coltiles = 0;
+        if (s->csr_variant == 1 && !s->csr_split) hipLaunchKernelGGL(k_csr_spmv<4608>, dim3((unsigned)nblocks), dim3(256), 0, s->stream, A);
         else if (s->csr_variant == 2) hipLaunchKernelGGL((k_csr_spmv2<256, 4608, false>), dim3((unsigned)nblocks), dim3(256), 0, s->stream, A);
         else if (s->csr_variant == 3) hipLaunchKernelGGL((k_csr_spmv2<128, 2304, false>), dim3((unsigned)nblocks), dim3(128), 0, s->stream, A);
         else if (s->csr_variant == 4) hipLaunchKernelGGL((k_csr_spmv2<128, 2304, true>), dim3((unsigned)nblocks), dim3(128), 0, s->stream, A);
         else if (s->csr_variant == 5) hipLaunchKernelGGL((k_csr_spmv2<64, 1152, true>), dim3((unsigned)nblocks), dim3(64), 0, s->stream, A);
-        else if (s->csr_variant == 6) hipLaunchKernelGGL((k_csr_spmv2<64, 1152, false>), dim3((unsigned)nblocks), dim3(64), 0, s->stream, A);
-        else hipLaunchKernelGGL((k_csr_spmv2<256, 4608, true>), dim3((unsigned)nblocks), dim3(256), 0, s->stream, A);
+        else if (s->csr_variant == 7) hipLaunchKernelGGL((k_csr_spmv2<256, 4608, true>), dim3((unsigned)nblocks), dim3(256), 0, s->stream, A);
+        else if (s->csr_persist && s->csr_split && s->csrL_small) { nblocks = std::min<int64_t>(nblocks, s->csr_pgrid); hipLaunchKernelGGL((k_csr_spmv3<640, false>), dim3((unsigned)nblocks), dim3(64), 0, s->stream, A); }
+        else if (s->csr_persist && !s->csr_split && s->csr_rpb <= 64) { nblocks = std::min<int64_t>(nblocks, s->csr_pgrid); hipLaunchKernelGGL((k_csr_spmv3<1152, false>), dim3((unsigned)nblocks), dim3(64), 0, s->stream, A); }
+        else if (s->csr_split && s->csrL_small) hipLaunchKernelGGL((k_csr_spmv2<64, 640, false>), dim3((unsigned)nblocks), dim3(64), 0, s->stream, A);
+        else hipLaunchKernelGGL((k_csr_spmv2<64, 1152, false>), dim3((unsigned)nblocks), dim3(64), 0, s->stream, A);
         HIPCHK(hipGetLastError());
+        if (s->csr_split) {
+            A.rowptr = s->csrD_rowptr.p; A.cols = s->csrD_cols.p; A.vals = s->csrD_vals.p;
+            A.rows_per_block = s->csrD_rpb; A.blocks_per_row = s->csrD_bpr; A.pass = 2; A.coltiles = 1; A.xcd_rows = 0;
+            nblocks = 8 * cdiv(s->csrD_bpr, 8) * H.Qdw;
+            if (s->csr_persist && s->csrD_small) {
+                nblocks = std::min<int64_t>(nblocks, s->csr_pgrid & ~7);
+                if (s->csrD_nt) hipLaunchKernelGGL((k_csr_spmv3<640, true>), dim3((unsigned)nblocks), dim3(64), 0, s->stream, A);
+                else hipLaunchKernelGGL((k_csr_spmv3<640, false>), dim3((unsigned)nblocks), dim3(64), 0, s->stream, A);
+            } else if (s->csrD_small) {
+                if (s->csrD_nt) hipLaunchKernelGGL((k_csr_spmv2<64, 640, true>), dim3((unsigned)nblocks), dim3(64), 0, s->stream, A);
+                else hipLaunchKernelGGL((k_csr_spmv2<64, 640, false>), dim3((unsigned)nblocks), dim3(64), 0, s->stream, A);
+            } else {
+                if (s->csrD_nt) hipLaunchKernelGGL((k_csr_spmv2<64, 1152, true>), dim3((unsigned)nblocks), dim3(64), 0, s->stream, A);
+                else hipLaunchKernelGGL((k_csr_spmv2<64, 1152, false>), dim3((unsigned)nblocks), dim3(64), 0, s->stream, A);
+            }
+            HIPCHK(hipGetLastError());
+        }
     } else if (s->two_factor) {
         Kron2Args A{};
         A.DimUp = (int32_t)H.DimUp; A.DimDw = (int32_t)H.DimDw; A.DimPh = H.DimPh; A.Norb = d.Norb; A.Qdw = H.Qdw; A.dw0 = H.dw0;
@@ -905,12 +955,31 @@ int edgpu_csr_rows(edgpu_handle h, int64_t row0, int64_t nrows, int64_t *row_ptr
     if (!h->csr_rowptr.p) return fail(EDGPU_EINVAL, "edgpu_csr_rows: sector was not created with storage=CSR");
     if (row0 < 0 || nrows < 0 || row0 + nrows > h->nloc_el) return fail(EDGPU_EINVAL, "edgpu_csr_rows: row window out of range");
     HIPCHK(hipStreamSynchronize(h->stream));
-    HIPCHK(hipMemcpy(row_ptr, h->csr_rowptr.p + row0, (size_t)(nrows + 1) * 8, hipMemcpyDeviceToHost));
-    int64_t n = row_ptr[nrows] - row_ptr[0];
-    if (n > cap) return fail(EDGPU_EINVAL, "edgpu_csr_rows: capacity too small");
-    if (n && cols && vals) {
-        HIPCHK(hipMemcpy(cols, h->csr_cols.p + row_ptr[0], (size_t)n * 4, hipMemcpyDeviceToHost));
-        HIPCHK(hipMemcpy(vals, h->csr_vals.p + row_ptr[0], (size_t)n * 8, hipMemcpyDeviceToHost));
+    auto fetch = [&](DevBuf<int64_t> &rp, DevBuf<int32_t> &cc, DevBuf<double> &vv, std::vector<int64_t> &hrp, std::vector<int32_t> &hc, std::vector<double> &hv) -> int {
+        hrp.resize(nrows + 1);
+        HIPCHK(hipMemcpy(hrp.data(), rp.p + row0, (size_t)(nrows + 1) * 8, hipMemcpyDeviceToHost));
+        int64_t n = hrp[nrows] - hrp[0];
+        hc.resize(n); hv.resize(n);
+        if (n) { HIPCHK(hipMemcpy(hc.data(), cc.p + hrp[0], (size_t)n * 4, hipMemcpyDeviceToHost)); HIPCHK(hipMemcpy(hv.data(), vv.p + hrp[0], (size_t)n * 8, hipMemcpyDeviceToHost)); }
+        return EDGPU_OK;
+    };
+    std::vector<int64_t> rl, rd; std::vector<int32_t> cl, cd; std::vector<double> vl, vd;
+    CHK(fetch(h->csr_rowptr, h->csr_cols, h->csr_vals, rl, cl, vl));
+    if (h->csr_split) CHK(fetch(h->csrD_rowptr, h->csrD_cols, h->csrD_vals, rd, cd, vd));
+    // merged view (ascending columns) of the one or two stored blocks
+    int64_t n = 0;
+    row_ptr[0] = 0;
+    for (int64_t r = 0; r < nrows; r++) {
+        int64_t a = rl[r] - rl[0], ae = rl[r + 1] - rl[0], b = 0, be = 0;
+        if (h->csr_split) { b = rd[r] - rd[0]; be = rd[r + 1] - rd[0]; }
+        while (a < ae || b < be) {
+            bool takeL = b >= be || (a < ae && cl[a] < cd[b]);
+            if (n >= cap) return fail(EDGPU_EINVAL, "edgpu_csr_rows: capacity too small");
+            if (cols && vals) { cols[n] = takeL ? cl[a] : cd[b]; vals[n] = takeL ? vl[a] : vd[b]; }
+            if (takeL) a++; else b++;
+            n++;
+        }
+        row_ptr[r + 1] = n;
     }
     return EDGPU_OK;
 }

@@ -546,24 +546,31 @@ struct CsrBuildArgs {
 
 // row (iup, idw) holds, in ascending column order: dw hops to jdw<idw, up hops jup<iup, the
 // diagonal, up hops jup>iup, dw hops jdw>idw.  Columns index the gathered vector (global idw).
-__global__ void __launch_bounds__(256) k_csr_build(CsrBuildArgs A)
+// part 0: the whole row; part 1: only diagonal + up hops ("local" block); part 2: only dw hops.
+__global__ void __launch_bounds__(256) k_csr_build(CsrBuildArgs A, int part)
 {
     const int64_t il = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t nloc = A.Qdw * A.DimUp;
     if (il > nloc) return;
-    if (il == nloc) { A.rowptr[nloc] = A.dwpre[A.Qdw]; return; }
+    const int64_t upall = A.uppre[A.DimUp];
+    if (il == nloc) { A.rowptr[nloc] = part == 0 ? A.dwpre[A.Qdw] : (part == 1 ? A.Qdw * upall : A.dwpre[A.Qdw] - A.Qdw * upall); return; }
     const int64_t idwl = il / A.DimUp; const int iup = (int)(il - idwl * A.DimUp); const int64_t idw = A.dw0 + idwl;
     const int ndw = A.dwrp[idw + 1] - A.dwrp[idw];
-    int64_t p = A.dwpre[idwl] + (int64_t)iup * ndw + A.uppre[iup];
+    int64_t p;
+    if (part == 0) p = A.dwpre[idwl] + (int64_t)iup * ndw + A.uppre[iup];
+    else if (part == 1) p = idwl * upall + A.uppre[iup];
+    else p = A.dwpre[idwl] - idwl * upall + (int64_t)iup * ndw;
     A.rowptr[il] = p;
     const int32_t d0 = A.dwrp[idw], d1 = A.dwrp[idw + 1], u0 = A.uprp[iup], u1 = A.uprp[iup + 1];
     int32_t q = d0;
-    for (; q < d1 && A.dwc[q] < idw; q++) { A.cols[p] = (int32_t)((int64_t)A.dwc[q] * A.DimUp + iup); A.vals[p] = A.dwv[q]; p++; }
-    int32_t r = u0;
-    for (; r < u1 && A.upc[r] < iup; r++) { A.cols[p] = (int32_t)(idw * A.DimUp + A.upc[r]); A.vals[p] = A.upv[r]; p++; }
-    A.cols[p] = (int32_t)(idw * A.DimUp + iup); A.vals[p] = A.diag[il]; p++;
-    for (; r < u1; r++) { A.cols[p] = (int32_t)(idw * A.DimUp + A.upc[r]); A.vals[p] = A.upv[r]; p++; }
-    for (; q < d1; q++) { A.cols[p] = (int32_t)((int64_t)A.dwc[q] * A.DimUp + iup); A.vals[p] = A.dwv[q]; p++; }
+    if (part != 1) for (; q < d1 && A.dwc[q] < idw; q++) { A.cols[p] = (int32_t)((int64_t)A.dwc[q] * A.DimUp + iup); A.vals[p] = A.dwv[q]; p++; }
+    if (part != 2) {
+        int32_t r = u0;
+        for (; r < u1 && A.upc[r] < iup; r++) { A.cols[p] = (int32_t)(idw * A.DimUp + A.upc[r]); A.vals[p] = A.upv[r]; p++; }
+        A.cols[p] = (int32_t)(idw * A.DimUp + iup); A.vals[p] = A.diag[il]; p++;
+        for (; r < u1; r++) { A.cols[p] = (int32_t)(idw * A.DimUp + A.upc[r]); A.vals[p] = A.upv[r]; p++; }
+    }
+    if (part != 1) for (; q < d1; q++) { A.cols[p] = (int32_t)((int64_t)A.dwc[q] * A.DimUp + iup); A.vals[p] = A.dwv[q]; p++; }
 }
 
 struct CsrArgs {
@@ -572,6 +579,8 @@ struct CsrArgs {
     const double *x; double *y;
     const double *v_local;  // x restricted to the local rows (== x on one GPU), for the alpha dot
     const double *uprev; const double *scal; double *partial; int32_t epi; int32_t xcd_rows;
+    int32_t pass;      // 0: whole product; 1: first block of a split CSR (no alpha); 2: second block (y +=, alpha)
+    int32_t coltiles;  // 1: blocks sweep XCD-affine column tiles (idw fastest) -- the dw block of a split CSR
 };
 
 // "CSR-stream": a workgroup owns `rows_per_block` consecutive rows of one idw row, streams their
@@ -629,7 +638,13 @@ __global__ void __launch_bounds__(ROWS) k_csr_spmv2(CsrArgs A)
     __shared__ __attribute__((aligned(16))) int32_t scol[CAPN + 4];
     __shared__ double red[4];
     int64_t idwl; int jb;
-    {
+    if (A.coltiles) {
+        // column tile jb is owned by XCD (jb % 8); that XCD walks all idw rows of the tile, so the
+        // x slab x(tile, all idw) that the dw hops gather from stays in its L2
+        const int xcd = blockIdx.x & 7; const int64_t sidx = blockIdx.x >> 3;
+        const int64_t tl = sidx / A.Qdw; idwl = sidx - tl * A.Qdw; jb = (int)(tl * 8 + xcd);
+        if (jb >= A.blocks_per_row) { if (A.epi && A.pass != 1 && threadIdx.x == 0) A.partial[blockIdx.x] = 0.0; return; }
+    } else {
         const int64_t b = blockIdx.x, per_tile = (int64_t)A.tile * A.Qdw;
         const int nt_full = A.blocks_per_row / A.tile;
         int64_t t, r; int tw;
@@ -654,7 +669,9 @@ __global__ void __launch_bounds__(ROWS) k_csr_spmv2(CsrArgs A)
     double up_i = 0.0, xl_i = 0.0;   // epilogue operands, requested before the stream so their latency hides under it
     if (tid < nr) {
         ra = (int)(A.rowptr[row0 + tid] - p0) + sh; re = (int)(A.rowptr[row0 + tid + 1] - p0) + sh;
-        if (A.epi) { up_i = A.uprev[row0 + tid]; xl_i = A.v_local[row0 + tid]; }
+        if (A.epi && A.pass != 2) up_i = A.uprev[row0 + tid];
+        if (A.epi && A.pass != 1) xl_i = A.v_local[row0 + tid];
+        if (A.pass == 2) up_i = A.y[row0 + tid];        // running value of the first block
     }
     {
         const double *gv = A.vals + (p0 - sh); const int32_t *gc = A.cols + (p0 - sh);   // 4-aligned base
@@ -688,10 +705,12 @@ __global__ void __launch_bounds__(ROWS) k_csr_spmv2(CsrArgs A)
         }
         for (; k < re; k++) acc0 += sval[k] * A.x[scol[k]];
         const double acc = acc0 + acc1;
-        if (A.epi) { double w = s_cur * acc - c_prev * up_i; A.y[row] = w; asum = (s_cur * xl_i) * w; }
-        else A.y[row] = acc;
+        if (A.epi) {
+            const double w = A.pass == 2 ? up_i + s_cur * acc : s_cur * acc - c_prev * up_i;
+            A.y[row] = w; asum = (s_cur * xl_i) * w;
+        } else A.y[row] = A.pass == 2 ? up_i + acc : acc;
     }
-    if (A.epi) { double r = block_sum(asum, red); if (tid == 0) A.partial[blockIdx.x] = r; }
+    if (A.epi && A.pass != 1) { double r = block_sum(asum, red); if (tid == 0) A.partial[blockIdx.x] = r; }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -727,6 +746,129 @@ __global__ void __launch_bounds__(256) k_apply_op(OpArgs A)
         if (ok) val = sgn * A.vin[isrc + iph * A.nel_from];
         A.vout[j] = val;
     }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Persistent, software-pipelined form of the row-block CSR product.  One wave per workgroup walks
+// a strided sequence of row blocks ("tasks").  While task t is computed out of LDS, the (value,
+// column) range of task t+1 is already in flight into registers and the row pointers of task t+2
+// are in flight too, so a wave keeps two tasks' worth of HBM requests outstanding with one LDS
+// image -- the LDS footprint, not the wave count, is what limits residency here.
+//   coltiles=0: tasks in natural row order (block jb of idw row, jb fastest)
+//   coltiles=1: XCD (blockIdx & 7) owns the column tiles jb = xcd, xcd+8, ... and sweeps all idw
+//               rows of a tile before the next one (dw block of a split CSR: x slab stays in L2)
+// ---------------------------------------------------------------------------------------------
+template <int CAPN, bool NT>
+__global__ void __launch_bounds__(64) k_csr_spmv3(CsrArgs A)
+{
+    constexpr int MAXG = (CAPN / 4 + 63) / 64 + 1;   // 4-entry groups per lane
+    __shared__ __attribute__((aligned(32))) double sval[CAPN + 8];
+    __shared__ __attribute__((aligned(16))) int32_t scol[CAPN + 8];
+    __shared__ double red[2];
+    const int tid = threadIdx.x;
+    int64_t s, sstep, send; int xcd = 0;
+    if (A.coltiles) {
+        xcd = blockIdx.x & 7;
+        const int tiles_x = (A.blocks_per_row - xcd + 7) >> 3;
+        s = blockIdx.x >> 3; sstep = gridDim.x >> 3; send = (int64_t)tiles_x * A.Qdw;
+    } else { s = blockIdx.x; sstep = gridDim.x; send = (int64_t)A.blocks_per_row * A.Qdw; }
+    struct Task { int64_t row0; int nr; };
+    auto task_of = [&](int64_t t) -> Task {
+        int64_t idwl; int jb;
+        if (A.coltiles) { const int64_t tl = t / A.Qdw; idwl = t - tl * A.Qdw; jb = (int)(tl * 8 + xcd); }
+        else { idwl = t / A.blocks_per_row; jb = (int)(t - idwl * A.blocks_per_row); }
+        const int iup0 = jb * A.rows_per_block;
+        int nr = A.DimUp - iup0; if (nr > A.rows_per_block) nr = A.rows_per_block;
+        return Task{idwl * A.DimUp + iup0, nr};
+    };
+    // stage A: per-lane row pointers (lane r: rowptr[row0+r], rowptr[row0+r+1]; lane 0 / lane nr-1 give p0 / p1)
+    auto load_rp = [&](const Task &T, int64_t &a, int64_t &b) {
+        const int r = tid < T.nr ? tid : T.nr - 1;
+        a = A.rowptr[T.row0 + r]; b = A.rowptr[T.row0 + r + 1];
+    };
+    struct Regs { dbl2_t v0[MAXG], v1[MAXG]; int4_t c[MAXG]; double hv, tv, yv, upv, xlv; int32_t hc, tc; };
+    // stage B: issue the stream of a task (4-entry groups, head and tail singles) and its epilogue operands
+    auto issue = [&](const Task &T, int64_t p0, int n, Regs &R) {
+        const int sh = (int)(p0 & 3);
+        const double *gv = A.vals + (p0 - sh); const int32_t *gc = A.cols + (p0 - sh);
+        const int end = sh + n, g0 = sh ? 1 : 0, g1 = end >> 2;
+        const dbl2_t *pv = reinterpret_cast<const dbl2_t *>(gv);
+        const int4_t *pc = reinterpret_cast<const int4_t *>(gc);
+#pragma unroll
+        for (int q = 0; q < MAXG; q++) {
+            const int g = g0 + tid + q * 64;
+            if (g < g1) {
+                if (NT) { R.v0[q] = __builtin_nontemporal_load(pv + 2 * g); R.v1[q] = __builtin_nontemporal_load(pv + 2 * g + 1); R.c[q] = __builtin_nontemporal_load(pc + g); }
+                else { R.v0[q] = pv[2 * g]; R.v1[q] = pv[2 * g + 1]; R.c[q] = pc[g]; }
+            }
+        }
+        if (sh && tid >= sh && tid < 4 && tid < end) { R.hv = gv[tid]; R.hc = gc[tid]; }
+        int ts = g1 << 2; if (sh && ts < 4) ts = 4;
+        if (ts + tid < end) { R.tv = gv[ts + tid]; R.tc = gc[ts + tid]; }
+        if (tid < T.nr) {
+            if (A.pass == 2) R.yv = A.y[T.row0 + tid];
+            if (A.epi && A.pass != 2) R.upv = A.uprev[T.row0 + tid];
+            if (A.epi && A.pass != 1) R.xlv = A.v_local[T.row0 + tid];
+        }
+    };
+    auto commit = [&](int64_t p0, int n, const Regs &R) {     // registers -> LDS image
+        const int sh = (int)(p0 & 3);
+        const int end = sh + n, g0 = sh ? 1 : 0, g1 = end >> 2;
+        dbl2_t *sv2 = reinterpret_cast<dbl2_t *>(sval); int4_t *sc4 = reinterpret_cast<int4_t *>(scol);
+#pragma unroll
+        for (int q = 0; q < MAXG; q++) { const int g = g0 + tid + q * 64; if (g < g1) { sv2[2 * g] = R.v0[q]; sv2[2 * g + 1] = R.v1[q]; sc4[g] = R.c[q]; } }
+        if (sh && tid >= sh && tid < 4 && tid < end) { sval[tid] = R.hv; scol[tid] = R.hc; }
+        int ts = g1 << 2; if (sh && ts < 4) ts = 4;
+        if (ts + tid < end) { sval[ts + tid] = R.tv; scol[ts + tid] = R.tc; }
+    };
+    double s_cur = 1.0, c_prev = 0.0, asum = 0.0;
+    if (A.epi) { s_cur = A.scal[SC_SCUR]; c_prev = A.scal[SC_BETA] * A.scal[SC_SPREV]; }
+    if (s < send) {
+        Task Tc = task_of(s), Tn = Tc, Tnn = Tc;
+        int64_t ac, bc, an = 0, bn = 0, ann = 0, bnn = 0;
+        Regs R;
+        load_rp(Tc, ac, bc);
+        const bool has1 = s + sstep < send, has2 = s + 2 * sstep < send;
+        if (has1) { Tn = task_of(s + sstep); load_rp(Tn, an, bn); }
+        int64_t p0c = __shfl(ac, 0, 64); int nc = (int)(__shfl(bc, Tc.nr - 1, 64) - p0c);
+        issue(Tc, p0c, nc, R);
+        bool more = true;
+        while (more) {
+            commit(p0c, nc, R);
+            const int shc = (int)(p0c & 3);
+            const int ra = (int)(ac - p0c) + shc, re = (int)(bc - p0c) + shc;
+            const double yv = R.yv, upv = R.upv, xlv = R.xlv;
+            const Task Tcur = Tc;
+            __syncthreads();
+            // advance the pipeline: task t+2 row pointers, task t+1 stream
+            const int64_t sn = s + sstep, snn = s + 2 * sstep;
+            const bool hn = sn < send, hnn = snn < send;
+            if (hnn) { Tnn = task_of(snn); load_rp(Tnn, ann, bnn); }
+            int64_t p0n = 0; int nn = 0;
+            if (hn) { p0n = __shfl(an, 0, 64); nn = (int)(__shfl(bn, Tn.nr - 1, 64) - p0n); issue(Tn, p0n, nn, R); }
+            // compute task t out of LDS
+            if (tid < Tcur.nr) {
+                const int64_t row = Tcur.row0 + tid;
+                double acc0 = 0.0, acc1 = 0.0;
+                int k = ra;
+                for (; k + 4 <= re; k += 4) {
+                    const double x0 = A.x[scol[k]], x1 = A.x[scol[k + 1]], x2 = A.x[scol[k + 2]], x3 = A.x[scol[k + 3]];
+                    acc0 += sval[k] * x0; acc1 += sval[k + 1] * x1; acc0 += sval[k + 2] * x2; acc1 += sval[k + 3] * x3;
+                }
+                for (; k < re; k++) acc0 += sval[k] * A.x[scol[k]];
+                const double acc = acc0 + acc1;
+                if (A.epi) {
+                    const double w = A.pass == 2 ? yv + s_cur * acc : s_cur * acc - c_prev * upv;
+                    A.y[row] = w; asum += (s_cur * xlv) * w;
+                } else A.y[row] = A.pass == 2 ? yv + acc : acc;
+            }
+            __syncthreads();
+            s = sn; more = hn;
+            Tc = Tn; ac = an; bc = bn; p0c = p0n; nc = nn;
+            Tn = Tnn; an = ann; bn = bnn;
+        }
+    }
+    if (A.epi && A.pass != 1) { double r = block_sum(asum, red); if (tid == 0) A.partial[blockIdx.x] = r; }
 }
 
 // ---------------------------------------------------------------------------------------------
