@@ -130,7 +130,8 @@ def main():
         "config": {"workload": "1-orbital Anderson impurity, Nbath=%d (Ns=%d), sector Nup=Ndw=%d, N=%d, default initial bath, operator storage=%s, one Lanczos iteration per step"
                                % (a.nbath, Ns, nu[0], N, a.storage),
                    "storage": a.storage, "N": N, "nnz": nnz, "parallelism": "dw-column split x%d, RCCL exchange of v per product" % world if world > 1 else "single GPU"},
-        "roofline": {"bound": "hbm", "kernel": {"csr": "k_csr_spmv", "kron": "k_kron2", "direct": "k_kron2"}[a.storage],
+        "roofline": {"bound": "hbm", "kernel": {"csr": "k_csr_spmv2<64,640,false> (local block) + k_csr_spmv2<64,640,true> (dw block): one product of the split explicit CSR",
+                                "kron": "k_uppass + k_dwpass2 (two-pass stored product)", "direct": "k_direct_tables + k_uppass + k_dwpass2"}[a.storage],
                      "achieved": bytes_fmt / (hxv_ms * 1e-3) / 1e9 if hxv_ms > 0 else None, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": (bytes_fmt / (hxv_ms * 1e-3) / 1e9) / HBM_PEAK_GBPS if hxv_ms > 0 else None,
                      "algorithmic_bytes_per_launch": bytes_fmt, "kernel_ms": hxv_ms, "traffic": None},

@@ -511,11 +511,14 @@ static int hxv(S *s, const double *v, double *out, bool epi, const double *uprev
     }
     int64_t nblocks = 0;
     if (d.storage == EDGPU_STORE_CSR) {
-        if (multi) HIPCHK(hipStreamWaitEvent(s->stream, s->ev_gather, 0));
+        // split CSR: the local block only reads columns of the rank's own dw columns, so it runs on the
+        // shard itself (pointer shifted to global column numbering) while the exchange is in flight
+        const bool overlap = multi && s->csr_split && H.DimPh == 1;
+        if (multi && !overlap) HIPCHK(hipStreamWaitEvent(s->stream, s->ev_gather, 0));
         CsrArgs A{};
         A.nrows = s->nloc_el; A.rows_per_block = s->csr_rpb; A.DimUp = (int32_t)H.DimUp; A.blocks_per_row = s->csr_bpr; A.Qdw = H.Qdw; A.tile = s->csr_tile;
         A.rowptr = s->csr_rowptr.p; A.cols = s->csr_cols.p; A.vals = s->csr_vals.p;
-        A.x = multi ? s->vfull.p : v; A.y = out; A.v_local = v; A.uprev = uprev; A.scal = s->scal.p; A.partial = s->partial.p; A.epi = epi; A.xcd_rows = dbg_int("EDGPU_CSR_XCD", 0);
+        A.x = overlap ? v - H.dw0 * H.DimUp : (multi ? s->vfull.p : v); A.y = out; A.v_local = v; A.uprev = uprev; A.scal = s->scal.p; A.partial = s->partial.p; A.epi = epi; A.xcd_rows = dbg_int("EDGPU_CSR_XCD", 0);
         // the column index is global; on one GPU local == global
         nblocks = (int64_t)s->csr_bpr * H.Qdw;
         A.pass = s->csr_split ? 1 : 0; A.coltiles = 0;
@@ -531,6 +534,7 @@ static int hxv(S *s, const double *v, double *out, bool epi, const double *uprev
         else hipLaunchKernelGGL((k_csr_spmv2<64, 1152, false>), dim3((unsigned)nblocks), dim3(64), 0, s->stream, A);
         HIPCHK(hipGetLastError());
         if (s->csr_split) {
+            if (overlap) { HIPCHK(hipStreamWaitEvent(s->stream, s->ev_gather, 0)); A.x = s->vfull.p; }
             A.rowptr = s->csrD_rowptr.p; A.cols = s->csrD_cols.p; A.vals = s->csrD_vals.p;
             A.rows_per_block = s->csrD_rpb; A.blocks_per_row = s->csrD_bpr; A.pass = 2; A.coltiles = 1; A.xcd_rows = 0;
             nblocks = 8 * cdiv(s->csrD_bpr, 8) * H.Qdw;
