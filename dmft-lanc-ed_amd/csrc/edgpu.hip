@@ -330,6 +330,8 @@ static int create(const edgpu_desc *desc, S **out)
         s->kron_lds = (s->use_lds ? rowbytes : 0) + 16 * sizeof(double);
         // two-pass product (local pass + column-tiled dw pass) once the vector no longer fits the caches
         s->kron_split = dbg_int("EDGPU_KRON_SPLIT", (H.DimUp * H.DimDw * 8 > ((int64_t)48 << 20)) ? 1 : 0) != 0;
+        // tile width of the dw pass: 64 columns measured best at Ns=16 (slab 6.6 MB, half of the gathers hit
+        // L2) and at Ns=18 (slab 25 MB: no re-use left, but narrower tiles lose more to short segments)
         s->dw_w = dbg_int("EDGPU_DW_W", 64);
         s->dw_variant = dbg_int("EDGPU_DW_VARIANT", 2);
         s->up_persistent = dbg_int("EDGPU_UP_PERSISTENT", 1) != 0;

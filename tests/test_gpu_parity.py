@@ -166,3 +166,41 @@ def test_device_pointer_path_and_errors(edgpu_mod):
     ms = G.hxv_time(dv, dh, 1, 3)
     assert ms > 0
     G.close()
+
+
+FORCED = [z for z in ZOO if z[0] in ("c_nb7_half", "nb5_offhalf_2_4", "nb6_even", "nspin2_random_bath", "norb2_normal_offdiag_hloc", "c_nb5_half")]
+
+
+@pytest.mark.parametrize("name,m,nu,nd", FORCED, ids=[z[0] for z in FORCED])
+def test_large_sector_code_paths_on_small_sectors(edgpu_mod, monkeypatch, name, m, nu, nd):
+    """The two-pass products (persistent local pass + column-tiled dw pass; split explicit CSR)
+    switch on automatically only for sectors that outgrow the caches.  Force them on small sectors
+    and compare with the oracle; also the persistent pipelined CSR variant and odd tile widths."""
+    S = oracle.Sector(m, nu, nd)
+    v = np.random.RandomState(21).uniform(-0.5, 0.5, S.Dim)
+    ref = S.spmatvec(v)
+    tol = HXV_RTOL * np.abs(ref).max()
+    w = np.linalg.eigvalsh(S.hmat())
+    for env in ({"EDGPU_KRON_SPLIT": "1", "EDGPU_CSR_SPLIT": "1"},
+                {"EDGPU_KRON_SPLIT": "1", "EDGPU_CSR_SPLIT": "1", "EDGPU_DW_W": "8", "EDGPU_DW_ROWS": "16", "EDGPU_CSRD_ROWS": "16", "EDGPU_UP_GRID": "3"},
+                {"EDGPU_KRON_SPLIT": "1", "EDGPU_DW_VARIANT": "1", "EDGPU_UP_PERSISTENT": "0", "EDGPU_CSR_SPLIT": "1", "EDGPU_CSR_PERSIST": "1", "EDGPU_CSR_PGRID": "16"},
+                {"EDGPU_CSR_SPLIT": "0", "EDGPU_CSR_PERSIST": "1", "EDGPU_CSR_PGRID": "24", "EDGPU_KRON_SPLIT": "1", "EDGPU_UP_THREADS": "512"}):
+        for k, val in env.items():
+            monkeypatch.setenv(k, val)
+        for st in _storages(m):
+            G = edgpu_mod.HvSector(m, nu, nd, storage=st)
+            hv = G.spHtimesV(v)
+            assert np.abs(hv - ref).max() <= tol, (env, st, np.abs(hv - ref).max())
+            e0, x, nl = G.sp_lanc_eigh(nitermax=min(400, S.Dim), threshold=1e-14)
+            assert abs(e0 - w[0]) <= 1e-10, (env, st)
+            if st == "csr":
+                rp, cols, vals = G.csr_rows(0, min(S.Dim, 500))
+                H = S.hmat()
+                for i in range(min(S.Dim, 500)):
+                    c = cols[rp[i]:rp[i + 1]]
+                    assert np.all(np.diff(c) > 0)
+                    row = np.zeros(S.Dim); row[c] = vals[rp[i]:rp[i + 1]]
+                    np.testing.assert_array_equal(row, H[i])
+            G.close()
+        for k in env:
+            monkeypatch.delenv(k)
