@@ -534,8 +534,20 @@ __global__ void __launch_bounds__(256) k_direct_tables(TabArgs A)
 // ---------------------------------------------------------------------------------------------
 // Explicit CSR (storage=CSR): expansion of the Kronecker sum, then a row-block streaming SpMV.
 // ---------------------------------------------------------------------------------------------
+// rows a peer needs, copied out of the shard into one contiguous message per peer
+struct PackArgs { int32_t DimUp, DimPh; int64_t Qdw, nrows; const int32_t *list; const double *v; double *out; };
+__global__ void __launch_bounds__(256) k_pack_rows(PackArgs A)
+{
+    const int64_t total = A.nrows * A.DimPh * (int64_t)A.DimUp;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = e / A.DimUp; const int i = (int)(e - r * A.DimUp);
+        const int64_t iph = r / A.nrows, q = r - iph * A.nrows;
+        A.out[e] = A.v[(iph * A.Qdw + A.list[q]) * A.DimUp + i];
+    }
+}
+
 struct CsrBuildArgs {
-    int32_t DimUp, DimDw; int64_t Qdw, dw0;
+    int32_t DimUp, DimDw; int64_t Qdw, dw0, rowshift;
     const int32_t *uprp, *upc; const double *upv;   // CSR of H_up (rowptr32)
     const int32_t *dwrp, *dwc; const double *dwv;   // CSR of H_dw
     const int64_t *uppre;                           // prefix over iup of (1 + nnz_up(iup)), [DimUp+1]
@@ -562,15 +574,15 @@ __global__ void __launch_bounds__(256) k_csr_build(CsrBuildArgs A, int part)
     else p = A.dwpre[idwl] - idwl * upall + (int64_t)iup * ndw;
     A.rowptr[il] = p;
     const int32_t d0 = A.dwrp[idw], d1 = A.dwrp[idw + 1], u0 = A.uprp[iup], u1 = A.uprp[iup + 1];
-    int32_t q = d0;
-    if (part != 1) for (; q < d1 && A.dwc[q] < idw; q++) { A.cols[p] = (int32_t)((int64_t)A.dwc[q] * A.DimUp + iup); A.vals[p] = A.dwv[q]; p++; }
+    const int64_t xrow = idw - A.rowshift;     // index of this dw row in the column (x) space
+    if (part != 1) for (int32_t q = d0; q < d1; q++) if (A.dwc[q] < xrow) { A.cols[p] = (int32_t)((int64_t)A.dwc[q] * A.DimUp + iup); A.vals[p] = A.dwv[q]; p++; }
     if (part != 2) {
         int32_t r = u0;
-        for (; r < u1 && A.upc[r] < iup; r++) { A.cols[p] = (int32_t)(idw * A.DimUp + A.upc[r]); A.vals[p] = A.upv[r]; p++; }
-        A.cols[p] = (int32_t)(idw * A.DimUp + iup); A.vals[p] = A.diag[il]; p++;
-        for (; r < u1; r++) { A.cols[p] = (int32_t)(idw * A.DimUp + A.upc[r]); A.vals[p] = A.upv[r]; p++; }
+        for (; r < u1 && A.upc[r] < iup; r++) { A.cols[p] = (int32_t)(xrow * A.DimUp + A.upc[r]); A.vals[p] = A.upv[r]; p++; }
+        A.cols[p] = (int32_t)(xrow * A.DimUp + iup); A.vals[p] = A.diag[il]; p++;
+        for (; r < u1; r++) { A.cols[p] = (int32_t)(xrow * A.DimUp + A.upc[r]); A.vals[p] = A.upv[r]; p++; }
     }
-    if (part != 1) for (; q < d1; q++) { A.cols[p] = (int32_t)((int64_t)A.dwc[q] * A.DimUp + iup); A.vals[p] = A.dwv[q]; p++; }
+    if (part != 1) for (int32_t q = d0; q < d1; q++) if (A.dwc[q] >= xrow) { A.cols[p] = (int32_t)((int64_t)A.dwc[q] * A.DimUp + iup); A.vals[p] = A.dwv[q]; p++; }
 }
 
 struct CsrArgs {

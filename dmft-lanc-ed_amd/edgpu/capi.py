@@ -50,6 +50,7 @@ class Info(C.Structure):
 
 ALLGATHERV_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.c_int32)
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_int32)
+EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.c_int32)
 
 _lib = None
 
@@ -96,7 +97,7 @@ def lib():
         "edgpu_gf_lanczos": (C.c_int, [vp, vp, i32, i32, i32, vp, i32, dbl, P(dbl), vp, vp, P(i32)]),
         "edgpu_comm_unique_id": (C.c_int, [vp]),
         "edgpu_comm_init_rccl": (C.c_int, [vp, vp]),
-        "edgpu_comm_init_callbacks": (C.c_int, [vp, ALLGATHERV_FN, ALLREDUCE_FN, vp]),
+        "edgpu_comm_init_callbacks": (C.c_int, [vp, ALLGATHERV_FN, EXCHANGE_FN, ALLREDUCE_FN, vp]),
         "edgpu_device_count": (C.c_int, [P(i32)]),
         "edgpu_malloc": (C.c_int, [P(vp), C.c_size_t]),
         "edgpu_free": (C.c_int, [vp]),

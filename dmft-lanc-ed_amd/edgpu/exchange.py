@@ -40,6 +40,31 @@ class StagedExchange:
             full[d - lo:d - lo + c] = outs[r].numpy()[:c]
         self.h2d(recv_ptr + lo * 8, full.ctypes.data, full.size * 8)
 
+    def exchange(self, send_ptr, scounts, sdispls, recv_ptr, rcounts, rdispls):
+        """all-to-all-v of doubles through pairwise isend/irecv of CPU tensors."""
+        import torch
+        rank = self.dist.get_rank(self.group)
+        ops, rbufs = [], {}
+        keep = []
+        for r, (c, d) in enumerate(zip(scounts, sdispls)):
+            if r == rank or c == 0:
+                continue
+            buf = np.empty(c, np.float64)
+            self.d2h(buf.ctypes.data, send_ptr + d * 8, c * 8)
+            t = torch.from_numpy(buf); keep.append(t)
+            ops.append(self.dist.P2POp(self.dist.isend, t, r, self.group))
+        for r, c in enumerate(rcounts):
+            if r == rank or c == 0:
+                continue
+            rbufs[r] = torch.empty(c, dtype=torch.float64)
+            ops.append(self.dist.P2POp(self.dist.irecv, rbufs[r], r, self.group))
+        if ops:
+            for req in self.dist.batch_isend_irecv(ops):
+                req.wait()
+        for r, t in rbufs.items():
+            a = t.numpy()
+            self.h2d(recv_ptr + rdispls[r] * 8, a.ctypes.data, a.size * 8)
+
     def allreduce(self, arr):
         import torch
         t = torch.from_numpy(np.array(arr, np.float64))

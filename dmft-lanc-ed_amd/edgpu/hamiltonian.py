@@ -203,14 +203,23 @@ class HvSector:
         buf = C.create_string_buffer(bytes(uid_bytes), 128)
         check(capi.lib().edgpu_comm_init_rccl(self._h, buf))
 
-    def comm_init_callbacks(self, allgatherv, allreduce):
-        """allgatherv(send_ptr, nsend, recv_ptr, counts, displs) / allreduce(np_array) in Python."""
+    def comm_init_callbacks(self, allgatherv, exchange, allreduce):
+        """allgatherv(send_ptr, nsend, recv_ptr, counts, displs) / exchange(send_ptr, scounts, sdispls,
+        recv_ptr, rcounts, rdispls) / allreduce(np_array) in Python."""
         def _ag(ctx, send, nsend, recv, counts, displs, nr):
             try:
                 allgatherv(send, nsend, recv, [counts[i] for i in range(nr)], [displs[i] for i in range(nr)])
                 return 0
             except Exception as e:  # pragma: no cover
                 print("allgatherv callback failed:", e)
+                return 1
+
+        def _xc(ctx, send, sc, sd, recv, rc, rd, nr):
+            try:
+                exchange(send, [sc[i] for i in range(nr)], [sd[i] for i in range(nr)], recv, [rc[i] for i in range(nr)], [rd[i] for i in range(nr)])
+                return 0
+            except Exception as e:  # pragma: no cover
+                print("exchange callback failed:", e)
                 return 1
 
         def _ar(ctx, buf, n):
@@ -222,8 +231,8 @@ class HvSector:
                 print("allreduce callback failed:", e)
                 return 1
 
-        self._cb = (capi.ALLGATHERV_FN(_ag), capi.ALLREDUCE_FN(_ar))
-        check(capi.lib().edgpu_comm_init_callbacks(self._h, self._cb[0], self._cb[1], None))
+        self._cb = (capi.ALLGATHERV_FN(_ag), capi.EXCHANGE_FN(_xc), capi.ALLREDUCE_FN(_ar))
+        check(capi.lib().edgpu_comm_init_callbacks(self._h, self._cb[0], self._cb[1], self._cb[2], None))
 
 
 def apply_op(sec_from, sec_to, iorb, ispin, dagger, vin_dev, vout_dev):

@@ -163,7 +163,13 @@ int edgpu_comm_init_rccl(edgpu_handle h, const void *id128);
 typedef int (*edgpu_allgatherv_fn)(void *ctx, const double *send_dev, int64_t nsend, double *recv_dev,
                                    const int64_t *counts, const int64_t *displs, int32_t nranks);
 typedef int (*edgpu_allreduce_fn)(void *ctx, double *buf_host, int32_t n);
-int edgpu_comm_init_callbacks(edgpu_handle h, edgpu_allgatherv_fn ag, edgpu_allreduce_fn ar, void *ctx);
+/* exchange (all-to-all-v): sendcounts[r] doubles at send_dev+sdispls[r] go to rank r; recvcounts[r]
+ * doubles from rank r land at recv_dev+rdispls[r].  Used for the "needed rows only" exchange: each
+ * rank receives just the dw rows its own rows couple to (53/36/24 % of an all-gather at 2/4/8 ranks,
+ * Ns=16).  allgatherv remains in use for sectors with Jx/Jp or phonon terms. */
+typedef int (*edgpu_exchange_fn)(void *ctx, const double *send_dev, const int64_t *sendcounts, const int64_t *sdispls,
+                                 double *recv_dev, const int64_t *recvcounts, const int64_t *rdispls, int32_t nranks);
+int edgpu_comm_init_callbacks(edgpu_handle h, edgpu_allgatherv_fn ag, edgpu_exchange_fn xch, edgpu_allreduce_fn ar, void *ctx);
 
 /* ---- device memory helpers for hosts without a HIP binding (Fortran) ---------------------- */
 int edgpu_device_count(int32_t *n);

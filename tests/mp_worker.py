@@ -44,6 +44,17 @@ def main():
             recv = full[iph * DimUp * DimDw:]
             ex.allgatherv(send.ctypes.data, send.size, recv.ctypes.data, counts, displs)
         assert np.array_equal(full, vglob)
+        # all-to-all-v of the "needed rows only" exchange: rank r sends (r+1)*(q+1) doubles tagged (r,q) to rank q
+        sc = [(rank + 1) * (r + 1) if r != rank else 0 for r in range(size)]
+        sd = list(np.cumsum([0] + sc[:-1]))
+        rc = [(r + 1) * (rank + 1) if r != rank else 0 for r in range(size)]
+        rd = list(np.cumsum([0] + rc[:-1]))
+        sbuf = np.concatenate([np.full(c, 100.0 * rank + r) for r, c in enumerate(sc)] + [np.zeros(1)])
+        rbuf = np.full(sum(rc) + 1, -1.0)
+        ex.exchange(sbuf.ctypes.data, sc, [int(x) for x in sd], rbuf.ctypes.data, rc, [int(x) for x in rd])
+        for r in range(size):
+            if r != rank:
+                assert np.all(rbuf[rd[r]:rd[r] + rc[r]] == 100.0 * r + rank)
         part = np.array([float(vloc @ local_slice(ref))])
         ex.allreduce(part)
         assert abs(part[0] - vglob @ ref) <= 1e-10 * abs(vglob @ ref) + 1e-12
@@ -53,7 +64,7 @@ def main():
         for st in (["kron", "direct", "csr"] if (m.get("Nph", 0) == 0 and not (m["Norb"] > 1 and (m.get("Jx", 0) or m.get("Jp", 0)))) else ["kron", "direct"]):
             G = edgpu.HvSector(m, nu, nd, storage=st, rank=rank, size=size)
             ex = exchange.device_staged(dist)
-            G.comm_init_callbacks(ex.allgatherv, ex.allreduce)
+            G.comm_init_callbacks(ex.allgatherv, ex.exchange, ex.allreduce)
             assert G.vecDim == vloc.size and G.mpiQdw == q and G.mpiIshift == d0 * DimUp
             hv = G.spHtimesV(vloc)
             err = np.abs(hv - local_slice(ref)).max()
