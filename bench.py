@@ -65,6 +65,7 @@ def main():
     ap.add_argument("--storage", default="csr", choices=["csr", "kron", "direct"])
     ap.add_argument("--no-extra", action="store_true", help="skip the kron/direct side measurements")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--comm", default="rccl", choices=["rccl", "torch"], help="N>1: communicator owned by libedgpu.so (rccl) or torch.distributed device callbacks")
     a = ap.parse_args()
 
     import torch
@@ -89,12 +90,28 @@ def main():
     m, nu, nd = model.half_filled_c(a.nbath)
     t_build = time.perf_counter()
     G = edgpu.HvSector(m, nu, nd, storage=a.storage, rank=rank, size=world, device=local_rank)
+    comm_used = "none"
     if world > 1:
-        uid = torch.zeros(128, dtype=torch.uint8, device="cuda")
-        if rank == 0:
-            uid.copy_(torch.frombuffer(bytearray(edgpu.rccl_unique_id()), dtype=torch.uint8))
-        dist.broadcast(uid, 0)
-        G.comm_init_rccl(bytes(uid.cpu().numpy().tobytes()))
+        ok = torch.ones(1, device="cuda")
+        if a.comm == "rccl":
+            # libedgpu.so opens its own RCCL communicator (id broadcast by torch.distributed)
+            try:
+                uid = torch.zeros(128, dtype=torch.uint8, device="cuda")
+                if rank == 0:
+                    uid.copy_(torch.frombuffer(bytearray(edgpu.rccl_unique_id()), dtype=torch.uint8))
+                dist.broadcast(uid, 0)
+                G.comm_init_rccl(bytes(uid.cpu().numpy().tobytes()))
+            except Exception as e:  # keep the job alive: every rank must take the same branch
+                print("rank %d: native RCCL communicator failed (%s)" % (rank, e), file=sys.stderr)
+                ok.zero_()
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if a.comm == "torch" or ok.item() == 0:
+            from edgpu import exchange
+            ex = exchange.TorchDeviceExchange(dist)
+            G.comm_init_callbacks(ex.allgatherv, ex.exchange, ex.allreduce)
+            comm_used = "torch.distributed(nccl) device callbacks"
+        else:
+            comm_used = "native RCCL communicator (ncclSend/ncclRecv group + ncclAllReduce)"
     torch.cuda.synchronize()
     t_build = time.perf_counter() - t_build
 
@@ -129,7 +146,7 @@ def main():
         "iters_per_sec": K / dt,
         "config": {"workload": "1-orbital Anderson impurity, Nbath=%d (Ns=%d), sector Nup=Ndw=%d, N=%d, default initial bath, operator storage=%s, one Lanczos iteration per step"
                                % (a.nbath, Ns, nu[0], N, a.storage),
-                   "storage": a.storage, "N": N, "nnz": nnz, "parallelism": "dw-column split x%d, RCCL exchange of v per product" % world if world > 1 else "single GPU"},
+                   "storage": a.storage, "N": N, "nnz": nnz, "parallelism": ("dw-column split x%d, needed-rows exchange per product over %s" % (world, comm_used)) if world > 1 else "single GPU"},
         "roofline": {"bound": "hbm", "kernel": {"csr": "k_csr_spmv2<64,640,false> (local block) + k_csr_spmv2<64,640,true> (dw block): one product of the split explicit CSR",
                                 "kron": "k_uppass + k_dwpass2 (two-pass stored product)", "direct": "k_direct_tables + k_uppass + k_dwpass2"}[a.storage],
                      "achieved": bytes_fmt / (hxv_ms * 1e-3) / 1e9 if hxv_ms > 0 else None, "peak": HBM_PEAK_GBPS, "unit": "GB/s",

@@ -57,9 +57,27 @@ struct Rccl {
     bool load()
     {
         if (ok) return true;
+        // Use the RCCL the process already has (an embedding PyTorch ships its own copy, built against the
+        // HIP runtime it loaded); only then fall back to the system library.
         void *h = RTLD_DEFAULT;
         if (!dlsym(h, "ncclCommInitRank")) {
-            h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+            h = nullptr;
+            if (const char *e = getenv("EDGPU_RCCL_LIB")) h = dlopen(e, RTLD_NOW | RTLD_GLOBAL);
+            if (!h) {
+                if (FILE *f = fopen("/proc/self/maps", "r")) {
+                    char line[4096];
+                    while (!h && fgets(line, sizeof(line), f)) {
+                        char *p = strstr(line, "librccl");
+                        if (!p) continue;
+                        char *path = strchr(line, '/');
+                        if (!path) continue;
+                        path[strcspn(path, "\n")] = 0;
+                        h = dlopen(path, RTLD_NOW | RTLD_GLOBAL);
+                    }
+                    fclose(f);
+                }
+            }
+            if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
             if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
             if (!h) return false;
         }

@@ -84,3 +84,50 @@ def device_staged(dist, group=None):
         capi.check(L.edgpu_memcpy_h2d(d, h, n))
 
     return StagedExchange(dist, d2h, h2d, group)
+
+
+class _RawCuda:
+    """minimal __cuda_array_interface__ view of a raw device pointer (fp64)"""
+
+    def __init__(self, ptr, n):
+        self.__cuda_array_interface__ = {"shape": (int(n),), "typestr": "<f8", "data": (int(ptr), False), "version": 2}
+
+
+class TorchDeviceExchange:
+    """The three collectives on DEVICE memory through torch.distributed (backend "nccl" = RCCL):
+    the library's raw pointers are viewed as torch tensors, nothing is staged through the host.
+    A host that already runs torch.distributed can hand these to HvSector.comm_init_callbacks
+    instead of letting libedgpu.so open its own RCCL communicator."""
+
+    def __init__(self, dist, group=None):
+        import torch
+        self.torch, self.dist, self.group = torch, dist, group
+
+    def _view(self, ptr, n):
+        return self.torch.as_tensor(_RawCuda(ptr, n), device="cuda")
+
+    def exchange(self, send_ptr, scounts, sdispls, recv_ptr, rcounts, rdispls):
+        rank = self.dist.get_rank(self.group)
+        ops = []
+        for r, (c, d) in enumerate(zip(scounts, sdispls)):
+            if r != rank and c:
+                ops.append(self.dist.P2POp(self.dist.isend, self._view(send_ptr + d * 8, c), r, self.group))
+        for r, (c, d) in enumerate(zip(rcounts, rdispls)):
+            if r != rank and c:
+                ops.append(self.dist.P2POp(self.dist.irecv, self._view(recv_ptr + d * 8, c), r, self.group))
+        if ops:
+            for req in self.dist.batch_isend_irecv(ops):
+                req.wait()
+        self.torch.cuda.synchronize()
+
+    def allgatherv(self, send_ptr, nsend, recv_ptr, counts, displs):
+        rank = self.dist.get_rank(self.group)
+        self._view(recv_ptr + displs[rank] * 8, nsend).copy_(self._view(send_ptr, nsend))
+        sc = [nsend if r != rank else 0 for r in range(len(counts))]
+        rc = [c if r != rank else 0 for r, c in enumerate(counts)]
+        self.exchange(send_ptr, sc, [0] * len(counts), recv_ptr, rc, displs)
+
+    def allreduce(self, arr):
+        t = self.torch.tensor(arr, dtype=self.torch.float64, device="cuda")
+        self.dist.all_reduce(t, group=self.group)
+        arr[:] = t.cpu().numpy()

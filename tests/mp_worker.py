@@ -59,6 +59,22 @@ def main():
         ex.allreduce(part)
         assert abs(part[0] - vglob @ ref) <= 1e-10 * abs(vglob @ ref) + 1e-12
         res["ok"] = True
+    elif mode == "torchdev":
+        import torch  # noqa: F401  (before libedgpu.so, as in bench.py)
+        import edgpu
+        ex = exchange.TorchDeviceExchange(dist)
+        for m2 in (m, dict(m, Nph=1, w0_ph=0.3, g_ph=(0.2,))):      # halo path and full-gather path
+            B = edgpu.HvSector(m2, nu, nd, storage="kron", force_exchange=True)
+            B.comm_init_callbacks(ex.allgatherv, ex.exchange, ex.allreduce)
+            x = cases.sinvec(B.Dim)
+            A = edgpu.HvSector(m2, nu, nd, storage="kron")
+            r0 = A.spHtimesV(x)
+            assert np.abs(B.spHtimesV(x) - r0).max() <= 1e-13 * np.abs(r0).max()
+            e1, _, _ = B.sp_lanc_eigh(x, nitermax=100, threshold=1e-13)
+            e2, _, _ = A.sp_lanc_eigh(x, nitermax=100, threshold=1e-13)
+            assert abs(e1 - e2) < 1e-11
+            A.close(); B.close()
+        res["ok"] = True
     else:
         import edgpu
         for st in (["kron", "direct", "csr"] if (m.get("Nph", 0) == 0 and not (m["Norb"] > 1 and (m.get("Jx", 0) or m.get("Jp", 0)))) else ["kron", "direct"]):

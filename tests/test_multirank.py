@@ -87,3 +87,12 @@ def test_rccl_code_path_single_rank(edgpu_mod):
         eb, _, _ = B.sp_lanc_eigh(v, nitermax=200, threshold=1e-14)
         assert abs(ea - eb) < 1e-11
         A.close(); B.close()
+
+
+@pytest.mark.gpu
+def test_torch_device_exchange_single_process():
+    """TorchDeviceExchange views libedgpu's raw device pointers as torch tensors (world_size 1: the
+    self-copy of allgatherv and the all-reduce run; peers are covered by the gloo variants).  Runs in
+    a child process that imports torch before libedgpu.so, as bench.py does."""
+    res = _launch("torchdev", "c_nb5_half", 1)
+    assert res[0]["ok"]
