@@ -138,6 +138,7 @@ struct edgpu_sector_s {
     std::vector<int64_t> send_rows_cnt, recv_rows_cnt, send_rows_off, recv_rows_off;
     DevBuf<int32_t> send_list, dw_ellc_x, dw_cols_x; DevBuf<double> sendbuf;
     hipEvent_t ev_pack = nullptr;
+    std::vector<std::unique_ptr<DevBuf<double>>> eigV; DevBuf<double> eig_h, eig_y, eig_partial;
     DevBuf<double> vfull, tmp_in, tmp_out, lz[5], scal, alphas, betas, zvec, partial, partial2;
     int64_t nloc = 0, nloc_el = 0, vecdim = 0;
     int32_t nmax = 0;
@@ -543,24 +544,25 @@ static int halo_exchange(S *s, const double *v_local, hipStream_t st)
     return EDGPU_OK;
 }
 
-// sum scal[SC_TMP] over ranks
-static int allreduce_tmp(S *s)
+// sum n device doubles over ranks (in place)
+static int allreduce_dev(S *s, double *p, int n)
 {
     Comm &c = s->comm;
     if (!s->multi) return EDGPU_OK;
-    double *p = s->scal.p + SC_TMP;
     if (c.kind == Comm::RCCL) {
-        int rc = g_rccl.AllReduce(p, p, 1, kNcclDouble, kNcclSum, c.nccl, s->stream);
+        int rc = g_rccl.AllReduce(p, p, (size_t)n, kNcclDouble, kNcclSum, c.nccl, s->stream);
         if (rc) return fail(EDGPU_ECOMM, std::string("edgpu: RCCL allreduce failed: ") + g_rccl.GetErrorString(rc));
     } else if (c.kind == Comm::CALLBACK) {
-        double h;
-        HIPCHK(hipMemcpyAsync(&h, p, 8, hipMemcpyDeviceToHost, s->stream)); HIPCHK(hipStreamSynchronize(s->stream));
-        if (c.ar(c.ctx, &h, 1)) return fail(EDGPU_ECOMM, "edgpu: allreduce callback failed");
-        HIPCHK(hipMemcpyAsync(p, &h, 8, hipMemcpyHostToDevice, s->stream)); HIPCHK(hipStreamSynchronize(s->stream));
+        std::vector<double> h(n);
+        HIPCHK(hipMemcpyAsync(h.data(), p, (size_t)n * 8, hipMemcpyDeviceToHost, s->stream)); HIPCHK(hipStreamSynchronize(s->stream));
+        if (c.ar(c.ctx, h.data(), n)) return fail(EDGPU_ECOMM, "edgpu: allreduce callback failed");
+        HIPCHK(hipMemcpyAsync(p, h.data(), (size_t)n * 8, hipMemcpyHostToDevice, s->stream)); HIPCHK(hipStreamSynchronize(s->stream));
     } else
         return fail(EDGPU_ECOMM, "edgpu: mpi_size>1 but no communicator attached");
     return EDGPU_OK;
 }
+// sum scal[SC_TMP] over ranks
+static int allreduce_tmp(S *s) { return allreduce_dev(s, s->scal.p + SC_TMP, 1); }
 
 // ---------------------------------------------------------------------------------------
 // one product  out = H*v  (epi=false)   or the Lanczos-fused form (epi=true):
@@ -980,6 +982,130 @@ static int lanczos_tridiag(S *s, const double *vin_dev, int nlanc, double thresh
     return EDGPU_OK;
 }
 
+// ---------------------------------------------------------------------------------------
+// Lowest `nev` eigenpairs: thick-restart Lanczos with full re-orthogonalisation in a basis of
+// `ncv` vectors held in HBM, explicit Rayleigh-Ritz on the host.  Stands in for the ARPACK call
+// sp_eigh(MatVec,eval,evec,Nblock,Nitermax,tol) of ED_DIAG.f90:153-170 (which='SA', ncv=Nblock,
+// maxiter=Nitermax restarts, residual test |r_i| <= tol*max(eps^(2/3),|theta_i|)).
+// ---------------------------------------------------------------------------------------
+static void jacobi_eig(std::vector<double> &A, int m, std::vector<double> &w, std::vector<double> &Y)
+{   // cyclic Jacobi on the symmetric m x m matrix A (row-major); eigenvalues ascending in w, vectors = columns of Y (Y[i + m*j])
+    std::vector<double> V((size_t)m * m, 0.0);
+    for (int i = 0; i < m; i++) V[(size_t)i * m + i] = 1.0;
+    for (int sweep = 0; sweep < 60; sweep++) {
+        double off = 0.0, dg = 0.0;
+        for (int p = 0; p < m; p++) { dg += A[(size_t)p * m + p] * A[(size_t)p * m + p]; for (int q = p + 1; q < m; q++) off += A[(size_t)p * m + q] * A[(size_t)p * m + q]; }
+        if (off <= 1e-32 * (dg + 1e-300)) break;
+        for (int p = 0; p < m; p++)
+            for (int q = p + 1; q < m; q++) {
+                const double apq = A[(size_t)p * m + q];
+                if (std::fabs(apq) < 1e-300) continue;
+                const double theta = (A[(size_t)q * m + q] - A[(size_t)p * m + p]) / (2.0 * apq);
+                const double t = (theta >= 0 ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(theta * theta + 1.0));
+                const double c = 1.0 / std::sqrt(t * t + 1.0), sn = t * c;
+                for (int k = 0; k < m; k++) { double akp = A[(size_t)k * m + p], akq = A[(size_t)k * m + q]; A[(size_t)k * m + p] = c * akp - sn * akq; A[(size_t)k * m + q] = sn * akp + c * akq; }
+                for (int k = 0; k < m; k++) { double apk = A[(size_t)p * m + k], aqk = A[(size_t)q * m + k]; A[(size_t)p * m + k] = c * apk - sn * aqk; A[(size_t)q * m + k] = sn * apk + c * aqk; }
+                for (int k = 0; k < m; k++) { double vkp = V[(size_t)k * m + p], vkq = V[(size_t)k * m + q]; V[(size_t)k * m + p] = c * vkp - sn * vkq; V[(size_t)k * m + q] = sn * vkp + c * vkq; }
+            }
+    }
+    std::vector<int> idx(m);
+    for (int i = 0; i < m; i++) idx[i] = i;
+    std::sort(idx.begin(), idx.end(), [&](int a, int b) { return A[(size_t)a * m + a] < A[(size_t)b * m + b]; });
+    w.resize(m); Y.assign((size_t)m * m, 0.0);
+    for (int j = 0; j < m; j++) { w[j] = A[(size_t)idx[j] * m + idx[j]]; for (int i = 0; i < m; i++) Y[i + (size_t)m * j] = V[(size_t)i * m + idx[j]]; }
+}
+
+static int eigsh(S *s, int nev, int ncv, int maxiter, double tol, double *evals, double *evecs_host, int *nconv_out, int *nrestart_out, int *nmatvec_out)
+{
+    const int64_t Dim = s->H.Dim, n = s->nloc;
+    if (nev < 1) return fail(EDGPU_EINVAL, "edgpu_eigsh: nev < 1");
+    if ((int64_t)nev >= Dim) return fail(EDGPU_EINVAL, "edgpu_eigsh: nev must be smaller than the sector dimension (the reference switches to LAPACK there, ED_DIAG.f90:105-107)");
+    if (ncv > kMaxBasis) ncv = kMaxBasis;
+    if ((int64_t)ncv > Dim) ncv = (int)Dim;
+    if (ncv <= nev) ncv = (int)std::min<int64_t>(std::min<int64_t>(2 * nev + 1, kMaxBasis), Dim);
+    if (ncv <= nev) return fail(EDGPU_EINVAL, "edgpu_eigsh: ncv must exceed nev");
+    if (maxiter < 1) maxiter = 1;
+    const double tol_eff = std::max(tol, 1e-12), eps23 = std::pow(2.220446049250313e-16, 2.0 / 3.0);
+    const int m = ncv;
+    while ((int)s->eigV.size() < m + 1) { auto b = std::make_unique<DevBuf<double>>(); CHK(b->alloc((size_t)n)); s->eigV.push_back(std::move(b)); }
+    const int nb = (int)std::max<int64_t>(1, std::min<int64_t>(cdiv(n, 256 * 8), 1024));
+    if (s->eig_h.n < (size_t)(m + 2)) CHK(s->eig_h.alloc((size_t)m + 2));
+    if (s->eig_partial.n < (size_t)nb * (m + 1)) CHK(s->eig_partial.alloc((size_t)nb * (m + 1)));
+    if (s->eig_y.n < (size_t)m * m) CHK(s->eig_y.alloc((size_t)m * m));
+    auto Vp = [&](int i) { return s->eigV[i]->p; };
+    const SectorHost &H = s->H;
+    hipLaunchKernelGGL(k_random_start, dim3(2048), dim3(256), 0, s->stream, Vp(0), H.DimUp, H.Qdw, H.dw0, H.DimDw, H.DimPh, (uint64_t)1234567);
+    HIPCHK(hipGetLastError());
+    auto norm_of = [&](const double *x, double &out) -> int {
+        CHK(reduce_dot(s, x, x));
+        HIPCHK(hipMemcpyAsync(&out, s->scal.p + SC_TMP, 8, hipMemcpyDeviceToHost, s->stream)); HIPCHK(hipStreamSynchronize(s->stream));
+        out = std::sqrt(out);
+        return EDGPU_OK;
+    };
+    const int gs = (int)std::max<int64_t>(1, std::min<int64_t>(cdiv(n, 256 * 4), 4096));
+    double nrm; CHK(norm_of(Vp(0), nrm));
+    hipLaunchKernelGGL(k_scale_copy, dim3(gs), dim3(256), 0, s->stream, Vp(0), (const double *)Vp(0), 1.0 / nrm, n);
+    std::vector<double> Hm((size_t)m * m, 0.0), theta, Y, hh(m + 1), h2(m + 1);
+    int l = 0, nconv = 0, it = 0, nmv = 0, meff = m; double beta_last = 0.0;
+    for (it = 0; it < maxiter; it++) {
+        meff = m;
+        for (int j = l; j < m; j++) {
+            double *w = Vp(j + 1);
+            CHK(hxv(s, Vp(j), w, false, nullptr)); nmv++;
+            BasisArgs B{}; B.nv = j + 1; for (int i = 0; i <= j; i++) B.V[i] = Vp(i);
+            std::fill(hh.begin(), hh.end(), 0.0);
+            for (int pass = 0; pass < 2; pass++) {      // classical Gram-Schmidt, twice
+                hipLaunchKernelGGL(k_multidot, dim3(nb), dim3(256), 0, s->stream, B, (const double *)w, n, s->eig_partial.p);
+                hipLaunchKernelGGL(k_multidot_final, dim3(1), dim3(256), 0, s->stream, (const double *)s->eig_partial.p, nb, B.nv, s->eig_h.p);
+                HIPCHK(hipGetLastError());
+                CHK(allreduce_dev(s, s->eig_h.p, B.nv));
+                hipLaunchKernelGGL(k_multiaxpy, dim3(gs), dim3(256), 0, s->stream, B, (const double *)s->eig_h.p, w, n);
+                HIPCHK(hipMemcpyAsync(h2.data(), s->eig_h.p, (size_t)B.nv * 8, hipMemcpyDeviceToHost, s->stream)); HIPCHK(hipStreamSynchronize(s->stream));
+                for (int i = 0; i <= j; i++) hh[i] += h2[i];
+            }
+            for (int i = 0; i <= j; i++) { Hm[(size_t)i * m + j] = hh[i]; Hm[(size_t)j * m + i] = hh[i]; }
+            double beta; CHK(norm_of(w, beta));
+            beta_last = beta;
+            if (j + 1 < m) { Hm[(size_t)(j + 1) * m + j] = beta; Hm[(size_t)j * m + (j + 1)] = beta; }
+            if (beta <= 1e-13 * std::max(1.0, std::fabs(hh[j]))) { meff = j + 1; break; }   // invariant subspace
+            hipLaunchKernelGGL(k_scale_copy, dim3(gs), dim3(256), 0, s->stream, w, (const double *)w, 1.0 / beta, n);
+            HIPCHK(hipGetLastError());
+        }
+        std::vector<double> Hs((size_t)meff * meff);
+        for (int i = 0; i < meff; i++) for (int j = 0; j < meff; j++) Hs[(size_t)i * meff + j] = Hm[(size_t)i * m + j];
+        jacobi_eig(Hs, meff, theta, Y);
+        nconv = 0;
+        const int want = std::min(nev, meff);
+        for (int i = 0; i < want; i++) {
+            const double resid = std::fabs(beta_last * Y[(meff - 1) + (size_t)meff * i]);
+            if (resid <= tol_eff * std::max(eps23, std::fabs(theta[i]))) nconv++;
+        }
+        if (nconv >= want || meff < m || it + 1 >= maxiter) break;
+        // thick restart: keep the lowest l Ritz vectors, append the residual direction
+        l = std::min(m - 1, nev + std::max(1, (m - nev) / 2));
+        HIPCHK(hipMemcpyAsync(s->eig_y.p, Y.data(), (size_t)m * l * 8, hipMemcpyHostToDevice, s->stream));
+        RotArgs R{}; R.nv = m; R.nout = l; R.Y = s->eig_y.p; for (int i = 0; i < m; i++) R.V[i] = Vp(i);
+        hipLaunchKernelGGL(k_basis_rotate, dim3(gs), dim3(256), (size_t)m * l * 8, s->stream, R, n);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(Vp(l), Vp(m), (size_t)n * 8, hipMemcpyDeviceToDevice, s->stream));
+        std::fill(Hm.begin(), Hm.end(), 0.0);
+        for (int i = 0; i < l; i++) Hm[(size_t)i * m + i] = theta[i];
+    }
+    const int nout = std::min(nev, meff);
+    HIPCHK(hipMemcpyAsync(s->eig_y.p, Y.data(), (size_t)meff * nout * 8, hipMemcpyHostToDevice, s->stream));
+    RotArgs R{}; R.nv = meff; R.nout = nout; R.Y = s->eig_y.p; for (int i = 0; i < meff; i++) R.V[i] = Vp(i);
+    hipLaunchKernelGGL(k_basis_rotate, dim3(gs), dim3(256), (size_t)meff * nout * 8, s->stream, R, n);
+    HIPCHK(hipGetLastError());
+    for (int i = 0; i < nev; i++) evals[i] = i < nout ? theta[i] : 0.0;
+    if (evecs_host)
+        for (int i = 0; i < nout; i++) HIPCHK(hipMemcpyAsync(evecs_host + (int64_t)i * n, Vp(i), (size_t)n * 8, hipMemcpyDeviceToHost, s->stream));
+    HIPCHK(hipStreamSynchronize(s->stream));
+    if (nconv_out) *nconv_out = nconv;
+    if (nrestart_out) *nrestart_out = it + 1;
+    if (nmatvec_out) *nmatvec_out = nmv;
+    return EDGPU_OK;
+}
+
 }  // namespace edgpu
 
 // =========================================================================================
@@ -1207,6 +1333,14 @@ int edgpu_lanczos_time(edgpu_handle h, int32_t nwarm, int32_t niter, float *ms_p
     HIPCHK(hipEventElapsedTime(&ms, h->ev_a, h->ev_b));
     *ms_per_iter = ms / niter;
     return EDGPU_OK;
+}
+
+int edgpu_eigsh(edgpu_handle h, int32_t nev, int32_t ncv, int32_t maxiter, double tol, double *evals, double *evecs,
+                int32_t *nconv, int32_t *nrestarts, int32_t *nmatvec)
+{
+    if (!h || !evals) return fail(EDGPU_EINVAL, "edgpu_eigsh: null argument");
+    HIPCHK(hipSetDevice(h->device));
+    return eigsh(h, nev, ncv, maxiter, tol, evals, evecs, nconv, nrestarts, nmatvec);
 }
 
 // ---- O|state> between two live sectors (GF builders, ED_GF_NORMAL.f90:190-213, 264-283) ------

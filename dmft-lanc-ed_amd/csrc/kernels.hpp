@@ -956,6 +956,79 @@ __global__ void __launch_bounds__(256) k_scale(double *__restrict__ x, const dou
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) x[i] *= s;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Krylov-basis kernels of the multi-eigenpair solver (thick-restart Lanczos, lanczos.hpp/eigsh)
+// ---------------------------------------------------------------------------------------------
+constexpr int kMaxBasis = 48;
+struct BasisArgs { const double *V[kMaxBasis + 1]; int32_t nv; };
+
+// partial[b*nv + i] = sum over the block's elements of V_i . w     (one pass over w)
+__global__ void __launch_bounds__(256) k_multidot(BasisArgs B, const double *__restrict__ w, int64_t n, double *__restrict__ partial)
+{
+    __shared__ double red[4];
+    double acc[kMaxBasis + 1];
+#pragma unroll
+    for (int i = 0; i <= kMaxBasis; i++) acc[i] = 0.0;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
+        const double x = w[e];
+#pragma unroll
+        for (int i = 0; i <= kMaxBasis; i++) if (i < B.nv) acc[i] += B.V[i][e] * x;
+    }
+    for (int i = 0; i < B.nv; i++) {
+        double r = block_sum(acc[i], red);
+        if (threadIdx.x == 0) partial[(int64_t)blockIdx.x * B.nv + i] = r;
+    }
+}
+// out[i] = sum_b partial[b*nv+i], single workgroup, fixed order
+__global__ void __launch_bounds__(256) k_multidot_final(const double *__restrict__ partial, int nb, int nv, double *__restrict__ out)
+{
+    __shared__ double red[4];
+    for (int i = 0; i < nv; i++) {
+        double s = 0.0;
+        for (int b = threadIdx.x; b < nb; b += blockDim.x) s += partial[(int64_t)b * nv + i];
+        double r = block_sum(s, red);
+        if (threadIdx.x == 0) out[i] = r;
+        __syncthreads();
+    }
+}
+// w -= sum_i h[i] V_i
+__global__ void __launch_bounds__(256) k_multiaxpy(BasisArgs B, const double *__restrict__ h, double *__restrict__ w, int64_t n)
+{
+    double c[kMaxBasis + 1];
+#pragma unroll
+    for (int i = 0; i <= kMaxBasis; i++) c[i] = i < B.nv ? h[i] : 0.0;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
+        double x = w[e];
+#pragma unroll
+        for (int i = 0; i <= kMaxBasis; i++) if (i < B.nv) x -= c[i] * B.V[i][e];
+        w[e] = x;
+    }
+}
+// in-place rotation of the basis: V_j <- sum_i V_i Y[i + nv*j], j < nout  (row by row)
+struct RotArgs { double *V[kMaxBasis + 1]; int32_t nv, nout; const double *Y; };
+__global__ void __launch_bounds__(256) k_basis_rotate(RotArgs R, int64_t n)
+{
+    extern __shared__ double ysh[];     // nv*nout
+    for (int t = threadIdx.x; t < R.nv * R.nout; t += blockDim.x) ysh[t] = R.Y[t];
+    __syncthreads();
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
+        double x[kMaxBasis + 1];
+#pragma unroll
+        for (int i = 0; i <= kMaxBasis; i++) x[i] = i < R.nv ? R.V[i][e] : 0.0;
+        for (int j = 0; j < R.nout; j++) {
+            double s = 0.0;
+#pragma unroll
+            for (int i = 0; i <= kMaxBasis; i++) if (i < R.nv) s += x[i] * ysh[i + R.nv * j];
+            R.V[j][e] = s;
+        }
+    }
+}
+// y = a*x
+__global__ void __launch_bounds__(256) k_scale_copy(double *__restrict__ y, const double *__restrict__ x, double a, int64_t n)
+{
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) y[e] = a * x[e];
+}
+
 // deterministic pseudo-random start vector in (0,1): counter-based hash of the GLOBAL index,
 // so the same vector is produced for any rank count (the library seeds a fixed-seed RNG,
 // SciFortran lanczos_eigh; the stream itself is compiler specific and not a parity quantity)

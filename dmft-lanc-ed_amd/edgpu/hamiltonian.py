@@ -175,6 +175,16 @@ class HvSector:
         check(capi.lib().edgpu_lanczos_gs_device(self._h, nitermax, threshold, ncheck, C.byref(e), vect_dev.ptr, C.byref(n)))
         return e.value, n.value
 
+    def sp_eigh(self, neigen, nblock=None, nitermax=512, tol=1e-12, vectors=True):
+        """sp_eigh(MatVec,eval,evec,Nblock,Nitermax,tol): lowest `neigen` pairs (ED_DIAG.f90:153-170).
+        Returns (evals, evecs[vecDim, neigen] or None, info dict)."""
+        nblock = nblock or min(int(self.Dim), 10 * max(neigen, 2))
+        ev = np.zeros(neigen); vec = np.zeros((self.vecDim, neigen), order="F") if vectors else None
+        nc, nr, nm = C.c_int32(), C.c_int32(), C.c_int32()
+        check(capi.lib().edgpu_eigsh(self._h, neigen, nblock, nitermax, tol, ev.ctypes.data, vec.ctypes.data if vectors else None,
+                                     C.byref(nc), C.byref(nr), C.byref(nm)))
+        return ev, vec, {"nconv": nc.value, "restarts": nr.value, "matvecs": nm.value}
+
     def sp_lanc_tridiag(self, vin, nlanc, threshold=1e-12):
         vin = np.ascontiguousarray(vin, np.float64)
         a = np.zeros(nlanc); b = np.zeros(nlanc); n = C.c_int32()

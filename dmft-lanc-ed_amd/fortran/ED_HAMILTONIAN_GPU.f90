@@ -26,6 +26,7 @@ module ED_HAMILTONIAN_GPU
   public :: spMatVec_gpu
   public :: sp_lanc_eigh_gpu
   public :: sp_lanc_tridiag_gpu
+  public :: sp_eigh_gpu
   public :: get_sector_map_gpu
 
 contains
@@ -143,6 +144,22 @@ contains
     call edgpu_check(edgpu_lanczos_gs(Hhandle, int(Nitermax, c_int32_t), thr, nchk, egs, vect, nl), "sp_lanc_eigh_gpu")
     if (present(nlanc)) nlanc = nl
   end subroutine sp_lanc_eigh_gpu
+
+  !> sp_eigh(MatVec,eval,evec,Nblock,Nitermax,tol,iverbose): ED_DIAG.f90:153-170 (lanc_method default)
+  subroutine sp_eigh_gpu(eval, evec, Nblock, Nitermax, tol, nconv)
+    real(8), intent(out)           :: eval(:)
+    real(8), intent(out)           :: evec(:,:)        ! (vecDim, Neigen)
+    integer, intent(in)            :: Nblock, Nitermax
+    real(8), intent(in), optional  :: tol
+    integer, intent(out), optional :: nconv
+    real(c_double)     :: tl
+    integer(c_int32_t) :: nc, nr, nm
+    tl = 0d0; if (present(tol)) tl = tol
+    if (size(evec,1) /= Hinfo%vecDim .or. size(evec,2) /= size(eval)) stop "sp_eigh_gpu ERROR: wrong shape of evec"
+    call edgpu_check(edgpu_eigsh(Hhandle, int(size(eval), c_int32_t), int(Nblock, c_int32_t), int(Nitermax, c_int32_t), tl, &
+         eval, evec, nc, nr, nm), "sp_eigh_gpu")
+    if (present(nconv)) nconv = nc
+  end subroutine sp_eigh_gpu
 
   !> sp_lanc_tridiag(MatVec,vin,alanc,blanc)
   subroutine sp_lanc_tridiag_gpu(vin, alanc, blanc, threshold, nused)

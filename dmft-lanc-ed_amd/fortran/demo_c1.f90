@@ -14,7 +14,8 @@ program demo_c1
   procedure(dd_sparse_HxV), pointer :: spHtimesV_p => null()
   integer, parameter :: Norb = 1, Nspin = 1, Nbath = 5
   real(8) :: impHloc(Nspin,Nspin,Norb,Norb), diag_hybr(Nspin,Norb,Nbath), bath_diag(Nspin,Norb,Nbath)
-  real(8) :: Uloc(5), g_ph(5), egs
+  real(8) :: Uloc(5), g_ph(5), egs, eval2(2)
+  real(8), allocatable :: evec2(:,:)
   real(8), allocatable :: v(:), Hv(:), vect(:), alanc(:), blanc(:)
   integer :: N, i, nlanc, isparse
   logical :: sparse_H
@@ -42,6 +43,9 @@ program demo_c1
      write(*,"(A,F20.14,A,I4)") "E0=", egs, " nlanc=", nlanc
      call sp_lanc_tridiag_gpu(v, alanc, blanc)
      write(*,"(A,2ES24.16)") "alanc_1_2=", alanc(1:2)
+     if (.not. allocated(evec2)) allocate(evec2(N,2))
+     call sp_eigh_gpu(eval2, evec2, 20, 300, tol=1d-12)
+     write(*,"(A,2F20.14)") "E0E1=", eval2
      spHtimesV_p => null()
      call delete_Hv_sector_gpu()
   end do

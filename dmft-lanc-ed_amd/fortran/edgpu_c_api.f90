@@ -102,6 +102,16 @@ module EDGPU_C_API
        integer(c_int32_t)         :: nused
        integer(c_int)             :: rc
      end function edgpu_lanczos_tridiag
+     function edgpu_eigsh(handle, nev, ncv, maxiter, tol, evals, evecs, nconv, nrestarts, nmatvec) bind(C, name="edgpu_eigsh") result(rc)
+       import :: c_int, c_int32_t, c_double, c_ptr
+       type(c_ptr), value        :: handle
+       integer(c_int32_t), value :: nev, ncv, maxiter
+       real(c_double), value     :: tol
+       real(c_double)            :: evals(*)
+       real(c_double)            :: evecs(*)
+       integer(c_int32_t)        :: nconv, nrestarts, nmatvec
+       integer(c_int)            :: rc
+     end function edgpu_eigsh
      function edgpu_last_error() bind(C, name="edgpu_last_error") result(msg)
        import :: c_ptr
        type(c_ptr) :: msg

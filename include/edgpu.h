@@ -132,6 +132,13 @@ int edgpu_lanczos_tridiag_device(edgpu_handle h, const double *vin_dev, int32_t 
  * inside the loop: the timed region of bench.py.  Returns mean ms/iteration (HIP events). */
 int edgpu_lanczos_time(edgpu_handle h, int32_t nwarm, int32_t niter, float *ms_per_iter);
 
+/* sp_eigh(MatVec,eval,evec,Nblock,Nitermax,tol)   ED_DIAG.f90:153-170 (ARPACK dsaupd/dseupd, which='SA'):
+ * the lowest `nev` eigenpairs from a thick-restart Lanczos with a basis of `ncv` (=Nblock) vectors kept in
+ * HBM; `maxiter` restarts at most.  evals[nev] ascending; evecs (host, vecDim x nev column-major, may be
+ * NULL).  nconv = number of requested pairs whose residual passed |r| <= tol*max(eps^(2/3),|theta|). */
+int edgpu_eigsh(edgpu_handle h, int32_t nev, int32_t ncv, int32_t maxiter, double tol, double *evals, double *evecs,
+                int32_t *nconv, int32_t *nrestarts, int32_t *nmatvec);
+
 /* ---- Green's-function leg: O|state> between two live sectors, in HBM ------
  * vout(j) = sgn * vin(i) with |j> = c^+_{iorb,ispin}|i> (dagger=1) or c_{iorb,ispin}|i> (dagger=0),
  * ED_GF_NORMAL.f90:190-213 / 264-283; `to` must be getCDGsector/getCsector of `from`

@@ -1,0 +1,52 @@
+"""a16 / SURVEY 8f rank 2: the multi-eigenpair solver behind the reference's default
+lanc_method=arpack (sp_eigh, ED_DIAG.f90:153-170) against dense diagonalisation of the oracle's Hmat."""
+import numpy as np
+import pytest
+
+import cases
+from oracle import oracle
+
+pytestmark = pytest.mark.gpu
+SEL = [z for z in cases.zoo() if z[0] in ("c_nb5_half", "c_nb7_half", "nb5_offhalf_2_4", "norb2_normal_JxJp", "replica_sz_sx_JxJp",
+                                         "orbs_norb2_nb3", "phonons_nb3_nph3", "nspin2_random_bath")]
+
+
+@pytest.mark.parametrize("name,m,nu,nd", SEL, ids=[z[0] for z in SEL])
+def test_lowest_eigenpairs_match_dense(edgpu_mod, name, m, nu, nd):
+    S = oracle.Sector(m, nu, nd)
+    w = np.linalg.eigvalsh(S.hmat())
+    for neigen, st in ((2, "kron"), (4, "direct")):
+        G = edgpu_mod.HvSector(m, nu, nd, storage=st)
+        ev, X, info = G.sp_eigh(neigen, nblock=min(S.Dim, 10 * neigen), nitermax=300, tol=1e-12)
+        assert info["nconv"] == neigen, info
+        np.testing.assert_allclose(ev, w[:neigen], rtol=0, atol=1e-10)
+        for i in range(neigen):       # eigenvectors: unit norm, small residual, mutually orthogonal (degenerate levels included)
+            x = X[:, i]
+            assert abs(np.linalg.norm(x) - 1.0) < 1e-10
+            assert np.linalg.norm(S.spmatvec(x) - ev[i] * x) < 1e-8
+        assert np.abs(X.T @ X - np.eye(neigen)).max() < 1e-10
+        G.close()
+
+
+def test_eigsh_agrees_with_plain_lanczos_on_c2(edgpu_mod):
+    from edgpu import model
+    m, nu, nd = model.half_filled_c(11)          # N = 853776
+    G = edgpu_mod.HvSector(m, nu, nd)
+    e0, x, nl = G.sp_lanc_eigh(nitermax=300, threshold=1e-13)
+    ev, X, info = G.sp_eigh(2, nblock=20, nitermax=100, tol=1e-11)
+    assert info["nconv"] == 2 and abs(ev[0] - e0) < 1e-9 and ev[1] > ev[0]
+    r = G.spHtimesV(X[:, 1]) - ev[1] * X[:, 1]
+    assert np.linalg.norm(r) < 1e-7
+    G.close()
+
+
+def test_eigsh_argument_errors(edgpu_mod):
+    from edgpu import model, capi
+    m, nu, nd = model.half_filled_c(1)           # N = 4
+    G = edgpu_mod.HvSector(m, nu, nd)
+    with pytest.raises(capi.EdgpuError):
+        G.sp_eigh(4)                             # Neigen == dim: the reference uses LAPACK there
+    ev, X, info = G.sp_eigh(2, nblock=4)
+    S = oracle.Sector(m, nu, nd)
+    np.testing.assert_allclose(ev, np.linalg.eigvalsh(S.hmat())[:2], atol=1e-12)
+    G.close()

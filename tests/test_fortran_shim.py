@@ -15,7 +15,7 @@ def test_shim_sources_declare_the_c_abi_names():
     src = open(os.path.join(ROOT, "dmft-lanc-ed_amd", "fortran", "edgpu_c_api.f90")).read()
     hdr = open(os.path.join(ROOT, "include", "edgpu.h")).read()
     names = re.findall(r'bind\(C, name="(edgpu_[a-z0-9_]+)"\)', src)
-    assert len(names) >= 9
+    assert len(names) >= 10
     for n in names:
         assert re.search(r"\b%s\s*\(" % n, hdr), n
 
@@ -36,3 +36,5 @@ def test_fortran_driver_config1_matches_reference_known_answers():
         for x, y in zip(f("Hv_1_3"), g["Hv_1_3"]):
             assert abs(x - y) < 1e-12
         assert abs(f("E0")[0] - g["E0"]) < 1e-10
+        e01 = f("E0E1")
+        assert abs(e01[0] - g["E0"]) < 1e-10 and abs(e01[1] - g["E1"]) < 1e-10     # sp_eigh_gpu, 2 pairs
