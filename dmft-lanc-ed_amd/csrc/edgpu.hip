@@ -1343,6 +1343,53 @@ int edgpu_eigsh(edgpu_handle h, int32_t nev, int32_t ncv, int32_t maxiter, doubl
     return eigsh(h, nev, ncv, maxiter, tol, evals, evecs, nconv, nrestarts, nmatvec);
 }
 
+// Impurity-configuration weights of a state vector (host or device resident), summed over ranks.
+// hist: (2^Norb * 2^Norb * DimPh) doubles, index (mu_imp*2^Norb + md_imp) + 4^Norb*iph.
+int edgpu_imp_histogram(edgpu_handle h, const double *vec, int32_t vec_on_device, double *hist)
+{
+    if (!h || !vec || !hist) return fail(EDGPU_EINVAL, "edgpu_imp_histogram: null argument");
+    HIPCHK(hipSetDevice(h->device));
+    const SectorHost &H = h->H; const int nI = 1 << H.desc.Norb, nb = nI * nI * H.DimPh;
+    const double *v = vec;
+    if (!vec_on_device) {
+        if (h->tmp_in.n != (size_t)h->nloc) { CHK(h->tmp_in.alloc((size_t)h->nloc)); CHK(h->tmp_out.alloc((size_t)h->nloc)); }
+        HIPCHK(hipMemcpy(h->tmp_in.p, vec, (size_t)h->nloc * 8, hipMemcpyHostToDevice));
+        v = h->tmp_in.p;
+    }
+    std::vector<double> acc(nb, 0.0);
+    if (h->two_factor) {
+        const int64_t nrows = H.Qdw * H.DimPh;
+        DevBuf<double> out; CHK(out.alloc((size_t)nrows * nI));
+        HistArgs A{}; A.DimUp = (int32_t)H.DimUp; A.nI = nI; A.impmask = nI - 1; A.nrows = nrows; A.mapup = h->fac[0]->map.p; A.v = v; A.out = out.p;
+        hipLaunchKernelGGL(k_imp_hist_rows, dim3((unsigned)nrows), dim3(256), 0, h->stream, A);
+        HIPCHK(hipGetLastError());
+        std::vector<double> part((size_t)nrows * nI);
+        HIPCHK(hipMemcpyAsync(part.data(), out.p, part.size() * 8, hipMemcpyDeviceToHost, h->stream)); HIPCHK(hipStreamSynchronize(h->stream));
+        for (int64_t r = 0; r < nrows; r++) {            // fixed order: deterministic
+            const int64_t iph = r / H.Qdw, idw = H.dw0 + (r - iph * H.Qdw);
+            const int md = H.fac[1].map[idw] & (nI - 1);
+            for (int mu = 0; mu < nI; mu++) acc[(size_t)(mu * nI + md) + (size_t)nI * nI * iph] += part[(size_t)r * nI + mu];
+        }
+    } else {
+        const int grid = 256;
+        DevBuf<double> out; CHK(out.alloc((size_t)grid * nb));
+        HistGenArgs A{}; A.nfac = 2 * H.Ns_Ud; A.nI = nI; A.DimPh = H.DimPh; A.Nel = h->nloc_el; A.v = v; A.out = out.p;
+        for (int k = 0; k < A.nfac; k++) { A.dims[k] = H.fac[k].dim; A.maps[k] = h->fac[k]->map.p; }
+        hipLaunchKernelGGL(k_imp_hist_generic, dim3(grid), dim3(256), (size_t)nb * 8, h->stream, A);
+        HIPCHK(hipGetLastError());
+        std::vector<double> part((size_t)grid * nb);
+        HIPCHK(hipMemcpyAsync(part.data(), out.p, part.size() * 8, hipMemcpyDeviceToHost, h->stream)); HIPCHK(hipStreamSynchronize(h->stream));
+        for (int b = 0; b < grid; b++) for (int t = 0; t < nb; t++) acc[t] += part[(size_t)b * nb + t];
+    }
+    if (h->multi && h->comm.size > 1) {
+        DevBuf<double> d; CHK(d.upload(acc));
+        CHK(allreduce_dev(h, d.p, nb));
+        HIPCHK(hipMemcpyAsync(acc.data(), d.p, (size_t)nb * 8, hipMemcpyDeviceToHost, h->stream)); HIPCHK(hipStreamSynchronize(h->stream));
+    }
+    for (int t = 0; t < nb; t++) hist[t] = acc[t];
+    return EDGPU_OK;
+}
+
 // ---- O|state> between two live sectors (GF builders, ED_GF_NORMAL.f90:190-213, 264-283) ------
 int edgpu_apply_op(edgpu_handle from, edgpu_handle to, int32_t iorb, int32_t ispin, int32_t dagger,
                    const double *vin_dev, double *vout_dev, double *norm2)

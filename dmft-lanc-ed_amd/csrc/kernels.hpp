@@ -957,6 +957,53 @@ __global__ void __launch_bounds__(256) k_scale(double *__restrict__ x, const dou
 }
 
 // ---------------------------------------------------------------------------------------------
+// Impurity-configuration weights of a state: hist[(mu_imp*nI + md_imp) + nI*nI*iph] = sum |v_i|^2.
+// Every local observable of lanc_observables (ED_OBSERVABLES.f90:150-215: dens, dens_up/dw, docc,
+// magz, sz2, n2, s2tot, Prob, prob_ph, dens_ph) is a function of this (2^Norb)^2 x DimPh table, so
+// the N-vector never leaves HBM.  Two-factor layout: one workgroup per (idw,iph) row produces the
+// nI partial sums over iup classes in a fixed order (deterministic); out[row*nI + mu].
+// ---------------------------------------------------------------------------------------------
+struct HistArgs { int32_t DimUp, nI, impmask; int64_t nrows; const int32_t *mapup; const double *v; double *out; };
+__global__ void __launch_bounds__(256) k_imp_hist_rows(HistArgs A)
+{
+    __shared__ double red[4];
+    const int64_t row = blockIdx.x;
+    double acc[32];
+#pragma unroll
+    for (int c = 0; c < 32; c++) acc[c] = 0.0;
+    for (int i = threadIdx.x; i < A.DimUp; i += blockDim.x) {
+        const double x = A.v[row * A.DimUp + i];
+        const int c = A.mapup[i] & A.impmask;
+#pragma unroll
+        for (int q = 0; q < 32; q++) if (q == c) acc[q] += x * x;
+    }
+    for (int c = 0; c < A.nI; c++) { double r = block_sum(acc[c], red); if (threadIdx.x == 0) A.out[row * A.nI + c] = r; }
+}
+// generic digit layout (ed_total_ud=F): LDS histogram with fp64 atomics (summation order not fixed)
+struct HistGenArgs { int32_t nfac, nI, DimPh; int32_t dims[2 * EDGPU_MAX_ORB]; const int32_t *maps[2 * EDGPU_MAX_ORB]; int64_t Nel; const double *v; double *out; };
+__global__ void __launch_bounds__(256) k_imp_hist_generic(HistGenArgs A)
+{
+    extern __shared__ double hs[];   // nI*nI*DimPh
+    const int nb = A.nI * A.nI * A.DimPh;
+    for (int t = threadIdx.x; t < nb; t += blockDim.x) hs[t] = 0.0;
+    __syncthreads();
+    const int64_t N = A.Nel * A.DimPh; const int nud = A.nfac / 2;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t iph = i / A.Nel; int64_t c = i - iph * A.Nel;
+        uint32_t mu = 0, md = 0;
+        for (int k = 0; k < A.nfac; k++) {
+            const int dg = (int)(c % A.dims[k]); c /= A.dims[k];
+            const uint32_t bit = (uint32_t)A.maps[k][dg] & 1u;
+            if (k < nud) mu |= bit << k; else md |= bit << (k - nud);
+        }
+        const double x = A.v[i];
+        atomicAdd(&hs[(mu * A.nI + md) + (int64_t)A.nI * A.nI * iph], x * x);
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < nb; t += blockDim.x) A.out[(int64_t)blockIdx.x * nb + t] = hs[t];
+}
+
+// ---------------------------------------------------------------------------------------------
 // Krylov-basis kernels of the multi-eigenpair solver (thick-restart Lanczos, lanczos.hpp/eigsh)
 // ---------------------------------------------------------------------------------------------
 constexpr int kMaxBasis = 48;

@@ -185,6 +185,38 @@ class HvSector:
                                      C.byref(nc), C.byref(nr), C.byref(nm)))
         return ev, vec, {"nconv": nc.value, "restarts": nr.value, "matvecs": nm.value}
 
+    def imp_histogram(self, vec):
+        """Impurity-configuration weights (nI, nI, DimPh) of a state (numpy array or DeviceVector)."""
+        nI = 1 << int(self._desc.Norb)
+        hist = np.zeros(nI * nI * int(self.DimPh))
+        if isinstance(vec, DeviceVector):
+            check(capi.lib().edgpu_imp_histogram(self._h, vec.ptr, 1, hist.ctypes.data))
+        else:
+            vec = np.ascontiguousarray(vec, np.float64)
+            check(capi.lib().edgpu_imp_histogram(self._h, vec.ctypes.data, 0, hist.ctypes.data))
+        return hist.reshape(int(self.DimPh), nI, nI).transpose(1, 2, 0)      # [mu, md, iph]
+
+    def observables(self, vec, peso=1.0):
+        """dens, dens_up, dens_dw, docc, magz, sz2, n2, s2tot, Prob, prob_ph, dens_ph of
+        lanc_observables (ED_OBSERVABLES.f90:150-215) from the impurity-configuration weights."""
+        Norb = int(self._desc.Norb)
+        Hst = self.imp_histogram(vec) * peso
+        nI = 1 << Norb
+        o = dict(dens=np.zeros(Norb), dens_up=np.zeros(Norb), dens_dw=np.zeros(Norb), docc=np.zeros(Norb), magz=np.zeros(Norb),
+                 sz2=np.zeros((Norb, Norb)), n2=np.zeros((Norb, Norb)), s2tot=0.0, Prob=np.zeros(3 ** Norb),
+                 prob_ph=Hst.sum(axis=(0, 1)), dens_ph=float((Hst.sum(axis=(0, 1)) * np.arange(Hst.shape[2])).sum()))
+        for mu in range(nI):
+            for md in range(nI):
+                wgt = Hst[mu, md].sum()
+                nup = np.array([(mu >> a) & 1 for a in range(Norb)], float); ndw = np.array([(md >> a) & 1 for a in range(Norb)], float)
+                sz, nt = (nup - ndw) / 2.0, nup + ndw
+                o["Prob"][int(sum(int(nt[a]) * 3 ** a for a in range(Norb)))] += wgt
+                o["dens"] += nt * wgt; o["dens_up"] += nup * wgt; o["dens_dw"] += ndw * wgt
+                o["docc"] += nup * ndw * wgt; o["magz"] += (nup - ndw) * wgt
+                o["sz2"] += np.outer(sz, sz) * wgt; o["n2"] += np.outer(nt, nt) * wgt
+                o["s2tot"] += sz.sum() ** 2 * wgt
+        return o
+
     def sp_lanc_tridiag(self, vin, nlanc, threshold=1e-12):
         vin = np.ascontiguousarray(vin, np.float64)
         a = np.zeros(nlanc); b = np.zeros(nlanc); n = C.c_int32()

@@ -139,6 +139,13 @@ int edgpu_lanczos_time(edgpu_handle h, int32_t nwarm, int32_t niter, float *ms_p
 int edgpu_eigsh(edgpu_handle h, int32_t nev, int32_t ncv, int32_t maxiter, double tol, double *evals, double *evecs,
                 int32_t *nconv, int32_t *nrestarts, int32_t *nmatvec);
 
+/* ---- observables: impurity-configuration weights of a state --------------------
+ * hist[(mu*2^Norb + md) + 4^Norb*iph] = sum_i |vec_i|^2 over the states whose impurity up/down
+ * occupation words are mu/md (bit a-1 = orbital a) and phonon number iph.  dens, dens_up/dw, docc, magz,
+ * sz2, n2, s2tot, Prob, prob_ph, dens_ph of lanc_observables (ED_OBSERVABLES.f90:150-215) are sums over
+ * this table, so the N-vector stays in HBM.  vec: host (vec_on_device=0) or device pointer, vecDim doubles. */
+int edgpu_imp_histogram(edgpu_handle h, const double *vec, int32_t vec_on_device, double *hist);
+
 /* ---- Green's-function leg: O|state> between two live sectors, in HBM ------
  * vout(j) = sgn * vin(i) with |j> = c^+_{iorb,ispin}|i> (dagger=1) or c_{iorb,ispin}|i> (dagger=0),
  * ED_GF_NORMAL.f90:190-213 / 264-283; `to` must be getCDGsector/getCsector of `from`

@@ -324,3 +324,42 @@ def apply_op(S_from, S_to, iorb, ispin, dagger, state):
         vv[j - 1] = sgn * state[i - 1]
     norm2 = float(vv @ vv)
     return (vv / np.sqrt(norm2) if norm2 > 0 else vv), norm2
+
+
+def lanc_observables(S, state, peso=1.0):
+    """Restatement of the per-state loop of lanc_observables (ED_OBSERVABLES.f90:150-215): loops over
+    all basis states of sector S and accumulates the local observables with weight peso*|state_i|^2."""
+    Norb = S.model["Norb"]; Ns_Ud, Ns_Orb = S.Ns_Ud, S.Ns_Orb
+    total_ud = S.model.get("ed_total_ud", True)
+    dims = [int(x) for x in list(S.DimUps) + list(S.DimDws)]
+    HI = [S.map(k) for k in range(2 * Ns_Ud)]
+    iel = S.DimUp * S.DimDw
+    o = dict(dens=np.zeros(Norb), dens_up=np.zeros(Norb), dens_dw=np.zeros(Norb), docc=np.zeros(Norb), magz=np.zeros(Norb),
+             sz2=np.zeros((Norb, Norb)), n2=np.zeros((Norb, Norb)), s2tot=0.0, Prob=np.zeros(3 ** Norb),
+             prob_ph=np.zeros(S.DimPh), dens_ph=0.0)
+    for i in range(1, S.Dim + 1):
+        iph = (i - 1) // iel + 1
+        c = (i - 1) % iel; ind = []
+        for d in dims:
+            ind.append(c % d + 1); c //= d
+        if total_ud:       # breorder: levels 1..Norb of the single up/dw word are the impurity orbitals
+            mup, mdw = int(HI[0][ind[0] - 1]), int(HI[1][ind[1] - 1])
+            nup = np.array([(mup >> a) & 1 for a in range(Norb)], float); ndw = np.array([(mdw >> a) & 1 for a in range(Norb)], float)
+        else:              # one (1+Nbath)-level word per orbital, level 1 = impurity
+            nup = np.array([int(HI[a][ind[a] - 1]) & 1 for a in range(Norb)], float)
+            ndw = np.array([int(HI[a + Ns_Ud][ind[a + Ns_Ud] - 1]) & 1 for a in range(Norb)], float)
+        w = peso * abs(state[i - 1]) ** 2
+        sz, nt = (nup - ndw) / 2.0, nup + ndw
+        iprob = 1 + sum(int(round(nt[a])) * 3 ** a for a in range(Norb))
+        o["Prob"][iprob - 1] += w
+        for a in range(Norb):
+            o["dens"][a] += nt[a] * w; o["dens_up"][a] += nup[a] * w; o["dens_dw"][a] += ndw[a] * w
+            o["docc"][a] += nup[a] * ndw[a] * w; o["magz"][a] += (nup[a] - ndw[a]) * w
+            o["sz2"][a, a] += sz[a] * sz[a] * w; o["n2"][a, a] += nt[a] * nt[a] * w
+            for b in range(a + 1, Norb):
+                o["sz2"][a, b] += sz[a] * sz[b] * w; o["sz2"][b, a] += sz[b] * sz[a] * w
+                o["n2"][a, b] += nt[a] * nt[b] * w; o["n2"][b, a] += nt[b] * nt[a] * w
+        o["s2tot"] += sz.sum() ** 2 * w
+        o["prob_ph"][iph - 1] += w
+        o["dens_ph"] += (iph - 1) * w
+    return o
