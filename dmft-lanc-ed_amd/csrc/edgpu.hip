@@ -108,7 +108,7 @@ template <class T> struct DevBuf {
 
 struct DevFactor {
     DevBuf<int32_t> map, rank, rowptr, cols, ellc, talpha, tbeta;
-    DevBuf<uint32_t> pcols, pcodes; DevBuf<double> ptval; bool packed = false; int32_t pterms = 0;
+    DevBuf<uint32_t> pcols, pcodes, pelem; DevBuf<double> ptval; bool packed = false, packed_elem = false; int32_t pterms = 0;
     DevBuf<double> vals, ellv, E, tval, lin;
     int32_t width = 0;
 };
@@ -143,7 +143,7 @@ struct edgpu_sector_s {
     int64_t nloc = 0, nloc_el = 0, vecdim = 0;
     int32_t nmax = 0;
     bool use_lds = false; int kron_threads = 256, kron_threads_override = 0; size_t kron_lds = 0;
-    bool two_factor = false, extra = false, multi = false, kron_split = false; int dw_w = 64, dw_variant = 2, dw_rows = 64; bool up_persistent = true; int up_grid = 256, up_threads = 1024;
+    bool two_factor = false, extra = false, multi = false, kron_split = false; int dw_w = 64, dw_variant = 2, dw_rows = 64; bool up_persistent = true, up_pairs = true; int up_grid = 256, up_threads = 1024;
     std::vector<hipEvent_t> bench_ev; int bench_k = 0; double *bv[3] = {nullptr, nullptr, nullptr};
     int64_t nnz_total = 0, bytes_stored = 0;
     int64_t npartial = 0;
@@ -202,6 +202,14 @@ static int upload_factor(S *s, int k)
                 pd[(size_t)(q / 4) * f.dim + i] |= code << (8 * (q & 3));
             }
         if (ok) { CHK(df->pcols.upload(pc)); CHK(df->pcodes.upload(pd)); CHK(df->ptval.upload(tvl)); df->packed = true; df->pterms = 128; }
+        if (ok && W <= 8 && f.dim % 2 == 0) {       // element-major image for the pair kernel: 6 dwords per up configuration
+            std::vector<uint32_t> pe((size_t)6 * f.dim, 0u);
+            for (int32_t i = 0; i < f.dim; i++) {
+                for (int c = 0; c < 4; c++) pe[(size_t)6 * i + c] = c < ncw ? pc[(size_t)c * f.dim + i] : ((uint32_t)i | ((uint32_t)i << 16));
+                for (int c = 0; c < 2; c++) pe[(size_t)6 * i + 4 + c] = c < ndw ? pd[(size_t)c * f.dim + i] : 0x7f7f7f7fu;
+            }
+            CHK(df->pelem.upload(pe)); df->packed_elem = true;
+        }
     }
     std::vector<int32_t> ta, tb; std::vector<double> tv;
     for (auto &t : f.terms) { ta.push_back(t.alpha); tb.push_back(t.beta); tv.push_back(t.t); }
@@ -417,6 +425,7 @@ static int create(const edgpu_desc *desc, S **out)
         s->dw_variant = dbg_int("EDGPU_DW_VARIANT", 2);
         s->up_persistent = dbg_int("EDGPU_UP_PERSISTENT", 1) != 0;
         s->up_grid = dbg_int("EDGPU_UP_GRID", 256);
+        s->up_pairs = dbg_int("EDGPU_UP_PAIRS", 1) != 0;
         s->up_threads = dbg_int("EDGPU_UP_THREADS", 1024) == 512 ? 512 : 1024;
         s->dw_rows = std::max(1, std::min(64, dbg_int("EDGPU_DW_ROWS", 64)));
         if (s->dw_w != 8 && s->dw_w != 16 && s->dw_w != 32 && s->dw_w != 64 && s->dw_w != 128 && s->dw_w != 256) s->dw_w = 32;
@@ -697,7 +706,24 @@ static int hxv(S *s, const double *v, double *out, bool epi, const double *uprev
         if (!split) CHK(dispatch_kron2(s, base | (s->use_lds ? KF_LDS : 0), A, nblocks));
         else {
             const bool persistent = s->up_persistent && !s->extra && s->fac[0]->packed && s->fac[0]->width <= 16 && s->use_lds && H.DimUp <= 13312 && !direct_tables_dirty(s);
-            if (persistent) {
+            if (persistent && s->up_pairs && s->fac[0]->packed_elem && !direct) {
+                UpArgs2 U{};
+                U.DimUp = A.DimUp; U.DimPh = A.DimPh; U.Qdw = A.Qdw; U.dw0 = A.dw0; U.nrows = H.Qdw * H.DimPh;
+                U.packed = reinterpret_cast<const uint4 *>(s->fac[0]->pelem.p); U.tval = s->fac[0]->ptval.p; U.nterms = s->fac[0]->pterms;
+                U.diag = A.diag; U.Eup = A.Eup; U.Edw = A.Edw; U.cross = A.cross; U.mapup = A.mapup; U.mapdw = A.mapdw; U.impmask = A.impmask; U.nI = A.nI; U.econst = A.econst;
+                U.v = v; U.out = out; U.uprev = uprev; U.scal = s->scal.p;
+                const size_t lds = (size_t)H.DimUp * 8 + 128 * 8;
+                const int grid = (int)std::min<int64_t>(U.nrows, s->up_grid);
+                static bool attr2 = false;
+                if (!attr2) {
+                    (void)hipFuncSetAttribute((const void *)k_uppass2<false, false, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                    (void)hipFuncSetAttribute((const void *)k_uppass2<false, true, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                    attr2 = true;
+                }
+                if (epi) hipLaunchKernelGGL((k_uppass2<false, true, 1024>), dim3(grid), dim3(1024), lds, s->stream, U);
+                else hipLaunchKernelGGL((k_uppass2<false, false, 1024>), dim3(grid), dim3(1024), lds, s->stream, U);
+                HIPCHK(hipGetLastError());
+            } else if (persistent) {
                 UpArgs U{};
                 U.DimUp = A.DimUp; U.DimPh = A.DimPh; U.Qdw = A.Qdw; U.dw0 = A.dw0; U.nrows = H.Qdw * H.DimPh;
                 U.pcols = s->fac[0]->pcols.p; U.pcodes = s->fac[0]->pcodes.p; U.upw = s->fac[0]->width; U.tval = s->fac[0]->ptval.p; U.nterms = s->fac[0]->pterms;

@@ -227,6 +227,7 @@ __global__ void __launch_bounds__(1024) k_kron2(Kron2Args A)
 }
 
 // ---------------------------------------------------------------------------------------------
+typedef double dbl2v __attribute__((ext_vector_type(2)));
 // Local pass (diagonal + up hops) of the split product, persistent form: one 1024-thread
 // workgroup per CU walks rows b, b+grid, ...  The row is staged in LDS for the up-hop gathers;
 // the NEXT row is already on its way into registers while the current one is computed, so the
@@ -315,6 +316,88 @@ __global__ void __launch_bounds__(NT) k_uppass(UpArgs A)
     }
 }
 
+// Pair form of the persistent local pass (needs DimUp even and <= 8 hops per up configuration):
+// a lane owns two consecutive iup, so the row, the stored diagonal, u_prev and the result move as
+// 16-byte accesses and the packed H_up image of the pair (2 x 24 B, element-major) as three 16-byte
+// loads: about a third of the vector-memory instructions of k_uppass.
+struct UpArgs2 {
+    int32_t DimUp, DimPh; int64_t Qdw, dw0, nrows;
+    const uint4 *packed;     // [iup/2][3] uint4: element e -> dwords {c01,c23,c45,c67,codes0123,codes4567}
+    const double *tval; int32_t nterms;
+    const double *diag, *Eup, *Edw, *cross; const int32_t *mapup, *mapdw; int32_t impmask, nI; double econst;
+    const double *v; double *out; const double *uprev; const double *scal;
+};
+
+template <bool DIRECT, bool EPI, int NT>
+__global__ void __launch_bounds__(NT) k_uppass2(UpArgs2 A)
+{
+    extern __shared__ double lds[];
+    constexpr int MAXQ = (13312 / 2 + NT - 1) / NT;      // pairs per lane
+    const int DimUp = A.DimUp, npair = DimUp >> 1, tid = threadIdx.x;
+    double *tv = lds + DimUp;
+    for (int t = tid; t < A.nterms; t += NT) tv[t] = A.tval[t];
+    const int nq = (npair + NT - 1) / NT;
+    dbl2v xr[MAXQ];
+    int64_t row = blockIdx.x;
+    if (row < A.nrows) {
+#pragma unroll
+        for (int q = 0; q < MAXQ; q++) { const int p = tid + q * NT; if (q < nq && p < npair) xr[q] = *reinterpret_cast<const dbl2v *>(A.v + row * DimUp + 2 * p); }
+    }
+    double s_cur = 1.0, c_prev = 0.0;
+    if (EPI) { s_cur = A.scal[SC_SCUR]; c_prev = A.scal[SC_BETA] * A.scal[SC_SPREV]; }
+    struct Ops { dbl2v d, u; uint4 w0, w1, w2; };
+    while (row < A.nrows) {
+        const int64_t idwl = row % A.Qdw, idw = A.dw0 + idwl;
+        auto load_ops = [&](int p, Ops &o) {
+            if (!DIRECT) o.d = *reinterpret_cast<const dbl2v *>(A.diag + idwl * DimUp + 2 * p);
+            if (EPI) o.u = *reinterpret_cast<const dbl2v *>(A.uprev + row * DimUp + 2 * p);
+            o.w0 = A.packed[3 * p]; o.w1 = A.packed[3 * p + 1]; o.w2 = A.packed[3 * p + 2];
+        };
+        Ops cur, nxt;
+        if (tid < npair) load_ops(tid, cur);
+#pragma unroll
+        for (int q = 0; q < MAXQ; q++) { const int p = tid + q * NT; if (q < nq && p < npair) *reinterpret_cast<dbl2v *>(lds + 2 * p) = xr[q]; }
+        __syncthreads();
+        const int64_t next = row + gridDim.x;
+        if (next < A.nrows) {
+#pragma unroll
+            for (int q = 0; q < MAXQ; q++) { const int p = tid + q * NT; if (q < nq && p < npair) xr[q] = *reinterpret_cast<const dbl2v *>(A.v + next * DimUp + 2 * p); }
+        }
+        uint32_t mdw = 0; double edw = 0.0;
+        if (DIRECT) { mdw = (uint32_t)A.mapdw[idw] & A.impmask; edw = A.Edw[idw] + A.econst; }
+        for (int p = tid; p < npair; p += NT) {
+            if (p + NT < npair) load_ops(p + NT, nxt);
+            const dbl2v x = *reinterpret_cast<const dbl2v *>(lds + 2 * p);
+            dbl2v dval;
+            if (DIRECT) {
+                const int2 mm = *reinterpret_cast<const int2 *>(A.mapup + 2 * p);
+                const dbl2v e2 = *reinterpret_cast<const dbl2v *>(A.Eup + 2 * p);
+                dval.x = edw + e2.x + A.cross[((uint32_t)mm.x & A.impmask) * A.nI + mdw];
+                dval.y = edw + e2.y + A.cross[((uint32_t)mm.y & A.impmask) * A.nI + mdw];
+            } else dval = cur.d;
+            // element 0 of the pair: dwords w0.x w0.y w0.z w0.w (cols) w1.x w1.y (codes); element 1: w1.z w1.w w2.x w2.y, w2.z w2.w
+            const uint32_t c0[4] = {cur.w0.x, cur.w0.y, cur.w0.z, cur.w0.w}, k0[2] = {cur.w1.x, cur.w1.y};
+            const uint32_t c1[4] = {cur.w1.z, cur.w1.w, cur.w2.x, cur.w2.y}, k1[2] = {cur.w2.z, cur.w2.w};
+            double a0 = dval.x * x.x, a1 = dval.y * x.y;
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                const uint32_t code0 = (k0[e >> 2] >> (8 * (e & 3))) & 0xffu, col0 = (c0[e >> 1] >> (16 * (e & 1))) & 0xffffu;
+                const uint32_t code1 = (k1[e >> 2] >> (8 * (e & 3))) & 0xffu, col1 = (c1[e >> 1] >> (16 * (e & 1))) & 0xffffu;
+                double t0 = tv[code0 & 0x7fu], t1 = tv[code1 & 0x7fu];
+                t0 = (code0 & 0x80u) ? -t0 : t0; t1 = (code1 & 0x80u) ? -t1 : t1;
+                a0 += t0 * lds[col0]; a1 += t1 * lds[col1];
+            }
+            dbl2v o;
+            if (EPI) { o.x = s_cur * a0 - c_prev * cur.u.x; o.y = s_cur * a1 - c_prev * cur.u.y; }
+            else { o.x = a0; o.y = a1; }
+            *reinterpret_cast<dbl2v *>(A.out + row * DimUp + 2 * p) = o;
+            cur = nxt;
+        }
+        __syncthreads();
+        row = next;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // dw-hop pass, column tiled: out(iup,idw) += sum_k Hdw[idw,k] * v(iup, jdw_k).
 // Every neighbour row jdw is needed by ~Ns/2 different idw rows that are spread over the whole
@@ -361,7 +444,6 @@ __global__ void __launch_bounds__(256) k_dwpass(DwArgs A)
 // Same pass with two iup per lane (16-byte loads/stores; needs DimUp even) and the Hdw rows of
 // the block staged in LDS once, which removes the per-lane table loads: ~5x fewer vector-memory
 // instructions per element than k_dwpass.
-typedef double dbl2v __attribute__((ext_vector_type(2)));
 template <bool EPI, bool NT>
 __global__ void __launch_bounds__(256) k_dwpass2(DwArgs A)
 {
