@@ -626,7 +626,7 @@ static int direct_tables(S *s)
         T.dim = H.fac[k].dim; T.nterms = (int32_t)H.fac[k].terms.size(); T.width = f.width; T.transposed = k < H.Ns_Ud;
         T.map = f.map.p; T.rank = f.rank.p; T.talpha = f.talpha.p; T.tbeta = f.tbeta.p; T.tval = f.tval.p;
         T.ellc = f.ellc.p; T.ellv = f.ellv.p; T.lin = f.lin.p; T.nlev = H.fac[k].nbits;
-        T.pcols = f.packed ? f.pcols.p : nullptr; T.pcodes = f.packed ? f.pcodes.p : nullptr;
+        T.pcols = f.packed ? f.pcols.p : nullptr; T.pcodes = f.packed ? f.pcodes.p : nullptr; T.pelem = f.packed_elem ? f.pelem.p : nullptr;
         T.impmask = d.ed_total_ud ? (1 << d.Norb) - 1 : 0; T.pair = d.ed_total_ud ? d.Ust - d.Jh : 0.0; T.E = f.E.p;
         hipLaunchKernelGGL(k_direct_tables, dim3((unsigned)cdiv(T.dim, 256)), dim3(256), 0, s->stream, T);
     }
@@ -706,7 +706,7 @@ static int hxv(S *s, const double *v, double *out, bool epi, const double *uprev
         if (!split) CHK(dispatch_kron2(s, base | (s->use_lds ? KF_LDS : 0), A, nblocks));
         else {
             const bool persistent = s->up_persistent && !s->extra && s->fac[0]->packed && s->fac[0]->width <= 16 && s->use_lds && H.DimUp <= 13312 && !direct_tables_dirty(s);
-            if (persistent && s->up_pairs && s->fac[0]->packed_elem && !direct) {
+            if (persistent && s->up_pairs && s->fac[0]->packed_elem) {
                 UpArgs2 U{};
                 U.DimUp = A.DimUp; U.DimPh = A.DimPh; U.Qdw = A.Qdw; U.dw0 = A.dw0; U.nrows = H.Qdw * H.DimPh;
                 U.packed = reinterpret_cast<const uint4 *>(s->fac[0]->pelem.p); U.tval = s->fac[0]->ptval.p; U.nterms = s->fac[0]->pterms;
@@ -720,7 +720,16 @@ static int hxv(S *s, const double *v, double *out, bool epi, const double *uprev
                     (void)hipFuncSetAttribute((const void *)k_uppass2<false, true, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
                     attr2 = true;
                 }
-                if (epi) hipLaunchKernelGGL((k_uppass2<false, true, 1024>), dim3(grid), dim3(1024), lds, s->stream, U);
+                if (direct) {
+                    static bool attr3 = false;
+                    if (!attr3) {
+                        (void)hipFuncSetAttribute((const void *)k_uppass2<true, false, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                        (void)hipFuncSetAttribute((const void *)k_uppass2<true, true, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                        attr3 = true;
+                    }
+                    if (epi) hipLaunchKernelGGL((k_uppass2<true, true, 1024>), dim3(grid), dim3(1024), lds, s->stream, U);
+                    else hipLaunchKernelGGL((k_uppass2<true, false, 1024>), dim3(grid), dim3(1024), lds, s->stream, U);
+                } else if (epi) hipLaunchKernelGGL((k_uppass2<false, true, 1024>), dim3(grid), dim3(1024), lds, s->stream, U);
                 else hipLaunchKernelGGL((k_uppass2<false, false, 1024>), dim3(grid), dim3(1024), lds, s->stream, U);
                 HIPCHK(hipGetLastError());
             } else if (persistent) {

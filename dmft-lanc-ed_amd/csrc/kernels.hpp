@@ -564,6 +564,7 @@ struct TabArgs {
     const int32_t *talpha, *tbeta; const double *tval;
     int32_t *ellc; double *ellv;
     uint32_t *pcols, *pcodes;   // optional packed image (k_uppass), zeroed by the caller
+    uint32_t *pelem;            // optional element-major packed image (k_uppass2): 6 dwords per row, width <= 8
     const double *lin; int32_t nlev; int32_t impmask; double pair;  // E[i] = sum lin[l] n_l + pair * C(#imp,2)
     double *E;
 };
@@ -599,6 +600,18 @@ __global__ void __launch_bounds__(256) k_direct_tables(TabArgs A)
             uint32_t w = 0;
             for (int e = 0; e < 4; e++) { const int q = 4 * c + e; w |= (uint32_t)(q < n ? ct[q] : 127u) << (8 * e); }
             A.pcodes[(int64_t)c * A.dim + i] = w;
+        }
+    }
+    if (A.pelem) {
+        for (int c = 0; c < 4; c++) {
+            uint32_t w = 0;
+            for (int e = 0; e < 2; e++) { const int q = 2 * c + e; w |= (uint32_t)(q < n ? cj[q] : i) << (16 * e); }
+            A.pelem[(int64_t)6 * i + c] = w;
+        }
+        for (int c = 0; c < 2; c++) {
+            uint32_t w = 0;
+            for (int e = 0; e < 4; e++) { const int q = 4 * c + e; w |= (uint32_t)(q < n ? ct[q] : 127u) << (8 * e); }
+            A.pelem[(int64_t)6 * i + 4 + c] = w;
         }
     }
     for (int k = 0; k < A.width; k++) {
@@ -1001,17 +1014,25 @@ __global__ void __launch_bounds__(256) k_dot_partial(const double *__restrict__ 
 }
 
 // w -= alpha*(s_cur*u) ; partial beta^2 ; optionally acc += zk*s_cur*u (eigenvector pass)
+// two elements per lane (16-byte accesses); n2 = n/2 pairs, the odd tail element handled by thread 0 of block 0
 __global__ void __launch_bounds__(256) k_axpy_norm(double *__restrict__ w, const double *__restrict__ u, double *__restrict__ acc,
                                                    const double *__restrict__ scal, int64_t n, double *__restrict__ partial)
 {
     __shared__ double red[4];
     const double s_cur = scal[SC_SCUR], alpha = scal[SC_ALPHA], zk = scal[SC_ZK];
     double s = 0.0;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        const double vi = s_cur * u[i];
-        const double wi = w[i] - alpha * vi;
-        w[i] = wi; s += wi * wi;
-        if (acc) acc[i] += zk * vi;
+    const int64_t n2 = n >> 1;
+    dbl2v *w2 = reinterpret_cast<dbl2v *>(w); const dbl2v *u2 = reinterpret_cast<const dbl2v *>(u); dbl2v *a2 = reinterpret_cast<dbl2v *>(acc);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += (int64_t)gridDim.x * blockDim.x) {
+        const dbl2v vi = s_cur * u2[i];
+        const dbl2v wi = w2[i] - alpha * vi;
+        w2[i] = wi; s += wi.x * wi.x + wi.y * wi.y;
+        if (acc) a2[i] += zk * vi;
+    }
+    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+        const double vi = s_cur * u[n - 1], wi = w[n - 1] - alpha * vi;
+        w[n - 1] = wi; s += wi * wi;
+        if (acc) acc[n - 1] += zk * vi;
     }
     double r = block_sum(s, red);
     if (threadIdx.x == 0) partial[blockIdx.x] = r;
