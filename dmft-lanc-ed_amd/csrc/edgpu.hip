@@ -1464,6 +1464,49 @@ int edgpu_apply_op(edgpu_handle from, edgpu_handle to, int32_t iorb, int32_t isp
     return EDGPU_OK;
 }
 
+// normalise a device vector in place; norm2 returned to the host (0 leaves it untouched)
+static int normalise_dev(S *s, double *v_dev, double *norm2)
+{
+    CHK(reduce_dot(s, v_dev, v_dev));
+    HIPCHK(hipMemcpyAsync(norm2, s->scal.p + SC_TMP, 8, hipMemcpyDeviceToHost, s->stream));
+    HIPCHK(hipStreamSynchronize(s->stream));
+    if (*norm2 > 0.0) {
+        const int nb = (int)std::max<int64_t>(1, std::min<int64_t>(cdiv(s->nloc, 256), 8192));
+        hipLaunchKernelGGL(k_scalar_step, dim3(1), dim3(1), 0, s->stream, s->scal.p, s->alphas.p, s->betas.p, (const double *)nullptr, 0, 2);
+        hipLaunchKernelGGL(k_scale, dim3(nb), dim3(256), 0, s->stream, v_dev, s->scal.p, (int)SC_SCUR, s->nloc);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(s->stream));
+    }
+    return EDGPU_OK;
+}
+
+// susceptibility leg: diagonal impurity operator on a state of this sector, normalise, sp_lanc_tridiag
+int edgpu_chi_lanczos(edgpu_handle h, const double *cup, const double *cdw, const double *state_host, int32_t nlanc,
+                      double threshold, double *norm2, double *alanc, double *blanc, int32_t *nused)
+{
+    if (!h || !cup || !cdw || !state_host || !norm2 || !alanc || !blanc || !nused) return fail(EDGPU_EINVAL, "edgpu_chi_lanczos: null argument");
+    HIPCHK(hipSetDevice(h->device));
+    const SectorHost &H = h->H;
+    if (h->tmp_in.n != (size_t)h->nloc) { CHK(h->tmp_in.alloc((size_t)h->nloc)); CHK(h->tmp_out.alloc((size_t)h->nloc)); }
+    HIPCHK(hipMemcpy(h->tmp_in.p, state_host, (size_t)h->nloc * 8, hipMemcpyHostToDevice));
+    CHK(lz_prepare(h, nlanc));
+    DiagOpArgs A{};
+    A.nfac = 2 * H.Ns_Ud; A.Norb = H.desc.Norb; A.total_ud = H.desc.ed_total_ud; A.Nel = h->nloc_el; A.N = h->nloc;
+    if (h->multi && h->comm.size > 1 && !h->two_factor) return fail(EDGPU_EUNSUPPORTED, "edgpu_chi_lanczos: ed_total_ud=F is single rank");
+    for (int k = 0; k < A.nfac; k++) { A.dims[k] = H.fac[k].dim; A.maps[k] = h->fac[k]->map.p; }
+    if (h->two_factor) { A.dims[1] = (int32_t)H.Qdw; A.maps[1] = h->fac[1]->map.p + H.dw0; }   // local dw columns
+    for (int a = 0; a < EDGPU_MAX_ORB; a++) { A.cu[a] = a < A.Norb ? cup[a] : 0.0; A.cd[a] = a < A.Norb ? cdw[a] : 0.0; }
+    A.vin = h->tmp_in.p; A.vout = h->tmp_out.p;
+    const int nb = (int)std::max<int64_t>(1, std::min<int64_t>(cdiv(h->nloc, 256), 8192));
+    hipLaunchKernelGGL(k_apply_diagop, dim3(nb), dim3(256), 0, h->stream, A);
+    HIPCHK(hipGetLastError());
+    CHK(normalise_dev(h, h->tmp_out.p, norm2));
+    for (int i = 0; i < nlanc; i++) { alanc[i] = 0.0; blanc[i] = 0.0; }
+    *nused = 0;
+    if (*norm2 <= 0.0) return EDGPU_OK;
+    return lanczos_tridiag(h, h->tmp_out.p, nlanc, threshold, alanc, blanc, nused);
+}
+
 // One Green's-function Lanczos leg entirely in HBM: O|state>, normalise, sp_lanc_tridiag.
 // state_host: vecdim(from) doubles on the host.  Returns norm2, alanc/blanc (nlanc) and nused.
 int edgpu_gf_lanczos(edgpu_handle from, edgpu_handle to, int32_t iorb, int32_t ispin, int32_t dagger,

@@ -1060,6 +1060,34 @@ __global__ void __launch_bounds__(256) k_scale(double *__restrict__ x, const dou
 }
 
 // ---------------------------------------------------------------------------------------------
+// Diagonal impurity operator applied to a state: out_i = (sum_a cu[a] n_up,a(i) + cd[a] n_dw,a(i)) * in_i.
+// Covers the start vectors of the susceptibility builders: Sz_a (cu=+1/2, cd=-1/2), n_a (1,1), their
+// two-orbital and total combinations (ED_GF_CHISPIN.f90:169-171, 282-284, 393-394; ED_GF_CHIDENS.f90:166-168,
+// 266-278, 389-390).
+// ---------------------------------------------------------------------------------------------
+struct DiagOpArgs {
+    int32_t nfac, Norb, total_ud; int32_t dims[2 * EDGPU_MAX_ORB]; const int32_t *maps[2 * EDGPU_MAX_ORB];
+    double cu[EDGPU_MAX_ORB], cd[EDGPU_MAX_ORB]; int64_t Nel, N; const double *vin; double *vout;
+};
+__global__ void __launch_bounds__(256) k_apply_diagop(DiagOpArgs A)
+{
+    const int nud = A.nfac / 2;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < A.N; i += (int64_t)gridDim.x * blockDim.x) {
+        int64_t c = i % A.Nel;
+        uint32_t mu = 0, md = 0;
+        for (int k = 0; k < A.nfac; k++) {
+            const int dg = (int)(c % A.dims[k]); c /= A.dims[k];
+            const uint32_t m = (uint32_t)A.maps[k][dg];
+            if (A.total_ud) { if (k == 0) mu = m; else md = m; }
+            else { if (k < nud) mu |= (m & 1u) << k; else md |= (m & 1u) << (k - nud); }
+        }
+        double f = 0.0;
+        for (int a = 0; a < A.Norb; a++) f += A.cu[a] * (double)((mu >> a) & 1u) + A.cd[a] * (double)((md >> a) & 1u);
+        A.vout[i] = f * A.vin[i];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Impurity-configuration weights of a state: hist[(mu_imp*nI + md_imp) + nI*nI*iph] = sum |v_i|^2.
 // Every local observable of lanc_observables (ED_OBSERVABLES.f90:150-215: dens, dens_up/dw, docc,
 // magz, sz2, n2, s2tot, Prob, prob_ph, dens_ph) is a function of this (2^Norb)^2 x DimPh table, so

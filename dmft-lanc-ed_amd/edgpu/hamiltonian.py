@@ -217,6 +217,17 @@ class HvSector:
                 o["s2tot"] += sz.sum() ** 2 * wgt
         return o
 
+    def chi_lanczos(self, cup, cdw, state, nlanc, threshold=1e-12):
+        """Susceptibility leg: (norm2, alanc, blanc, nused) for the diagonal impurity operator
+        sum_a cup[a] n_up,a + cdw[a] n_dw,a applied to `state` (ED_GF_CHISPIN/CHIDENS builders)."""
+        Norb = int(self._desc.Norb)
+        cu = np.zeros(Norb); cu[:len(cup)] = cup; cd = np.zeros(Norb); cd[:len(cdw)] = cdw
+        state = np.ascontiguousarray(state, np.float64)
+        a = np.zeros(nlanc); b = np.zeros(nlanc); n2 = C.c_double(); nu = C.c_int32()
+        check(capi.lib().edgpu_chi_lanczos(self._h, cu.ctypes.data, cd.ctypes.data, state.ctypes.data, nlanc, threshold,
+                                           C.byref(n2), a.ctypes.data, b.ctypes.data, C.byref(nu)))
+        return n2.value, a, b, nu.value
+
     def sp_lanc_tridiag(self, vin, nlanc, threshold=1e-12):
         vin = np.ascontiguousarray(vin, np.float64)
         a = np.zeros(nlanc); b = np.zeros(nlanc); n = C.c_int32()

@@ -158,6 +158,13 @@ int edgpu_gf_lanczos(edgpu_handle from, edgpu_handle to, int32_t iorb, int32_t i
                      const double *state_host, int32_t nlanc, double threshold, double *norm2,
                      double *alanc, double *blanc, int32_t *nused);
 
+/* susceptibility leg: vvinit_i = (sum_a cup[a] n_up,a + cdw[a] n_dw,a) state_i, normalised,
+ * then sp_lanc_tridiag in the same sector.  Sz_a: cup=+1/2,cdw=-1/2 (ED_GF_CHISPIN.f90:169-171); n_a: 1,1
+ * (ED_GF_CHIDENS.f90:166-168); mixed/total variants are sums of these (CHISPIN 282-284, 393-394).
+ * cup/cdw: Norb doubles; norm2 is the weight passed to add_to_lanczos_spinChi/densChi. */
+int edgpu_chi_lanczos(edgpu_handle h, const double *cup, const double *cdw, const double *state_host, int32_t nlanc,
+                      double threshold, double *norm2, double *alanc, double *blanc, int32_t *nused);
+
 /* Step-wise form of the same loop for an external clock (bench.py): `begin` sets up a fixed
  * start vector, `steps` enqueues iterations asynchronously on the library's stream (the caller
  * synchronises the device), `result` returns the mean product-kernel time measured with HIP

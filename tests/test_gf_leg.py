@@ -55,3 +55,47 @@ def test_gf_leg_matches_oracle_and_dense(edgpu_mod, case, iorb, ispin):
             assert abs(_gf_from_lanczos(z, n2b, a, b, used, e0, sign) - dense) <= 1e-8 * max(1.0, abs(dense))
         Gt.close()
     G0.close()
+
+
+CHI = [("c_nb5_half", 1, None), ("norb2_normal_JxJp", 2, 1), ("orbs_norb2_nb3", 1, 2), ("phonons_nb3_nph3", 1, None)]
+
+
+@pytest.mark.parametrize("case,iorb,jorb", CHI)
+def test_susceptibility_leg(edgpu_mod, case, iorb, jorb):
+    """Sz_a, n_a and the mixed (a,b) start vectors of the chi builders (ED_GF_CHISPIN.f90:169-171,
+    393-394; ED_GF_CHIDENS.f90:166-168, 389-390): norm2 and Lanczos coefficients against a direct
+    numpy evaluation on the oracle's basis + the oracle's sp_lanc_tridiag."""
+    name, m, nu, nd = [z for z in cases.zoo() if z[0] == case][0]
+    S = oracle.Sector(m, nu, nd)
+    w, U = np.linalg.eigh(S.hmat()); gs = U[:, 0]
+    O = oracle.lanc_observables          # occupations via the same basis walk: weights of single basis states
+    Norb = m["Norb"]
+    # impurity occupations of every basis state, from the oracle's restatement
+    nup = np.zeros((S.Dim, Norb)); ndw = np.zeros((S.Dim, Norb))
+    for i in range(S.Dim):
+        e = np.zeros(S.Dim); e[i] = 1.0
+        o = O(S, e)
+        nup[i], ndw[i] = o["dens_up"], o["dens_dw"]
+    G = edgpu_mod.HvSector(m, nu, nd)
+    combos = [("spin", {iorb: (0.5, -0.5)}), ("dens", {iorb: (1.0, 1.0)})]
+    if jorb:
+        combos.append(("spin_mix", {iorb: (0.5, -0.5), jorb: (0.5, -0.5)}))
+        combos.append(("dens_mix", {iorb: (1.0, 1.0), jorb: (1.0, 1.0)}))
+    for label, coef in combos:
+        cu = np.zeros(Norb); cd = np.zeros(Norb)
+        for a, (x, y) in coef.items():
+            cu[a - 1] += x; cd[a - 1] += y
+        v = (nup @ cu + ndw @ cd) * gs
+        n2ref = float(v @ v)
+        nl = min(S.Dim, 40)
+        n2, a, b, used = G.chi_lanczos(cu, cd, gs, nl)
+        assert abs(n2 - n2ref) <= 1e-13, label
+        if n2ref < 1e-20:
+            assert used == 0
+            continue
+        a_ref, b_ref, used_ref = oracle.sp_lanc_tridiag(S.spmatvec, v / np.sqrt(n2ref), nl)
+        assert used == used_ref, label
+        k = min(used, 20)
+        np.testing.assert_allclose(a[:k], a_ref[:k], rtol=1e-9, atol=1e-9, err_msg=label)
+        np.testing.assert_allclose(b[1:k], b_ref[1:k], rtol=1e-9, atol=1e-9, err_msg=label)
+    G.close()
