@@ -204,3 +204,36 @@ def test_large_sector_code_paths_on_small_sectors(edgpu_mod, monkeypatch, name, 
             G.close()
         for k in env:
             monkeypatch.delenv(k)
+
+
+def test_c3_full_size_properties(edgpu_mod):
+    """BASELINE config 3 (Ns=16, N=165,636,900) at full size, where the oracle cannot go: the three storages
+    must agree with each other, H must be symmetric (<u,Hv> = <Hu,v>) and linear, and a short Lanczos run
+    must give the same coefficients for every storage."""
+    from edgpu import model
+    m, nu, nd = model.half_filled_c(15)
+    rng = np.random.default_rng(5)
+    N = 165636900
+    u = rng.random(N) - 0.5
+    v = rng.random(N) - 0.5
+    du, dv, dh = edgpu_mod.DeviceVector(N).upload(u), edgpu_mod.DeviceVector(N).upload(v), edgpu_mod.DeviceVector(N)
+    ref_hv = None; coeffs = {}
+    for st in ("kron", "direct", "csr"):
+        G = edgpu_mod.HvSector(m, nu, nd, storage=st)
+        assert G.Dim == N and G.isector == 1 + 8 * 17 + 8
+        G.spHtimesV_device(dv, dh); hv = dh.download()
+        G.spHtimesV_device(du, dh); hu = dh.download()
+        scale = float(np.abs(u) @ np.abs(hv))
+        assert abs(float(u @ hv) - float(hu @ v)) <= 1e-12 * scale, st
+        if ref_hv is None:
+            ref_hv = hv
+        else:
+            assert np.abs(hv - ref_hv).max() <= 1e-12 * np.abs(ref_hv).max(), st
+        del hv, hu
+        G.bench_begin(8); G.bench_steps(6)
+        _, a, b = G.bench_result(0, ncoef=6)
+        coeffs[st] = (a, b)
+        G.close()
+    for st in ("direct", "csr"):
+        np.testing.assert_allclose(coeffs[st][0], coeffs["kron"][0], rtol=1e-10, atol=1e-10)
+        np.testing.assert_allclose(coeffs[st][1], coeffs["kron"][1], rtol=1e-10, atol=1e-10)
