@@ -129,8 +129,8 @@ struct edgpu_sector_s {
     // explicit CSR
     DevBuf<int64_t> csr_rowptr, uppre, dwpre; DevBuf<int32_t> csr_cols; DevBuf<double> csr_vals;
     DevBuf<int64_t> csrD_rowptr; DevBuf<int32_t> csrD_cols; DevBuf<double> csrD_vals;   // dw block of the split form
-    bool csr_split = false; int64_t csrL_nnz = 0, csrD_nnz = 0; int32_t csrD_rpb = 64, csrD_bpr = 0; int csrD_nt = 1; bool csrL_small = false, csrD_small = false, csr_persist = false; int csr_pgrid = 4096;
-    int64_t csr_nnz = 0; int32_t csr_rpb = 0, csr_bpr = 0, csr_tile = 1, csr_variant = 6;
+    bool csr_split = false; int64_t csrL_nnz = 0, csrD_nnz = 0; int32_t csrD_rpb = 64, csrD_bpr = 0; int csrD_nt = 1; bool csrL_small = false, csrD_small = false;
+    int64_t csr_nnz = 0; int32_t csr_rpb = 0, csr_bpr = 0, csr_tile = 1;
     // work vectors
     // halo exchange (multi-rank, ed_total_ud=T without Jx/Jp/phonon extras): x-space of the dw hops is
     // [own rows | rows needed from rank 0 | rank 1 | ...] instead of the whole gathered vector
@@ -358,13 +358,8 @@ static int build_csr(S *s)
         s->csrD_small = ndmax * s->csrD_rpb <= 640 && dbg_int("EDGPU_CSR_SMALL", 1);
     }
     HIPCHK(hipGetLastError());
-    s->csr_variant = dbg_int("EDGPU_CSR_VARIANT", 6);
-    s->csr_persist = dbg_int("EDGPU_CSR_PERSIST", 0) != 0 && s->csr_variant == 6;   // measured: no faster than the plain form
-    s->csr_pgrid = std::max(8, dbg_int("EDGPU_CSR_PGRID", 4096));
-    const int v_ = s->csr_variant;
-    const int CAP = (v_ == 3 || v_ == 4) ? 2304 : ((v_ == 5 || v_ == 6) ? 1152 : 4608), RMAX = (v_ == 3 || v_ == 4) ? 128 : ((v_ == 5 || v_ == 6) ? 64 : 256);
-    s->csr_rpb = (int32_t)std::min<int64_t>(RMAX, CAP / std::max<int64_t>(maxrow, 1));
-    if (s->csr_rpb < 1) return fail(EDGPU_EUNSUPPORTED, "edgpu: a CSR row exceeds the LDS product tile");
+    s->csr_rpb = (int32_t)std::min<int64_t>(64, 1152 / std::max<int64_t>(maxrow, 1));      // one wave per row block
+    if (s->csr_rpb < 1) return fail(EDGPU_EUNSUPPORTED, "edgpu: a CSR row exceeds the LDS tile");
     s->csr_bpr = (int32_t)cdiv(H.DimUp, s->csr_rpb);
     s->csr_tile = std::max(1, std::min(dbg_int("EDGPU_CSR_TILE", 1 << 20), s->csr_bpr));
     return EDGPU_OK;
@@ -659,15 +654,7 @@ static int hxv(S *s, const double *v, double *out, bool epi, const double *uprev
         // the column index is global; on one GPU local == global
         nblocks = (int64_t)s->csr_bpr * H.Qdw;
         A.pass = s->csr_split ? 1 : 0; A.coltiles = 0;
-        if (s->csr_variant == 1 && !s->csr_split) hipLaunchKernelGGL(k_csr_spmv<4608>, dim3((unsigned)nblocks), dim3(256), 0, s->stream, A);
-        else if (s->csr_variant == 2) hipLaunchKernelGGL((k_csr_spmv2<256, 4608, false>), dim3((unsigned)nblocks), dim3(256), 0, s->stream, A);
-        else if (s->csr_variant == 3) hipLaunchKernelGGL((k_csr_spmv2<128, 2304, false>), dim3((unsigned)nblocks), dim3(128), 0, s->stream, A);
-        else if (s->csr_variant == 4) hipLaunchKernelGGL((k_csr_spmv2<128, 2304, true>), dim3((unsigned)nblocks), dim3(128), 0, s->stream, A);
-        else if (s->csr_variant == 5) hipLaunchKernelGGL((k_csr_spmv2<64, 1152, true>), dim3((unsigned)nblocks), dim3(64), 0, s->stream, A);
-        else if (s->csr_variant == 7) hipLaunchKernelGGL((k_csr_spmv2<256, 4608, true>), dim3((unsigned)nblocks), dim3(256), 0, s->stream, A);
-        else if (s->csr_persist && s->csr_split && s->csrL_small) { nblocks = std::min<int64_t>(nblocks, s->csr_pgrid); hipLaunchKernelGGL((k_csr_spmv3<640, false>), dim3((unsigned)nblocks), dim3(64), 0, s->stream, A); }
-        else if (s->csr_persist && !s->csr_split && s->csr_rpb <= 64) { nblocks = std::min<int64_t>(nblocks, s->csr_pgrid); hipLaunchKernelGGL((k_csr_spmv3<1152, false>), dim3((unsigned)nblocks), dim3(64), 0, s->stream, A); }
-        else if (s->csr_split && s->csrL_small) hipLaunchKernelGGL((k_csr_spmv2<64, 640, false>), dim3((unsigned)nblocks), dim3(64), 0, s->stream, A);
+        if (s->csr_split && s->csrL_small) hipLaunchKernelGGL((k_csr_spmv2<64, 640, false>), dim3((unsigned)nblocks), dim3(64), 0, s->stream, A);
         else hipLaunchKernelGGL((k_csr_spmv2<64, 1152, false>), dim3((unsigned)nblocks), dim3(64), 0, s->stream, A);
         HIPCHK(hipGetLastError());
         if (s->csr_split) {
@@ -675,11 +662,7 @@ static int hxv(S *s, const double *v, double *out, bool epi, const double *uprev
             A.rowptr = s->csrD_rowptr.p; A.cols = s->csrD_cols.p; A.vals = s->csrD_vals.p;
             A.rows_per_block = s->csrD_rpb; A.blocks_per_row = s->csrD_bpr; A.pass = 2; A.coltiles = 1; A.xcd_rows = 0;
             nblocks = 8 * cdiv(s->csrD_bpr, 8) * H.Qdw;
-            if (s->csr_persist && s->csrD_small) {
-                nblocks = std::min<int64_t>(nblocks, s->csr_pgrid & ~7);
-                if (s->csrD_nt) hipLaunchKernelGGL((k_csr_spmv3<640, true>), dim3((unsigned)nblocks), dim3(64), 0, s->stream, A);
-                else hipLaunchKernelGGL((k_csr_spmv3<640, false>), dim3((unsigned)nblocks), dim3(64), 0, s->stream, A);
-            } else if (s->csrD_small) {
+            if (s->csrD_small) {
                 if (s->csrD_nt) hipLaunchKernelGGL((k_csr_spmv2<64, 640, true>), dim3((unsigned)nblocks), dim3(64), 0, s->stream, A);
                 else hipLaunchKernelGGL((k_csr_spmv2<64, 640, false>), dim3((unsigned)nblocks), dim3(64), 0, s->stream, A);
             } else {

@@ -136,7 +136,6 @@ struct Kron2Args {
     const double *v, *vfull;  // local shard / gathered vector (same pointer on one GPU)
     double *out;
     const double *uprev; const double *scal; double *partial;  // Lanczos epilogue
-    int32_t rows_per_tile;    // blockIdx -> row remap granularity (0 = identity)
 };
 
 enum { KF_DIRECT = 1, KF_LDS = 2, KF_EPI = 4, KF_PH = 8, KF_ND = 16, KF_NOLOCAL = 32, KF_NODW = 64 };
@@ -690,49 +689,11 @@ struct CsrArgs {
     int32_t coltiles;  // 1: blocks sweep XCD-affine column tiles (idw fastest) -- the dw block of a split CSR
 };
 
-// "CSR-stream": a workgroup owns `rows_per_block` consecutive rows of one idw row, streams their
-// contiguous nnz range coalesced (value*x[col] -> LDS), then one thread per row sums its segment.
-template <int CAP>
-__global__ void __launch_bounds__(256) k_csr_spmv(CsrArgs A)
-{
-    __shared__ double prod[CAP];
-    __shared__ double red[4];
-    // blockIdx -> (idw, jb): tiles of `tile` row-blocks sweep all idw before moving on in iup,
-    // so the dw-hop gathers of one sweep stay inside a DimDw x (tile*rows_per_block) slab of x.
-    int64_t idwl; int jb;
-    {
-        const int64_t b = blockIdx.x, per_tile = (int64_t)A.tile * A.Qdw;
-        const int nt_full = A.blocks_per_row / A.tile;
-        int64_t t, r; int tw;
-        if (b < (int64_t)nt_full * per_tile) { t = b / per_tile; r = b - t * per_tile; tw = A.tile; }
-        else { t = nt_full; r = b - (int64_t)nt_full * per_tile; tw = A.blocks_per_row - nt_full * A.tile; }
-        idwl = r / tw; jb = (int)(t * A.tile + (r - idwl * tw));
-    }
-    const int iup0 = jb * A.rows_per_block;
-    int nr = A.DimUp - iup0; if (nr > A.rows_per_block) nr = A.rows_per_block;
-    const int64_t row0 = idwl * A.DimUp + iup0;
-    const int64_t p0 = A.rowptr[row0], p1 = A.rowptr[row0 + nr];
-    const int n = (int)(p1 - p0);
-    for (int k = threadIdx.x; k < n; k += blockDim.x) prod[k] = A.vals[p0 + k] * A.x[A.cols[p0 + k]];
-    __syncthreads();
-    double s_cur = 1.0, c_prev = 0.0, asum = 0.0;
-    if (A.epi) { s_cur = A.scal[SC_SCUR]; c_prev = A.scal[SC_BETA] * A.scal[SC_SPREV]; }
-    if ((int)threadIdx.x < nr) {
-        const int64_t row = row0 + threadIdx.x;
-        const int a = (int)(A.rowptr[row] - p0), e = (int)(A.rowptr[row + 1] - p0);
-        double acc = 0.0;
-        for (int k = a; k < e; k++) acc += prod[k];
-        if (A.epi) { double w = s_cur * acc - c_prev * A.uprev[row]; A.y[row] = w; asum = (s_cur * A.v_local[row]) * w; }
-        else A.y[row] = acc;
-    }
-    if (A.epi) { double r = block_sum(asum, red); if (threadIdx.x == 0) A.partial[blockIdx.x] = r; }
-}
-
-// Second form: the contiguous (value, column) range of the row block is copied to LDS with wide
-// coalesced loads (16 B per lane, all issued before the first use), then lane r walks row r out
-// of LDS.  For a fixed entry slot k the lanes of a wave then gather x at consecutive addresses
-// for the dw hops and the diagonal (9 of 17 entries at half filling) instead of 17 clusters per
-// instruction, and no product array / segmented sum is needed.
+// Row-block CSR product.  A workgroup owns `rows_per_block` consecutive rows of one idw row.  Their
+// contiguous (value, column) range is copied to LDS with wide coalesced loads (16 B per lane, all
+// issued before the first use), then lane r walks row r out of LDS.  For a fixed entry slot k the
+// lanes of a wave gather x at consecutive addresses for the dw hops and the diagonal (9 of 17 entries
+// at half filling), and no product array / segmented sum is needed.
 typedef double dbl2_t __attribute__((ext_vector_type(2)));
 typedef int int4_t __attribute__((ext_vector_type(4)));
 
@@ -856,130 +817,7 @@ __global__ void __launch_bounds__(256) k_apply_op(OpArgs A)
 }
 
 // ---------------------------------------------------------------------------------------------
-// Persistent, software-pipelined form of the row-block CSR product.  One wave per workgroup walks
-// a strided sequence of row blocks ("tasks").  While task t is computed out of LDS, the (value,
-// column) range of task t+1 is already in flight into registers and the row pointers of task t+2
-// are in flight too, so a wave keeps two tasks' worth of HBM requests outstanding with one LDS
-// image -- the LDS footprint, not the wave count, is what limits residency here.
-//   coltiles=0: tasks in natural row order (block jb of idw row, jb fastest)
-//   coltiles=1: XCD (blockIdx & 7) owns the column tiles jb = xcd, xcd+8, ... and sweeps all idw
-//               rows of a tile before the next one (dw block of a split CSR: x slab stays in L2)
-// ---------------------------------------------------------------------------------------------
-template <int CAPN, bool NT>
-__global__ void __launch_bounds__(64) k_csr_spmv3(CsrArgs A)
-{
-    constexpr int MAXG = (CAPN / 4 + 63) / 64 + 1;   // 4-entry groups per lane
-    __shared__ __attribute__((aligned(32))) double sval[CAPN + 8];
-    __shared__ __attribute__((aligned(16))) int32_t scol[CAPN + 8];
-    __shared__ double red[2];
-    const int tid = threadIdx.x;
-    int64_t s, sstep, send; int xcd = 0;
-    if (A.coltiles) {
-        xcd = blockIdx.x & 7;
-        const int tiles_x = (A.blocks_per_row - xcd + 7) >> 3;
-        s = blockIdx.x >> 3; sstep = gridDim.x >> 3; send = (int64_t)tiles_x * A.Qdw;
-    } else { s = blockIdx.x; sstep = gridDim.x; send = (int64_t)A.blocks_per_row * A.Qdw; }
-    struct Task { int64_t row0; int nr; };
-    auto task_of = [&](int64_t t) -> Task {
-        int64_t idwl; int jb;
-        if (A.coltiles) { const int64_t tl = t / A.Qdw; idwl = t - tl * A.Qdw; jb = (int)(tl * 8 + xcd); }
-        else { idwl = t / A.blocks_per_row; jb = (int)(t - idwl * A.blocks_per_row); }
-        const int iup0 = jb * A.rows_per_block;
-        int nr = A.DimUp - iup0; if (nr > A.rows_per_block) nr = A.rows_per_block;
-        return Task{idwl * A.DimUp + iup0, nr};
-    };
-    // stage A: per-lane row pointers (lane r: rowptr[row0+r], rowptr[row0+r+1]; lane 0 / lane nr-1 give p0 / p1)
-    auto load_rp = [&](const Task &T, int64_t &a, int64_t &b) {
-        const int r = tid < T.nr ? tid : T.nr - 1;
-        a = A.rowptr[T.row0 + r]; b = A.rowptr[T.row0 + r + 1];
-    };
-    struct Regs { dbl2_t v0[MAXG], v1[MAXG]; int4_t c[MAXG]; double hv, tv, yv, upv, xlv; int32_t hc, tc; };
-    // stage B: issue the stream of a task (4-entry groups, head and tail singles) and its epilogue operands
-    auto issue = [&](const Task &T, int64_t p0, int n, Regs &R) {
-        const int sh = (int)(p0 & 3);
-        const double *gv = A.vals + (p0 - sh); const int32_t *gc = A.cols + (p0 - sh);
-        const int end = sh + n, g0 = sh ? 1 : 0, g1 = end >> 2;
-        const dbl2_t *pv = reinterpret_cast<const dbl2_t *>(gv);
-        const int4_t *pc = reinterpret_cast<const int4_t *>(gc);
-#pragma unroll
-        for (int q = 0; q < MAXG; q++) {
-            const int g = g0 + tid + q * 64;
-            if (g < g1) {
-                if (NT) { R.v0[q] = __builtin_nontemporal_load(pv + 2 * g); R.v1[q] = __builtin_nontemporal_load(pv + 2 * g + 1); R.c[q] = __builtin_nontemporal_load(pc + g); }
-                else { R.v0[q] = pv[2 * g]; R.v1[q] = pv[2 * g + 1]; R.c[q] = pc[g]; }
-            }
-        }
-        if (sh && tid >= sh && tid < 4 && tid < end) { R.hv = gv[tid]; R.hc = gc[tid]; }
-        int ts = g1 << 2; if (sh && ts < 4) ts = 4;
-        if (ts + tid < end) { R.tv = gv[ts + tid]; R.tc = gc[ts + tid]; }
-        if (tid < T.nr) {
-            if (A.pass == 2) R.yv = A.y[T.row0 + tid];
-            if (A.epi && A.pass != 2) R.upv = A.uprev[T.row0 + tid];
-            if (A.epi && A.pass != 1) R.xlv = A.v_local[T.row0 + tid];
-        }
-    };
-    auto commit = [&](int64_t p0, int n, const Regs &R) {     // registers -> LDS image
-        const int sh = (int)(p0 & 3);
-        const int end = sh + n, g0 = sh ? 1 : 0, g1 = end >> 2;
-        dbl2_t *sv2 = reinterpret_cast<dbl2_t *>(sval); int4_t *sc4 = reinterpret_cast<int4_t *>(scol);
-#pragma unroll
-        for (int q = 0; q < MAXG; q++) { const int g = g0 + tid + q * 64; if (g < g1) { sv2[2 * g] = R.v0[q]; sv2[2 * g + 1] = R.v1[q]; sc4[g] = R.c[q]; } }
-        if (sh && tid >= sh && tid < 4 && tid < end) { sval[tid] = R.hv; scol[tid] = R.hc; }
-        int ts = g1 << 2; if (sh && ts < 4) ts = 4;
-        if (ts + tid < end) { sval[ts + tid] = R.tv; scol[ts + tid] = R.tc; }
-    };
-    double s_cur = 1.0, c_prev = 0.0, asum = 0.0;
-    if (A.epi) { s_cur = A.scal[SC_SCUR]; c_prev = A.scal[SC_BETA] * A.scal[SC_SPREV]; }
-    if (s < send) {
-        Task Tc = task_of(s), Tn = Tc, Tnn = Tc;
-        int64_t ac, bc, an = 0, bn = 0, ann = 0, bnn = 0;
-        Regs R;
-        load_rp(Tc, ac, bc);
-        const bool has1 = s + sstep < send, has2 = s + 2 * sstep < send;
-        if (has1) { Tn = task_of(s + sstep); load_rp(Tn, an, bn); }
-        int64_t p0c = __shfl(ac, 0, 64); int nc = (int)(__shfl(bc, Tc.nr - 1, 64) - p0c);
-        issue(Tc, p0c, nc, R);
-        bool more = true;
-        while (more) {
-            commit(p0c, nc, R);
-            const int shc = (int)(p0c & 3);
-            const int ra = (int)(ac - p0c) + shc, re = (int)(bc - p0c) + shc;
-            const double yv = R.yv, upv = R.upv, xlv = R.xlv;
-            const Task Tcur = Tc;
-            __syncthreads();
-            // advance the pipeline: task t+2 row pointers, task t+1 stream
-            const int64_t sn = s + sstep, snn = s + 2 * sstep;
-            const bool hn = sn < send, hnn = snn < send;
-            if (hnn) { Tnn = task_of(snn); load_rp(Tnn, ann, bnn); }
-            int64_t p0n = 0; int nn = 0;
-            if (hn) { p0n = __shfl(an, 0, 64); nn = (int)(__shfl(bn, Tn.nr - 1, 64) - p0n); issue(Tn, p0n, nn, R); }
-            // compute task t out of LDS
-            if (tid < Tcur.nr) {
-                const int64_t row = Tcur.row0 + tid;
-                double acc0 = 0.0, acc1 = 0.0;
-                int k = ra;
-                for (; k + 4 <= re; k += 4) {
-                    const double x0 = A.x[scol[k]], x1 = A.x[scol[k + 1]], x2 = A.x[scol[k + 2]], x3 = A.x[scol[k + 3]];
-                    acc0 += sval[k] * x0; acc1 += sval[k + 1] * x1; acc0 += sval[k + 2] * x2; acc1 += sval[k + 3] * x3;
-                }
-                for (; k < re; k++) acc0 += sval[k] * A.x[scol[k]];
-                const double acc = acc0 + acc1;
-                if (A.epi) {
-                    const double w = A.pass == 2 ? yv + s_cur * acc : s_cur * acc - c_prev * upv;
-                    A.y[row] = w; asum += (s_cur * xlv) * w;
-                } else A.y[row] = A.pass == 2 ? yv + acc : acc;
-            }
-            __syncthreads();
-            s = sn; more = hn;
-            Tc = Tn; ac = an; bc = bn; p0c = p0n; nc = nn;
-            Tn = Tnn; an = ann; bn = bnn;
-        }
-    }
-    if (A.epi && A.pass != 1) { double r = block_sum(asum, red); if (tid == 0) A.partial[blockIdx.x] = r; }
-}
-
-// ---------------------------------------------------------------------------------------------
-// Lanczos vector kernels (SciFortran lanczos_iteration semantics, see lanczos.hpp)
+// Lanczos vector kernels (SciFortran lanczos_iteration semantics, driver in edgpu.hip)
 // ---------------------------------------------------------------------------------------------
 // out[0] = sum(in[0..n)) in a fixed order; single workgroup
 __global__ void __launch_bounds__(1024) k_reduce_final(const double *__restrict__ in, int64_t n, double *__restrict__ out)
@@ -1135,7 +973,7 @@ __global__ void __launch_bounds__(256) k_imp_hist_generic(HistGenArgs A)
 }
 
 // ---------------------------------------------------------------------------------------------
-// Krylov-basis kernels of the multi-eigenpair solver (thick-restart Lanczos, lanczos.hpp/eigsh)
+// Krylov-basis kernels of the multi-eigenpair solver (thick-restart Lanczos, eigsh() in edgpu.hip)
 // ---------------------------------------------------------------------------------------------
 constexpr int kMaxBasis = 48;
 struct BasisArgs { const double *V[kMaxBasis + 1]; int32_t nv; };

@@ -15,4 +15,5 @@ ms = G.hxv_time(v, h, 2, nrep)
 nnz = N * (1 + m["Ns"])
 bcsr = 12 * nnz + 8 * (N + 1) + 16 * N
 fmt = {"csr": bcsr, "kron": 24 * N, "direct": 16 * N}[st]
-print("nbath=%d st=%s EDGPU_DEBUG=%s CSRV=%s TILE=%s THR=%s : %.4f ms  fmt %.0f GB/s  eqcsr %.0f GB/s" % (nbath, st, os.environ.get("EDGPU_DEBUG"), os.environ.get("EDGPU_CSR_VARIANT"), os.environ.get("EDGPU_CSR_TILE"), os.environ.get("EDGPU_KRON_THREADS"), ms, fmt / ms / 1e6, bcsr / ms / 1e6))
+knobs = " ".join("%s=%s" % (k, v) for k, v in sorted(os.environ.items()) if k.startswith("EDGPU_"))
+print("nbath=%d st=%s %s : %.4f ms  fmt %.0f GB/s  eqcsr %.0f GB/s" % (nbath, st, knobs, ms, fmt / ms / 1e6, bcsr / ms / 1e6))

@@ -175,7 +175,7 @@ FORCED = [z for z in ZOO if z[0] in ("c_nb7_half", "nb5_offhalf_2_4", "nb6_even"
 def test_large_sector_code_paths_on_small_sectors(edgpu_mod, monkeypatch, name, m, nu, nd):
     """The two-pass products (persistent local pass + column-tiled dw pass; split explicit CSR)
     switch on automatically only for sectors that outgrow the caches.  Force them on small sectors
-    and compare with the oracle; also the persistent pipelined CSR variant and odd tile widths."""
+    and compare with the oracle; also the non-default variants and odd tile widths."""
     S = oracle.Sector(m, nu, nd)
     v = np.random.RandomState(21).uniform(-0.5, 0.5, S.Dim)
     ref = S.spmatvec(v)
@@ -183,8 +183,8 @@ def test_large_sector_code_paths_on_small_sectors(edgpu_mod, monkeypatch, name, 
     w = np.linalg.eigvalsh(S.hmat())
     for env in ({"EDGPU_KRON_SPLIT": "1", "EDGPU_CSR_SPLIT": "1"},
                 {"EDGPU_KRON_SPLIT": "1", "EDGPU_CSR_SPLIT": "1", "EDGPU_DW_W": "8", "EDGPU_DW_ROWS": "16", "EDGPU_CSRD_ROWS": "16", "EDGPU_UP_GRID": "3"},
-                {"EDGPU_KRON_SPLIT": "1", "EDGPU_DW_VARIANT": "1", "EDGPU_UP_PERSISTENT": "0", "EDGPU_CSR_SPLIT": "1", "EDGPU_CSR_PERSIST": "1", "EDGPU_CSR_PGRID": "16"},
-                {"EDGPU_CSR_SPLIT": "0", "EDGPU_CSR_PERSIST": "1", "EDGPU_CSR_PGRID": "24", "EDGPU_KRON_SPLIT": "1", "EDGPU_UP_THREADS": "512"}):
+                {"EDGPU_KRON_SPLIT": "1", "EDGPU_DW_VARIANT": "1", "EDGPU_UP_PERSISTENT": "0", "EDGPU_CSR_SPLIT": "1", "EDGPU_CSRD_NT": "0"},
+                {"EDGPU_CSR_SPLIT": "0", "EDGPU_KRON_SPLIT": "1", "EDGPU_UP_THREADS": "512", "EDGPU_UP_PAIRS": "0"}):
         for k, val in env.items():
             monkeypatch.setenv(k, val)
         for st in _storages(m):
