@@ -143,7 +143,7 @@ struct edgpu_sector_s {
     int64_t nloc = 0, nloc_el = 0, vecdim = 0;
     int32_t nmax = 0;
     bool use_lds = false; int kron_threads = 256, kron_threads_override = 0; size_t kron_lds = 0;
-    bool two_factor = false, extra = false, multi = false, kron_split = false; int dw_w = 64, dw_variant = 2, dw_rows = 64; bool up_persistent = true, up_pairs = true; int up_grid = 256, up_threads = 1024;
+    bool two_factor = false, extra = false, multi = false, kron_split = false; int dw_w = 64, dw_variant = 2, dw_rows = 64; bool up_persistent = true, up_pairs = true; int up_grid = 256, up_threads = 1024, row_split = 4;
     std::vector<hipEvent_t> bench_ev; int bench_k = 0; double *bv[3] = {nullptr, nullptr, nullptr};
     int64_t nnz_total = 0, bytes_stored = 0;
     int64_t npartial = 0;
@@ -421,6 +421,7 @@ static int create(const edgpu_desc *desc, S **out)
         s->up_persistent = dbg_int("EDGPU_UP_PERSISTENT", 1) != 0;
         s->up_grid = dbg_int("EDGPU_UP_GRID", 256);
         s->up_pairs = dbg_int("EDGPU_UP_PAIRS", 1) != 0;
+        s->row_split = std::max(1, std::min(32, dbg_int("EDGPU_ROW_SPLIT", 4)));
         s->up_threads = dbg_int("EDGPU_UP_THREADS", 1024) == 512 ? 512 : 1024;
         s->dw_rows = std::max(1, std::min(64, dbg_int("EDGPU_DW_ROWS", 64)));
         if (s->dw_w != 8 && s->dw_w != 16 && s->dw_w != 32 && s->dw_w != 64 && s->dw_w != 128 && s->dw_w != 256) s->dw_w = 32;
@@ -612,6 +613,7 @@ static int dispatch_kron2(S *s, int flags, const Kron2Args &A, int64_t rows)
 }
 
 static bool direct_tables_dirty(S *) { return false; }
+static bool epi_partials_needed(int flags) { return (flags & KF_EPI) && !(flags & KF_NODW); }
 static int direct_tables(S *s)
 {
     const SectorHost &H = s->H; const edgpu_desc &d = H.desc;
@@ -738,6 +740,9 @@ static int hxv(S *s, const double *v, double *out, bool epi, const double *uprev
                 }
 #undef UP_LAUNCH
                 HIPCHK(hipGetLastError());
+            } else if (!s->use_lds && !epi_partials_needed(base | KF_NODW)) {
+                Kron2Args A2 = A; A2.rsplit = s->row_split;
+                CHK(dispatch_kron2(s, base | KF_NODW, A2, s->row_split > 1 ? cdiv(nblocks, 8) * 8 * s->row_split : nblocks));
             } else
                 CHK(dispatch_kron2(s, base | KF_NODW | (s->use_lds ? KF_LDS : 0), A, nblocks));
             if (multi) HIPCHK(hipStreamWaitEvent(s->stream, s->ev_gather, 0));

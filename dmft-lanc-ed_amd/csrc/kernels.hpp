@@ -136,6 +136,7 @@ struct Kron2Args {
     const double *v, *vfull;  // local shard / gathered vector (same pointer on one GPU)
     double *out;
     const double *uprev; const double *scal; double *partial;  // Lanczos epilogue
+    int32_t rsplit;   // >1 (rows too long for LDS, local-only pass): `rsplit` workgroups of one XCD share a row
 };
 
 enum { KF_DIRECT = 1, KF_LDS = 2, KF_EPI = 4, KF_PH = 8, KF_ND = 16, KF_NOLOCAL = 32, KF_NODW = 64 };
@@ -146,7 +147,15 @@ __global__ void __launch_bounds__(1024) k_kron2(Kron2Args A)
     extern __shared__ double lds[];
     const int DimUp = A.DimUp;
     double *red = lds + ((F & KF_LDS) ? DimUp : 0);
-    const int64_t row = blockIdx.x;
+    // rsplit > 1: blocks b, b+8, b+16, ... (same blockIdx % 8, hence the same XCD under round-robin dispatch)
+    // take consecutive parts of one row, so that row -- which every up hop gathers from -- is fetched into
+    // one L2 once and at most 8 rows per XCD are live.  Placement only affects speed.
+    int64_t row = blockIdx.x; int part = 0;
+    if (A.rsplit > 1) {
+        const int64_t g = blockIdx.x / (8 * A.rsplit); const int w = (int)(blockIdx.x - g * 8 * A.rsplit);
+        row = g * 8 + (w & 7); part = w >> 3;
+    }
+    if (row >= A.Qdw * A.DimPh) return;                                // never true for a well-formed launch
     const int iph = (int)(row / A.Qdw);
     const int64_t idwl = row - (int64_t)iph * A.Qdw, idw = A.dw0 + idwl;
     const int64_t rbase = ((int64_t)iph * A.Qdw + idwl) * DimUp;       // local row base
@@ -165,7 +174,9 @@ __global__ void __launch_bounds__(1024) k_kron2(Kron2Args A)
     double s_cur = 1.0, c_prev = 0.0, asum = 0.0;
     if (F & KF_EPI) { s_cur = A.scal[SC_SCUR]; c_prev = A.scal[SC_BETA] * A.scal[SC_SPREV]; }
 
-    for (int iup = threadIdx.x; iup < DimUp; iup += blockDim.x) {
+    int iup_lo = 0, iup_hi = DimUp;
+    if (A.rsplit > 1) { const int chunk = (DimUp + A.rsplit - 1) / A.rsplit; iup_lo = part * chunk; iup_hi = iup_lo + chunk < DimUp ? iup_lo + chunk : DimUp; }
+    for (int iup = iup_lo + threadIdx.x; iup < iup_hi; iup += blockDim.x) {
         const double x = (F & KF_LDS) ? lds[iup] : vrow[iup];
         double acc = 0.0;
         uint32_t mup = 0;
