@@ -108,7 +108,7 @@ template <class T> struct DevBuf {
 
 struct DevFactor {
     DevBuf<int32_t> map, rank, rowptr, cols, ellc, talpha, tbeta;
-    DevBuf<uint32_t> pcols, pcodes, pelem; DevBuf<double> ptval; bool packed = false, packed_elem = false; int32_t pterms = 0;
+    DevBuf<uint32_t> pcols, pcodes, pelem, pelem8; DevBuf<double> ptval; bool packed = false, packed_elem = false, packed_elem8 = false; int32_t pterms = 0;
     DevBuf<double> vals, ellv, E, tval, lin;
     int32_t width = 0;
 };
@@ -143,7 +143,7 @@ struct edgpu_sector_s {
     int64_t nloc = 0, nloc_el = 0, vecdim = 0;
     int32_t nmax = 0;
     bool use_lds = false; int kron_threads = 256, kron_threads_override = 0; size_t kron_lds = 0;
-    bool two_factor = false, extra = false, multi = false, kron_split = false; int dw_w = 64, dw_variant = 2, dw_rows = 64; bool up_persistent = true, up_pairs = true; int up_grid = 256, up_threads = 1024, row_split = 4;
+    bool two_factor = false, extra = false, multi = false, kron_split = false; int dw_w = 64, dw_variant = 2, dw_rows = 64; bool up_persistent = true, up_pairs = true; int up_grid = 256, up_threads = 1024, row_split = 4; bool up_big = true;
     std::vector<hipEvent_t> bench_ev; int bench_k = 0; double *bv[3] = {nullptr, nullptr, nullptr};
     int64_t nnz_total = 0, bytes_stored = 0;
     int64_t npartial = 0;
@@ -153,7 +153,7 @@ namespace edgpu {
 using S = edgpu_sector_s;
 
 static int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
-static int dbg_flags() { static int f = -1; if (f < 0) { const char *e = getenv("EDGPU_DEBUG"); f = e ? atoi(e) : 0; } return f; }
+static int dbg_flags() { const char *e = getenv("EDGPU_DEBUG"); return e ? atoi(e) : 0; }
 static int dbg_int(const char *name, int dflt) { const char *e = getenv(name); return e ? atoi(e) : dflt; }
 
 // ---------------------------------------------------------------------------------------
@@ -202,6 +202,23 @@ static int upload_factor(S *s, int k)
                 pd[(size_t)(q / 4) * f.dim + i] |= code << (8 * (q & 3));
             }
         if (ok) { CHK(df->pcols.upload(pc)); CHK(df->pcodes.upload(pd)); CHK(df->ptval.upload(tvl)); df->packed = true; df->pterms = 128; }
+        if (ok && W <= 10) {                        // element-major image of 8 dwords for rows that do not fit LDS
+            std::vector<uint32_t> pe((size_t)8 * f.dim, 0u);
+            for (int32_t i = 0; i < f.dim; i++) {
+                for (int q = 0; q < 10; q++) {
+                    int64_t p = f.rowptr[i] + q; bool has = q < W && p < f.rowptr[i + 1];
+                    uint32_t col = has ? (uint32_t)f.cols[p] : (uint32_t)i;
+                    pe[(size_t)8 * i + q / 2] |= col << (16 * (q & 1));
+                }
+                for (int q = 0; q < 12; q++) {
+                    int64_t p = f.rowptr[i] + q; bool has = q < W && p < f.rowptr[i + 1];
+                    uint32_t code = 127u;
+                    if (has) { code = (pd[(size_t)(q / 4) * f.dim + i] >> (8 * (q & 3))) & 0xffu; }
+                    pe[(size_t)8 * i + 5 + q / 4] |= code << (8 * (q & 3));
+                }
+            }
+            CHK(df->pelem8.upload(pe)); df->packed_elem8 = true;
+        }
         if (ok && W <= 8 && f.dim % 2 == 0) {       // element-major image for the pair kernel: 6 dwords per up configuration
             std::vector<uint32_t> pe((size_t)6 * f.dim, 0u);
             for (int32_t i = 0; i < f.dim; i++) {
@@ -422,6 +439,7 @@ static int create(const edgpu_desc *desc, S **out)
         s->up_grid = dbg_int("EDGPU_UP_GRID", 256);
         s->up_pairs = dbg_int("EDGPU_UP_PAIRS", 1) != 0;
         s->row_split = std::max(1, std::min(32, dbg_int("EDGPU_ROW_SPLIT", 4)));
+        s->up_big = dbg_int("EDGPU_UP_BIG", 1) != 0;
         s->up_threads = dbg_int("EDGPU_UP_THREADS", 1024) == 512 ? 512 : 1024;
         s->dw_rows = std::max(1, std::min(64, dbg_int("EDGPU_DW_ROWS", 64)));
         if (s->dw_w != 8 && s->dw_w != 16 && s->dw_w != 32 && s->dw_w != 64 && s->dw_w != 128 && s->dw_w != 256) s->dw_w = 32;
@@ -623,7 +641,7 @@ static int direct_tables(S *s)
         T.dim = H.fac[k].dim; T.nterms = (int32_t)H.fac[k].terms.size(); T.width = f.width; T.transposed = k < H.Ns_Ud;
         T.map = f.map.p; T.rank = f.rank.p; T.talpha = f.talpha.p; T.tbeta = f.tbeta.p; T.tval = f.tval.p;
         T.ellc = f.ellc.p; T.ellv = f.ellv.p; T.lin = f.lin.p; T.nlev = H.fac[k].nbits;
-        T.pcols = f.packed ? f.pcols.p : nullptr; T.pcodes = f.packed ? f.pcodes.p : nullptr; T.pelem = f.packed_elem ? f.pelem.p : nullptr;
+        T.pcols = f.packed ? f.pcols.p : nullptr; T.pcodes = f.packed ? f.pcodes.p : nullptr; T.pelem = f.packed_elem ? f.pelem.p : nullptr; T.pelem8 = f.packed_elem8 ? f.pelem8.p : nullptr;
         T.impmask = d.ed_total_ud ? (1 << d.Norb) - 1 : 0; T.pair = d.ed_total_ud ? d.Ust - d.Jh : 0.0; T.E = f.E.p;
         hipLaunchKernelGGL(k_direct_tables, dim3((unsigned)cdiv(T.dim, 256)), dim3(256), 0, s->stream, T);
     }
@@ -739,6 +757,16 @@ static int hxv(S *s, const double *v, double *out, bool epi, const double *uprev
                     else { if (epi) UP_LAUNCH(false, true, 1024); else UP_LAUNCH(false, false, 1024); }
                 }
 #undef UP_LAUNCH
+                HIPCHK(hipGetLastError());
+            } else if (!s->use_lds && !s->extra && s->fac[0]->packed_elem8 && s->up_big) {
+                UpBigArgs U{};
+                U.DimUp = A.DimUp; U.DimPh = A.DimPh; U.rsplit = s->row_split; U.Qdw = A.Qdw; U.dw0 = A.dw0; U.nrows = H.Qdw * H.DimPh;
+                U.packed8 = reinterpret_cast<const uint4 *>(s->fac[0]->pelem8.p); U.tval = s->fac[0]->ptval.p; U.nterms = s->fac[0]->pterms;
+                U.diag = A.diag; U.Eup = A.Eup; U.Edw = A.Edw; U.cross = A.cross; U.mapup = A.mapup; U.mapdw = A.mapdw; U.impmask = A.impmask; U.nI = A.nI; U.econst = A.econst;
+                U.v = v; U.out = out; U.uprev = uprev; U.scal = s->scal.p;
+                const unsigned grid = (unsigned)(cdiv(U.nrows, 8) * 8 * s->row_split);
+                if (direct) { if (epi) hipLaunchKernelGGL((k_uppass_big<true, true>), dim3(grid), dim3(512), 0, s->stream, U); else hipLaunchKernelGGL((k_uppass_big<true, false>), dim3(grid), dim3(512), 0, s->stream, U); }
+                else { if (epi) hipLaunchKernelGGL((k_uppass_big<false, true>), dim3(grid), dim3(512), 0, s->stream, U); else hipLaunchKernelGGL((k_uppass_big<false, false>), dim3(grid), dim3(512), 0, s->stream, U); }
                 HIPCHK(hipGetLastError());
             } else if (!s->use_lds && !epi_partials_needed(base | KF_NODW)) {
                 Kron2Args A2 = A; A2.rsplit = s->row_split;

@@ -408,6 +408,56 @@ __global__ void __launch_bounds__(NT) k_uppass2(UpArgs2 A)
     }
 }
 
+// Local pass for rows too long for LDS (Ns=18: DimUp=48620, 389 KB): the up-hop gathers go to the row in
+// global memory.  `rsplit` workgroups with equal blockIdx % 8 (one XCD under round-robin dispatch) share a row
+// so it is served from that XCD's L2; H_up comes from an element-major packed image of 8 dwords per up
+// configuration (5 dwords of 16-bit columns + 3 dwords of 8-bit codes: up to 10 hops) -- 32 B instead of the
+// 108 B of the wide image, which was the bulk of the L2 traffic of the unpacked kernel.
+struct UpBigArgs {
+    int32_t DimUp, DimPh, rsplit; int64_t Qdw, dw0, nrows;
+    const uint4 *packed8;     // [iup][2] uint4
+    const double *tval; int32_t nterms;
+    const double *diag, *Eup, *Edw, *cross; const int32_t *mapup, *mapdw; int32_t impmask, nI; double econst;
+    const double *v; double *out; const double *uprev; const double *scal;
+};
+template <bool DIRECT, bool EPI>
+__global__ void __launch_bounds__(512) k_uppass_big(UpBigArgs A)
+{
+    __shared__ double tv[128];
+    for (int t = threadIdx.x; t < A.nterms && t < 128; t += blockDim.x) tv[t] = A.tval[t];
+    __syncthreads();
+    const int64_t g = blockIdx.x / (8 * A.rsplit); const int w = (int)(blockIdx.x - g * 8 * A.rsplit);
+    const int64_t row = g * 8 + (w & 7); const int part = w >> 3;
+    if (row >= A.nrows) return;
+    const int DimUp = A.DimUp;
+    const int64_t idwl = row % A.Qdw, idw = A.dw0 + idwl, rbase = row * DimUp;
+    const double *vrow = A.v + rbase;
+    const int chunk = (DimUp + A.rsplit - 1) / A.rsplit, lo = part * chunk, hi = lo + chunk < DimUp ? lo + chunk : DimUp;
+    double s_cur = 1.0, c_prev = 0.0;
+    if (EPI) { s_cur = A.scal[SC_SCUR]; c_prev = A.scal[SC_BETA] * A.scal[SC_SPREV]; }
+    uint32_t mdw = 0; double edw = 0.0;
+    if (DIRECT) { mdw = (uint32_t)A.mapdw[idw] & A.impmask; edw = A.Edw[idw] + A.econst; }
+    for (int i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+        const uint4 p0 = A.packed8[2 * i], p1 = A.packed8[2 * i + 1];
+        const double x = vrow[i];
+        double dval;
+        if (DIRECT) dval = edw + A.Eup[i] + A.cross[((uint32_t)A.mapup[i] & A.impmask) * A.nI + mdw];
+        else dval = A.diag[idwl * DimUp + i];
+        double up = 0.0;
+        if (EPI) up = A.uprev[rbase + i];
+        const uint32_t c[5] = {p0.x, p0.y, p0.z, p0.w, p1.x}, k[3] = {p1.y, p1.z, p1.w};
+        double acc = dval * x;
+#pragma unroll
+        for (int e = 0; e < 10; e++) {
+            const uint32_t code = (k[e >> 2] >> (8 * (e & 3))) & 0xffu, col = (c[e >> 1] >> (16 * (e & 1))) & 0xffffu;
+            double t = tv[code & 0x7fu];
+            t = (code & 0x80u) ? -t : t;
+            acc += t * vrow[col];
+        }
+        A.out[rbase + i] = EPI ? s_cur * acc - c_prev * up : acc;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // dw-hop pass, column tiled: out(iup,idw) += sum_k Hdw[idw,k] * v(iup, jdw_k).
 // Every neighbour row jdw is needed by ~Ns/2 different idw rows that are spread over the whole
@@ -575,6 +625,7 @@ struct TabArgs {
     int32_t *ellc; double *ellv;
     uint32_t *pcols, *pcodes;   // optional packed image (k_uppass), zeroed by the caller
     uint32_t *pelem;            // optional element-major packed image (k_uppass2): 6 dwords per row, width <= 8
+    uint32_t *pelem8;           // optional element-major image of 8 dwords (k_uppass_big): width <= 10
     const double *lin; int32_t nlev; int32_t impmask; double pair;  // E[i] = sum lin[l] n_l + pair * C(#imp,2)
     double *E;
 };
@@ -610,6 +661,18 @@ __global__ void __launch_bounds__(256) k_direct_tables(TabArgs A)
             uint32_t w = 0;
             for (int e = 0; e < 4; e++) { const int q = 4 * c + e; w |= (uint32_t)(q < n ? ct[q] : 127u) << (8 * e); }
             A.pcodes[(int64_t)c * A.dim + i] = w;
+        }
+    }
+    if (A.pelem8) {
+        for (int c = 0; c < 5; c++) {
+            uint32_t w = 0;
+            for (int e = 0; e < 2; e++) { const int q = 2 * c + e; w |= (uint32_t)(q < n ? cj[q] : i) << (16 * e); }
+            A.pelem8[(int64_t)8 * i + c] = w;
+        }
+        for (int c = 0; c < 3; c++) {
+            uint32_t w = 0;
+            for (int e = 0; e < 4; e++) { const int q = 4 * c + e; w |= (uint32_t)(q < n ? ct[q] : 127u) << (8 * e); }
+            A.pelem8[(int64_t)8 * i + 5 + c] = w;
         }
     }
     if (A.pelem) {
