@@ -1523,6 +1523,25 @@ int edgpu_chi_lanczos(edgpu_handle h, const double *cup, const double *cdw, cons
     return lanczos_tridiag(h, h->tmp_out.p, nlanc, threshold, alanc, blanc, nused);
 }
 
+// phonon propagator leg (lanc_build_gf_phonon_main, ED_GF_PHONON.f90:40-123): (b+b^+)|state>, normalise, tridiag
+int edgpu_phonon_lanczos(edgpu_handle h, const double *state_host, int32_t nlanc, double threshold, double *norm2,
+                         double *alanc, double *blanc, int32_t *nused)
+{
+    if (!h || !state_host || !norm2 || !alanc || !blanc || !nused) return fail(EDGPU_EINVAL, "edgpu_phonon_lanczos: null argument");
+    HIPCHK(hipSetDevice(h->device));
+    if (h->tmp_in.n != (size_t)h->nloc) { CHK(h->tmp_in.alloc((size_t)h->nloc)); CHK(h->tmp_out.alloc((size_t)h->nloc)); }
+    HIPCHK(hipMemcpy(h->tmp_in.p, state_host, (size_t)h->nloc * 8, hipMemcpyHostToDevice));
+    CHK(lz_prepare(h, nlanc));
+    const int nb = (int)std::max<int64_t>(1, std::min<int64_t>(cdiv(h->nloc, 256), 8192));
+    hipLaunchKernelGGL(k_apply_phonon_x, dim3(nb), dim3(256), 0, h->stream, (const double *)h->tmp_in.p, h->tmp_out.p, h->nloc_el, h->H.DimPh);
+    HIPCHK(hipGetLastError());
+    CHK(normalise_dev(h, h->tmp_out.p, norm2));
+    for (int i = 0; i < nlanc; i++) { alanc[i] = 0.0; blanc[i] = 0.0; }
+    *nused = 0;
+    if (*norm2 <= 0.0) return EDGPU_OK;
+    return lanczos_tridiag(h, h->tmp_out.p, nlanc, threshold, alanc, blanc, nused);
+}
+
 // One Green's-function Lanczos leg entirely in HBM: O|state>, normalise, sp_lanc_tridiag.
 // state_host: vecdim(from) doubles on the host.  Returns norm2, alanc/blanc (nlanc) and nused.
 int edgpu_gf_lanczos(edgpu_handle from, edgpu_handle to, int32_t iorb, int32_t ispin, int32_t dagger,

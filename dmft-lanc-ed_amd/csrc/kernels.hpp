@@ -999,6 +999,20 @@ __global__ void __launch_bounds__(256) k_apply_diagop(DiagOpArgs A)
     }
 }
 
+// (b + b^+)|in> on the phonon index (ED_GF_PHONON.f90:76-90 scatters; gather form here):
+// out(e,p) = sqrt(p+1) in(e,p+1) + sqrt(p) in(e,p-1)
+__global__ void __launch_bounds__(256) k_apply_phonon_x(const double *__restrict__ vin, double *__restrict__ vout, int64_t nel, int dimph)
+{
+    const int64_t n = nel * dimph;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int p = (int)(i / nel);
+        double x = 0.0;
+        if (p + 1 < dimph) x += sqrt((double)(p + 1)) * vin[i + nel];
+        if (p > 0) x += sqrt((double)p) * vin[i - nel];
+        vout[i] = x;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // Impurity-configuration weights of a state: hist[(mu_imp*nI + md_imp) + nI*nI*iph] = sum |v_i|^2.
 // Every local observable of lanc_observables (ED_OBSERVABLES.f90:150-215: dens, dens_up/dw, docc,

@@ -228,6 +228,13 @@ class HvSector:
                                            C.byref(n2), a.ctypes.data, b.ctypes.data, C.byref(nu)))
         return n2.value, a, b, nu.value
 
+    def phonon_lanczos(self, state, nlanc, threshold=1e-12):
+        """Phonon propagator leg: (norm2, alanc, blanc, nused) for (b+b^+)|state> (ED_GF_PHONON.f90)."""
+        state = np.ascontiguousarray(state, np.float64)
+        a = np.zeros(nlanc); b = np.zeros(nlanc); n2 = C.c_double(); nu = C.c_int32()
+        check(capi.lib().edgpu_phonon_lanczos(self._h, state.ctypes.data, nlanc, threshold, C.byref(n2), a.ctypes.data, b.ctypes.data, C.byref(nu)))
+        return n2.value, a, b, nu.value
+
     def sp_lanc_tridiag(self, vin, nlanc, threshold=1e-12):
         vin = np.ascontiguousarray(vin, np.float64)
         a = np.zeros(nlanc); b = np.zeros(nlanc); n = C.c_int32()

@@ -165,6 +165,10 @@ int edgpu_gf_lanczos(edgpu_handle from, edgpu_handle to, int32_t iorb, int32_t i
 int edgpu_chi_lanczos(edgpu_handle h, const double *cup, const double *cdw, const double *state_host, int32_t nlanc,
                       double threshold, double *norm2, double *alanc, double *blanc, int32_t *nused);
 
+/* phonon propagator leg: vvinit = (b + b^+)|state> (ED_GF_PHONON.f90:76-93), normalised, then sp_lanc_tridiag */
+int edgpu_phonon_lanczos(edgpu_handle h, const double *state_host, int32_t nlanc, double threshold, double *norm2,
+                         double *alanc, double *blanc, int32_t *nused);
+
 /* Step-wise form of the same loop for an external clock (bench.py): `begin` sets up a fixed
  * start vector, `steps` enqueues iterations asynchronously on the library's stream (the caller
  * synchronises the device), `result` returns the mean product-kernel time measured with HIP

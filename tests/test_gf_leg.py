@@ -99,3 +99,30 @@ def test_susceptibility_leg(edgpu_mod, case, iorb, jorb):
         np.testing.assert_allclose(a[:k], a_ref[:k], rtol=1e-9, atol=1e-9, err_msg=label)
         np.testing.assert_allclose(b[1:k], b_ref[1:k], rtol=1e-9, atol=1e-9, err_msg=label)
     G.close()
+
+
+@pytest.mark.parametrize("case", ["phonons_nb3_nph3", "phonons_norb2_JxJp", "phonons_orbs"])
+def test_phonon_propagator_leg(edgpu_mod, case):
+    """(b+b^+)|gs> restated from ED_GF_PHONON.f90:76-90 (scatter over source states) vs the device gather."""
+    name, m, nu, nd = [z for z in cases.zoo() if z[0] == case][0]
+    S = oracle.Sector(m, nu, nd)
+    w, U = np.linalg.eigh(S.hmat()); gs = U[:, 0]
+    nel = S.DimUp * S.DimDw
+    v = np.zeros(S.Dim)
+    for i in range(1, S.Dim + 1):
+        iph = (i - 1) // nel + 1; i_el = (i - 1) % nel + 1
+        if iph > 1:
+            v[i_el + (iph - 2) * nel - 1] += np.sqrt(float(iph - 1)) * gs[i - 1]
+        if iph < S.DimPh:
+            v[i_el + iph * nel - 1] += np.sqrt(float(iph)) * gs[i - 1]
+    n2ref = float(v @ v)
+    G = edgpu_mod.HvSector(m, nu, nd)
+    nl = min(S.Dim, 40)
+    n2, a, b, used = G.phonon_lanczos(gs, nl)
+    assert abs(n2 - n2ref) <= 1e-12 * max(1.0, n2ref)
+    a_ref, b_ref, used_ref = oracle.sp_lanc_tridiag(S.spmatvec, v / np.sqrt(n2ref), nl)
+    assert used == used_ref
+    k = min(used, 20)
+    np.testing.assert_allclose(a[:k], a_ref[:k], rtol=1e-9, atol=1e-9)
+    np.testing.assert_allclose(b[1:k], b_ref[1:k], rtol=1e-9, atol=1e-9)
+    G.close()
