@@ -239,3 +239,51 @@ def test_c3_full_size_properties(edgpu_mod):
     for st in ("direct", "csr"):
         np.testing.assert_allclose(coeffs[st][0], coeffs["kron"][0], rtol=1e-10, atol=1e-10)
         np.testing.assert_allclose(coeffs[st][1], coeffs["kron"][1], rtol=1e-10, atol=1e-10)
+
+
+def test_edge_sectors(edgpu_mod):
+    """Degenerate shapes the reference can meet: one-state sectors, no hopping at all (V=0: empty H_up/H_dw),
+    five orbitals, the largest phonon cut-off used in the zoo, and a sector with a single dw column."""
+    from edgpu import model
+    edge = []
+    m = model.make_model(Norb=1, Nbath=3, Uloc=(2.0,))
+    edge += [("vacuum", m, [0], [0]), ("full", m, [4], [4]), ("one_dw_column", m, [2], [0])]
+    m0 = model.make_model(Norb=1, Nbath=3, Uloc=(2.0,), bath_v=np.zeros((1, 1, 3)))
+    edge += [("no_hybridisation", m0, [2], [2])]
+    m5 = model.make_model(Norb=5, Nbath=1, Uloc=(2.0, 1.9, 1.8, 1.7, 1.6), Ust=1.0, Jh=0.2, Jx=0.2, Jp=0.2)
+    edge += [("five_orbitals", m5, [5], [5])]
+    for name, m, nu, nd in edge:
+        S = oracle.Sector(m, nu, nd)
+        v = np.random.RandomState(3).uniform(-0.5, 0.5, S.Dim)
+        ref = S.spmatvec(v)
+        tol = HXV_RTOL * max(np.abs(ref).max(), 1e-300)
+        for st in _storages(m):
+            G = edgpu_mod.HvSector(m, nu, nd, storage=st)
+            assert G.Dim == S.Dim
+            assert np.abs(G.spHtimesV(v) - ref).max() <= tol, (name, st)
+            if S.Dim <= 4000:
+                w = np.linalg.eigvalsh(S.hmat())
+                e0, x, nl = G.sp_lanc_eigh(v if np.abs(v).max() > 0 else None, nitermax=300, threshold=1e-14)
+                assert abs(e0 - w[0]) <= 1e-10, (name, st, e0, w[0])
+            G.close()
+
+
+def test_bad_descriptors_are_rejected(edgpu_mod):
+    import ctypes as C
+    from edgpu import model, capi
+    m, nu, nd = model.half_filled_c(3)
+    L = capi.lib()
+    for bad in (dict(Nspin=3), dict(Norb=0), dict(bath_type="hybrid", ed_total_ud=False)):
+        mm = dict(m); mm.update(bad)
+        with pytest.raises(capi.EdgpuError):
+            edgpu_mod.HvSector(mm, nu, nd)
+    with pytest.raises(capi.EdgpuError):
+        edgpu_mod.HvSector(m, [9], [1])                       # quantum number out of range
+    with pytest.raises(capi.EdgpuError):
+        edgpu_mod.HvSector(m, nu, nd, rank=0, size=50)        # DimDw < ranks
+    G = edgpu_mod.HvSector(m, nu, nd)
+    G._desc.abi_version = 99
+    h = C.c_void_p()
+    assert L.edgpu_sector_create(C.byref(G._desc), C.byref(h)) != 0 and b"abi_version" in L.edgpu_last_error()
+    assert L.edgpu_hxv_device(None, None, None) != 0
+    G.close()
