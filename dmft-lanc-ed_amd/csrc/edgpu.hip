@@ -1394,6 +1394,25 @@ int edgpu_eigsh(edgpu_handle h, int32_t nev, int32_t ncv, int32_t maxiter, doubl
     return eigsh(h, nev, ncv, maxiter, tol, evals, evecs, nconv, nrestarts, nmatvec);
 }
 
+// cvec of the twin sector from the cvec of this sector (host vectors, single rank)
+int edgpu_twin_reorder(edgpu_handle h, const double *vin_host, double *vout_host)
+{
+    if (!h || !vin_host || !vout_host) return fail(EDGPU_EINVAL, "edgpu_twin_reorder: null argument");
+    if (h->multi && h->comm.size > 1) return fail(EDGPU_EUNSUPPORTED, "edgpu_twin_reorder: single rank only");
+    HIPCHK(hipSetDevice(h->device));
+    const SectorHost &H = h->H;
+    if (h->tmp_in.n != (size_t)h->nloc) { CHK(h->tmp_in.alloc((size_t)h->nloc)); CHK(h->tmp_out.alloc((size_t)h->nloc)); }
+    HIPCHK(hipMemcpy(h->tmp_in.p, vin_host, (size_t)h->nloc * 8, hipMemcpyHostToDevice));
+    TwinArgs A{}; A.nud = H.Ns_Ud; A.DimPh = H.DimPh; A.nel = h->nloc_el; A.vin = h->tmp_in.p; A.vout = h->tmp_out.p;
+    for (int k = 0; k < 2 * H.Ns_Ud; k++) A.dimsA[k] = H.fac[k].dim;
+    const int nb = (int)std::max<int64_t>(1, std::min<int64_t>(cdiv(h->nloc, 256), 8192));
+    hipLaunchKernelGGL(k_twin_reorder, dim3(nb), dim3(256), 0, h->stream, A);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(vout_host, h->tmp_out.p, (size_t)h->nloc * 8, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return EDGPU_OK;
+}
+
 // Impurity-configuration weights of a state vector (host or device resident), summed over ranks.
 // hist: (2^Norb * 2^Norb * DimPh) doubles, index (mu_imp*2^Norb + md_imp) + 4^Norb*iph.
 int edgpu_imp_histogram(edgpu_handle h, const double *vec, int32_t vec_on_device, double *hist)

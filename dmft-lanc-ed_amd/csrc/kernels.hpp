@@ -999,6 +999,26 @@ __global__ void __launch_bounds__(256) k_apply_diagop(DiagOpArgs A)
     }
 }
 
+// State of the twin sector B(ndw,nup) from the state of A(nup,ndw): vector_B(i) = cvec_A(Order(i)) with
+// Order = twin_sector_order (ED_SETUP.f90:852-880, ED_EIGENSPACE.f90:486-497).  Sorting the flipped global
+// state numbers is the index permutation that swaps the up and dw halves of the digit tuple, i.e. a
+// generalised transpose per phonon block -- computed directly, no sort.
+struct TwinArgs { int32_t nud, DimPh; int32_t dimsA[2 * EDGPU_MAX_ORB]; int64_t nel; const double *vin; double *vout; };
+__global__ void __launch_bounds__(256) k_twin_reorder(TwinArgs A)
+{
+    const int64_t n = A.nel * A.DimPh;
+    for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t iph = j / A.nel; int64_t c = j - iph * A.nel;
+        // digits of the B index: [ups_B (= dws_A) ..., dws_B (= ups_A) ...]
+        int32_t dg[2 * EDGPU_MAX_ORB];
+        for (int k = 0; k < A.nud; k++) { const int d = A.dimsA[k + A.nud]; dg[k + A.nud] = (int32_t)(c % d); c /= d; }   // dws_A
+        for (int k = 0; k < A.nud; k++) { const int d = A.dimsA[k]; dg[k] = (int32_t)(c % d); c /= d; }                  // ups_A
+        int64_t i = 0, stride = 1;
+        for (int k = 0; k < 2 * A.nud; k++) { i += dg[k] * stride; stride *= A.dimsA[k]; }
+        A.vout[j] = A.vin[i + iph * A.nel];
+    }
+}
+
 // (b + b^+)|in> on the phonon index (ED_GF_PHONON.f90:76-90 scatters; gather form here):
 // out(e,p) = sqrt(p+1) in(e,p+1) + sqrt(p) in(e,p-1)
 __global__ void __launch_bounds__(256) k_apply_phonon_x(const double *__restrict__ vin, double *__restrict__ vout, int64_t nel, int dimph)

@@ -185,6 +185,13 @@ class HvSector:
                                      C.byref(nc), C.byref(nr), C.byref(nm)))
         return ev, vec, {"nconv": nc.value, "restarts": nr.value, "matvecs": nm.value}
 
+    def twin_reorder(self, vec):
+        """State of the twin sector (ndw,nup) from a state of this sector (es_return_cvector, itwin branch)."""
+        vec = np.ascontiguousarray(vec, np.float64)
+        out = np.empty_like(vec)
+        check(capi.lib().edgpu_twin_reorder(self._h, vec.ctypes.data, out.ctypes.data))
+        return out
+
     def imp_histogram(self, vec):
         """Impurity-configuration weights (nI, nI, DimPh) of a state (numpy array or DeviceVector)."""
         nI = 1 << int(self._desc.Norb)

@@ -146,6 +146,11 @@ int edgpu_eigsh(edgpu_handle h, int32_t nev, int32_t ncv, int32_t maxiter, doubl
  * this table, so the N-vector stays in HBM.  vec: host (vec_on_device=0) or device pointer, vecDim doubles. */
 int edgpu_imp_histogram(edgpu_handle h, const double *vec, int32_t vec_on_device, double *hist);
 
+/* eigenvector hand-off for twin sectors (ed_twin): the state of sector B(ndw,nup) from the state of this
+ * sector A(nup,ndw), vector_B(i) = cvec_A(Order(i)), Order = twin_sector_order (ED_SETUP.f90:852-880,
+ * ED_EIGENSPACE.f90:486-497).  Host vectors of getDim doubles. */
+int edgpu_twin_reorder(edgpu_handle h, const double *vin_host, double *vout_host);
+
 /* ---- Green's-function leg: O|state> between two live sectors, in HBM ------
  * vout(j) = sgn * vin(i) with |j> = c^+_{iorb,ispin}|i> (dagger=1) or c_{iorb,ispin}|i> (dagger=0),
  * ED_GF_NORMAL.f90:190-213 / 264-283; `to` must be getCDGsector/getCsector of `from`

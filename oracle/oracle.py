@@ -363,3 +363,28 @@ def lanc_observables(S, state, peso=1.0):
         o["prob_ph"][iph - 1] += w
         o["dens_ph"] += (iph - 1) * w
     return o
+
+
+def twin_sector_order(S):
+    """Order(1:Dim) of twin_sector_order (ED_SETUP.f90:852-880): flip every state of sector S to
+    |{dw}>|{up}>, take its global number (+ phonon offset) and return the sorting permutation (1-based),
+    so that vector_twin(i) = cvec(Order(i)) (ED_EIGENSPACE.f90:486-497)."""
+    Ns_Ud, Ns_Orb = S.Ns_Ud, S.Ns_Orb
+    dims = [int(x) for x in list(S.DimUps) + list(S.DimDws)]
+    H = [S.map(k) for k in range(2 * Ns_Ud)]
+    iel = S.DimUp * S.DimDw
+    Ns = S.Ns
+    flipped = np.zeros(S.Dim, dtype=object)
+    for i in range(1, S.Dim + 1):
+        iph = (i - 1) // iel + 1
+        c = (i - 1) % iel; ind = []
+        for d in dims:
+            ind.append(c % d + 1); c //= d
+        ist = [int(H[k][ind[k] - 1]) for k in range(2 * Ns_Ud)]
+        jv = ist[Ns_Ud:] + ist[:Ns_Ud]                      # flip_state: [jups,jdws] = [dws,ups]
+        j = jv[0]; prod = 1
+        for k in range(1, len(jv)):                         # indices2state with dims = 2**Ns_Orb
+            prod *= 2 ** Ns_Orb; j += (jv[k] - 1) * prod
+        flipped[i - 1] = j + (iph - 1) * 2 ** (2 * Ns)
+    order = sorted(range(S.Dim), key=lambda k: flipped[k])
+    return np.array(order, dtype=np.int64) + 1

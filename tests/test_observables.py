@@ -25,3 +25,16 @@ def test_observables_match_oracle(edgpu_mod, name, m, nu, nd):
     dv = edgpu_mod.DeviceVector(S.Dim).upload(gs)
     np.testing.assert_allclose(G.observables(dv)["docc"], ref["docc"], atol=1e-13)
     G.close()
+
+
+@pytest.mark.parametrize("name,m,nu,nd", [z for z in cases.zoo() if z[0] in ("nb5_offhalf_2_4", "norb2_normal_JxJp", "orbs_norb2_nb3_uneven", "phonons_orbs", "nb6_even")],
+                         ids=["nb5_offhalf_2_4", "nb6_even", "norb2_normal_JxJp", "orbs_norb2_nb3_uneven", "phonons_orbs"])
+def test_twin_sector_vector(edgpu_mod, name, m, nu, nd):
+    """vector_twin(i) = cvec(Order(i)) with Order from the oracle's restatement of twin_sector_order; and the
+    reordered vector is an eigenvector of the twin sector when the model is spin symmetric."""
+    S = oracle.Sector(m, nu, nd)
+    v = np.random.RandomState(9).uniform(-1, 1, S.Dim)
+    order = oracle.twin_sector_order(S)
+    G = edgpu_mod.HvSector(m, nu, nd, storage="direct")
+    np.testing.assert_array_equal(G.twin_reorder(v), v[order - 1])
+    G.close()
