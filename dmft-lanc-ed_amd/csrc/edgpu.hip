@@ -1394,6 +1394,34 @@ int edgpu_eigsh(edgpu_handle h, int32_t nev, int32_t ncv, int32_t maxiter, doubl
     return eigsh(h, nev, ncv, maxiter, tol, evals, evecs, nconv, nrestarts, nmatvec);
 }
 
+// off-diagonal impurity density matrix of a host state: dm[(s*Norb + a)*Norb + b], s=0 up, 1 dw (diagonal left 0:
+// it follows from the impurity-configuration weights).  ed_total_ud=T, single rank.
+int edgpu_imp_density_offdiag(edgpu_handle h, const double *vec_host, double *dm)
+{
+    if (!h || !vec_host || !dm) return fail(EDGPU_EINVAL, "edgpu_imp_density_offdiag: null argument");
+    if (!h->two_factor) return fail(EDGPU_EUNSUPPORTED, "edgpu_imp_density_offdiag: ed_total_ud=F has no off-diagonal density matrix (ED_OBSERVABLES.f90:283)");
+    if (h->multi && h->comm.size > 1) return fail(EDGPU_EUNSUPPORTED, "edgpu_imp_density_offdiag: single rank only");
+    HIPCHK(hipSetDevice(h->device));
+    const SectorHost &H = h->H; const int Norb = H.desc.Norb;
+    for (int t = 0; t < 2 * Norb * Norb; t++) dm[t] = 0.0;
+    if (Norb < 2) return EDGPU_OK;
+    if (h->tmp_in.n != (size_t)h->nloc) { CHK(h->tmp_in.alloc((size_t)h->nloc)); CHK(h->tmp_out.alloc((size_t)h->nloc)); }
+    HIPCHK(hipMemcpy(h->tmp_in.p, vec_host, (size_t)h->nloc * 8, hipMemcpyHostToDevice));
+    const int64_t nrows = H.Qdw * H.DimPh;
+    DevBuf<double> out; CHK(out.alloc((size_t)nrows * 50));
+    HIPCHK(hipMemsetAsync(out.p, 0, (size_t)nrows * 50 * 8, h->stream));
+    DmArgs A{}; A.DimUp = (int32_t)H.DimUp; A.DimDw = (int32_t)H.DimDw; A.Norb = Norb; A.Qdw = H.Qdw; A.dw0 = H.dw0; A.nrows = nrows;
+    A.mapup = h->fac[0]->map.p; A.mapdw = h->fac[1]->map.p; A.rankup = h->fac[0]->rank.p; A.rankdw = h->fac[1]->rank.p; A.v = h->tmp_in.p; A.out = out.p;
+    hipLaunchKernelGGL(k_imp_dm_rows, dim3((unsigned)nrows), dim3(256), 0, h->stream, A);
+    HIPCHK(hipGetLastError());
+    std::vector<double> part((size_t)nrows * 50);
+    HIPCHK(hipMemcpyAsync(part.data(), out.p, part.size() * 8, hipMemcpyDeviceToHost, h->stream)); HIPCHK(hipStreamSynchronize(h->stream));
+    for (int64_t r = 0; r < nrows; r++)
+        for (int s2 = 0; s2 < 2; s2++) for (int a = 0; a < Norb; a++) for (int b = 0; b < Norb; b++)
+            dm[(s2 * Norb + a) * Norb + b] += part[(size_t)r * 50 + s2 * 25 + a * 5 + b];
+    return EDGPU_OK;
+}
+
 // cvec of the twin sector from the cvec of this sector (host vectors, single rank)
 int edgpu_twin_reorder(edgpu_handle h, const double *vin_host, double *vout_host)
 {

@@ -1019,6 +1019,44 @@ __global__ void __launch_bounds__(256) k_twin_reorder(TwinArgs A)
     }
 }
 
+// Off-diagonal impurity density matrix <c^+_a c_b> per spin (ED_OBSERVABLES.f90:283-313, ed_total_ud=T):
+// dm[s][a][b] = sum_i sgn1*sgn2 * v_i * v_j, |j> = c^+_a c_b |i> acting on the spin-s word (a != b).
+// One workgroup per (idw,iph) row; out[row*50 + s*25 + a*5 + b] partial sums in a fixed order.
+struct DmArgs { int32_t DimUp, DimDw, Norb; int64_t Qdw, dw0, nrows; const int32_t *mapup, *mapdw, *rankup, *rankdw; const double *v; double *out; };
+__global__ void __launch_bounds__(256) k_imp_dm_rows(DmArgs A)
+{
+    __shared__ double red[4];
+    const int64_t row = blockIdx.x;
+    const int64_t iph = row / A.Qdw, idwl = row - iph * A.Qdw, idw = A.dw0 + idwl;
+    const uint32_t mdw = (uint32_t)A.mapdw[idw];
+    const double *vrow = A.v + row * A.DimUp;
+    for (int s = 0; s < 2; s++)
+        for (int a = 0; a < A.Norb; a++)
+            for (int b = 0; b < A.Norb; b++) {
+                if (a == b) continue;
+                double acc = 0.0;
+                const uint32_t ba = 1u << a, bb = 1u << b;
+                if (s == 0) {          // up word changes: partner in the same row
+                    for (int i = threadIdx.x; i < A.DimUp; i += blockDim.x) {
+                        const uint32_t m = (uint32_t)A.mapup[i];
+                        if ((m & bb) && !(m & ba)) {
+                            const uint32_t r = m & ~bb, k = r | ba;
+                            const int sg = __popc(m & (bb - 1u)) + __popc(r & (ba - 1u));
+                            acc += ((sg & 1) ? -1.0 : 1.0) * vrow[i] * vrow[A.rankup[k]];
+                        }
+                    }
+                } else if ((mdw & bb) && !(mdw & ba)) {   // dw word changes: partner row (single rank: all rows local)
+                    const uint32_t r = mdw & ~bb, k = r | ba;
+                    const int sg = __popc(mdw & (bb - 1u)) + __popc(r & (ba - 1u));
+                    const double sgn = (sg & 1) ? -1.0 : 1.0;
+                    const double *prow = A.v + (iph * A.Qdw + (A.rankdw[k] - A.dw0)) * A.DimUp;
+                    for (int i = threadIdx.x; i < A.DimUp; i += blockDim.x) acc += sgn * vrow[i] * prow[i];
+                }
+                double t = block_sum(acc, red);
+                if (threadIdx.x == 0) A.out[row * 50 + s * 25 + a * 5 + b] = t;
+            }
+}
+
 // (b + b^+)|in> on the phonon index (ED_GF_PHONON.f90:76-90 scatters; gather form here):
 // out(e,p) = sqrt(p+1) in(e,p+1) + sqrt(p) in(e,p-1)
 __global__ void __launch_bounds__(256) k_apply_phonon_x(const double *__restrict__ vin, double *__restrict__ vout, int64_t nel, int dimph)

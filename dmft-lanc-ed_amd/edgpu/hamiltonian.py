@@ -192,6 +192,14 @@ class HvSector:
         check(capi.lib().edgpu_twin_reorder(self._h, vec.ctypes.data, out.ctypes.data))
         return out
 
+    def imp_density_offdiag(self, vec):
+        """<c^+_a c_b>_s, a != b, shape (2, Norb, Norb) (ED_OBSERVABLES.f90:283-313)."""
+        Norb = int(self._desc.Norb)
+        vec = np.ascontiguousarray(vec, np.float64)
+        dm = np.zeros(2 * Norb * Norb)
+        check(capi.lib().edgpu_imp_density_offdiag(self._h, vec.ctypes.data, dm.ctypes.data))
+        return dm.reshape(2, Norb, Norb)
+
     def imp_histogram(self, vec):
         """Impurity-configuration weights (nI, nI, DimPh) of a state (numpy array or DeviceVector)."""
         nI = 1 << int(self._desc.Norb)

@@ -146,6 +146,10 @@ int edgpu_eigsh(edgpu_handle h, int32_t nev, int32_t ncv, int32_t maxiter, doubl
  * this table, so the N-vector stays in HBM.  vec: host (vec_on_device=0) or device pointer, vecDim doubles. */
 int edgpu_imp_histogram(edgpu_handle h, const double *vec, int32_t vec_on_device, double *hist);
 
+/* off-diagonal impurity density matrix <c^+_a c_b>_s of a state (ED_OBSERVABLES.f90:283-313, ed_total_ud=T only):
+ * dm[(s*Norb + a)*Norb + b], s = 0 (up) / 1 (dw), a != b; the diagonal follows from edgpu_imp_histogram. */
+int edgpu_imp_density_offdiag(edgpu_handle h, const double *vec_host, double *dm);
+
 /* eigenvector hand-off for twin sectors (ed_twin): the state of sector B(ndw,nup) from the state of this
  * sector A(nup,ndw), vector_B(i) = cvec_A(Order(i)), Order = twin_sector_order (ED_SETUP.f90:852-880,
  * ED_EIGENSPACE.f90:486-497).  Host vectors of getDim doubles. */

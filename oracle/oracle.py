@@ -388,3 +388,31 @@ def twin_sector_order(S):
         flipped[i - 1] = j + (iph - 1) * 2 ** (2 * Ns)
     order = sorted(range(S.Dim), key=lambda k: flipped[k])
     return np.array(order, dtype=np.int64) + 1
+
+
+def imp_density_offdiag(S, state):
+    """Off-diagonal part of imp_density_matrix (ED_OBSERVABLES.f90:283-313, ed_total_ud=T): loops over the
+    states i, applies c_jorb then c^+_iorb to the spin word and accumulates sgn1*state(i)*sgn2*state(j).
+    Returns dm[s, iorb-1, jorb-1], s = 0 up / 1 dw."""
+    Norb = S.model["Norb"]
+    H = [S.map(0), S.map(1)]
+    dims = [int(S.DimUps[0]), int(S.DimDws[0])]
+    iel = S.DimUp * S.DimDw
+    dm = np.zeros((2, Norb, Norb))
+    for i in range(1, S.Dim + 1):
+        iph = (i - 1) // iel + 1
+        c = (i - 1) % iel
+        ind = [c % dims[0] + 1, c // dims[0] + 1]
+        iud = [int(H[0][ind[0] - 1]), int(H[1][ind[1] - 1])]
+        for ispin in (1, 2):
+            for iorb in range(1, Norb + 1):
+                for jorb in range(1, Norb + 1):
+                    nj = (iud[ispin - 1] >> (jorb - 1)) & 1; ni = (iud[ispin - 1] >> (iorb - 1)) & 1
+                    if nj == 1 and ni == 0:
+                        r, sgn1 = c_op(jorb, iud[ispin - 1])
+                        k, sgn2 = cdg_op(iorb, r)
+                        jnd = list(ind)
+                        jnd[ispin - 1] = binary_search(H[ispin - 1], k)
+                        j = jnd[0] + (jnd[1] - 1) * dims[0] + (iph - 1) * iel
+                        dm[ispin - 1, iorb - 1, jorb - 1] += sgn1 * state[i - 1] * sgn2 * state[j - 1]
+    return dm

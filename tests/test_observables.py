@@ -38,3 +38,14 @@ def test_twin_sector_vector(edgpu_mod, name, m, nu, nd):
     G = edgpu_mod.HvSector(m, nu, nd, storage="direct")
     np.testing.assert_array_equal(G.twin_reorder(v), v[order - 1])
     G.close()
+
+
+@pytest.mark.parametrize("case", ["norb2_normal_offdiag_hloc", "norb2_normal_JxJp", "norb3_nb1_JxJp", "phonons_norb2_JxJp"])
+def test_offdiagonal_impurity_density_matrix(edgpu_mod, case):
+    name, m, nu, nd = [z for z in cases.zoo() if z[0] == case][0]
+    S = oracle.Sector(m, nu, nd)
+    w, U = np.linalg.eigh(S.hmat()); gs = U[:, 0]
+    ref = oracle.imp_density_offdiag(S, gs)
+    G = edgpu_mod.HvSector(m, nu, nd, storage="direct")
+    np.testing.assert_allclose(G.imp_density_offdiag(gs), ref, rtol=0, atol=1e-13)
+    G.close()
