@@ -66,6 +66,7 @@ def main():
     ap.add_argument("--no-extra", action="store_true", help="skip the kron/direct side measurements")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--comm", default="rccl", choices=["rccl", "torch"], help="N>1: communicator owned by libedgpu.so (rccl) or torch.distributed device callbacks")
+    ap.add_argument("--force-dist", action="store_true", help="run the N>1 code path (process group, communicator, exchange) even with one rank (self-test)")
     a = ap.parse_args()
 
     import torch
@@ -78,9 +79,12 @@ def main():
         raise SystemExit("bench.py needs a GPU (libedgpu.so has no CPU path)")
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    multi = world > 1 or a.force_dist
+    if multi:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     import numpy as np
@@ -89,9 +93,9 @@ def main():
 
     m, nu, nd = model.half_filled_c(a.nbath)
     t_build = time.perf_counter()
-    G = edgpu.HvSector(m, nu, nd, storage=a.storage, rank=rank, size=world, device=local_rank)
+    G = edgpu.HvSector(m, nu, nd, storage=a.storage, rank=rank, size=world, device=local_rank, force_exchange=a.force_dist)
     comm_used = "none"
-    if world > 1:
+    if multi:
         ok = torch.ones(1, device="cuda")
         if a.comm == "rccl":
             # libedgpu.so opens its own RCCL communicator (id broadcast by torch.distributed)
@@ -146,7 +150,7 @@ def main():
         "iters_per_sec": K / dt,
         "config": {"workload": "1-orbital Anderson impurity, Nbath=%d (Ns=%d), sector Nup=Ndw=%d, N=%d, default initial bath, operator storage=%s, one Lanczos iteration per step"
                                % (a.nbath, Ns, nu[0], N, a.storage),
-                   "storage": a.storage, "N": N, "nnz": nnz, "parallelism": ("dw-column split x%d, needed-rows exchange per product over %s" % (world, comm_used)) if world > 1 else "single GPU"},
+                   "storage": a.storage, "N": N, "nnz": nnz, "parallelism": ("dw-column split x%d, needed-rows exchange per product over %s" % (world, comm_used)) if multi else "single GPU"},
         "roofline": {"bound": "hbm", "kernel": {"csr": "k_csr_spmv2<64,640,false> (local block) + k_csr_spmv2<64,640,true> (dw block): one product of the split explicit CSR",
                                 "kron": "k_uppass + k_dwpass2 (two-pass stored product)", "direct": "k_direct_tables + k_uppass + k_dwpass2"}[a.storage],
                      "achieved": bytes_fmt / (hxv_ms * 1e-3) / 1e9 if hxv_ms > 0 else None, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
