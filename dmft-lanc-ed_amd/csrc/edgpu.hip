@@ -1159,6 +1159,19 @@ static int eigsh(S *s, int nev, int ncv, int maxiter, double tol, double *evals,
 
 }  // namespace edgpu
 
+// ---------------------------------------------------------------------------------------
+// Sparse-matrix container with the semantics of ED_SPARSE_MATRIX.f90 (row-wise growable storage,
+// duplicate-summing insert in storage order) whose product runs on the GPU.
+// ---------------------------------------------------------------------------------------
+struct edgpu_spmat_s {
+    int64_t nrow = 0, ncol = 0;
+    std::vector<std::vector<int64_t>> cols;      // 1-based columns, insertion order (ED_SPARSE_MATRIX.f90:13-17)
+    std::vector<std::vector<double>> vals;
+    bool dirty = true;
+    edgpu::DevBuf<int64_t> d_rp; edgpu::DevBuf<int32_t> d_cols; edgpu::DevBuf<double> d_vals, d_x, d_y;
+    int64_t nnz = 0;
+};
+
 // =========================================================================================
 // C ABI
 // =========================================================================================
@@ -1665,6 +1678,71 @@ int edgpu_lanczos_bench_result(edgpu_handle h, int32_t nsteps_timed, float *hxv_
         HIPCHK(hipMemcpy(alphas, h->alphas.p, (size_t)ncoef * 8, hipMemcpyDeviceToHost));
         HIPCHK(hipMemcpy(betas, h->betas.p + 1, (size_t)ncoef * 8, hipMemcpyDeviceToHost));
     }
+    return EDGPU_OK;
+}
+
+// ---- sparse container: sp_init_matrix / sp_insert_element / sp_delete_matrix / sp_dump_matrix ---------
+int edgpu_sp_init_matrix(int64_t nrow, int64_t ncol, edgpu_spmat *out)
+{
+    if (!out || nrow < 0 || ncol < 0) return fail(EDGPU_EINVAL, "edgpu_sp_init_matrix: bad argument");
+    if (ncol >= ((int64_t)1 << 31)) return fail(EDGPU_EUNSUPPORTED, "edgpu_sp_init_matrix: Ncol must fit int32");
+    auto *m = new edgpu_spmat_s();
+    m->nrow = nrow; m->ncol = ncol ? ncol : nrow;
+    m->cols.resize((size_t)nrow); m->vals.resize((size_t)nrow);
+    *out = m;
+    return EDGPU_OK;
+}
+int edgpu_sp_delete_matrix(edgpu_spmat m) { delete m; return EDGPU_OK; }
+int edgpu_sp_insert_element(edgpu_spmat m, double value, int64_t i, int64_t j)
+{
+    if (!m) return fail(EDGPU_EINVAL, "sp_insert_element: matrix not allocated");
+    if (i < 1 || i > m->nrow || j < 1 || j > m->ncol) return fail(EDGPU_EINVAL, "sp_insert_element: index out of range");
+    auto &c = m->cols[(size_t)i - 1]; auto &v = m->vals[(size_t)i - 1];
+    for (size_t k = 0; k < c.size(); k++) if (c[k] == j) { v[k] += value; m->dirty = true; return EDGPU_OK; }   // column exists: sum it up
+    c.push_back(j); v.push_back(value);                                                                       // new column: append
+    if ((int64_t)c.size() > m->ncol) return fail(EDGPU_EINVAL, "sp_insert_element_csr ERROR: row%Size > sparse%Ncol");
+    m->dirty = true;
+    return EDGPU_OK;
+}
+int edgpu_sp_row(edgpu_spmat m, int64_t i, int32_t *size, int64_t *cols, double *vals, int32_t cap)
+{
+    if (!m || !size || i < 1 || i > m->nrow) return fail(EDGPU_EINVAL, "edgpu_sp_row: bad argument");
+    const auto &c = m->cols[(size_t)i - 1]; const auto &v = m->vals[(size_t)i - 1];
+    *size = (int32_t)c.size();
+    if (cols && vals) { if ((int32_t)c.size() > cap) return fail(EDGPU_EINVAL, "edgpu_sp_row: capacity too small"); for (size_t k = 0; k < c.size(); k++) { cols[k] = c[k]; vals[k] = v[k]; } }
+    return EDGPU_OK;
+}
+int edgpu_sp_dump_matrix(edgpu_spmat m, double *dense)
+{
+    if (!m || !dense) return fail(EDGPU_EINVAL, "edgpu_sp_dump_matrix: null argument");
+    for (int64_t i = 0; i < m->nrow; i++)
+        for (size_t k = 0; k < m->cols[(size_t)i].size(); k++) dense[i + m->nrow * (m->cols[(size_t)i][k] - 1)] += m->vals[(size_t)i][k];   // ED_SPARSE_MATRIX.f90:399-405
+    return EDGPU_OK;
+}
+int edgpu_sp_matvec(edgpu_spmat m, const double *v_host, double *hv_host, int32_t accumulate)
+{
+    if (!m || !v_host || !hv_host) return fail(EDGPU_EINVAL, "edgpu_sp_matvec: null argument");
+    CHK(require_device());
+    if (m->dirty) {
+        std::vector<int64_t> rp((size_t)m->nrow + 1, 0); std::vector<int32_t> cc; std::vector<double> vv;
+        for (int64_t i = 0; i < m->nrow; i++) {
+            for (size_t k = 0; k < m->cols[(size_t)i].size(); k++) { cc.push_back((int32_t)(m->cols[(size_t)i][k] - 1)); vv.push_back(m->vals[(size_t)i][k]); }
+            rp[(size_t)i + 1] = (int64_t)cc.size();
+        }
+        m->nnz = (int64_t)cc.size();
+        if (cc.empty()) { cc.push_back(0); vv.push_back(0.0); }
+        CHK(m->d_rp.upload(rp)); CHK(m->d_cols.upload(cc)); CHK(m->d_vals.upload(vv));
+        CHK(m->d_x.alloc((size_t)std::max<int64_t>(m->ncol, 1))); CHK(m->d_y.alloc((size_t)std::max<int64_t>(m->nrow, 1)));
+        m->dirty = false;
+    }
+    if (m->nrow == 0) return EDGPU_OK;
+    HIPCHK(hipMemcpy(m->d_x.p, v_host, (size_t)m->ncol * 8, hipMemcpyHostToDevice));
+    if (accumulate) HIPCHK(hipMemcpy(m->d_y.p, hv_host, (size_t)m->nrow * 8, hipMemcpyHostToDevice));
+    const bool longrows = m->nnz > 32 * m->nrow;
+    if (longrows) hipLaunchKernelGGL(k_spgen_wave, dim3((unsigned)std::min<int64_t>(cdiv(m->nrow, 4), 65536)), dim3(256), 0, 0, m->nrow, (const int64_t *)m->d_rp.p, (const int32_t *)m->d_cols.p, (const double *)m->d_vals.p, (const double *)m->d_x.p, m->d_y.p, (int)accumulate);
+    else hipLaunchKernelGGL(k_spgen_lane, dim3((unsigned)std::min<int64_t>(cdiv(m->nrow, 256), 65536)), dim3(256), 0, 0, m->nrow, (const int64_t *)m->d_rp.p, (const int32_t *)m->d_cols.p, (const double *)m->d_vals.p, (const double *)m->d_x.p, m->d_y.p, (int)accumulate);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpy(hv_host, m->d_y.p, (size_t)m->nrow * 8, hipMemcpyDeviceToHost));
     return EDGPU_OK;
 }
 

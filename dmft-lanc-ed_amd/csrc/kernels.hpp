@@ -891,6 +891,31 @@ __global__ void __launch_bounds__(256) k_apply_op(OpArgs A)
 }
 
 // ---------------------------------------------------------------------------------------------
+// Generic device CSR product for the sparse-matrix container (edgpu_sp_*): y (+)= A x.
+// Short rows: one lane per row; long rows (mean nnz > 32): one wave per row with a shuffle reduction.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_spgen_lane(int64_t nrow, const int64_t *__restrict__ rp, const int32_t *__restrict__ cols,
+                                                    const double *__restrict__ vals, const double *__restrict__ x, double *__restrict__ y, int accumulate)
+{
+    for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < nrow; r += (int64_t)gridDim.x * blockDim.x) {
+        double acc = accumulate ? y[r] : 0.0;
+        for (int64_t p = rp[r]; p < rp[r + 1]; p++) acc += vals[p] * x[cols[p]];
+        y[r] = acc;
+    }
+}
+__global__ void __launch_bounds__(256) k_spgen_wave(int64_t nrow, const int64_t *__restrict__ rp, const int32_t *__restrict__ cols,
+                                                    const double *__restrict__ vals, const double *__restrict__ x, double *__restrict__ y, int accumulate)
+{
+    const int lane = threadIdx.x & 63;
+    for (int64_t r = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6; r < nrow; r += ((int64_t)gridDim.x * blockDim.x) >> 6) {
+        double acc = 0.0;
+        for (int64_t p = rp[r] + lane; p < rp[r + 1]; p += 64) acc += vals[p] * x[cols[p]];
+        acc = wave_sum(acc);
+        if (lane == 0) y[r] = accumulate ? y[r] + acc : acc;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Lanczos vector kernels (SciFortran lanczos_iteration semantics, driver in edgpu.hip)
 // ---------------------------------------------------------------------------------------------
 // out[0] = sum(in[0..n)) in a fixed order; single workgroup

@@ -1,0 +1,57 @@
+"""Host mirror of ED_SPARSE_MATRIX.f90's public interface over the C ABI (sp_init_matrix, sp_insert_element,
+sp_delete_matrix, sp_dump_matrix; ED_SPARSE_MATRIX.f90:95-105), with the product computed on the GPU."""
+import ctypes as C
+
+import numpy as np
+
+from . import capi
+from .capi import check
+
+
+class sparse_matrix_csr:
+    def __init__(self):
+        self._h = None
+        self.Nrow = self.Ncol = 0
+        self.status = False
+
+
+def sp_init_matrix(sparse, N, N1=None):
+    if sparse.status:
+        raise RuntimeError("sp_init_matrix: already allocated can not init")
+    h = C.c_void_p()
+    check(capi.lib().edgpu_sp_init_matrix(int(N), int(N1 if N1 is not None else N), C.byref(h)))
+    sparse._h, sparse.Nrow, sparse.Ncol, sparse.status = h, int(N), int(N1 if N1 is not None else N), True
+
+
+def sp_insert_element(sparse, value, i, j):
+    check(capi.lib().edgpu_sp_insert_element(sparse._h, float(value), int(i), int(j)))
+
+
+def sp_delete_matrix(sparse):
+    if sparse.status:
+        capi.lib().edgpu_sp_delete_matrix(sparse._h)
+    sparse._h, sparse.status, sparse.Nrow, sparse.Ncol = None, False, 0, 0
+
+
+def sp_dump_matrix(sparse, matrix):
+    m = np.asfortranarray(matrix, dtype=np.float64)
+    assert m.shape == (sparse.Nrow, sparse.Ncol)
+    check(capi.lib().edgpu_sp_dump_matrix(sparse._h, m.ctypes.data))
+    matrix[...] = m
+
+
+def sp_row(sparse, i):
+    n = C.c_int32()
+    check(capi.lib().edgpu_sp_row(sparse._h, int(i), C.byref(n), None, None, 0))
+    cols = np.zeros(n.value, np.int64); vals = np.zeros(n.value)
+    if n.value:
+        check(capi.lib().edgpu_sp_row(sparse._h, int(i), C.byref(n), cols.ctypes.data, vals.ctypes.data, n.value))
+    return cols, vals
+
+
+def sp_matvec(sparse, v, hv=None):
+    v = np.ascontiguousarray(v, np.float64)
+    acc = hv is not None
+    out = np.ascontiguousarray(hv, np.float64).copy() if acc else np.zeros(sparse.Nrow)
+    check(capi.lib().edgpu_sp_matvec(sparse._h, v.ctypes.data, out.ctypes.data, 1 if acc else 0))
+    return out

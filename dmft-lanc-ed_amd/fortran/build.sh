@@ -9,5 +9,6 @@ mkdir -p "$HERE/_build"
 cd "$HERE/_build"
 "$FC" -O2 -c "$HERE/edgpu_c_api.f90" -o edgpu_c_api.o
 "$FC" -O2 -c "$HERE/ED_HAMILTONIAN_GPU.f90" -o ED_HAMILTONIAN_GPU.o
-"$FC" -O2 "$HERE/demo_c1.f90" edgpu_c_api.o ED_HAMILTONIAN_GPU.o -L"$HERE/../edgpu" -ledgpu -Wl,-rpath,'$ORIGIN/../../edgpu' -o demo_c1
+"$FC" -O2 -c "$HERE/ED_SPARSE_MATRIX_GPU.f90" -o ED_SPARSE_MATRIX_GPU.o
+"$FC" -O2 "$HERE/demo_c1.f90" edgpu_c_api.o ED_HAMILTONIAN_GPU.o ED_SPARSE_MATRIX_GPU.o -L"$HERE/../edgpu" -ledgpu -Wl,-rpath,'$ORIGIN/../../edgpu' -o demo_c1
 echo "built $HERE/_build/demo_c1"

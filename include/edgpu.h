@@ -205,6 +205,20 @@ typedef int (*edgpu_exchange_fn)(void *ctx, const double *send_dev, const int64_
                                  double *recv_dev, const int64_t *recvcounts, const int64_t *rdispls, int32_t nranks);
 int edgpu_comm_init_callbacks(edgpu_handle h, edgpu_allgatherv_fn ag, edgpu_exchange_fn xch, edgpu_allreduce_fn ar, void *ctx);
 
+/* ---- sparse-matrix container (ED_SPARSE_MATRIX.f90): same semantics, product on the GPU ------------------
+ * sp_init_matrix (127-172), sp_insert_element = duplicate-summing append in storage order (255-323),
+ * sp_delete_matrix (184-237), sp_dump_matrix adds into a dense column-major Nrow x Ncol array (386-438).
+ * Indices are 1-based as in the reference.  The sector operator does NOT go through this container (it
+ * builds its factors directly); it is provided for host code that assembles other operators. */
+typedef struct edgpu_spmat_s *edgpu_spmat;
+int edgpu_sp_init_matrix(int64_t nrow, int64_t ncol /* 0 -> nrow */, edgpu_spmat *out);
+int edgpu_sp_insert_element(edgpu_spmat m, double value, int64_t i, int64_t j);
+int edgpu_sp_delete_matrix(edgpu_spmat m);
+int edgpu_sp_dump_matrix(edgpu_spmat m, double *dense);
+int edgpu_sp_row(edgpu_spmat m, int64_t i, int32_t *size, int64_t *cols, double *vals, int32_t cap);
+/* Hv = A v (accumulate=0) or Hv += A v (accumulate=1); host vectors, product on the device */
+int edgpu_sp_matvec(edgpu_spmat m, const double *v_host, double *hv_host, int32_t accumulate);
+
 /* ---- device memory helpers for hosts without a HIP binding (Fortran) ---------------------- */
 int edgpu_device_count(int32_t *n);
 int edgpu_malloc(void **dev, size_t bytes);

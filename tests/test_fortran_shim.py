@@ -26,6 +26,8 @@ def test_fortran_driver_config1_matches_reference_known_answers():
         pytest.skip("Fortran demo not built (amdflang absent at build time)")
     out = subprocess.run([DEMO], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300).stdout.decode()
     g = [c for c in cases.golden_cases() if c["name"] == "c1_Nbath5"][0]
+    assert re.search(r"sp_dense_row1=\s+2\.00000\s+0\.00000\s+-0\.50000", out), out      # duplicate-summing insert
+    assert re.search(r"sp_matvec=\s+0\.50000\s+0\.00000\s+8\.00000", out), out
     blocks = out.split("ed_sparse_H=")[1:]
     assert len(blocks) == 2, out
     for b in blocks:          # stored (T) and on-the-fly (F)
