@@ -1,0 +1,104 @@
+// exchange.hpp -- the per-product exchange between ranks (needed dw rows or full gather) and the scalar all-reduce
+// Part of libedgpu.so (one translation unit: edgpu.hip includes these headers in order).
+#pragma once
+
+namespace edgpu {
+
+// ---------------------------------------------------------------------------------------
+// exchange step: gather the input vector of every rank (phonon block by phonon block)
+// ---------------------------------------------------------------------------------------
+static int halo_exchange(S *s, const double *v_local, hipStream_t st);
+static int gather_vector(S *s, const double *v_local, hipStream_t st)
+{
+    if (s->halo) return halo_exchange(s, v_local, st);
+    const SectorHost &H = s->H; Comm &c = s->comm;
+    const int P = c.size;
+    std::vector<int64_t> counts(P), displs(P);
+    for (int r = 0; r < P; r++) {
+        int64_t q = H.DimDw / P, rem = H.DimDw % P;
+        int64_t qd = r < rem ? q + 1 : q, d0 = r < rem ? r * (q + 1) : r * q + rem;
+        counts[r] = qd * H.DimUp; displs[r] = d0 * H.DimUp;
+    }
+    const int64_t nel_loc = s->nloc_el, nel = H.DimUp * H.DimDw;
+    for (int iph = 0; iph < H.DimPh; iph++) {
+        const double *send = v_local + (int64_t)iph * nel_loc;
+        double *recv = s->vfull.p + (int64_t)iph * nel;
+        if (c.kind == Comm::RCCL) {
+            HIPCHK(hipMemcpyAsync(recv + displs[c.rank], send, (size_t)nel_loc * 8, hipMemcpyDeviceToDevice, st));
+            int rc = g_rccl.GroupStart();
+            for (int r = 0; r < P && rc == 0; r++) {
+                if (r == c.rank) continue;
+                rc = g_rccl.Send(send, (size_t)nel_loc, kNcclDouble, r, c.nccl, st);
+                if (rc == 0) rc = g_rccl.Recv(recv + displs[r], (size_t)counts[r], kNcclDouble, r, c.nccl, st);
+            }
+            int rc2 = g_rccl.GroupEnd();
+            if (rc || rc2) return fail(EDGPU_ECOMM, std::string("edgpu: RCCL send/recv failed: ") + g_rccl.GetErrorString(rc ? rc : rc2));
+        } else if (c.kind == Comm::CALLBACK) {
+            HIPCHK(hipStreamSynchronize(st));
+            if (c.ag(c.ctx, send, nel_loc, recv, counts.data(), displs.data(), P)) return fail(EDGPU_ECOMM, "edgpu: allgatherv callback failed");
+        } else
+            return fail(EDGPU_ECOMM, "edgpu: mpi_size>1 but no communicator attached (edgpu_comm_init_*)");
+    }
+    return EDGPU_OK;
+}
+
+// x = [own rows | needed rows of the other ranks]: pack what each peer needs, one send/recv pair per peer
+static int halo_exchange(S *s, const double *v_local, hipStream_t st)
+{
+    const SectorHost &H = s->H; Comm &c = s->comm;
+    const int P = c.size;
+    int64_t nsend_rows = 0; for (int r = 0; r < P; r++) nsend_rows += s->send_rows_cnt[r];
+    const int64_t rowlen = H.DimUp;
+    if (nsend_rows > 0) {
+        PackArgs K{}; K.DimUp = (int32_t)H.DimUp; K.DimPh = H.DimPh; K.Qdw = H.Qdw; K.nrows = nsend_rows; K.list = s->send_list.p; K.v = v_local; K.out = s->sendbuf.p;
+        const int64_t tot = nsend_rows * H.DimPh * cdiv(rowlen, 2);
+        hipLaunchKernelGGL(k_pack_rows, dim3((unsigned)std::min<int64_t>(cdiv(tot, 256), 65536)), dim3(256), 0, st, K);
+        HIPCHK(hipGetLastError());
+    }
+    for (int iph = 0; iph < H.DimPh; iph++) {
+        double *x = s->vfull.p + (int64_t)iph * s->nhalo * rowlen;
+        HIPCHK(hipMemcpyAsync(x, v_local + (int64_t)iph * s->nloc_el, (size_t)s->nloc_el * 8, hipMemcpyDeviceToDevice, st));
+        const double *sb = s->sendbuf.p + (int64_t)iph * nsend_rows * rowlen;
+        if (P == 1) continue;
+        if (c.kind == Comm::RCCL) {
+            int rc = g_rccl.GroupStart();
+            for (int r = 0; r < P && rc == 0; r++) {
+                if (r == c.rank) continue;
+                if (s->send_rows_cnt[r]) rc = g_rccl.Send(sb + s->send_rows_off[r] * rowlen, (size_t)(s->send_rows_cnt[r] * rowlen), kNcclDouble, r, c.nccl, st);
+                if (rc == 0 && s->recv_rows_cnt[r]) rc = g_rccl.Recv(x + (H.Qdw + s->recv_rows_off[r]) * rowlen, (size_t)(s->recv_rows_cnt[r] * rowlen), kNcclDouble, r, c.nccl, st);
+            }
+            int rc2 = g_rccl.GroupEnd();
+            if (rc || rc2) return fail(EDGPU_ECOMM, std::string("edgpu: RCCL send/recv failed: ") + g_rccl.GetErrorString(rc ? rc : rc2));
+        } else if (c.kind == Comm::CALLBACK) {
+            if (!c.xch) return fail(EDGPU_ECOMM, "edgpu: the callback exchange needs an all-to-all-v callback");
+            std::vector<int64_t> sc(P), sd(P), rcv(P), rd(P);
+            for (int r = 0; r < P; r++) { sc[r] = s->send_rows_cnt[r] * rowlen; sd[r] = s->send_rows_off[r] * rowlen; rcv[r] = s->recv_rows_cnt[r] * rowlen; rd[r] = (H.Qdw + s->recv_rows_off[r]) * rowlen; }
+            HIPCHK(hipStreamSynchronize(st));
+            if (c.xch(c.ctx, sb, sc.data(), sd.data(), x, rcv.data(), rd.data(), P)) return fail(EDGPU_ECOMM, "edgpu: exchange callback failed");
+        } else
+            return fail(EDGPU_ECOMM, "edgpu: mpi_size>1 but no communicator attached (edgpu_comm_init_*)");
+    }
+    return EDGPU_OK;
+}
+
+// sum n device doubles over ranks (in place)
+static int allreduce_dev(S *s, double *p, int n)
+{
+    Comm &c = s->comm;
+    if (!s->multi) return EDGPU_OK;
+    if (c.kind == Comm::RCCL) {
+        int rc = g_rccl.AllReduce(p, p, (size_t)n, kNcclDouble, kNcclSum, c.nccl, s->stream);
+        if (rc) return fail(EDGPU_ECOMM, std::string("edgpu: RCCL allreduce failed: ") + g_rccl.GetErrorString(rc));
+    } else if (c.kind == Comm::CALLBACK) {
+        std::vector<double> h(n);
+        HIPCHK(hipMemcpyAsync(h.data(), p, (size_t)n * 8, hipMemcpyDeviceToHost, s->stream)); HIPCHK(hipStreamSynchronize(s->stream));
+        if (c.ar(c.ctx, h.data(), n)) return fail(EDGPU_ECOMM, "edgpu: allreduce callback failed");
+        HIPCHK(hipMemcpyAsync(p, h.data(), (size_t)n * 8, hipMemcpyHostToDevice, s->stream)); HIPCHK(hipStreamSynchronize(s->stream));
+    } else
+        return fail(EDGPU_ECOMM, "edgpu: mpi_size>1 but no communicator attached");
+    return EDGPU_OK;
+}
+// sum scal[SC_TMP] over ranks
+static int allreduce_tmp(S *s) { return allreduce_dev(s, s->scal.p + SC_TMP, 1); }
+
+}  // namespace edgpu

@@ -1,0 +1,343 @@
+// lanczos.hpp -- device-resident Lanczos (ground state, tridiagonalisation) and the thick-restart multi-eigenpair solver
+// Part of libedgpu.so (one translation unit: edgpu.hip includes these headers in order).
+#pragma once
+
+namespace edgpu {
+
+// ---------------------------------------------------------------------------------------
+// symmetric tridiagonal eigen-solver (implicit QL with Wilkinson shifts), host, n <= ~1000.
+// d: diagonal (n), e: sub-diagonal e[1..n-1] (e[0] unused).  On exit d = eigenvalues
+// (unsorted); if z != nullptr (n*n, row-major z[i*n+j], identity on entry) columns = vectors.
+// ---------------------------------------------------------------------------------------
+static bool tqli(std::vector<double> &d, std::vector<double> &e, int n, double *z)
+{
+    for (int i = 1; i < n; i++) e[i - 1] = e[i];
+    if (n > 0) e[n - 1] = 0.0;
+    for (int l = 0; l < n; l++) {
+        int iter = 0, m;
+        do {
+            for (m = l; m < n - 1; m++) {
+                double dd = std::fabs(d[m]) + std::fabs(d[m + 1]);
+                if (std::fabs(e[m]) <= 2.3e-16 * dd) break;
+            }
+            if (m != l) {
+                if (iter++ == 120) return false;
+                double g = (d[l + 1] - d[l]) / (2.0 * e[l]);
+                double r = std::hypot(g, 1.0);
+                g = d[m] - d[l] + e[l] / (g + (g >= 0.0 ? std::fabs(r) : -std::fabs(r)));
+                double sn = 1.0, c = 1.0, p = 0.0;
+                int i;
+                for (i = m - 1; i >= l; i--) {
+                    double f = sn * e[i], b = c * e[i];
+                    e[i + 1] = (r = std::hypot(f, g));
+                    if (r == 0.0) { d[i + 1] -= p; e[m] = 0.0; break; }
+                    sn = f / r; c = g / r;
+                    g = d[i + 1] - p;
+                    r = (d[i] - g) * sn + 2.0 * c * b;
+                    d[i + 1] = g + (p = sn * r);
+                    g = c * r - b;
+                    if (z)
+                        for (int k = 0; k < n; k++) {
+                            double f2 = z[(size_t)k * n + i + 1];
+                            z[(size_t)k * n + i + 1] = sn * z[(size_t)k * n + i] + c * f2;
+                            z[(size_t)k * n + i] = c * z[(size_t)k * n + i] - sn * f2;
+                        }
+                }
+                if (r == 0.0 && i >= l) continue;
+                d[l] -= p; e[l] = g; e[m] = 0.0;
+            }
+        } while (m != l);
+    }
+    return true;
+}
+
+// lowest eigenvalue (and optionally its eigenvector) of T_k = tridiag(alphas[0..k), betas[1..k))
+static bool tridiag_lowest(const double *al, const double *be, int k, double *e0, std::vector<double> *zcol)
+{
+    std::vector<double> d(al, al + k), e(k, 0.0);
+    for (int i = 1; i < k; i++) e[i] = be[i];
+    std::vector<double> z;
+    if (zcol) { z.assign((size_t)k * k, 0.0); for (int i = 0; i < k; i++) z[(size_t)i * k + i] = 1.0; }
+    if (!tqli(d, e, k, zcol ? z.data() : nullptr)) return false;
+    int im = 0;
+    for (int i = 1; i < k; i++) if (d[i] < d[im]) im = i;
+    *e0 = d[im];
+    if (zcol) { zcol->resize(k); for (int i = 0; i < k; i++) (*zcol)[i] = z[(size_t)i * k + im]; }
+    return true;
+}
+
+// ---------------------------------------------------------------------------------------
+// Lanczos loop, device resident.  Restates SciFortran's lanczos_iteration / sp_lanc_eigh /
+// sp_lanc_tridiag (module SF_SP_LINALG, not part of the reference tree; call sites
+// ED_DIAG.f90:177-185, ED_GF_NORMAL.f90:232-237) with vectors kept unnormalised in HBM and the
+// 1/beta scale carried in a device scalar, so one iteration is: fused product+alpha, one
+// axpy+norm pass, two single-workgroup reductions -- and no host synchronisation.
+// ---------------------------------------------------------------------------------------
+static int lz_prepare(S *s, int nmax)
+{
+    for (int i = 0; i < 3; i++) if (s->lz[i].n != (size_t)s->nloc) CHK(s->lz[i].alloc((size_t)s->nloc));
+    if (s->nmax < nmax) {
+        CHK(s->alphas.alloc((size_t)nmax + 2)); CHK(s->betas.alloc((size_t)nmax + 2)); CHK(s->zvec.alloc((size_t)nmax + 2));
+        s->nmax = nmax;
+    }
+    HIPCHK(hipMemsetAsync(s->alphas.p, 0, ((size_t)nmax + 2) * 8, s->stream));
+    HIPCHK(hipMemsetAsync(s->betas.p, 0, ((size_t)nmax + 2) * 8, s->stream));
+    return EDGPU_OK;
+}
+
+static int reduce_dot(S *s, const double *a, const double *b)
+{
+    int nb = (int)std::min<int64_t>(cdiv(s->nloc, 256 * 8), 2048);
+    nb = std::max(nb, 1);
+    hipLaunchKernelGGL(k_dot_partial, dim3(nb), dim3(256), 0, s->stream, a, b, s->nloc, s->partial.p);
+    hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(1024), 0, s->stream, s->partial.p, (int64_t)nb, s->scal.p + SC_TMP);
+    HIPCHK(hipGetLastError());
+    return allreduce_tmp(s);
+}
+
+struct LzVecs { double *uprev, *ucur, *w; };
+
+// start: ucur holds the (unnormalised) start vector
+static int lz_start(S *s, LzVecs &V)
+{
+    HIPCHK(hipMemsetAsync(V.uprev, 0, (size_t)s->nloc * 8, s->stream));
+    CHK(reduce_dot(s, V.ucur, V.ucur));
+    hipLaunchKernelGGL(k_scalar_step, dim3(1), dim3(1), 0, s->stream, s->scal.p, s->alphas.p, s->betas.p, (const double *)nullptr, 0, 2);
+    HIPCHK(hipGetLastError());
+    return EDGPU_OK;
+}
+
+// iteration k (0-based): fills alphas[k], betas[k+1]; optional eigenvector accumulation
+static int lz_iter_tail(S *s, LzVecs &V, int k, double *acc)
+{
+    hipLaunchKernelGGL(k_scalar_step, dim3(1), dim3(1), 0, s->stream, s->scal.p, s->alphas.p, s->betas.p, (const double *)nullptr, k, 0);
+    if (acc) hipLaunchKernelGGL(k_scalar_step, dim3(1), dim3(1), 0, s->stream, s->scal.p, s->alphas.p, s->betas.p, (const double *)s->zvec.p, k, 3);
+    int nb = (int)std::max<int64_t>(1, std::min<int64_t>(cdiv(s->nloc, 256 * 4), 4096));
+    hipLaunchKernelGGL(k_axpy_norm, dim3(nb), dim3(256), 0, s->stream, V.w, V.ucur, acc, s->scal.p, s->nloc, s->partial.p);
+    hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(1024), 0, s->stream, s->partial.p, (int64_t)nb, s->scal.p + SC_TMP);
+    HIPCHK(hipGetLastError());
+    CHK(allreduce_tmp(s));
+    hipLaunchKernelGGL(k_scalar_step, dim3(1), dim3(1), 0, s->stream, s->scal.p, s->alphas.p, s->betas.p, (const double *)nullptr, k, 1);
+    HIPCHK(hipGetLastError());
+    double *t = V.uprev; V.uprev = V.ucur; V.ucur = V.w; V.w = t;
+    return EDGPU_OK;
+}
+static int lz_iter(S *s, LzVecs &V, int k, double *acc)
+{
+    CHK(hxv(s, V.ucur, V.w, true, V.uprev));
+    return lz_iter_tail(s, V, k, acc);
+}
+
+static int fetch_coeffs(S *s, int k, std::vector<double> &al, std::vector<double> &be)
+{
+    al.resize(k + 1); be.resize(k + 2);
+    HIPCHK(hipMemcpyAsync(al.data(), s->alphas.p, (size_t)(k + 1) * 8, hipMemcpyDeviceToHost, s->stream));
+    HIPCHK(hipMemcpyAsync(be.data(), s->betas.p, (size_t)(k + 2) * 8, hipMemcpyDeviceToHost, s->stream));
+    HIPCHK(hipStreamSynchronize(s->stream));
+    return EDGPU_OK;
+}
+
+static int lanczos_gs(S *s, int nitermax, double threshold, int ncheck, double *egs, double *vect_dev, int *nlanc_out)
+{
+    if (nitermax < 1) return fail(EDGPU_EINVAL, "edgpu_lanczos_gs: nitermax < 1");
+    if (ncheck < 1) ncheck = 10;
+    if ((int64_t)nitermax > s->H.Dim) nitermax = (int)s->H.Dim;   // ED_DIAG.f90:100 Nitermax=min(dim,lanc_niter)
+    CHK(lz_prepare(s, nitermax));
+    for (int i = 3; i < 5; i++) if (s->lz[i].n != (size_t)s->nloc) CHK(s->lz[i].alloc((size_t)s->nloc));
+    double *start = s->lz[3].p, *acc = s->lz[4].p;
+    // zero input => library-generated start vector (ED_DIAG.f90:147 passes eig_basis=0)
+    HIPCHK(hipMemcpyAsync(start, vect_dev, (size_t)s->nloc * 8, hipMemcpyDeviceToDevice, s->stream));
+    CHK(reduce_dot(s, start, start));
+    double nrm2;
+    HIPCHK(hipMemcpyAsync(&nrm2, s->scal.p + SC_TMP, 8, hipMemcpyDeviceToHost, s->stream)); HIPCHK(hipStreamSynchronize(s->stream));
+    if (nrm2 == 0.0) {
+        const SectorHost &H = s->H;
+        hipLaunchKernelGGL(k_random_start, dim3(2048), dim3(256), 0, s->stream, start, H.DimUp, H.Qdw, H.dw0, H.DimDw, H.DimPh, (uint64_t)1234567);
+        HIPCHK(hipGetLastError());
+    }
+    LzVecs V{s->lz[0].p, s->lz[1].p, s->lz[2].p};
+    HIPCHK(hipMemcpyAsync(V.ucur, start, (size_t)s->nloc * 8, hipMemcpyDeviceToDevice, s->stream));
+    CHK(lz_start(s, V));
+    std::vector<double> al, be;
+    int nlanc = 0; double esave = 0.0, e0 = 0.0;
+    for (int k = 0; k < nitermax; k++) {
+        CHK(lz_iter(s, V, k, nullptr));
+        CHK(fetch_coeffs(s, k, al, be));
+        nlanc = k + 1;
+        if (std::fabs(be[k + 1]) < threshold) break;       // invariant subspace reached
+        if (!tridiag_lowest(al.data(), be.data(), nlanc, &e0, nullptr)) return fail(EDGPU_ENOTCONVERGED, "edgpu: tridiagonal QL did not converge");
+        if (nlanc >= ncheck && std::fabs(e0 - esave) <= threshold) break;
+        esave = e0;
+    }
+    std::vector<double> z;
+    if (!tridiag_lowest(al.data(), be.data(), nlanc, &e0, &z)) return fail(EDGPU_ENOTCONVERGED, "edgpu: tridiagonal QL did not converge");
+    *egs = e0; *nlanc_out = nlanc;
+    // second pass: regenerate the Krylov vectors and accumulate vect = sum_k Z(k,1) v_k
+    HIPCHK(hipMemcpyAsync(s->zvec.p, z.data(), (size_t)nlanc * 8, hipMemcpyHostToDevice, s->stream));
+    HIPCHK(hipMemsetAsync(acc, 0, (size_t)s->nloc * 8, s->stream));
+    V = LzVecs{s->lz[0].p, s->lz[1].p, s->lz[2].p};
+    HIPCHK(hipMemcpyAsync(V.ucur, start, (size_t)s->nloc * 8, hipMemcpyDeviceToDevice, s->stream));
+    CHK(lz_start(s, V));
+    for (int k = 0; k < nlanc; k++) CHK(lz_iter(s, V, k, acc));
+    CHK(reduce_dot(s, acc, acc));
+    hipLaunchKernelGGL(k_scalar_step, dim3(1), dim3(1), 0, s->stream, s->scal.p, s->alphas.p, s->betas.p, (const double *)nullptr, 0, 2);
+    int nb = (int)std::max<int64_t>(1, std::min<int64_t>(cdiv(s->nloc, 256 * 4), 4096));
+    hipLaunchKernelGGL(k_scale, dim3(nb), dim3(256), 0, s->stream, acc, s->scal.p, (int)SC_SCUR, s->nloc);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(vect_dev, acc, (size_t)s->nloc * 8, hipMemcpyDeviceToDevice, s->stream));
+    HIPCHK(hipStreamSynchronize(s->stream));
+    return EDGPU_OK;
+}
+
+static int lanczos_tridiag(S *s, const double *vin_dev, int nlanc, double threshold, double *alanc, double *blanc, int *nused)
+{
+    if (nlanc < 1) return fail(EDGPU_EINVAL, "edgpu_lanczos_tridiag: nlanc < 1");
+    CHK(lz_prepare(s, nlanc));
+    LzVecs V{s->lz[0].p, s->lz[1].p, s->lz[2].p};
+    HIPCHK(hipMemcpyAsync(V.ucur, vin_dev, (size_t)s->nloc * 8, hipMemcpyDeviceToDevice, s->stream));
+    CHK(lz_start(s, V));
+    for (int i = 0; i < nlanc; i++) { alanc[i] = 0.0; blanc[i] = 0.0; }
+    std::vector<double> al, be;
+    int used = 0;
+    const int chunk = 8;  // look at beta on the host every `chunk` iterations
+    for (int k = 0; k < nlanc;) {
+        int kend = std::min(nlanc, k + chunk);
+        for (; k < kend; k++) CHK(lz_iter(s, V, k, nullptr));
+        CHK(fetch_coeffs(s, k - 1, al, be));
+        bool stop = false;
+        for (int i = used; i < k; i++) {
+            alanc[i] = al[i]; used = i + 1;
+            if (std::fabs(be[i + 1]) < threshold) { stop = true; break; }
+            if (i + 1 < nlanc) blanc[i + 1] = be[i + 1];
+        }
+        if (stop) break;
+    }
+    *nused = used;
+    return EDGPU_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// Lowest `nev` eigenpairs: thick-restart Lanczos with full re-orthogonalisation in a basis of
+// `ncv` vectors held in HBM, explicit Rayleigh-Ritz on the host.  Stands in for the ARPACK call
+// sp_eigh(MatVec,eval,evec,Nblock,Nitermax,tol) of ED_DIAG.f90:153-170 (which='SA', ncv=Nblock,
+// maxiter=Nitermax restarts, residual test |r_i| <= tol*max(eps^(2/3),|theta_i|)).
+// ---------------------------------------------------------------------------------------
+static void jacobi_eig(std::vector<double> &A, int m, std::vector<double> &w, std::vector<double> &Y)
+{   // cyclic Jacobi on the symmetric m x m matrix A (row-major); eigenvalues ascending in w, vectors = columns of Y (Y[i + m*j])
+    std::vector<double> V((size_t)m * m, 0.0);
+    for (int i = 0; i < m; i++) V[(size_t)i * m + i] = 1.0;
+    for (int sweep = 0; sweep < 60; sweep++) {
+        double off = 0.0, dg = 0.0;
+        for (int p = 0; p < m; p++) { dg += A[(size_t)p * m + p] * A[(size_t)p * m + p]; for (int q = p + 1; q < m; q++) off += A[(size_t)p * m + q] * A[(size_t)p * m + q]; }
+        if (off <= 1e-32 * (dg + 1e-300)) break;
+        for (int p = 0; p < m; p++)
+            for (int q = p + 1; q < m; q++) {
+                const double apq = A[(size_t)p * m + q];
+                if (std::fabs(apq) < 1e-300) continue;
+                const double theta = (A[(size_t)q * m + q] - A[(size_t)p * m + p]) / (2.0 * apq);
+                const double t = (theta >= 0 ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(theta * theta + 1.0));
+                const double c = 1.0 / std::sqrt(t * t + 1.0), sn = t * c;
+                for (int k = 0; k < m; k++) { double akp = A[(size_t)k * m + p], akq = A[(size_t)k * m + q]; A[(size_t)k * m + p] = c * akp - sn * akq; A[(size_t)k * m + q] = sn * akp + c * akq; }
+                for (int k = 0; k < m; k++) { double apk = A[(size_t)p * m + k], aqk = A[(size_t)q * m + k]; A[(size_t)p * m + k] = c * apk - sn * aqk; A[(size_t)q * m + k] = sn * apk + c * aqk; }
+                for (int k = 0; k < m; k++) { double vkp = V[(size_t)k * m + p], vkq = V[(size_t)k * m + q]; V[(size_t)k * m + p] = c * vkp - sn * vkq; V[(size_t)k * m + q] = sn * vkp + c * vkq; }
+            }
+    }
+    std::vector<int> idx(m);
+    for (int i = 0; i < m; i++) idx[i] = i;
+    std::sort(idx.begin(), idx.end(), [&](int a, int b) { return A[(size_t)a * m + a] < A[(size_t)b * m + b]; });
+    w.resize(m); Y.assign((size_t)m * m, 0.0);
+    for (int j = 0; j < m; j++) { w[j] = A[(size_t)idx[j] * m + idx[j]]; for (int i = 0; i < m; i++) Y[i + (size_t)m * j] = V[(size_t)i * m + idx[j]]; }
+}
+
+static int eigsh(S *s, int nev, int ncv, int maxiter, double tol, double *evals, double *evecs_host, int *nconv_out, int *nrestart_out, int *nmatvec_out)
+{
+    const int64_t Dim = s->H.Dim, n = s->nloc;
+    if (nev < 1) return fail(EDGPU_EINVAL, "edgpu_eigsh: nev < 1");
+    if ((int64_t)nev >= Dim) return fail(EDGPU_EINVAL, "edgpu_eigsh: nev must be smaller than the sector dimension (the reference switches to LAPACK there, ED_DIAG.f90:105-107)");
+    if (ncv > kMaxBasis) ncv = kMaxBasis;
+    if ((int64_t)ncv > Dim) ncv = (int)Dim;
+    if (ncv <= nev) ncv = (int)std::min<int64_t>(std::min<int64_t>(2 * nev + 1, kMaxBasis), Dim);
+    if (ncv <= nev) return fail(EDGPU_EINVAL, "edgpu_eigsh: ncv must exceed nev");
+    if (maxiter < 1) maxiter = 1;
+    const double tol_eff = std::max(tol, 1e-12), eps23 = std::pow(2.220446049250313e-16, 2.0 / 3.0);
+    const int m = ncv;
+    while ((int)s->eigV.size() < m + 1) { auto b = std::make_unique<DevBuf<double>>(); CHK(b->alloc((size_t)n)); s->eigV.push_back(std::move(b)); }
+    const int nb = (int)std::max<int64_t>(1, std::min<int64_t>(cdiv(n, 256 * 8), 1024));
+    if (s->eig_h.n < (size_t)(m + 2)) CHK(s->eig_h.alloc((size_t)m + 2));
+    if (s->eig_partial.n < (size_t)nb * (m + 1)) CHK(s->eig_partial.alloc((size_t)nb * (m + 1)));
+    if (s->eig_y.n < (size_t)m * m) CHK(s->eig_y.alloc((size_t)m * m));
+    auto Vp = [&](int i) { return s->eigV[i]->p; };
+    const SectorHost &H = s->H;
+    hipLaunchKernelGGL(k_random_start, dim3(2048), dim3(256), 0, s->stream, Vp(0), H.DimUp, H.Qdw, H.dw0, H.DimDw, H.DimPh, (uint64_t)1234567);
+    HIPCHK(hipGetLastError());
+    auto norm_of = [&](const double *x, double &out) -> int {
+        CHK(reduce_dot(s, x, x));
+        HIPCHK(hipMemcpyAsync(&out, s->scal.p + SC_TMP, 8, hipMemcpyDeviceToHost, s->stream)); HIPCHK(hipStreamSynchronize(s->stream));
+        out = std::sqrt(out);
+        return EDGPU_OK;
+    };
+    const int gs = (int)std::max<int64_t>(1, std::min<int64_t>(cdiv(n, 256 * 4), 4096));
+    double nrm; CHK(norm_of(Vp(0), nrm));
+    hipLaunchKernelGGL(k_scale_copy, dim3(gs), dim3(256), 0, s->stream, Vp(0), (const double *)Vp(0), 1.0 / nrm, n);
+    std::vector<double> Hm((size_t)m * m, 0.0), theta, Y, hh(m + 1), h2(m + 1);
+    int l = 0, nconv = 0, it = 0, nmv = 0, meff = m; double beta_last = 0.0;
+    for (it = 0; it < maxiter; it++) {
+        meff = m;
+        for (int j = l; j < m; j++) {
+            double *w = Vp(j + 1);
+            CHK(hxv(s, Vp(j), w, false, nullptr)); nmv++;
+            BasisArgs B{}; B.nv = j + 1; for (int i = 0; i <= j; i++) B.V[i] = Vp(i);
+            std::fill(hh.begin(), hh.end(), 0.0);
+            for (int pass = 0; pass < 2; pass++) {      // classical Gram-Schmidt, twice
+                hipLaunchKernelGGL(k_multidot, dim3(nb), dim3(256), 0, s->stream, B, (const double *)w, n, s->eig_partial.p);
+                hipLaunchKernelGGL(k_multidot_final, dim3(1), dim3(256), 0, s->stream, (const double *)s->eig_partial.p, nb, B.nv, s->eig_h.p);
+                HIPCHK(hipGetLastError());
+                CHK(allreduce_dev(s, s->eig_h.p, B.nv));
+                hipLaunchKernelGGL(k_multiaxpy, dim3(gs), dim3(256), 0, s->stream, B, (const double *)s->eig_h.p, w, n);
+                HIPCHK(hipMemcpyAsync(h2.data(), s->eig_h.p, (size_t)B.nv * 8, hipMemcpyDeviceToHost, s->stream)); HIPCHK(hipStreamSynchronize(s->stream));
+                for (int i = 0; i <= j; i++) hh[i] += h2[i];
+            }
+            for (int i = 0; i <= j; i++) { Hm[(size_t)i * m + j] = hh[i]; Hm[(size_t)j * m + i] = hh[i]; }
+            double beta; CHK(norm_of(w, beta));
+            beta_last = beta;
+            if (j + 1 < m) { Hm[(size_t)(j + 1) * m + j] = beta; Hm[(size_t)j * m + (j + 1)] = beta; }
+            if (beta <= 1e-13 * std::max(1.0, std::fabs(hh[j]))) { meff = j + 1; break; }   // invariant subspace
+            hipLaunchKernelGGL(k_scale_copy, dim3(gs), dim3(256), 0, s->stream, w, (const double *)w, 1.0 / beta, n);
+            HIPCHK(hipGetLastError());
+        }
+        std::vector<double> Hs((size_t)meff * meff);
+        for (int i = 0; i < meff; i++) for (int j = 0; j < meff; j++) Hs[(size_t)i * meff + j] = Hm[(size_t)i * m + j];
+        jacobi_eig(Hs, meff, theta, Y);
+        nconv = 0;
+        const int want = std::min(nev, meff);
+        for (int i = 0; i < want; i++) {
+            const double resid = std::fabs(beta_last * Y[(meff - 1) + (size_t)meff * i]);
+            if (resid <= tol_eff * std::max(eps23, std::fabs(theta[i]))) nconv++;
+        }
+        if (nconv >= want || meff < m || it + 1 >= maxiter) break;
+        // thick restart: keep the lowest l Ritz vectors, append the residual direction
+        l = std::min(m - 1, nev + std::max(1, (m - nev) / 2));
+        HIPCHK(hipMemcpyAsync(s->eig_y.p, Y.data(), (size_t)m * l * 8, hipMemcpyHostToDevice, s->stream));
+        RotArgs R{}; R.nv = m; R.nout = l; R.Y = s->eig_y.p; for (int i = 0; i < m; i++) R.V[i] = Vp(i);
+        hipLaunchKernelGGL(k_basis_rotate, dim3(gs), dim3(256), (size_t)m * l * 8, s->stream, R, n);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(Vp(l), Vp(m), (size_t)n * 8, hipMemcpyDeviceToDevice, s->stream));
+        std::fill(Hm.begin(), Hm.end(), 0.0);
+        for (int i = 0; i < l; i++) Hm[(size_t)i * m + i] = theta[i];
+    }
+    const int nout = std::min(nev, meff);
+    HIPCHK(hipMemcpyAsync(s->eig_y.p, Y.data(), (size_t)meff * nout * 8, hipMemcpyHostToDevice, s->stream));
+    RotArgs R{}; R.nv = meff; R.nout = nout; R.Y = s->eig_y.p; for (int i = 0; i < meff; i++) R.V[i] = Vp(i);
+    hipLaunchKernelGGL(k_basis_rotate, dim3(gs), dim3(256), (size_t)meff * nout * 8, s->stream, R, n);
+    HIPCHK(hipGetLastError());
+    for (int i = 0; i < nev; i++) evals[i] = i < nout ? theta[i] : 0.0;
+    if (evecs_host)
+        for (int i = 0; i < nout; i++) HIPCHK(hipMemcpyAsync(evecs_host + (int64_t)i * n, Vp(i), (size_t)n * 8, hipMemcpyDeviceToHost, s->stream));
+    HIPCHK(hipStreamSynchronize(s->stream));
+    if (nconv_out) *nconv_out = nconv;
+    if (nrestart_out) *nrestart_out = it + 1;
+    if (nmatvec_out) *nmatvec_out = nmv;
+    return EDGPU_OK;
+}
+
+}  // namespace edgpu

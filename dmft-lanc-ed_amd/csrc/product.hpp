@@ -1,0 +1,241 @@
+// product.hpp -- hxv(): launches of one sector product for every storage / partition / epilogue variant
+// Part of libedgpu.so (one translation unit: edgpu.hip includes these headers in order).
+#pragma once
+
+namespace edgpu {
+
+// ---------------------------------------------------------------------------------------
+// one product  out = H*v  (epi=false)   or the Lanczos-fused form (epi=true):
+//   out = s_cur*H*u - beta*s_prev*u_prev ;  scal[TMP] = (s_cur*u) . out
+// ---------------------------------------------------------------------------------------
+// scal[TMP] = sum(partial[0..n)) : one pass for short arrays, two passes for long ones
+static int reduce_partials(S *s, int64_t n)
+{
+    const double *src = s->partial.p;
+    if (n > 16384) {
+        const int64_t chunk = cdiv(n, 1024);
+        const int nb = (int)cdiv(n, chunk);
+        hipLaunchKernelGGL(k_reduce_chunks, dim3(nb), dim3(256), 0, s->stream, src, n, chunk, s->partial2.p);
+        src = s->partial2.p; n = nb;
+    }
+    hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(1024), 0, s->stream, src, n, s->scal.p + SC_TMP);
+    HIPCHK(hipGetLastError());
+    return EDGPU_OK;
+}
+
+template <int F> static void launch_kron2(S *s, const Kron2Args &A, int64_t rows)
+{
+    size_t lds = (F & KF_LDS) ? s->kron_lds : 16 * sizeof(double);
+    static bool attr_set = false;
+    if (!attr_set && lds > 64 * 1024) { (void)hipFuncSetAttribute((const void *)k_kron2<F>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; }
+    hipLaunchKernelGGL(k_kron2<F>, dim3((unsigned)rows), dim3(s->kron_threads), lds, s->stream, A);
+}
+
+static int dispatch_kron2(S *s, int flags, const Kron2Args &A, int64_t rows)
+{
+#define CASE(f) case (f): launch_kron2<(f)>(s, A, rows); break;
+#define CASE4(b) CASE(b) CASE((b) | KF_DIRECT) CASE((b) | KF_EPI) CASE((b) | KF_DIRECT | KF_EPI)
+#define CASE8(b) CASE4(b) CASE4((b) | KF_PH | KF_ND)
+    switch (flags) {
+        CASE8(0) CASE8(KF_LDS) CASE8(KF_NODW) CASE8(KF_NODW | KF_LDS) CASE8(KF_NOLOCAL)
+    default: return fail(EDGPU_EINVAL, "edgpu: internal kernel variant missing");
+    }
+#undef CASE8
+#undef CASE4
+#undef CASE
+    HIPCHK(hipGetLastError());
+    return EDGPU_OK;
+}
+
+static bool direct_tables_dirty(S *) { return false; }
+static bool epi_partials_needed(int flags) { return (flags & KF_EPI) && !(flags & KF_NODW); }
+static int direct_tables(S *s)
+{
+    const SectorHost &H = s->H; const edgpu_desc &d = H.desc;
+    for (int k = 0; k < 2 * H.Ns_Ud; k++) {
+        DevFactor &f = *s->fac[k];
+        TabArgs T{};
+        T.dim = H.fac[k].dim; T.nterms = (int32_t)H.fac[k].terms.size(); T.width = f.width; T.transposed = k < H.Ns_Ud;
+        T.map = f.map.p; T.rank = f.rank.p; T.talpha = f.talpha.p; T.tbeta = f.tbeta.p; T.tval = f.tval.p;
+        T.ellc = f.ellc.p; T.ellv = f.ellv.p; T.lin = f.lin.p; T.nlev = H.fac[k].nbits;
+        T.pcols = f.packed ? f.pcols.p : nullptr; T.pcodes = f.packed ? f.pcodes.p : nullptr; T.pelem = f.packed_elem ? f.pelem.p : nullptr; T.pelem8 = f.packed_elem8 ? f.pelem8.p : nullptr;
+        T.impmask = d.ed_total_ud ? (1 << d.Norb) - 1 : 0; T.pair = d.ed_total_ud ? d.Ust - d.Jh : 0.0; T.E = f.E.p;
+        hipLaunchKernelGGL(k_direct_tables, dim3((unsigned)cdiv(T.dim, 256)), dim3(256), 0, s->stream, T);
+    }
+    HIPCHK(hipGetLastError());
+    return EDGPU_OK;
+}
+
+static int hxv(S *s, const double *v, double *out, bool epi, const double *uprev)
+{
+    const SectorHost &H = s->H; const edgpu_desc &d = H.desc;
+    const bool multi = s->multi;
+    const bool direct = d.storage == EDGPU_STORE_DIRECT;
+    if (direct) CHK(direct_tables(s));
+    if (multi) {  // start the exchange on the comm stream; local work overlaps it
+        HIPCHK(hipEventRecord(s->ev_ready, s->stream));
+        HIPCHK(hipStreamWaitEvent(s->cstream, s->ev_ready, 0));
+        CHK(gather_vector(s, v, s->cstream));
+        HIPCHK(hipEventRecord(s->ev_gather, s->cstream));
+    }
+    int64_t nblocks = 0;
+    if (d.storage == EDGPU_STORE_CSR) {
+        // split CSR: the local block only reads columns of the rank's own dw columns, so it runs on the
+        // shard itself (pointer shifted to global column numbering) while the exchange is in flight
+        const bool overlap = multi && s->csr_split && H.DimPh == 1;
+        if (multi && !overlap) HIPCHK(hipStreamWaitEvent(s->stream, s->ev_gather, 0));
+        CsrArgs A{};
+        A.nrows = s->nloc_el; A.rows_per_block = s->csr_rpb; A.DimUp = (int32_t)H.DimUp; A.blocks_per_row = s->csr_bpr; A.Qdw = H.Qdw; A.tile = s->csr_tile;
+        A.rowptr = s->csr_rowptr.p; A.cols = s->csr_cols.p; A.vals = s->csr_vals.p;
+        A.x = overlap ? (s->halo ? v : v - H.dw0 * H.DimUp) : (multi ? s->vfull.p : v); A.y = out; A.v_local = v; A.uprev = uprev; A.scal = s->scal.p; A.partial = s->partial.p; A.epi = epi; A.xcd_rows = dbg_int("EDGPU_CSR_XCD", 0);
+        // the column index is global; on one GPU local == global
+        nblocks = (int64_t)s->csr_bpr * H.Qdw;
+        A.pass = s->csr_split ? 1 : 0; A.coltiles = 0;
+        if (s->csr_split && s->csrL_small) hipLaunchKernelGGL((k_csr_spmv2<64, 640, false>), dim3((unsigned)nblocks), dim3(64), 0, s->stream, A);
+        else hipLaunchKernelGGL((k_csr_spmv2<64, 1152, false>), dim3((unsigned)nblocks), dim3(64), 0, s->stream, A);
+        HIPCHK(hipGetLastError());
+        if (s->csr_split) {
+            if (overlap) { HIPCHK(hipStreamWaitEvent(s->stream, s->ev_gather, 0)); A.x = s->vfull.p; }
+            A.rowptr = s->csrD_rowptr.p; A.cols = s->csrD_cols.p; A.vals = s->csrD_vals.p;
+            A.rows_per_block = s->csrD_rpb; A.blocks_per_row = s->csrD_bpr; A.pass = 2; A.coltiles = 1; A.xcd_rows = 0;
+            nblocks = 8 * cdiv(s->csrD_bpr, 8) * H.Qdw;
+            if (s->csrD_small) {
+                if (s->csrD_nt) hipLaunchKernelGGL((k_csr_spmv2<64, 640, true>), dim3((unsigned)nblocks), dim3(64), 0, s->stream, A);
+                else hipLaunchKernelGGL((k_csr_spmv2<64, 640, false>), dim3((unsigned)nblocks), dim3(64), 0, s->stream, A);
+            } else {
+                if (s->csrD_nt) hipLaunchKernelGGL((k_csr_spmv2<64, 1152, true>), dim3((unsigned)nblocks), dim3(64), 0, s->stream, A);
+                else hipLaunchKernelGGL((k_csr_spmv2<64, 1152, false>), dim3((unsigned)nblocks), dim3(64), 0, s->stream, A);
+            }
+            HIPCHK(hipGetLastError());
+        }
+    } else if (s->two_factor) {
+        Kron2Args A{};
+        A.DimUp = (int32_t)H.DimUp; A.DimDw = (int32_t)(s->halo ? s->nhalo : H.DimDw); A.DimPh = H.DimPh; A.Norb = d.Norb; A.Qdw = H.Qdw; A.dw0 = H.dw0;
+        A.upc = s->fac[0]->ellc.p; A.upv = s->fac[0]->ellv.p; A.upw = s->fac[0]->width;
+        A.dwc = s->halo ? s->dw_ellc_x.p : s->fac[1]->ellc.p; A.dwv = s->fac[1]->ellv.p; A.dww = s->fac[1]->width;
+        A.diag = s->diag.p; A.Eup = s->fac[0]->E.p; A.Edw = s->fac[1]->E.p; A.cross = s->cross.p;
+        A.mapup = s->fac[0]->map.p; A.mapdw = s->fac[1]->map.p; A.rankup = s->fac[0]->rank.p; A.rankdw = s->fac[1]->rank.p;
+        A.impmask = (1 << d.Norb) - 1; A.nI = 1 << d.Norb; A.econst = H.econst; A.w0 = d.w0_ph; A.gsum = H.gph_sum; A.Jx = d.Jx; A.Jp = d.Jp;
+        A.gup = s->gup.p; A.gdw = s->gdw.p;
+        A.v = v; A.vfull = multi ? s->vfull.p : v; A.out = out; A.uprev = uprev; A.scal = s->scal.p; A.partial = s->partial.p;
+        if (dbg_flags() & 1) A.upw = 0;
+        if (dbg_flags() & 2) A.dww = 0;
+        int base = (direct ? KF_DIRECT : 0) | (epi ? KF_EPI : 0) | (s->extra ? (KF_PH | KF_ND) : 0);
+        nblocks = H.Qdw * H.DimPh;
+        const bool split = multi || (s->kron_split && !s->extra);
+        if (!split) CHK(dispatch_kron2(s, base | (s->use_lds ? KF_LDS : 0), A, nblocks));
+        else {
+            const bool persistent = s->up_persistent && !s->extra && s->fac[0]->packed && s->fac[0]->width <= 16 && s->use_lds && H.DimUp <= 13312 && !direct_tables_dirty(s);
+            if (persistent && s->up_pairs && s->fac[0]->packed_elem) {
+                UpArgs2 U{};
+                U.DimUp = A.DimUp; U.DimPh = A.DimPh; U.Qdw = A.Qdw; U.dw0 = A.dw0; U.nrows = H.Qdw * H.DimPh;
+                U.packed = reinterpret_cast<const uint4 *>(s->fac[0]->pelem.p); U.tval = s->fac[0]->ptval.p; U.nterms = s->fac[0]->pterms;
+                U.diag = A.diag; U.Eup = A.Eup; U.Edw = A.Edw; U.cross = A.cross; U.mapup = A.mapup; U.mapdw = A.mapdw; U.impmask = A.impmask; U.nI = A.nI; U.econst = A.econst;
+                U.v = v; U.out = out; U.uprev = uprev; U.scal = s->scal.p;
+                const size_t lds = (size_t)H.DimUp * 8 + 128 * 8;
+                const int grid = (int)std::min<int64_t>(U.nrows, s->up_grid);
+                static bool attr2 = false;
+                if (!attr2) {
+                    (void)hipFuncSetAttribute((const void *)k_uppass2<false, false, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                    (void)hipFuncSetAttribute((const void *)k_uppass2<false, true, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                    attr2 = true;
+                }
+                if (direct) {
+                    static bool attr3 = false;
+                    if (!attr3) {
+                        (void)hipFuncSetAttribute((const void *)k_uppass2<true, false, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                        (void)hipFuncSetAttribute((const void *)k_uppass2<true, true, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                        attr3 = true;
+                    }
+                    if (epi) hipLaunchKernelGGL((k_uppass2<true, true, 1024>), dim3(grid), dim3(1024), lds, s->stream, U);
+                    else hipLaunchKernelGGL((k_uppass2<true, false, 1024>), dim3(grid), dim3(1024), lds, s->stream, U);
+                } else if (epi) hipLaunchKernelGGL((k_uppass2<false, true, 1024>), dim3(grid), dim3(1024), lds, s->stream, U);
+                else hipLaunchKernelGGL((k_uppass2<false, false, 1024>), dim3(grid), dim3(1024), lds, s->stream, U);
+                HIPCHK(hipGetLastError());
+            } else if (persistent) {
+                UpArgs U{};
+                U.DimUp = A.DimUp; U.DimPh = A.DimPh; U.Qdw = A.Qdw; U.dw0 = A.dw0; U.nrows = H.Qdw * H.DimPh;
+                U.pcols = s->fac[0]->pcols.p; U.pcodes = s->fac[0]->pcodes.p; U.upw = s->fac[0]->width; U.tval = s->fac[0]->ptval.p; U.nterms = s->fac[0]->pterms;
+                U.diag = A.diag; U.Eup = A.Eup; U.Edw = A.Edw; U.cross = A.cross; U.mapup = A.mapup; U.mapdw = A.mapdw; U.impmask = A.impmask; U.nI = A.nI; U.econst = A.econst;
+                U.v = v; U.out = out; U.uprev = uprev; U.scal = s->scal.p;
+                const size_t lds = (((size_t)H.DimUp + 1) & ~(size_t)1) * 8 + 128 * 8;
+                const int grid = (int)std::min<int64_t>(U.nrows, s->up_grid);
+#define UP_LAUNCH(D_, E_, T_)                                                                                                   \
+    do {                                                                                                                            \
+        static bool attr_ = false;                                                                                                  \
+        if (!attr_) { (void)hipFuncSetAttribute((const void *)k_uppass<D_, E_, T_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_ = true; } \
+        hipLaunchKernelGGL((k_uppass<D_, E_, T_>), dim3(grid), dim3(T_), lds, s->stream, U);                                        \
+    } while (0)
+                if (s->up_threads == 512) {
+                    if (direct) { if (epi) UP_LAUNCH(true, true, 512); else UP_LAUNCH(true, false, 512); }
+                    else { if (epi) UP_LAUNCH(false, true, 512); else UP_LAUNCH(false, false, 512); }
+                } else {
+                    if (direct) { if (epi) UP_LAUNCH(true, true, 1024); else UP_LAUNCH(true, false, 1024); }
+                    else { if (epi) UP_LAUNCH(false, true, 1024); else UP_LAUNCH(false, false, 1024); }
+                }
+#undef UP_LAUNCH
+                HIPCHK(hipGetLastError());
+            } else if (!s->use_lds && !s->extra && s->fac[0]->packed_elem8 && s->up_big) {
+                UpBigArgs U{};
+                U.DimUp = A.DimUp; U.DimPh = A.DimPh; U.rsplit = s->row_split; U.Qdw = A.Qdw; U.dw0 = A.dw0; U.nrows = H.Qdw * H.DimPh;
+                U.packed8 = reinterpret_cast<const uint4 *>(s->fac[0]->pelem8.p); U.tval = s->fac[0]->ptval.p; U.nterms = s->fac[0]->pterms;
+                U.diag = A.diag; U.Eup = A.Eup; U.Edw = A.Edw; U.cross = A.cross; U.mapup = A.mapup; U.mapdw = A.mapdw; U.impmask = A.impmask; U.nI = A.nI; U.econst = A.econst;
+                U.v = v; U.out = out; U.uprev = uprev; U.scal = s->scal.p;
+                const unsigned grid = (unsigned)(cdiv(U.nrows, 8) * 8 * s->row_split);
+                if (direct) { if (epi) hipLaunchKernelGGL((k_uppass_big<true, true>), dim3(grid), dim3(512), 0, s->stream, U); else hipLaunchKernelGGL((k_uppass_big<true, false>), dim3(grid), dim3(512), 0, s->stream, U); }
+                else { if (epi) hipLaunchKernelGGL((k_uppass_big<false, true>), dim3(grid), dim3(512), 0, s->stream, U); else hipLaunchKernelGGL((k_uppass_big<false, false>), dim3(grid), dim3(512), 0, s->stream, U); }
+                HIPCHK(hipGetLastError());
+            } else if (!s->use_lds && !epi_partials_needed(base | KF_NODW)) {
+                Kron2Args A2 = A; A2.rsplit = s->row_split;
+                CHK(dispatch_kron2(s, base | KF_NODW, A2, s->row_split > 1 ? cdiv(nblocks, 8) * 8 * s->row_split : nblocks));
+            } else
+                CHK(dispatch_kron2(s, base | KF_NODW | (s->use_lds ? KF_LDS : 0), A, nblocks));
+            if (multi) HIPCHK(hipStreamWaitEvent(s->stream, s->ev_gather, 0));
+            if (s->extra) CHK(dispatch_kron2(s, base | KF_NOLOCAL, A, nblocks));   // Jx/Jp and phonon cases: row-wise dw pass
+            else {
+                DwArgs D{};
+                D.DimUp = A.DimUp; D.DimDw = A.DimDw; D.DimPh = A.DimPh; D.Qdw = A.Qdw; D.dw0 = A.dw0;
+                D.dwc = A.dwc; D.dwv = A.dwv; D.dww = A.dww; D.v = v; D.vfull = A.vfull; D.out = out; D.scal = s->scal.p; D.partial = s->partial.p;
+                D.w = s->dw_w; D.wshift = 0; while ((1 << D.wshift) < D.w) D.wshift++;
+                const int dv = s->dw_variant;
+                const bool vec2 = dv >= 2 && (H.DimUp % 2 == 0) && D.w >= 4 && D.dww <= 64;
+                D.ntiles = (int32_t)cdiv(H.DimUp, D.w);
+                D.R = vec2 ? std::min(64, s->dw_rows) : 256 / D.w;
+                D.chunks = (int32_t)cdiv(H.Qdw * H.DimPh, D.R);
+                nblocks = 8 * cdiv(D.ntiles, 8) * (int64_t)D.chunks;
+                if (!vec2) {
+                    if (epi) hipLaunchKernelGGL(k_dwpass<true>, dim3((unsigned)nblocks), dim3(256), 0, s->stream, D);
+                    else hipLaunchKernelGGL(k_dwpass<false>, dim3((unsigned)nblocks), dim3(256), 0, s->stream, D);
+                } else if (dv == 2) {
+                    if (epi) hipLaunchKernelGGL((k_dwpass2<true, false>), dim3((unsigned)nblocks), dim3(256), 0, s->stream, D);
+                    else hipLaunchKernelGGL((k_dwpass2<false, false>), dim3((unsigned)nblocks), dim3(256), 0, s->stream, D);
+                } else {
+                    if (epi) hipLaunchKernelGGL((k_dwpass2<true, true>), dim3((unsigned)nblocks), dim3(256), 0, s->stream, D);
+                    else hipLaunchKernelGGL((k_dwpass2<false, true>), dim3((unsigned)nblocks), dim3(256), 0, s->stream, D);
+                }
+                HIPCHK(hipGetLastError());
+            }
+        }
+    } else {
+        GenArgs A{};
+        A.nfac = 2 * H.Ns_Ud; A.DimPh = H.DimPh; A.Norb = d.Norb; A.direct = direct;
+        int64_t st = 1;
+        for (int k = 0; k < A.nfac; k++) {
+            A.dims[k] = H.fac[k].dim; A.strides[k] = st; st *= H.fac[k].dim;
+            A.rowptr[k] = s->fac[k]->rowptr.p; A.cols[k] = s->fac[k]->cols.p; A.vals[k] = s->fac[k]->vals.p; A.E[k] = s->fac[k]->E.p; A.maps[k] = s->fac[k]->map.p;
+        }
+        A.diag = s->diag.p; A.cross = s->cross.p; A.gup = s->gup.p; A.gdw = s->gdw.p; A.nI = 1 << d.Norb; A.total_ud = d.ed_total_ud; A.impmask = (1 << d.Norb) - 1;
+        A.econst = H.econst; A.w0 = d.w0_ph; A.gsum = H.gph_sum; A.Nel = s->nloc_el;
+        A.v = v; A.out = out; A.uprev = uprev; A.scal = s->scal.p; A.partial = s->partial.p; A.epi = epi;
+        nblocks = std::min<int64_t>(cdiv(s->nloc, 256), 4096);
+        hipLaunchKernelGGL(k_generic, dim3((unsigned)nblocks), dim3(256), 0, s->stream, A);
+        HIPCHK(hipGetLastError());
+    }
+    if (epi) {
+        CHK(reduce_partials(s, nblocks));
+        CHK(allreduce_tmp(s));
+    }
+    return EDGPU_OK;
+}
+
+}  // namespace edgpu

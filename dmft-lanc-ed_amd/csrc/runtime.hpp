@@ -1,0 +1,160 @@
+// runtime.hpp -- error channel, RCCL loader, device buffers and the per-sector state behind edgpu_handle
+// Part of libedgpu.so (one translation unit: edgpu.hip includes these headers in order).
+#pragma once
+
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/edgpu.h"
+#include "sector_host.hpp"
+#include "kernels.hpp"
+
+namespace edgpu {
+
+static thread_local std::string g_err;
+static int fail(int code, const std::string &msg) { g_err = msg; return code; }
+
+#define HIPCHK(expr)                                                                                   \
+    do {                                                                                               \
+        hipError_t e_ = (expr);                                                                        \
+        if (e_ != hipSuccess) {                                                                        \
+            int c_ = (e_ == hipErrorNoDevice || e_ == hipErrorInvalidDevice) ? EDGPU_ENODEVICE         \
+                     : (e_ == hipErrorOutOfMemory ? EDGPU_ENOMEM : EDGPU_EHIP);                        \
+            return fail(c_, std::string(#expr) + ": " + hipGetErrorString(e_));                       \
+        }                                                                                              \
+    } while (0)
+#define CHK(expr) do { int r_ = (expr); if (r_ != EDGPU_OK) return r_; } while (0)
+
+static int require_device()
+{
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n < 1) return fail(EDGPU_ENODEVICE, "edgpu: no HIP device visible (this library has no CPU fallback)");
+    return EDGPU_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// RCCL, resolved at run time so that the library loads on hosts without it and shares the
+// copy an embedding process (e.g. PyTorch) may already have loaded.
+// ------------------------------------------------------------------------------------------
+struct NcclUid { char b[128]; };
+struct Rccl {
+    int (*GetUniqueId)(NcclUid *) = nullptr;
+    int (*CommInitRank)(void **, int, NcclUid, int) = nullptr;
+    int (*CommDestroy)(void *) = nullptr;
+    int (*Send)(const void *, size_t, int, int, void *, hipStream_t) = nullptr;
+    int (*Recv)(void *, size_t, int, int, void *, hipStream_t) = nullptr;
+    int (*AllReduce)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    const char *(*GetErrorString)(int) = nullptr;
+    bool ok = false;
+    bool load()
+    {
+        if (ok) return true;
+        // Use the RCCL the process already has (an embedding PyTorch ships its own copy, built against the
+        // HIP runtime it loaded); only then fall back to the system library.
+        void *h = RTLD_DEFAULT;
+        if (!dlsym(h, "ncclCommInitRank")) {
+            h = nullptr;
+            if (const char *e = getenv("EDGPU_RCCL_LIB")) h = dlopen(e, RTLD_NOW | RTLD_GLOBAL);
+            if (!h) {
+                if (FILE *f = fopen("/proc/self/maps", "r")) {
+                    char line[4096];
+                    while (!h && fgets(line, sizeof(line), f)) {
+                        char *p = strstr(line, "librccl");
+                        if (!p) continue;
+                        char *path = strchr(line, '/');
+                        if (!path) continue;
+                        path[strcspn(path, "\n")] = 0;
+                        h = dlopen(path, RTLD_NOW | RTLD_GLOBAL);
+                    }
+                    fclose(f);
+                }
+            }
+            if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+            if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+            if (!h) return false;
+        }
+#define L(name) *(void **)(&name) = dlsym(h, "nccl" #name); if (!name) return false
+        L(GetUniqueId); L(CommInitRank); L(CommDestroy); L(Send); L(Recv); L(AllReduce); L(GroupStart); L(GroupEnd); L(GetErrorString);
+#undef L
+        ok = true;
+        return true;
+    }
+};
+static Rccl g_rccl;
+constexpr int kNcclDouble = 8, kNcclSum = 0;
+
+struct Comm {
+    enum Kind { NONE, RCCL, CALLBACK } kind = NONE;
+    int rank = 0, size = 1;
+    void *nccl = nullptr;
+    edgpu_allgatherv_fn ag = nullptr; edgpu_exchange_fn xch = nullptr; edgpu_allreduce_fn ar = nullptr; void *ctx = nullptr;
+};
+
+template <class T> struct DevBuf {
+    T *p = nullptr; size_t n = 0;
+    int alloc(size_t count) { release(); n = count; if (!count) return EDGPU_OK; HIPCHK(hipMalloc((void **)&p, count * sizeof(T))); return EDGPU_OK; }
+    int upload(const std::vector<T> &h) { CHK(alloc(h.size())); if (h.size()) HIPCHK(hipMemcpy(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice)); return EDGPU_OK; }
+    void release() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
+    ~DevBuf() { release(); }
+};
+
+struct DevFactor {
+    DevBuf<int32_t> map, rank, rowptr, cols, ellc, talpha, tbeta;
+    DevBuf<uint32_t> pcols, pcodes, pelem, pelem8; DevBuf<double> ptval; bool packed = false, packed_elem = false, packed_elem8 = false; int32_t pterms = 0;
+    DevBuf<double> vals, ellv, E, tval, lin;
+    int32_t width = 0;
+};
+
+}  // namespace edgpu
+
+using namespace edgpu;
+
+struct edgpu_sector_s {
+    SectorHost H;
+    Comm comm;
+    int device = 0;
+    hipStream_t stream = nullptr, cstream = nullptr;
+    hipEvent_t ev_a = nullptr, ev_b = nullptr, ev_gather = nullptr, ev_ready = nullptr;
+    std::vector<std::unique_ptr<DevFactor>> fac;
+    DevBuf<double> diag, cross, gup, gdw, bd_up, bd_dw;
+    DevBuf<int32_t> stride;
+    // explicit CSR
+    DevBuf<int64_t> csr_rowptr, uppre, dwpre; DevBuf<int32_t> csr_cols; DevBuf<double> csr_vals;
+    DevBuf<int64_t> csrD_rowptr; DevBuf<int32_t> csrD_cols; DevBuf<double> csrD_vals;   // dw block of the split form
+    bool csr_split = false; int64_t csrL_nnz = 0, csrD_nnz = 0; int32_t csrD_rpb = 64, csrD_bpr = 0; int csrD_nt = 1; bool csrL_small = false, csrD_small = false;
+    int64_t csr_nnz = 0; int32_t csr_rpb = 0, csr_bpr = 0, csr_tile = 1;
+    // work vectors
+    // halo exchange (multi-rank, ed_total_ud=T without Jx/Jp/phonon extras): x-space of the dw hops is
+    // [own rows | rows needed from rank 0 | rank 1 | ...] instead of the whole gathered vector
+    bool halo = false; int64_t nhalo = 0;
+    std::vector<int64_t> send_rows_cnt, recv_rows_cnt, send_rows_off, recv_rows_off;
+    DevBuf<int32_t> send_list, dw_ellc_x, dw_cols_x; DevBuf<double> sendbuf;
+    hipEvent_t ev_pack = nullptr;
+    std::vector<std::unique_ptr<DevBuf<double>>> eigV; DevBuf<double> eig_h, eig_y, eig_partial;
+    DevBuf<double> vfull, tmp_in, tmp_out, lz[5], scal, alphas, betas, zvec, partial, partial2;
+    int64_t nloc = 0, nloc_el = 0, vecdim = 0;
+    int32_t nmax = 0;
+    bool use_lds = false; int kron_threads = 256, kron_threads_override = 0; size_t kron_lds = 0;
+    bool two_factor = false, extra = false, multi = false, kron_split = false; int dw_w = 64, dw_variant = 2, dw_rows = 64; bool up_persistent = true, up_pairs = true; int up_grid = 256, up_threads = 1024, row_split = 4; bool up_big = true;
+    std::vector<hipEvent_t> bench_ev; int bench_k = 0; double *bv[3] = {nullptr, nullptr, nullptr};
+    int64_t nnz_total = 0, bytes_stored = 0;
+    int64_t npartial = 0;
+};
+
+namespace edgpu {
+using S = edgpu_sector_s;
+
+static int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+static int dbg_flags() { const char *e = getenv("EDGPU_DEBUG"); return e ? atoi(e) : 0; }
+static int dbg_int(const char *name, int dflt) { const char *e = getenv(name); return e ? atoi(e) : dflt; }
+
+}  // namespace edgpu

@@ -1,0 +1,341 @@
+// sector_dev.hpp -- device-side construction of a sector: factor images, halo lists, diagonal, explicit CSR; create/destroy
+// Part of libedgpu.so (one translation unit: edgpu.hip includes these headers in order).
+#pragma once
+
+namespace edgpu {
+
+// ---------------------------------------------------------------------------------------
+// device-side construction
+// ---------------------------------------------------------------------------------------
+static int upload_factor(S *s, int k)
+{
+    const Factor &f = s->H.fac[k];
+    auto df = std::make_unique<DevFactor>();
+    CHK(df->map.upload(f.map)); CHK(df->rank.upload(f.rank));
+    std::vector<int32_t> rp32(f.rowptr.begin(), f.rowptr.end());
+    CHK(df->rowptr.upload(rp32)); CHK(df->cols.upload(f.cols)); CHK(df->vals.upload(f.vals));
+    CHK(df->E.upload(f.E));
+    df->width = std::max(f.width, 1);
+    if (df->width > 64) return fail(EDGPU_EUNSUPPORTED, "edgpu: more than 64 hops per spin configuration");
+    if ((int)f.terms.size() > kMaxTerms) return fail(EDGPU_EUNSUPPORTED, "edgpu: too many one-body hop terms");
+    // ELL image: up factors transposed [width][dim] (lanes run over rows), dw factors [dim][width]
+    const bool transposed = k < s->H.Ns_Ud;
+    std::vector<int32_t> ec((size_t)df->width * f.dim); std::vector<double> ev((size_t)df->width * f.dim);
+    for (int32_t i = 0; i < f.dim; i++)
+        for (int32_t q = 0; q < df->width; q++) {
+            int64_t p = f.rowptr[i] + q; bool has = p < f.rowptr[i + 1];
+            size_t o = transposed ? (size_t)q * f.dim + i : (size_t)i * df->width + q;
+            ec[o] = has ? f.cols[p] : i; ev[o] = has ? f.vals[p] : 0.0;
+        }
+    CHK(df->ellc.upload(ec)); CHK(df->ellv.upload(ev));
+    // packed image for the persistent local pass: 16-bit column + (sign | term index) byte per hop;
+    // padded slots use code 127 -> amplitude 0.  Only when every entry is a single hop term.
+    if (transposed && f.dim <= 65536 && f.terms.size() < 127) {
+        const int W = df->width, ncw = (W + 1) / 2, ndw = (W + 3) / 4;
+        std::vector<uint32_t> pc((size_t)ncw * f.dim, 0u), pd((size_t)ndw * f.dim, 0u);
+        std::vector<double> tvl(128, 0.0);
+        for (size_t t = 0; t < f.terms.size(); t++) tvl[t] = std::fabs(f.terms[t].t);
+        bool ok = true;
+        for (int32_t i = 0; i < f.dim && ok; i++)
+            for (int32_t q = 0; q < 4 * ndw; q++) {
+                int64_t p = f.rowptr[i] + q; bool has = q < W && p < f.rowptr[i + 1];
+                uint32_t col = has ? (uint32_t)f.cols[p] : (uint32_t)i, code = 127u;
+                if (has) {
+                    int tid = -1;
+                    for (size_t t = 0; t < f.terms.size(); t++) if (std::fabs(f.terms[t].t) == std::fabs(f.vals[p])) { tid = (int)t; break; }
+                    if (tid < 0) { ok = false; break; }     // summed duplicates: keep the wide image
+                    code = (uint32_t)tid | (f.vals[p] < 0.0 ? 0x80u : 0u);
+                }
+                if (q < 2 * ncw) pc[(size_t)(q / 2) * f.dim + i] |= col << (16 * (q & 1));
+                pd[(size_t)(q / 4) * f.dim + i] |= code << (8 * (q & 3));
+            }
+        if (ok) { CHK(df->pcols.upload(pc)); CHK(df->pcodes.upload(pd)); CHK(df->ptval.upload(tvl)); df->packed = true; df->pterms = 128; }
+        if (ok && W <= 10) {                        // element-major image of 8 dwords for rows that do not fit LDS
+            std::vector<uint32_t> pe((size_t)8 * f.dim, 0u);
+            for (int32_t i = 0; i < f.dim; i++) {
+                for (int q = 0; q < 10; q++) {
+                    int64_t p = f.rowptr[i] + q; bool has = q < W && p < f.rowptr[i + 1];
+                    uint32_t col = has ? (uint32_t)f.cols[p] : (uint32_t)i;
+                    pe[(size_t)8 * i + q / 2] |= col << (16 * (q & 1));
+                }
+                for (int q = 0; q < 12; q++) {
+                    int64_t p = f.rowptr[i] + q; bool has = q < W && p < f.rowptr[i + 1];
+                    uint32_t code = 127u;
+                    if (has) { code = (pd[(size_t)(q / 4) * f.dim + i] >> (8 * (q & 3))) & 0xffu; }
+                    pe[(size_t)8 * i + 5 + q / 4] |= code << (8 * (q & 3));
+                }
+            }
+            CHK(df->pelem8.upload(pe)); df->packed_elem8 = true;
+        }
+        if (ok && W <= 8 && f.dim % 2 == 0) {       // element-major image for the pair kernel: 6 dwords per up configuration
+            std::vector<uint32_t> pe((size_t)6 * f.dim, 0u);
+            for (int32_t i = 0; i < f.dim; i++) {
+                for (int c = 0; c < 4; c++) pe[(size_t)6 * i + c] = c < ncw ? pc[(size_t)c * f.dim + i] : ((uint32_t)i | ((uint32_t)i << 16));
+                for (int c = 0; c < 2; c++) pe[(size_t)6 * i + 4 + c] = c < ndw ? pd[(size_t)c * f.dim + i] : 0x7f7f7f7fu;
+            }
+            CHK(df->pelem.upload(pe)); df->packed_elem = true;
+        }
+    }
+    std::vector<int32_t> ta, tb; std::vector<double> tv;
+    for (auto &t : f.terms) { ta.push_back(t.alpha); tb.push_back(t.beta); tv.push_back(t.t); }
+    if (ta.empty()) { ta.push_back(1); tb.push_back(1); tv.push_back(0.0); }
+    CHK(df->talpha.upload(ta)); CHK(df->tbeta.upload(tb)); CHK(df->tval.upload(tv));
+    // per-level one-body coefficients for the on-the-fly energy table
+    {
+        const edgpu_desc &d = s->H.desc; const SectorHost &H = s->H;
+        int spin = k < H.Ns_Ud ? 1 : d.Nspin;
+        std::vector<double> lin(f.nbits, 0.0);
+        auto hf = [&](int a) { return d.hfmode ? -0.5 * d.Uloc[a - 1] - (d.Norb - 1) * (0.5 * d.Ust + 0.5 * (d.Ust - d.Jh)) : 0.0; };
+        if (d.ed_total_ud) {
+            for (int a = 1; a <= d.Norb; a++) lin[a - 1] += H.imp(spin, spin, a, a) - d.xmu + hf(a);
+            for (int a = 1; a <= d.Nfoo; a++) for (int kp = 1; kp <= d.Nbath; kp++) lin[H.stride[a - 1][kp - 1] - 1] += H.bdiag(spin, a, kp);
+        } else {
+            int a = (k % H.Ns_Ud) + 1;
+            lin[0] += H.imp(spin, spin, a, a) - d.xmu + hf(a);
+            for (int kp = 1; kp <= d.Nbath; kp++) lin[kp] += H.bdiag(spin, a, kp);
+        }
+        CHK(df->lin.upload(lin));
+    }
+    s->fac.push_back(std::move(df));
+    return EDGPU_OK;
+}
+
+// Which dw rows does each rank need from each other rank?  Row j of rank r is needed here iff some
+// local row i has H_dw[i,j] != 0.  H_dw is small and known to every rank, so the lists are
+// computed locally on both sides (no set-up communication).  At Ns=16 this is 53 % / 36 % / 24 %
+// of the all-gather volume at 2 / 4 / 8 ranks.
+static int setup_halo(S *s)
+{
+    const SectorHost &H = s->H; const Factor &dw = H.fac[1];
+    const int P = s->comm.size, me = s->comm.rank;
+    auto range_of = [&](int r, int64_t &d0, int64_t &qd) { int64_t q = H.DimDw / P, rem = H.DimDw % P; qd = r < rem ? q + 1 : q; d0 = r < rem ? r * (q + 1) : r * q + rem; };
+    std::vector<int> owner(H.DimDw);
+    for (int r = 0; r < P; r++) { int64_t d0, qd; range_of(r, d0, qd); for (int64_t j = d0; j < d0 + qd; j++) owner[j] = r; }
+    std::vector<std::vector<int32_t>> recv_rows(P), send_rows(P);
+    {
+        std::vector<char> mark(H.DimDw, 0);
+        for (int64_t i = H.dw0; i < H.dw0 + H.Qdw; i++)
+            for (int64_t p = dw.rowptr[i]; p < dw.rowptr[i + 1]; p++) mark[dw.cols[p]] = 1;
+        for (int64_t j = 0; j < H.DimDw; j++) if (mark[j] && owner[j] != me) recv_rows[owner[j]].push_back((int32_t)j);
+        // what rank r needs from me: rows j of mine that some row i of r couples to
+        for (int r = 0; r < P; r++) {
+            if (r == me) continue;
+            int64_t d0, qd; range_of(r, d0, qd);
+            std::fill(mark.begin(), mark.end(), 0);
+            for (int64_t i = d0; i < d0 + qd; i++)
+                for (int64_t p = dw.rowptr[i]; p < dw.rowptr[i + 1]; p++) mark[dw.cols[p]] = 1;
+            for (int64_t j = H.dw0; j < H.dw0 + H.Qdw; j++) if (mark[j]) send_rows[r].push_back((int32_t)(j - H.dw0));
+        }
+    }
+    s->send_rows_cnt.assign(P, 0); s->recv_rows_cnt.assign(P, 0); s->send_rows_off.assign(P, 0); s->recv_rows_off.assign(P, 0);
+    std::vector<int32_t> send_list, xmap(H.DimDw, -1);
+    int64_t so = 0, ro = 0;
+    for (int64_t q = 0; q < H.Qdw; q++) xmap[H.dw0 + q] = (int32_t)q;
+    for (int r = 0; r < P; r++) {
+        s->send_rows_cnt[r] = (int64_t)send_rows[r].size(); s->send_rows_off[r] = so; so += s->send_rows_cnt[r];
+        s->recv_rows_cnt[r] = (int64_t)recv_rows[r].size(); s->recv_rows_off[r] = ro;
+        for (size_t k = 0; k < recv_rows[r].size(); k++) xmap[recv_rows[r][k]] = (int32_t)(H.Qdw + ro + (int64_t)k);
+        ro += s->recv_rows_cnt[r];
+        send_list.insert(send_list.end(), send_rows[r].begin(), send_rows[r].end());
+    }
+    s->nhalo = H.Qdw + ro;
+    if (send_list.empty()) send_list.push_back(0);
+    CHK(s->send_list.upload(send_list));
+    CHK(s->sendbuf.alloc((size_t)std::max<int64_t>(so, 1) * H.DimUp * H.DimPh));
+    // H_dw column indices translated to x-space for the local rows (ELL image and CSR image)
+    const int W = s->fac[1]->width;
+    std::vector<int32_t> ec((size_t)W * dw.dim, 0), cc(dw.cols.size(), 0);
+    for (int64_t i = H.dw0; i < H.dw0 + H.Qdw; i++) {
+        for (int q = 0; q < W; q++) { int64_t p = dw.rowptr[i] + q; bool has = p < dw.rowptr[i + 1]; ec[(size_t)i * W + q] = has ? xmap[dw.cols[p]] : xmap[i]; }
+        for (int64_t p = dw.rowptr[i]; p < dw.rowptr[i + 1]; p++) cc[p] = xmap[dw.cols[p]];
+    }
+    CHK(s->dw_ellc_x.upload(ec)); CHK(s->dw_cols_x.upload(cc));
+    HIPCHK(hipEventCreateWithFlags(&s->ev_pack, hipEventDisableTiming));
+    s->halo = true;
+    return EDGPU_OK;
+}
+
+static int build_diag(S *s)
+{
+    const SectorHost &H = s->H; const edgpu_desc &d = H.desc;
+    DiagArgs A{};
+    A.Norb = d.Norb; A.Nspin = d.Nspin; A.Nbath = d.Nbath; A.Nfoo = d.Nfoo; A.hfmode = d.hfmode; A.total_ud = d.ed_total_ud; A.Ns_Ud = H.Ns_Ud;
+    for (int k = 0; k < 2 * H.Ns_Ud; k++) { A.dims[k] = H.fac[k].dim; A.maps[k] = s->fac[k]->map.p; }
+    A.nloc = s->nloc_el; A.shift = H.dw0 * H.DimUp;
+    for (int a = 0; a < EDGPU_MAX_ORB; a++) { A.Uloc[a] = d.Uloc[a]; A.imp_up[a] = A.imp_dw[a] = 0.0; }
+    for (int a = 1; a <= d.Norb; a++) { A.imp_up[a - 1] = H.imp(1, 1, a, a); A.imp_dw[a - 1] = H.imp(d.Nspin, d.Nspin, a, a); }
+    A.Ust = d.Ust; A.Jh = d.Jh; A.xmu = d.xmu;
+    A.bd_up = s->bd_up.p; A.bd_dw = s->bd_dw.p; A.stride = s->stride.p;
+    CHK(s->diag.alloc((size_t)s->nloc_el));
+    hipLaunchKernelGGL(k_build_diag, dim3((unsigned)cdiv(s->nloc_el, 256)), dim3(256), 0, s->stream, A, s->diag.p);
+    HIPCHK(hipGetLastError());
+    return EDGPU_OK;
+}
+
+static int build_csr(S *s)
+{
+    const SectorHost &H = s->H;
+    if (!s->two_factor || H.DimPh > 1 || H.Jhflag) return fail(EDGPU_EUNSUPPORTED, "edgpu: storage=CSR supports ed_total_ud=T without phonons and Jx/Jp");
+    if (H.DimUp * s->nhalo >= ((int64_t)1 << 31)) return fail(EDGPU_EUNSUPPORTED, "edgpu: storage=CSR needs DimUp*(rows of x) < 2^31 (int32 columns)");
+    const Factor &up = H.fac[0], &dw = H.fac[1];
+    std::vector<int64_t> uppre(up.dim + 1, 0), dwpre(H.Qdw + 1, 0);
+    for (int i = 0; i < up.dim; i++) uppre[i + 1] = uppre[i] + 1 + (up.rowptr[i + 1] - up.rowptr[i]);
+    int64_t maxrow = 0; int upmax = 0;
+    for (int i = 0; i < up.dim; i++) upmax = std::max<int>(upmax, (int)(up.rowptr[i + 1] - up.rowptr[i]));
+    for (int64_t q = 0; q < H.Qdw; q++) {
+        int64_t nd = dw.rowptr[H.dw0 + q + 1] - dw.rowptr[H.dw0 + q];
+        dwpre[q + 1] = dwpre[q] + uppre[up.dim] + nd * up.dim;
+        maxrow = std::max<int64_t>(maxrow, 1 + upmax + nd);
+    }
+    s->csr_nnz = dwpre[H.Qdw];
+    CHK(s->uppre.upload(uppre)); CHK(s->dwpre.upload(dwpre));
+    // Two storage forms of the same explicit matrix: one CSR, or (default for large sectors) two CSR
+    // blocks H = H_loc + H_dw so that each block can be streamed in the order that keeps ITS gathers
+    // cache resident (rows for the up hops, XCD-owned column tiles for the dw hops).
+    s->csr_split = dbg_int("EDGPU_CSR_SPLIT", (H.DimUp * H.DimDw * 8 > ((int64_t)48 << 20)) ? 1 : 0) != 0;
+    s->csrL_nnz = H.Qdw * uppre[up.dim]; s->csrD_nnz = s->csr_nnz - s->csrL_nnz;
+    CsrBuildArgs A{};
+    A.DimUp = (int32_t)H.DimUp; A.DimDw = (int32_t)H.DimDw; A.Qdw = H.Qdw; A.dw0 = H.dw0;
+    A.uprp = s->fac[0]->rowptr.p; A.upc = s->fac[0]->cols.p; A.upv = s->fac[0]->vals.p;
+    A.dwrp = s->fac[1]->rowptr.p; A.dwc = s->halo ? s->dw_cols_x.p : s->fac[1]->cols.p; A.dwv = s->fac[1]->vals.p;
+    A.rowshift = s->halo ? H.dw0 : 0;     // x-space index of local row idw is idw - rowshift
+    A.uppre = s->uppre.p; A.dwpre = s->dwpre.p; A.diag = s->diag.p;
+    const unsigned gb = (unsigned)cdiv(s->nloc_el + 1, 256);
+    if (!s->csr_split) {
+        CHK(s->csr_rowptr.alloc((size_t)s->nloc_el + 1)); CHK(s->csr_cols.alloc((size_t)s->csr_nnz)); CHK(s->csr_vals.alloc((size_t)s->csr_nnz));
+        A.rowptr = s->csr_rowptr.p; A.cols = s->csr_cols.p; A.vals = s->csr_vals.p;
+        hipLaunchKernelGGL(k_csr_build, dim3(gb), dim3(256), 0, s->stream, A, 0);
+    } else {
+        CHK(s->csr_rowptr.alloc((size_t)s->nloc_el + 1)); CHK(s->csr_cols.alloc((size_t)s->csrL_nnz)); CHK(s->csr_vals.alloc((size_t)s->csrL_nnz));
+        CHK(s->csrD_rowptr.alloc((size_t)s->nloc_el + 1)); CHK(s->csrD_cols.alloc((size_t)s->csrD_nnz)); CHK(s->csrD_vals.alloc((size_t)s->csrD_nnz));
+        A.rowptr = s->csr_rowptr.p; A.cols = s->csr_cols.p; A.vals = s->csr_vals.p;
+        hipLaunchKernelGGL(k_csr_build, dim3(gb), dim3(256), 0, s->stream, A, 1);
+        A.rowptr = s->csrD_rowptr.p; A.cols = s->csrD_cols.p; A.vals = s->csrD_vals.p;
+        hipLaunchKernelGGL(k_csr_build, dim3(gb), dim3(256), 0, s->stream, A, 2);
+        int64_t ndmax = 0;
+        for (int64_t q = 0; q < H.Qdw; q++) ndmax = std::max<int64_t>(ndmax, dw.rowptr[H.dw0 + q + 1] - dw.rowptr[H.dw0 + q]);
+        s->csrD_rpb = (int32_t)std::min<int64_t>(dbg_int("EDGPU_CSRD_ROWS", 64), 1152 / std::max<int64_t>(ndmax, 1));
+        if (s->csrD_rpb < 1) return fail(EDGPU_EUNSUPPORTED, "edgpu: a CSR row exceeds the LDS tile");
+        s->csrD_bpr = (int32_t)cdiv(H.DimUp, s->csrD_rpb);
+        s->csrD_nt = dbg_int("EDGPU_CSRD_NT", 1);
+        maxrow = 1 + upmax;
+        s->csrL_small = (1 + upmax) * 64 <= 640 && dbg_int("EDGPU_CSR_SMALL", 1);     // smaller LDS image -> more resident workgroups
+        s->csrD_small = ndmax * s->csrD_rpb <= 640 && dbg_int("EDGPU_CSR_SMALL", 1);
+    }
+    HIPCHK(hipGetLastError());
+    s->csr_rpb = (int32_t)std::min<int64_t>(64, 1152 / std::max<int64_t>(maxrow, 1));      // one wave per row block
+    if (s->csr_rpb < 1) return fail(EDGPU_EUNSUPPORTED, "edgpu: a CSR row exceeds the LDS tile");
+    s->csr_bpr = (int32_t)cdiv(H.DimUp, s->csr_rpb);
+    s->csr_tile = std::max(1, std::min(dbg_int("EDGPU_CSR_TILE", 1 << 20), s->csr_bpr));
+    return EDGPU_OK;
+}
+
+static int64_t max_partials(const S *s)
+{
+    int64_t n = std::max<int64_t>(s->H.Qdw * s->H.DimPh, 4096);
+    if (s->two_factor) {   // column-tiled dw pass: one partial per workgroup
+        const int w = s->dw_w, R = std::min(256 / w, s->dw_rows);
+        n = std::max<int64_t>(n, 8 * cdiv(cdiv(s->H.DimUp, w), 8) * cdiv(s->H.Qdw * s->H.DimPh, std::max(R, 1)));
+    }
+    if (s->csr_bpr) n = std::max<int64_t>(n, (int64_t)s->csr_bpr * s->H.Qdw);
+    if (s->csrD_bpr) n = std::max<int64_t>(n, 8 * cdiv(s->csrD_bpr, 8) * s->H.Qdw);
+    return n;
+}
+
+static int create(const edgpu_desc *desc, S **out)
+{
+    CHK(require_device());
+    auto s = std::unique_ptr<S>(new S());
+    std::string e = s->H.init(*desc);
+    if (!e.empty()) return fail(EDGPU_EINVAL, e);
+    if (desc->storage < EDGPU_STORE_KRON || desc->storage > EDGPU_STORE_DIRECT) return fail(EDGPU_EINVAL, "edgpu: bad storage");
+    if (desc->device >= 0) HIPCHK(hipSetDevice(desc->device));
+    HIPCHK(hipGetDevice(&s->device));
+    HIPCHK(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
+    HIPCHK(hipStreamCreateWithFlags(&s->cstream, hipStreamNonBlocking));
+    HIPCHK(hipEventCreate(&s->ev_a)); HIPCHK(hipEventCreate(&s->ev_b));
+    HIPCHK(hipEventCreateWithFlags(&s->ev_gather, hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&s->ev_ready, hipEventDisableTiming));
+    SectorHost &H = s->H;
+    s->comm.rank = desc->mpi_rank; s->comm.size = desc->mpi_size;
+    s->two_factor = desc->ed_total_ud != 0;
+    s->extra = H.DimPh > 1 || H.Jhflag;
+    s->nloc_el = H.DimUp * H.Qdw; s->nloc = s->nloc_el * H.DimPh; s->vecdim = s->nloc;
+    for (int k = 0; k < 2 * H.Ns_Ud; k++) CHK(upload_factor(s.get(), k));
+    CHK(s->cross.upload(H.cross)); CHK(s->gup.upload(H.gph_up)); CHK(s->gdw.upload(H.gph_dw));
+    {
+        std::vector<double> bu((size_t)desc->Nfoo * desc->Nbath), bd((size_t)desc->Nfoo * desc->Nbath);
+        for (int a = 1; a <= desc->Nfoo; a++) for (int k = 1; k <= desc->Nbath; k++) { bu[(a - 1) + desc->Nfoo * (k - 1)] = H.bdiag(1, a, k); bd[(a - 1) + desc->Nfoo * (k - 1)] = H.bdiag(desc->Nspin, a, k); }
+        std::vector<int32_t> st((size_t)desc->Norb * desc->Nbath);
+        for (int a = 1; a <= desc->Norb; a++) for (int k = 1; k <= desc->Nbath; k++) st[(a - 1) + desc->Norb * (k - 1)] = H.stride[a - 1][k - 1];
+        CHK(s->bd_up.upload(bu)); CHK(s->bd_dw.upload(bd)); CHK(s->stride.upload(st));
+    }
+    // launch geometry of the fused two-factor kernel
+    if (s->two_factor) {
+        size_t rowbytes = (size_t)H.DimUp * sizeof(double);
+        s->use_lds = rowbytes + 128 <= 150 * 1024 && !(dbg_flags() & 4);
+        if (dbg_int("EDGPU_KRON_THREADS", 0)) s->kron_threads_override = dbg_int("EDGPU_KRON_THREADS", 0);
+        s->kron_threads = H.DimUp >= 4096 ? 1024 : (H.DimUp >= 1024 ? 512 : 256);
+        if (s->kron_threads_override) s->kron_threads = s->kron_threads_override;
+        s->kron_lds = (s->use_lds ? rowbytes : 0) + 16 * sizeof(double);
+        // two-pass product (local pass + column-tiled dw pass) once the vector no longer fits the caches
+        s->kron_split = dbg_int("EDGPU_KRON_SPLIT", (H.DimUp * H.DimDw * 8 > ((int64_t)48 << 20)) ? 1 : 0) != 0;
+        // tile width of the dw pass: 64 columns measured best at Ns=16 (slab 6.6 MB, half of the gathers hit
+        // L2) and at Ns=18 (slab 25 MB: no re-use left, but narrower tiles lose more to short segments)
+        s->dw_w = dbg_int("EDGPU_DW_W", 64);
+        s->dw_variant = dbg_int("EDGPU_DW_VARIANT", 2);
+        s->up_persistent = dbg_int("EDGPU_UP_PERSISTENT", 1) != 0;
+        s->up_grid = dbg_int("EDGPU_UP_GRID", 256);
+        s->up_pairs = dbg_int("EDGPU_UP_PAIRS", 1) != 0;
+        s->row_split = std::max(1, std::min(32, dbg_int("EDGPU_ROW_SPLIT", 4)));
+        s->up_big = dbg_int("EDGPU_UP_BIG", 1) != 0;
+        s->up_threads = dbg_int("EDGPU_UP_THREADS", 1024) == 512 ? 512 : 1024;
+        s->dw_rows = std::max(1, std::min(64, dbg_int("EDGPU_DW_ROWS", 64)));
+        if (s->dw_w != 8 && s->dw_w != 16 && s->dw_w != 32 && s->dw_w != 64 && s->dw_w != 128 && s->dw_w != 256) s->dw_w = 32;
+    }
+    // operator storage
+    int64_t nnz_fac = 0;
+    if (s->two_factor) {
+        const Factor &up = H.fac[0], &dw = H.fac[1];
+        int64_t nd = dw.rowptr[H.dw0 + H.Qdw] - dw.rowptr[H.dw0];
+        nnz_fac = (int64_t)up.cols.size() * H.Qdw + nd * H.DimUp;
+    } else {
+        for (int k = 0; k < 2 * H.Ns_Ud; k++) nnz_fac += (int64_t)H.fac[k].cols.size() * (s->nloc_el / H.fac[k].dim);
+    }
+    s->nnz_total = (s->nloc_el + nnz_fac) * H.DimPh;
+    s->multi = desc->mpi_size > 1 || (desc->reserved & 1);   // reserved bit 0: run the exchange path even on one rank (tests)
+    s->nhalo = H.DimDw;
+    if (s->multi && s->two_factor && !s->extra && dbg_int("EDGPU_HALO", 1)) CHK(setup_halo(s.get()));
+    if (desc->storage != EDGPU_STORE_DIRECT) { CHK(build_diag(s.get())); s->bytes_stored = s->nloc_el * 8; }
+    if (desc->storage == EDGPU_STORE_CSR) {
+        CHK(build_csr(s.get()));
+        s->bytes_stored = s->csr_nnz * 12 + (s->nloc_el + 1) * 8 * (s->csr_split ? 2 : 1);
+    }
+    if (s->multi) CHK(s->vfull.alloc((size_t)(H.DimUp * s->nhalo * H.DimPh)));
+    s->npartial = max_partials(s.get());
+    CHK(s->partial.alloc((size_t)s->npartial));
+    CHK(s->partial2.alloc(1024));
+    CHK(s->scal.alloc(SC_COUNT));
+    HIPCHK(hipMemsetAsync(s->scal.p, 0, SC_COUNT * sizeof(double), s->stream));
+    HIPCHK(hipStreamSynchronize(s->stream));
+    *out = s.release();
+    return EDGPU_OK;
+}
+
+static void destroy(S *s)
+{
+    if (!s) return;
+    (void)hipSetDevice(s->device);
+    (void)hipDeviceSynchronize();
+    if (s->comm.kind == Comm::RCCL && s->comm.nccl && g_rccl.ok) g_rccl.CommDestroy(s->comm.nccl);
+    for (auto e : s->bench_ev) (void)hipEventDestroy(e);
+    if (s->ev_pack) (void)hipEventDestroy(s->ev_pack);
+    if (s->ev_a) (void)hipEventDestroy(s->ev_a);
+    if (s->ev_b) (void)hipEventDestroy(s->ev_b);
+    if (s->ev_gather) (void)hipEventDestroy(s->ev_gather);
+    if (s->ev_ready) (void)hipEventDestroy(s->ev_ready);
+    if (s->stream) (void)hipStreamDestroy(s->stream);
+    if (s->cstream) (void)hipStreamDestroy(s->cstream);
+    delete s;
+}
+
+}  // namespace edgpu
