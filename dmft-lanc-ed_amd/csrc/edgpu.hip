@@ -268,7 +268,6 @@ int edgpu_imp_density_offdiag(edgpu_handle h, const double *vec_host, double *dm
 {
     if (!h || !vec_host || !dm) return fail(EDGPU_EINVAL, "edgpu_imp_density_offdiag: null argument");
     if (!h->two_factor) return fail(EDGPU_EUNSUPPORTED, "edgpu_imp_density_offdiag: ed_total_ud=F has no off-diagonal density matrix (ED_OBSERVABLES.f90:283)");
-    if (h->multi && h->comm.size > 1) return fail(EDGPU_EUNSUPPORTED, "edgpu_imp_density_offdiag: single rank only");
     HIPCHK(hipSetDevice(h->device));
     const SectorHost &H = h->H; const int Norb = H.desc.Norb;
     for (int t = 0; t < 2 * Norb * Norb; t++) dm[t] = 0.0;
@@ -280,6 +279,13 @@ int edgpu_imp_density_offdiag(edgpu_handle h, const double *vec_host, double *dm
     HIPCHK(hipMemsetAsync(out.p, 0, (size_t)nrows * 50 * 8, h->stream));
     DmArgs A{}; A.DimUp = (int32_t)H.DimUp; A.DimDw = (int32_t)H.DimDw; A.Norb = Norb; A.Qdw = H.Qdw; A.dw0 = H.dw0; A.nrows = nrows;
     A.mapup = h->fac[0]->map.p; A.mapdw = h->fac[1]->map.p; A.rankup = h->fac[0]->rank.p; A.rankdw = h->fac[1]->rank.p; A.v = h->tmp_in.p; A.out = out.p;
+    const bool dist = h->multi && h->comm.size > 1;
+    DevBuf<double> full;
+    if (dist) {   // the dw-spin partner rows belong to other ranks
+        CHK(full.alloc((size_t)(H.DimUp * H.DimDw * H.DimPh)));
+        CHK(gather_full(h, h->tmp_in.p, full.p, h->stream));
+        A.vg = full.p;
+    }
     hipLaunchKernelGGL(k_imp_dm_rows, dim3((unsigned)nrows), dim3(256), 0, h->stream, A);
     HIPCHK(hipGetLastError());
     std::vector<double> part((size_t)nrows * 50);
@@ -287,24 +293,48 @@ int edgpu_imp_density_offdiag(edgpu_handle h, const double *vec_host, double *dm
     for (int64_t r = 0; r < nrows; r++)
         for (int s2 = 0; s2 < 2; s2++) for (int a = 0; a < Norb; a++) for (int b = 0; b < Norb; b++)
             dm[(s2 * Norb + a) * Norb + b] += part[(size_t)r * 50 + s2 * 25 + a * 5 + b];
+    if (dist) {
+        std::vector<double> acc(dm, dm + 2 * Norb * Norb);
+        DevBuf<double> d; CHK(d.upload(acc));
+        CHK(allreduce_dev(h, d.p, 2 * Norb * Norb));
+        HIPCHK(hipMemcpyAsync(dm, d.p, (size_t)2 * Norb * Norb * 8, hipMemcpyDeviceToHost, h->stream)); HIPCHK(hipStreamSynchronize(h->stream));
+    }
     return EDGPU_OK;
 }
 
-// cvec of the twin sector from the cvec of this sector (host vectors, single rank)
+// cvec of the twin sector from the cvec of this sector (host vectors).  With more than one rank: vin is this
+// rank's shard of sector A, vout its shard of the twin sector B (dw split of DimDw_B = DimUp_A); the state is
+// all-gathered once, vout must hold DimDw_A * Qdw_B * DimPh doubles, Qdw_B = this rank's share of DimUp_A
+// (same rule as ED_HAMILTONIAN.f90:96-110).
 int edgpu_twin_reorder(edgpu_handle h, const double *vin_host, double *vout_host)
 {
     if (!h || !vin_host || !vout_host) return fail(EDGPU_EINVAL, "edgpu_twin_reorder: null argument");
-    if (h->multi && h->comm.size > 1) return fail(EDGPU_EUNSUPPORTED, "edgpu_twin_reorder: single rank only");
     HIPCHK(hipSetDevice(h->device));
     const SectorHost &H = h->H;
     if (h->tmp_in.n != (size_t)h->nloc) { CHK(h->tmp_in.alloc((size_t)h->nloc)); CHK(h->tmp_out.alloc((size_t)h->nloc)); }
     HIPCHK(hipMemcpy(h->tmp_in.p, vin_host, (size_t)h->nloc * 8, hipMemcpyHostToDevice));
-    TwinArgs A{}; A.nud = H.Ns_Ud; A.DimPh = H.DimPh; A.nel = h->nloc_el; A.vin = h->tmp_in.p; A.vout = h->tmp_out.p;
+    const bool dist = h->multi && h->comm.size > 1;
+    const int64_t nelG = H.DimUp * H.DimDw;
+    TwinArgs A{}; A.nud = H.Ns_Ud; A.DimPh = H.DimPh; A.nel = dist ? nelG : h->nloc_el; A.nel_out = h->nloc_el; A.row0_out = 0;
+    A.vin = h->tmp_in.p; A.vout = h->tmp_out.p;
     for (int k = 0; k < 2 * H.Ns_Ud; k++) A.dimsA[k] = H.fac[k].dim;
-    const int nb = (int)std::max<int64_t>(1, std::min<int64_t>(cdiv(h->nloc, 256), 8192));
+    DevBuf<double> full, outb;
+    int64_t nout = h->nloc;
+    if (dist) {
+        CHK(full.alloc((size_t)(nelG * H.DimPh)));
+        CHK(gather_full(h, h->tmp_in.p, full.p, h->stream));
+        // shard of the twin sector: DimUp_B = DimDw_A rows long, dw columns of B = up index of A split over the ranks
+        const int64_t P = h->comm.size, r = h->comm.rank, q = H.DimUp / P, rem = H.DimUp % P;
+        if (H.DimUp < P) return fail(EDGPU_EUNSUPPORTED, "edgpu_twin_reorder: twin sector has fewer dw columns than ranks");
+        const int64_t qb = r < rem ? q + 1 : q, b0 = r < rem ? r * (q + 1) : r * q + rem;
+        A.vin = full.p; A.nel_out = H.DimDw * qb; A.row0_out = H.DimDw * b0;
+        nout = A.nel_out * H.DimPh;
+        CHK(outb.alloc((size_t)nout)); A.vout = outb.p;
+    }
+    const int nb = (int)std::max<int64_t>(1, std::min<int64_t>(cdiv(nout, 256), 8192));
     hipLaunchKernelGGL(k_twin_reorder, dim3(nb), dim3(256), 0, h->stream, A);
     HIPCHK(hipGetLastError());
-    HIPCHK(hipMemcpyAsync(vout_host, h->tmp_out.p, (size_t)h->nloc * 8, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipMemcpyAsync(vout_host, A.vout, (size_t)nout * 8, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     return EDGPU_OK;
 }
@@ -339,7 +369,7 @@ int edgpu_imp_histogram(edgpu_handle h, const double *vec, int32_t vec_on_device
     } else {
         const int grid = 256;
         DevBuf<double> out; CHK(out.alloc((size_t)grid * nb));
-        HistGenArgs A{}; A.nfac = 2 * H.Ns_Ud; A.nI = nI; A.DimPh = H.DimPh; A.Nel = h->nloc_el; A.v = v; A.out = out.p;
+        HistGenArgs A{}; A.nfac = 2 * H.Ns_Ud; A.nI = nI; A.DimPh = H.DimPh; A.Nel = h->nloc_el; A.row0 = H.dw0 * H.DimUp; A.v = v; A.out = out.p;
         for (int k = 0; k < A.nfac; k++) { A.dims[k] = H.fac[k].dim; A.maps[k] = h->fac[k]->map.p; }
         hipLaunchKernelGGL(k_imp_hist_generic, dim3(grid), dim3(256), (size_t)nb * 8, h->stream, A);
         HIPCHK(hipGetLastError());
@@ -364,7 +394,8 @@ int edgpu_apply_op(edgpu_handle from, edgpu_handle to, int32_t iorb, int32_t isp
     const SectorHost &F = from->H, &T = to->H;
     if (F.Ns_Ud != T.Ns_Ud || F.Ns_Orb != T.Ns_Orb || F.DimPh != T.DimPh || F.desc.Norb != T.desc.Norb)
         return fail(EDGPU_EINVAL, "edgpu_apply_op: sectors belong to different models");
-    if (from->multi || to->multi) return fail(EDGPU_EUNSUPPORTED, "edgpu_apply_op: single rank only for now");
+    if (from->multi != to->multi || from->comm.size != to->comm.size || from->comm.rank != to->comm.rank)
+        return fail(EDGPU_EINVAL, "edgpu_apply_op: the two sectors must live on the same rank layout");
     if (iorb < 1 || iorb > F.desc.Norb || ispin < 1 || ispin > 2) return fail(EDGPU_EINVAL, "edgpu_apply_op: bad iorb/ispin");
     // ED_GF_NORMAL.f90:138-145: (ialfa,iorb1) = (1,iorb) for ed_total_ud else (iorb,1); ibeta = ialfa+(ispin-1)*Ns_Ud
     const int ialfa = F.desc.ed_total_ud ? 1 : iorb, iorb1 = F.desc.ed_total_ud ? iorb : 1;
@@ -379,6 +410,20 @@ int edgpu_apply_op(edgpu_handle from, edgpu_handle to, int32_t iorb, int32_t isp
     for (int k = 0; k < A.nfac; k++) { A.dims_to[k] = T.fac[k].dim; A.dims_from[k] = F.fac[k].dim; }
     A.map_to_fb = to->fac[fb]->map.p; A.rank_from_fb = from->fac[fb]->rank.p;
     A.nel_to = to->nloc_el; A.nel_from = from->nloc_el; A.vin = vin_dev; A.vout = vout_dev;
+    DevBuf<double> full;
+    if (to->multi) {
+        // target rows are the rank's dw columns of the TARGET sector.  An up-spin operator leaves the dw
+        // index alone and both sectors split the same DimDw the same way: the source entry is local.  A
+        // dw-spin operator couples to dw columns of other ranks: all-gather the source state first.
+        A.row0_to = T.dw0 * T.DimUp;
+        if (fb < F.Ns_Ud) { A.src_off = F.dw0 * F.DimUp; if (F.DimDw != T.DimDw || F.dw0 != T.dw0) return fail(EDGPU_EINVAL, "edgpu_apply_op: partitions differ"); }
+        else {
+            CHK(full.alloc((size_t)(F.DimUp * F.DimDw * F.DimPh)));
+            HIPCHK(hipSetDevice(from->device));
+            CHK(gather_full(from, vin_dev, full.p, from->stream));
+            A.vin = full.p; A.nel_from = F.DimUp * F.DimDw; A.src_off = 0;
+        }
+    }
     const int nb = (int)std::max<int64_t>(1, std::min<int64_t>(cdiv(to->nloc, 256), 8192));
     HIPCHK(hipStreamSynchronize(from->stream));
     hipLaunchKernelGGL(k_apply_op, dim3(nb), dim3(256), 0, to->stream, A);
@@ -423,9 +468,9 @@ int edgpu_chi_lanczos(edgpu_handle h, const double *cup, const double *cdw, cons
     CHK(lz_prepare(h, nlanc));
     DiagOpArgs A{};
     A.nfac = 2 * H.Ns_Ud; A.Norb = H.desc.Norb; A.total_ud = H.desc.ed_total_ud; A.Nel = h->nloc_el; A.N = h->nloc;
-    if (h->multi && h->comm.size > 1 && !h->two_factor) return fail(EDGPU_EUNSUPPORTED, "edgpu_chi_lanczos: ed_total_ud=F is single rank");
     for (int k = 0; k < A.nfac; k++) { A.dims[k] = H.fac[k].dim; A.maps[k] = h->fac[k]->map.p; }
     if (h->two_factor) { A.dims[1] = (int32_t)H.Qdw; A.maps[1] = h->fac[1]->map.p + H.dw0; }   // local dw columns
+    else A.row0 = H.dw0 * H.DimUp;                                                              // mixed-radix digits are global
     for (int a = 0; a < EDGPU_MAX_ORB; a++) { A.cu[a] = a < A.Norb ? cup[a] : 0.0; A.cd[a] = a < A.Norb ? cdw[a] : 0.0; }
     A.vin = h->tmp_in.p; A.vout = h->tmp_out.p;
     const int nb = (int)std::max<int64_t>(1, std::min<int64_t>(cdiv(h->nloc, 256), 8192));

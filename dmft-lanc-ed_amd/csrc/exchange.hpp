@@ -8,9 +8,9 @@ namespace edgpu {
 // exchange step: gather the input vector of every rank (phonon block by phonon block)
 // ---------------------------------------------------------------------------------------
 static int halo_exchange(S *s, const double *v_local, hipStream_t st);
-static int gather_vector(S *s, const double *v_local, hipStream_t st)
+// all-gather into the global layout [iph][idw][iup] at dst (allgather_vector_MPI, ED_SETUP.f90:689-733)
+static int gather_full(S *s, const double *v_local, double *dst, hipStream_t st)
 {
-    if (s->halo) return halo_exchange(s, v_local, st);
     const SectorHost &H = s->H; Comm &c = s->comm;
     const int P = c.size;
     std::vector<int64_t> counts(P), displs(P);
@@ -22,7 +22,7 @@ static int gather_vector(S *s, const double *v_local, hipStream_t st)
     const int64_t nel_loc = s->nloc_el, nel = H.DimUp * H.DimDw;
     for (int iph = 0; iph < H.DimPh; iph++) {
         const double *send = v_local + (int64_t)iph * nel_loc;
-        double *recv = s->vfull.p + (int64_t)iph * nel;
+        double *recv = dst + (int64_t)iph * nel;
         if (c.kind == Comm::RCCL) {
             HIPCHK(hipMemcpyAsync(recv + displs[c.rank], send, (size_t)nel_loc * 8, hipMemcpyDeviceToDevice, st));
             int rc = g_rccl.GroupStart();
@@ -40,6 +40,11 @@ static int gather_vector(S *s, const double *v_local, hipStream_t st)
             return fail(EDGPU_ECOMM, "edgpu: mpi_size>1 but no communicator attached (edgpu_comm_init_*)");
     }
     return EDGPU_OK;
+}
+static int gather_vector(S *s, const double *v_local, hipStream_t st)
+{
+    if (s->halo) return halo_exchange(s, v_local, st);
+    return gather_full(s, v_local, s->vfull.p, st);
 }
 
 // x = [own rows | needed rows of the other ranks]: pack what each peer needs, one send/recv pair per peer

@@ -568,8 +568,10 @@ struct GenArgs {
     const double *diag, *cross, *gup, *gdw;
     int32_t nI, total_ud, impmask;
     double econst, w0, gsum;
-    int64_t Nel;
+    int64_t Nel;               // local electronic rows (DimUp * Qdw)
+    int64_t NelG, row0;        // global electronic dimension; global index of the first local row (dw split)
     const double *v; double *out;
+    const double *x;           // input vector in global layout (the gathered vector with more than one rank, else v)
     const double *uprev; const double *scal; double *partial; int32_t epi;
 };
 
@@ -583,7 +585,8 @@ __global__ void __launch_bounds__(256) k_generic(GenArgs A)
         const int iph = (int)(i / A.Nel);
         const int64_t iel = i - (int64_t)iph * A.Nel;
         int32_t dig[2 * EDGPU_MAX_ORB];
-        { int64_t c = iel; for (int k = 0; k < A.nfac; k++) { dig[k] = (int32_t)(c % A.dims[k]); c /= A.dims[k]; } }
+        { int64_t c = iel + A.row0; for (int k = 0; k < A.nfac; k++) { dig[k] = (int32_t)(c % A.dims[k]); c /= A.dims[k]; } }
+        const int64_t gi = (int64_t)iph * A.NelG + iel + A.row0;   // position of this row in the global layout of x
         const double x = A.v[i];
         double dval;
         uint32_t mu = 0, md = 0;
@@ -600,12 +603,12 @@ __global__ void __launch_bounds__(256) k_generic(GenArgs A)
         double acc = dval * x;
         for (int k = 0; k < A.nfac; k++) {
             const int32_t r0 = A.rowptr[k][dig[k]], r1 = A.rowptr[k][dig[k] + 1];
-            for (int32_t p = r0; p < r1; p++) acc += A.vals[k][p] * A.v[i + (int64_t)(A.cols[k][p] - dig[k]) * A.strides[k]];
+            for (int32_t p = r0; p < r1; p++) acc += A.vals[k][p] * A.x[gi + (int64_t)(A.cols[k][p] - dig[k]) * A.strides[k]];
         }
         if (A.DimPh > 1) {
             double g = A.gup[mu] + A.gdw[md] - A.gsum;
-            if (iph + 1 < A.DimPh) acc += g * sqrt((double)(iph + 1)) * A.v[i + A.Nel];
-            if (iph > 0) acc += g * sqrt((double)iph) * A.v[i - A.Nel];
+            if (iph + 1 < A.DimPh) acc += g * sqrt((double)(iph + 1)) * A.x[gi + A.NelG];
+            if (iph > 0) acc += g * sqrt((double)iph) * A.x[gi - A.NelG];
         }
         if (A.epi) { double w = s_cur * acc - c_prev * A.uprev[i]; A.out[i] = w; asum += (s_cur * x) * w; }
         else A.out[i] = acc;
@@ -864,7 +867,8 @@ struct OpArgs {
     int32_t nfac, fb, bitpos, dagger, DimPh;        // fb: factor (digit) that changes; bitpos: 0-based level
     int32_t dims_to[2 * EDGPU_MAX_ORB], dims_from[2 * EDGPU_MAX_ORB];
     const int32_t *map_to_fb, *rank_from_fb;
-    int64_t nel_to, nel_from;
+    int64_t nel_to, nel_from;                        // rows of the local target shard; phonon-block stride of vin
+    int64_t row0_to, src_off;                        // global index of the first target row; global -> vin index shift
     const double *vin; double *vout;
 };
 
@@ -872,8 +876,8 @@ __global__ void __launch_bounds__(256) k_apply_op(OpArgs A)
 {
     const int64_t N = A.nel_to * A.DimPh;
     for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < N; j += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t iph = j / A.nel_to; int64_t c = j - iph * A.nel_to;
-        int64_t isrc = 0, stride = 1; double val = 0.0; bool ok = true; double sgn = 1.0;
+        const int64_t iph = j / A.nel_to; int64_t c = j - iph * A.nel_to + A.row0_to;
+        int64_t isrc = -A.src_off, stride = 1; double val = 0.0; bool ok = true; double sgn = 1.0;
         for (int k = 0; k < A.nfac; k++) {
             int32_t dg = (int32_t)(c % A.dims_to[k]); c /= A.dims_to[k];
             if (k == A.fb) {
@@ -1004,13 +1008,13 @@ __global__ void __launch_bounds__(256) k_scale(double *__restrict__ x, const dou
 // ---------------------------------------------------------------------------------------------
 struct DiagOpArgs {
     int32_t nfac, Norb, total_ud; int32_t dims[2 * EDGPU_MAX_ORB]; const int32_t *maps[2 * EDGPU_MAX_ORB];
-    double cu[EDGPU_MAX_ORB], cd[EDGPU_MAX_ORB]; int64_t Nel, N; const double *vin; double *vout;
+    double cu[EDGPU_MAX_ORB], cd[EDGPU_MAX_ORB]; int64_t Nel, N, row0; const double *vin; double *vout;
 };
 __global__ void __launch_bounds__(256) k_apply_diagop(DiagOpArgs A)
 {
     const int nud = A.nfac / 2;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < A.N; i += (int64_t)gridDim.x * blockDim.x) {
-        int64_t c = i % A.Nel;
+        int64_t c = i % A.Nel + A.row0;
         uint32_t mu = 0, md = 0;
         for (int k = 0; k < A.nfac; k++) {
             const int dg = (int)(c % A.dims[k]); c /= A.dims[k];
@@ -1028,12 +1032,12 @@ __global__ void __launch_bounds__(256) k_apply_diagop(DiagOpArgs A)
 // Order = twin_sector_order (ED_SETUP.f90:852-880, ED_EIGENSPACE.f90:486-497).  Sorting the flipped global
 // state numbers is the index permutation that swaps the up and dw halves of the digit tuple, i.e. a
 // generalised transpose per phonon block -- computed directly, no sort.
-struct TwinArgs { int32_t nud, DimPh; int32_t dimsA[2 * EDGPU_MAX_ORB]; int64_t nel; const double *vin; double *vout; };
+struct TwinArgs { int32_t nud, DimPh; int32_t dimsA[2 * EDGPU_MAX_ORB]; int64_t nel; int64_t nel_out, row0_out; const double *vin; double *vout; };   // nel: global electronic dim (vin is global); output window [row0_out, row0_out+nel_out) per phonon block
 __global__ void __launch_bounds__(256) k_twin_reorder(TwinArgs A)
 {
-    const int64_t n = A.nel * A.DimPh;
+    const int64_t n = A.nel_out * A.DimPh;
     for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t iph = j / A.nel; int64_t c = j - iph * A.nel;
+        const int64_t iph = j / A.nel_out; int64_t c = j - iph * A.nel_out + A.row0_out;
         // digits of the B index: [ups_B (= dws_A) ..., dws_B (= ups_A) ...]
         int32_t dg[2 * EDGPU_MAX_ORB];
         for (int k = 0; k < A.nud; k++) { const int d = A.dimsA[k + A.nud]; dg[k + A.nud] = (int32_t)(c % d); c /= d; }   // dws_A
@@ -1047,7 +1051,7 @@ __global__ void __launch_bounds__(256) k_twin_reorder(TwinArgs A)
 // Off-diagonal impurity density matrix <c^+_a c_b> per spin (ED_OBSERVABLES.f90:283-313, ed_total_ud=T):
 // dm[s][a][b] = sum_i sgn1*sgn2 * v_i * v_j, |j> = c^+_a c_b |i> acting on the spin-s word (a != b).
 // One workgroup per (idw,iph) row; out[row*50 + s*25 + a*5 + b] partial sums in a fixed order.
-struct DmArgs { int32_t DimUp, DimDw, Norb; int64_t Qdw, dw0, nrows; const int32_t *mapup, *mapdw, *rankup, *rankdw; const double *v; double *out; };
+struct DmArgs { int32_t DimUp, DimDw, Norb; int64_t Qdw, dw0, nrows; const int32_t *mapup, *mapdw, *rankup, *rankdw; const double *v; const double *vg; double *out; };   // vg: gathered vector (global layout) with more than one rank, else null
 __global__ void __launch_bounds__(256) k_imp_dm_rows(DmArgs A)
 {
     __shared__ double red[4];
@@ -1070,11 +1074,11 @@ __global__ void __launch_bounds__(256) k_imp_dm_rows(DmArgs A)
                             acc += ((sg & 1) ? -1.0 : 1.0) * vrow[i] * vrow[A.rankup[k]];
                         }
                     }
-                } else if ((mdw & bb) && !(mdw & ba)) {   // dw word changes: partner row (single rank: all rows local)
+                } else if ((mdw & bb) && !(mdw & ba)) {   // dw word changes: partner row (of another rank: read from the gathered vector)
                     const uint32_t r = mdw & ~bb, k = r | ba;
                     const int sg = __popc(mdw & (bb - 1u)) + __popc(r & (ba - 1u));
                     const double sgn = (sg & 1) ? -1.0 : 1.0;
-                    const double *prow = A.v + (iph * A.Qdw + (A.rankdw[k] - A.dw0)) * A.DimUp;
+                    const double *prow = A.vg ? A.vg + (iph * (int64_t)A.DimDw + A.rankdw[k]) * A.DimUp : A.v + (iph * A.Qdw + (A.rankdw[k] - A.dw0)) * A.DimUp;
                     for (int i = threadIdx.x; i < A.DimUp; i += blockDim.x) acc += sgn * vrow[i] * prow[i];
                 }
                 double t = block_sum(acc, red);
@@ -1120,7 +1124,7 @@ __global__ void __launch_bounds__(256) k_imp_hist_rows(HistArgs A)
     for (int c = 0; c < A.nI; c++) { double r = block_sum(acc[c], red); if (threadIdx.x == 0) A.out[row * A.nI + c] = r; }
 }
 // generic digit layout (ed_total_ud=F): LDS histogram with fp64 atomics (summation order not fixed)
-struct HistGenArgs { int32_t nfac, nI, DimPh; int32_t dims[2 * EDGPU_MAX_ORB]; const int32_t *maps[2 * EDGPU_MAX_ORB]; int64_t Nel; const double *v; double *out; };
+struct HistGenArgs { int32_t nfac, nI, DimPh; int32_t dims[2 * EDGPU_MAX_ORB]; const int32_t *maps[2 * EDGPU_MAX_ORB]; int64_t Nel, row0; const double *v; double *out; };
 __global__ void __launch_bounds__(256) k_imp_hist_generic(HistGenArgs A)
 {
     extern __shared__ double hs[];   // nI*nI*DimPh
@@ -1129,7 +1133,7 @@ __global__ void __launch_bounds__(256) k_imp_hist_generic(HistGenArgs A)
     __syncthreads();
     const int64_t N = A.Nel * A.DimPh; const int nud = A.nfac / 2;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t iph = i / A.Nel; int64_t c = i - iph * A.Nel;
+        const int64_t iph = i / A.Nel; int64_t c = i - iph * A.Nel + A.row0;
         uint32_t mu = 0, md = 0;
         for (int k = 0; k < A.nfac; k++) {
             const int dg = (int)(c % A.dims[k]); c /= A.dims[k];

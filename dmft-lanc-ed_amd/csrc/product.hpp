@@ -226,6 +226,9 @@ static int hxv(S *s, const double *v, double *out, bool epi, const double *uprev
         }
         A.diag = s->diag.p; A.cross = s->cross.p; A.gup = s->gup.p; A.gdw = s->gdw.p; A.nI = 1 << d.Norb; A.total_ud = d.ed_total_ud; A.impmask = (1 << d.Norb) - 1;
         A.econst = H.econst; A.w0 = d.w0_ph; A.gsum = H.gph_sum; A.Nel = s->nloc_el;
+        A.NelG = multi ? H.DimUp * H.DimDw : s->nloc_el; A.row0 = multi ? H.dw0 * H.DimUp : 0;
+        if (multi) HIPCHK(hipStreamWaitEvent(s->stream, s->ev_gather, 0));   // digits are global: every hop reads the gathered vector
+        A.x = multi ? s->vfull.p : v;
         A.v = v; A.out = out; A.uprev = uprev; A.scal = s->scal.p; A.partial = s->partial.p; A.epi = epi;
         nblocks = std::min<int64_t>(cdiv(s->nloc, 256), 4096);
         hipLaunchKernelGGL(k_generic, dim3((unsigned)nblocks), dim3(256), 0, s->stream, A);

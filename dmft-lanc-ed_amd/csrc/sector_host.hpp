@@ -144,7 +144,6 @@ struct SectorHost {
             int64_t q = DimDw / d.mpi_size, r = DimDw % d.mpi_size;
             if (d.mpi_rank < r) { Qdw = q + 1; dw0 = d.mpi_rank * (q + 1); } else { Qdw = q; dw0 = d.mpi_rank * q + r; }
         }
-        if (!d.ed_total_ud && d.mpi_size > 1) return "edgpu: ed_total_ud=F with more than one rank is not supported yet";
         build_terms();
         for (auto &f : fac) build_rows(f);
         build_energy_tables();

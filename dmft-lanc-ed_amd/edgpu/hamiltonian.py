@@ -189,6 +189,10 @@ class HvSector:
         """State of the twin sector (ndw,nup) from a state of this sector (es_return_cvector, itwin branch)."""
         vec = np.ascontiguousarray(vec, np.float64)
         out = np.empty_like(vec)
+        if int(self._desc.mpi_size) > 1:   # shard of the twin sector: its dw columns are this sector's up index
+            from .model import dw_partition
+            qb, _ = dw_partition(int(self.info.DimUp), int(self._desc.mpi_size), int(self._desc.mpi_rank))
+            out = np.empty(int(self.info.DimDw) * qb * int(self.info.DimPh))
         check(capi.lib().edgpu_twin_reorder(self._h, vec.ctypes.data, out.ctypes.data))
         return out
 

@@ -152,7 +152,9 @@ int edgpu_imp_density_offdiag(edgpu_handle h, const double *vec_host, double *dm
 
 /* eigenvector hand-off for twin sectors (ed_twin): the state of sector B(ndw,nup) from the state of this
  * sector A(nup,ndw), vector_B(i) = cvec_A(Order(i)), Order = twin_sector_order (ED_SETUP.f90:852-880,
- * ED_EIGENSPACE.f90:486-497).  Host vectors of getDim doubles. */
+ * ED_EIGENSPACE.f90:486-497).  Host vectors of getDim doubles.  With more than one rank vin is the rank's shard of
+ * A and vout its shard of B: DimDw_A * Qdw_B * DimPh doubles, Qdw_B = the rank's share of DimUp_A under the dw split
+ * of ED_HAMILTONIAN.f90:96-110 (the state is all-gathered once on the device). */
 int edgpu_twin_reorder(edgpu_handle h, const double *vin_host, double *vout_host);
 
 /* ---- Green's-function leg: O|state> between two live sectors, in HBM ------

@@ -1,7 +1,7 @@
 /*
  * ed_oracle.c -- TEST INFRASTRUCTURE ONLY.  Not part of the product.
  *
- * Plain-C, single-thread restatement of the CPU algorithm of the reference
+ * Plain-C restatement (single thread unless orc_set_threads is called) of the CPU algorithm of the reference
  * (lcrippa/dmft-lanc-ed) for the sector Hamiltonian-times-vector hot path.
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
  * load this.  The product (dmft-lanc-ed_amd/csrc) never links or calls it.
@@ -514,24 +514,33 @@ void orc_sp_export(orc_sector *S, int which, int iud, int64_t *rowptr, int64_t *
 }
 
 /* spMatVec_main: ED_HAMILTONIAN_SPARSE_HxV.f90:391-485 */
+static int orc_threads = 1;
+void orc_set_threads(int n) { orc_threads = n < 1 ? 1 : n; }
+
 static void spmatvec_main(orc_sector *S, const double *v, double *Hv)
 {
     int64_t Nloc = S->Dim, DimUp = S->DimUp, DimDw = S->DimDw, Nel = DimUp * DimDw;
 #define V(j) v[(j)-1]
 #define HV(i) Hv[(i)-1]
+    /* Every loop below writes only HV(i) of its own row i (gather form), so the optional OpenMP split over
+       rows (orc_set_threads > 1; the CPU-baseline leg of bench.py) leaves each row's summation order, and
+       therefore every bit of the result, unchanged.  The reference itself is single-threaded. */
     for (int64_t i = 0; i < Nloc; i++) Hv[i] = 0.0;
+    _Pragma("omp parallel for schedule(static) num_threads(orc_threads)")
     for (int64_t i = 1; i <= Nloc; i++) {
         int64_t iph = (i - 1) / Nel + 1, i_el = (i - 1) % Nel + 1;
         orc_row *r = &S->spH0d.row[i_el - 1];
         for (int j_el = 0; j_el < r->size; j_el++) { double val = r->vals[j_el]; int64_t j = r->cols[j_el] + (iph - 1) * Nel; HV(i) = HV(i) + val * V(j); }
     }
     for (int64_t iph = 1; iph <= S->DimPh; iph++) {
+        _Pragma("omp parallel for schedule(static) num_threads(orc_threads)")
         for (int64_t iup = 1; iup <= DimUp; iup++)
             for (int64_t idw = 1; idw <= DimDw; idw++) {
                 int64_t i = iup + (idw - 1) * DimUp + (iph - 1) * Nel;
                 orc_row *r = &S->spH0dws[0].row[idw - 1];
                 for (int jj = 0; jj < r->size; jj++) { int64_t j = iup + (r->cols[jj] - 1) * DimUp + (iph - 1) * Nel; HV(i) = HV(i) + r->vals[jj] * V(j); }
             }
+        _Pragma("omp parallel for schedule(static) num_threads(orc_threads)")
         for (int64_t idw = 1; idw <= DimDw; idw++)
             for (int64_t iup = 1; iup <= DimUp; iup++) {
                 int64_t i = iup + (idw - 1) * DimUp + (iph - 1) * Nel;

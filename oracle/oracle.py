@@ -29,8 +29,13 @@ def build(force=False):
     if (not force) and os.path.exists(_LIB) and os.path.getmtime(_LIB) >= os.path.getmtime(_SRC):
         return _LIB
     os.makedirs(os.path.dirname(_LIB), exist_ok=True)
-    subprocess.check_call(["gcc", "-O2", "-fPIC", "-shared", "-std=c99", "-o", _LIB, _SRC, "-lm"])
+    subprocess.check_call(["gcc", "-O2", "-fopenmp", "-fPIC", "-shared", "-std=c99", "-o", _LIB, _SRC, "-lm"])
     return _LIB
+
+
+def set_threads(n):
+    """OpenMP row split of the stored product (bench.py's CPU baseline; results are bit-identical to 1 thread)."""
+    lib().orc_set_threads(int(n))
 
 
 class _Params(C.Structure):
@@ -69,6 +74,7 @@ def lib():
         L.orc_binary_search.argtypes = [C.c_void_p, C.c_int, C.c_int]
         L.orc_c.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_double)]
         L.orc_cdg.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_double)]
+        L.orc_set_threads.argtypes = [C.c_int]
         _lib = L
     return _lib
 

@@ -47,7 +47,8 @@ def test_partition_and_staged_exchange_gloo_cpu(case, size):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("case,size", [("c_nb5_half", 2), ("c_nb7_half", 3), ("norb2_normal_JxJp", 2), ("phonons_norb2_JxJp", 2), ("nb5_offhalf_2_4", 4)])
+@pytest.mark.parametrize("case,size", [("c_nb5_half", 2), ("c_nb7_half", 3), ("norb2_normal_JxJp", 2), ("phonons_norb2_JxJp", 2), ("nb5_offhalf_2_4", 4),
+                                       ("orbs_norb2_nb3", 2), ("orbs_norb2_nb3_uneven", 3), ("phonons_orbs", 2)])
 def test_multirank_on_one_gpu_callback_exchange(edgpu_mod, case, size):
     import cases
     from oracle import oracle
@@ -67,6 +68,15 @@ def test_multirank_on_one_gpu_callback_exchange(edgpu_mod, case, size):
                 np.testing.assert_allclose(v, a1, rtol=1e-9, atol=1e-9)
             if k.startswith("b_"):
                 np.testing.assert_allclose(v, b1, rtol=1e-9, atol=1e-9)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case,size", [("c_nb5_half", 2), ("norb2_normal_JxJp", 3), ("orbs_norb2_nb3", 2), ("phonons_nb3_nph3", 2), ("phonons_orbs", 2)])
+def test_multirank_legs_observables_twin(edgpu_mod, case, size):
+    """GF / chi / phonon legs, impurity histogram + density matrix and the twin-sector hand-off with the
+    state split over ranks: same numbers as the single-rank library and the oracle's apply_op."""
+    res = _launch("legs", case, size)
+    assert all(r["ok"] for r in res) and res[0]["nlegs"] >= 2
 
 
 @pytest.mark.gpu
