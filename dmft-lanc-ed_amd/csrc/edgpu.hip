@@ -551,9 +551,12 @@ int edgpu_lanczos_bench_steps(edgpu_handle h, int32_t nsteps, int32_t timed)
         const int k = h->bench_k;
         if (timed) {   // lz_iter with the product bracketed by events
             HIPCHK(hipEventRecord(h->bench_ev[2 * i], h->stream));
-            CHK(hxv(h, V.ucur, V.w, true, V.uprev));
+            if (!h->multi) h->fuse_mode = 0;          // as lz_iter: the alpha step rides on the product's final reduction
+            const int rc = hxv(h, V.ucur, V.w, true, V.uprev);
+            h->fuse_mode = -1;
+            if (rc) return rc;
             HIPCHK(hipEventRecord(h->bench_ev[2 * i + 1], h->stream));
-            CHK(lz_iter_tail(h, V, k, nullptr));
+            CHK(lz_iter_tail(h, V, k, nullptr, !h->multi));
         } else
             CHK(lz_iter(h, V, k, nullptr));
         h->bench_k++;

@@ -16,7 +16,7 @@ namespace edgpu {
 constexpr int kMaxTerms = 256;
 
 // scalars of the Lanczos recurrence, resident in HBM so the loop needs no host round trip
-enum { SC_SCUR = 0, SC_SPREV = 1, SC_BETA = 2, SC_ALPHA = 3, SC_TMP = 4, SC_ZK = 5, SC_COUNT = 8 };
+enum { SC_SCUR = 0, SC_SPREV = 1, SC_BETA = 2, SC_ALPHA = 3, SC_TMP = 4, SC_ZK = 5, SC_K = 6, SC_COUNT = 8 };   // SC_K: iteration counter kept on the device (fused reduce+step kernels)
 
 struct DiagArgs {  // bit-exact diagonal (stored/H_local.f90:13-71, stored/Orbs/H_local.f90:1-80)
     int32_t Norb, Nspin, Nbath, Nfoo, hfmode, total_ud, Ns_Ud;
@@ -633,12 +633,73 @@ struct TabArgs {
     double *E;
 };
 
-__global__ void __launch_bounds__(256) k_direct_tables(TabArgs A)
+// emit one finished row (entries sorted by column in row buffers cj/cv/ct, n valid) into every image
+#define TAB_EMIT_ROW(CJ, CV, CT)                                                                                         \
+    do {                                                                                                                 \
+        if (A.pcols) {                                                                                                   \
+            const int ncw = (A.width + 1) >> 1, ndw = (A.width + 3) >> 2;                                                \
+            for (int c = 0; c < ncw; c++) {                                                                              \
+                uint32_t wd_ = 0;                                                                                         \
+                for (int e = 0; e < 2; e++) { const int q = 2 * c + e; wd_ |= (uint32_t)(q < n ? CJ(q) : i) << (16 * e); } \
+                A.pcols[(int64_t)c * A.dim + i] = wd_;                                                                   \
+            }                                                                                                            \
+            for (int c = 0; c < ndw; c++) {                                                                              \
+                uint32_t wd_ = 0;                                                                                         \
+                for (int e = 0; e < 4; e++) { const int q = 4 * c + e; wd_ |= (uint32_t)(q < n ? CT(q) : 127u) << (8 * e); } \
+                A.pcodes[(int64_t)c * A.dim + i] = wd_;                                                                  \
+            }                                                                                                            \
+        }                                                                                                                \
+        if (A.pelem8) {                                                                                                  \
+            for (int c = 0; c < 5; c++) {                                                                                \
+                uint32_t wd_ = 0;                                                                                         \
+                for (int e = 0; e < 2; e++) { const int q = 2 * c + e; wd_ |= (uint32_t)(q < n ? CJ(q) : i) << (16 * e); } \
+                A.pelem8[(int64_t)8 * i + c] = wd_;                                                                      \
+            }                                                                                                            \
+            for (int c = 0; c < 3; c++) {                                                                                \
+                uint32_t wd_ = 0;                                                                                         \
+                for (int e = 0; e < 4; e++) { const int q = 4 * c + e; wd_ |= (uint32_t)(q < n ? CT(q) : 127u) << (8 * e); } \
+                A.pelem8[(int64_t)8 * i + 5 + c] = wd_;                                                                  \
+            }                                                                                                            \
+        }                                                                                                                \
+        if (A.pelem) {                                                                                                   \
+            for (int c = 0; c < 4; c++) {                                                                                \
+                uint32_t wd_ = 0;                                                                                         \
+                for (int e = 0; e < 2; e++) { const int q = 2 * c + e; wd_ |= (uint32_t)(q < n ? CJ(q) : i) << (16 * e); } \
+                A.pelem[(int64_t)6 * i + c] = wd_;                                                                       \
+            }                                                                                                            \
+            for (int c = 0; c < 2; c++) {                                                                                \
+                uint32_t wd_ = 0;                                                                                         \
+                for (int e = 0; e < 4; e++) { const int q = 4 * c + e; wd_ |= (uint32_t)(q < n ? CT(q) : 127u) << (8 * e); } \
+                A.pelem[(int64_t)6 * i + 4 + c] = wd_;                                                                   \
+            }                                                                                                            \
+        }                                                                                                                \
+        for (int k = 0; k < A.width; k++) {                                                                              \
+            int32_t j = k < n ? CJ(k) : i; double val = k < n ? CV(k) : 0.0;                                             \
+            int64_t o = A.transposed ? (int64_t)k * A.dim + i : (int64_t)i * A.width + k;                                \
+            A.ellc[o] = j; A.ellv[o] = val;                                                                              \
+        }                                                                                                                \
+        double e = 0.0;                                                                                                  \
+        for (int l = 0; l < A.nlev; l++) if (mi & (1u << l)) e += A.lin[l];                                              \
+        int ni = __popc(mi & A.impmask);                                                                                 \
+        e += A.pair * (double)(ni * (ni - 1) / 2);                                                                       \
+        A.E[i] = e;                                                                                                      \
+    } while (0)
+
+// General form: one lane per row, terms walked serially (any number of terms, duplicate (alpha,beta) pairs summed in
+// term order).  The row buffers live in LDS, [entry][lane]: as private arrays they are dynamically indexed, i.e.
+// scratch memory, and every dispatch of a scratch-using kernel pays a set-up of tens of microseconds.
+template <int MAXW>
+__global__ void __launch_bounds__(64) k_direct_tables(TabArgs A)
 {
+    __shared__ int32_t cj_s[MAXW][64]; __shared__ double cv_s[MAXW][64]; __shared__ uint8_t ct_s[MAXW][64];
+    const int lane = threadIdx.x;
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= A.dim) return;
     const uint32_t mi = (uint32_t)A.map[i];
-    int32_t cj[64]; double cv[64]; uint8_t ct[64]; int n = 0;
+    int n = 0;
+#define cj(q) cj_s[q][lane]
+#define cv(q) cv_s[q][lane]
+#define ct(q) ct_s[q][lane]
     for (int t = 0; t < A.nterms; t++) {
         const uint32_t ba = 1u << (A.talpha[t] - 1), bb = 1u << (A.tbeta[t] - 1);
         if (!(mi & ba) || (mi & bb)) continue;
@@ -648,59 +709,56 @@ __global__ void __launch_bounds__(256) k_direct_tables(TabArgs A)
         int32_t j = A.rank[mj];
         int p = n;
         bool dup = false;
-        for (int q = 0; q < n; q++) if (cj[q] == j) { cv[q] += val; dup = true; break; }
-        if (dup) continue;
-        while (p > 0 && cj[p - 1] > j) { cj[p] = cj[p - 1]; cv[p] = cv[p - 1]; ct[p] = ct[p - 1]; p--; }   // keep cols ascending
-        cj[p] = j; cv[p] = val; ct[p] = (uint8_t)(t | ((sg & 1) ^ (A.tval[t] < 0.0 ? 1 : 0) ? 0x80 : 0)); n++;
+        for (int q = 0; q < n; q++) if (cj(q) == j) { cv(q) += val; dup = true; break; }
+        if (dup || n >= MAXW) continue;
+        while (p > 0 && cj(p - 1) > j) { cj(p) = cj(p - 1); cv(p) = cv(p - 1); ct(p) = ct(p - 1); p--; }   // keep cols ascending
+        cj(p) = j; cv(p) = val; ct(p) = (uint8_t)(t | ((sg & 1) ^ (A.tval[t] < 0.0 ? 1 : 0) ? 0x80 : 0)); n++;
     }
-    if (A.pcols) {
-        const int ncw = (A.width + 1) >> 1, ndw = (A.width + 3) >> 2;
-        for (int c = 0; c < ncw; c++) {
-            uint32_t w = 0;
-            for (int e = 0; e < 2; e++) { const int q = 2 * c + e; w |= (uint32_t)(q < n ? cj[q] : i) << (16 * e); }
-            A.pcols[(int64_t)c * A.dim + i] = w;
-        }
-        for (int c = 0; c < ndw; c++) {
-            uint32_t w = 0;
-            for (int e = 0; e < 4; e++) { const int q = 4 * c + e; w |= (uint32_t)(q < n ? ct[q] : 127u) << (8 * e); }
-            A.pcodes[(int64_t)c * A.dim + i] = w;
-        }
-    }
-    if (A.pelem8) {
-        for (int c = 0; c < 5; c++) {
-            uint32_t w = 0;
-            for (int e = 0; e < 2; e++) { const int q = 2 * c + e; w |= (uint32_t)(q < n ? cj[q] : i) << (16 * e); }
-            A.pelem8[(int64_t)8 * i + c] = w;
-        }
-        for (int c = 0; c < 3; c++) {
-            uint32_t w = 0;
-            for (int e = 0; e < 4; e++) { const int q = 4 * c + e; w |= (uint32_t)(q < n ? ct[q] : 127u) << (8 * e); }
-            A.pelem8[(int64_t)8 * i + 5 + c] = w;
-        }
-    }
-    if (A.pelem) {
-        for (int c = 0; c < 4; c++) {
-            uint32_t w = 0;
-            for (int e = 0; e < 2; e++) { const int q = 2 * c + e; w |= (uint32_t)(q < n ? cj[q] : i) << (16 * e); }
-            A.pelem[(int64_t)6 * i + c] = w;
-        }
-        for (int c = 0; c < 2; c++) {
-            uint32_t w = 0;
-            for (int e = 0; e < 4; e++) { const int q = 4 * c + e; w |= (uint32_t)(q < n ? ct[q] : 127u) << (8 * e); }
-            A.pelem[(int64_t)6 * i + 4 + c] = w;
-        }
-    }
-    for (int k = 0; k < A.width; k++) {
-        int32_t j = k < n ? cj[k] : i; double val = k < n ? cv[k] : 0.0;
-        int64_t o = A.transposed ? (int64_t)k * A.dim + i : (int64_t)i * A.width + k;
-        A.ellc[o] = j; A.ellv[o] = val;
-    }
-    double e = 0.0;
-    for (int l = 0; l < A.nlev; l++) if (mi & (1u << l)) e += A.lin[l];
-    int ni = __popc(mi & A.impmask);
-    e += A.pair * (double)(ni * (ni - 1) / 2);
-    A.E[i] = e;
+    TAB_EMIT_ROW(cj, cv, ct);
+#undef cj
+#undef cv
+#undef ct
 }
+
+// Fast form (<= 64 terms with distinct (alpha,beta) pairs -- every 1-orbital model and most others): one WAVE per
+// row, one lane per term.  The serial form is a chain of dependent look-ups (term -> bit test -> rank table ->
+// sorted insert) and takes 25-35 us whatever the factor size; here each lane tests its term, the slot of a
+// surviving hop is the number of surviving hops with a smaller target pattern (columns ascend with the pattern),
+// found with 'nterms' readlane+compare steps, and lane 0 emits the row.
+__global__ void __launch_bounds__(256) k_direct_tables_wave(TabArgs A)
+{
+    __shared__ int32_t cj_s[4][64]; __shared__ double cv_s[4][64]; __shared__ uint8_t ct_s[4][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int i = blockIdx.x * 4 + w;
+    const bool row = i < A.dim;
+    const uint32_t mi = row ? (uint32_t)A.map[i] : 0u;
+    const bool in = row && lane < A.nterms;
+    const int ta = in ? A.talpha[lane] : 1, tb = in ? A.tbeta[lane] : 1;
+    const double tv = in ? A.tval[lane] : 0.0;
+    const uint32_t ba = 1u << (ta - 1), bb = 1u << (tb - 1);
+    const bool ok = in && (mi & ba) && !(mi & bb);
+    const uint32_t k1 = mi & ~ba, mj = k1 | bb;
+    const int sg = __popc(mj & (bb - 1)) + __popc(k1 & (ba - 1));   // c_beta on source, c^+_alpha on k1
+    const int32_t j = row ? A.rank[ok ? mj : mi] : 0;
+    const uint32_t key = ok ? mj : 0xffffffffu;
+    int p = 0;
+    for (int u = 0; u < A.nterms; u++) p += (__shfl(key, u) < key) ? 1 : 0;
+    const int n = __popcll(__ballot(ok));
+    if (ok) {
+        cj_s[w][p] = j; cv_s[w][p] = (sg & 1) ? -tv : tv;
+        ct_s[w][p] = (uint8_t)(lane | ((sg & 1) ^ (tv < 0.0 ? 1 : 0) ? 0x80 : 0));
+    }
+    __syncthreads();
+    if (!row || lane != 0) return;
+#define cj(q) cj_s[w][q]
+#define cv(q) cv_s[w][q]
+#define ct(q) ct_s[w][q]
+    TAB_EMIT_ROW(cj, cv, ct);
+#undef cj
+#undef cv
+#undef ct
+}
+#undef TAB_EMIT_ROW
 
 // ---------------------------------------------------------------------------------------------
 // Explicit CSR (storage=CSR): expansion of the Kronecker sum, then a row-block streaming SpMV.
@@ -982,15 +1040,32 @@ __global__ void __launch_bounds__(256) k_axpy_norm(double *__restrict__ w, const
 // scalar bookkeeping, one thread.  mode 0: alpha = TMP ; store alphas[k].
 // mode 1: beta = sqrt(TMP) ; store betas[k+1] ; rotate scales (s_prev=s_cur, s_cur=1/beta).
 // mode 2: start: s_cur = 1/sqrt(TMP), s_prev = 0, beta = 0.   mode 3: ZK = zvec[k].
+__device__ __forceinline__ void scalar_step(double *scal, double *alphas, double *betas, const double *zvec, int k, int mode)
+{
+    if (k < 0) k = (int)scal[SC_K];      // device-side iteration counter
+    if (mode == 0) { scal[SC_ALPHA] = scal[SC_TMP]; alphas[k] = scal[SC_TMP]; if (zvec) scal[SC_ZK] = zvec[k]; }
+    else if (mode == 1) {
+        double b = sqrt(scal[SC_TMP]);
+        betas[k + 1] = b; scal[SC_BETA] = b; scal[SC_SPREV] = scal[SC_SCUR]; scal[SC_SCUR] = b > 0.0 ? 1.0 / b : 0.0; scal[SC_K] = (double)(k + 1);
+    } else if (mode == 2) { scal[SC_SCUR] = 1.0 / sqrt(scal[SC_TMP]); scal[SC_SPREV] = 0.0; scal[SC_BETA] = 0.0; scal[SC_ALPHA] = 0.0; scal[SC_ZK] = 0.0; scal[SC_K] = 0.0; }
+    else if (mode == 3) { scal[SC_ZK] = zvec ? zvec[k] : 0.0; }
+}
 __global__ void k_scalar_step(double *scal, double *alphas, double *betas, const double *zvec, int k, int mode)
 {
     if (threadIdx.x | blockIdx.x) return;
-    if (mode == 0) { scal[SC_ALPHA] = scal[SC_TMP]; alphas[k] = scal[SC_TMP]; }
-    else if (mode == 1) {
-        double b = sqrt(scal[SC_TMP]);
-        betas[k + 1] = b; scal[SC_BETA] = b; scal[SC_SPREV] = scal[SC_SCUR]; scal[SC_SCUR] = b > 0.0 ? 1.0 / b : 0.0;
-    } else if (mode == 2) { scal[SC_SCUR] = 1.0 / sqrt(scal[SC_TMP]); scal[SC_SPREV] = 0.0; scal[SC_BETA] = 0.0; scal[SC_ALPHA] = 0.0; scal[SC_ZK] = 0.0; }
-    else if (mode == 3) { scal[SC_ZK] = zvec ? zvec[k] : 0.0; }
+    scalar_step(scal, alphas, betas, mode == 0 ? nullptr : zvec, k, mode);
+}
+
+// final reduction fused with the scalar step that consumes it (single rank: no all-reduce in between):
+// scal[TMP] = sum(in[0..n)) in the same fixed order as k_reduce_final, then step `mode` with the device counter
+__global__ void __launch_bounds__(1024) k_reduce_final_step(const double *__restrict__ in, int64_t n, double *scal, double *alphas, double *betas,
+                                                            const double *zvec, int mode)
+{
+    __shared__ double red[16];
+    double s = 0.0;
+    for (int64_t i = threadIdx.x; i < n; i += blockDim.x) s += in[i];
+    double r = block_sum(s, red);
+    if (threadIdx.x == 0) { scal[SC_TMP] = r; scalar_step(scal, alphas, betas, zvec, -1, mode); }
 }
 
 // x[i] *= scal[idx]
@@ -1121,7 +1196,8 @@ __global__ void __launch_bounds__(256) k_imp_hist_rows(HistArgs A)
 #pragma unroll
         for (int q = 0; q < 32; q++) if (q == c) acc[q] += x * x;
     }
-    for (int c = 0; c < A.nI; c++) { double r = block_sum(acc[c], red); if (threadIdx.x == 0) A.out[row * A.nI + c] = r; }
+#pragma unroll
+    for (int c = 0; c < 32; c++) if (c < A.nI) { double r = block_sum(acc[c], red); if (threadIdx.x == 0) A.out[row * A.nI + c] = r; }   // uniform guard, registers only
 }
 // generic digit layout (ed_total_ud=F): LDS histogram with fp64 atomics (summation order not fixed)
 struct HistGenArgs { int32_t nfac, nI, DimPh; int32_t dims[2 * EDGPU_MAX_ORB]; const int32_t *maps[2 * EDGPU_MAX_ORB]; int64_t Nel, row0; const double *v; double *out; };
@@ -1165,9 +1241,12 @@ __global__ void __launch_bounds__(256) k_multidot(BasisArgs B, const double *__r
 #pragma unroll
         for (int i = 0; i <= kMaxBasis; i++) if (i < B.nv) acc[i] += B.V[i][e] * x;
     }
-    for (int i = 0; i < B.nv; i++) {
-        double r = block_sum(acc[i], red);
-        if (threadIdx.x == 0) partial[(int64_t)blockIdx.x * B.nv + i] = r;
+#pragma unroll
+    for (int i = 0; i <= kMaxBasis; i++) {     // unrolled with a uniform guard: acc[] stays in registers (no scratch)
+        if (i < B.nv) {
+            double r = block_sum(acc[i], red);
+            if (threadIdx.x == 0) partial[(int64_t)blockIdx.x * B.nv + i] = r;
+        }
     }
 }
 // out[i] = sum_b partial[b*nv+i], single workgroup, fixed order

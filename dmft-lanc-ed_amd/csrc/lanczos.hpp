@@ -108,24 +108,52 @@ static int lz_start(S *s, LzVecs &V)
 }
 
 // iteration k (0-based): fills alphas[k], betas[k+1]; optional eigenvector accumulation
-static int lz_iter_tail(S *s, LzVecs &V, int k, double *acc)
+static int lz_iter_tail(S *s, LzVecs &V, int k, double *acc, bool alpha_done = false)
 {
-    hipLaunchKernelGGL(k_scalar_step, dim3(1), dim3(1), 0, s->stream, s->scal.p, s->alphas.p, s->betas.p, (const double *)nullptr, k, 0);
-    if (acc) hipLaunchKernelGGL(k_scalar_step, dim3(1), dim3(1), 0, s->stream, s->scal.p, s->alphas.p, s->betas.p, (const double *)s->zvec.p, k, 3);
+    if (!alpha_done) {
+        hipLaunchKernelGGL(k_scalar_step, dim3(1), dim3(1), 0, s->stream, s->scal.p, s->alphas.p, s->betas.p, (const double *)nullptr, k, 0);
+        if (acc) hipLaunchKernelGGL(k_scalar_step, dim3(1), dim3(1), 0, s->stream, s->scal.p, s->alphas.p, s->betas.p, (const double *)s->zvec.p, k, 3);
+    }
     int nb = (int)std::max<int64_t>(1, std::min<int64_t>(cdiv(s->nloc, 256 * 4), 4096));
     hipLaunchKernelGGL(k_axpy_norm, dim3(nb), dim3(256), 0, s->stream, V.w, V.ucur, acc, s->scal.p, s->nloc, s->partial.p);
-    hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(1024), 0, s->stream, s->partial.p, (int64_t)nb, s->scal.p + SC_TMP);
-    HIPCHK(hipGetLastError());
-    CHK(allreduce_tmp(s));
-    hipLaunchKernelGGL(k_scalar_step, dim3(1), dim3(1), 0, s->stream, s->scal.p, s->alphas.p, s->betas.p, (const double *)nullptr, k, 1);
-    HIPCHK(hipGetLastError());
+    if (!s->multi) {   // no all-reduce between the sum and the step that uses it: one launch
+        hipLaunchKernelGGL(k_reduce_final_step, dim3(1), dim3(1024), 0, s->stream, s->partial.p, (int64_t)nb, s->scal.p, s->alphas.p, s->betas.p, (const double *)nullptr, 1);
+        HIPCHK(hipGetLastError());
+    } else {
+        hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(1024), 0, s->stream, s->partial.p, (int64_t)nb, s->scal.p + SC_TMP);
+        HIPCHK(hipGetLastError());
+        CHK(allreduce_tmp(s));
+        hipLaunchKernelGGL(k_scalar_step, dim3(1), dim3(1), 0, s->stream, s->scal.p, s->alphas.p, s->betas.p, (const double *)nullptr, k, 1);
+        HIPCHK(hipGetLastError());
+    }
     double *t = V.uprev; V.uprev = V.ucur; V.ucur = V.w; V.w = t;
     return EDGPU_OK;
 }
 static int lz_iter(S *s, LzVecs &V, int k, double *acc)
 {
+    if (!s->multi) {   // alpha step rides on the product's final reduction (device counter == k by construction)
+        s->fuse_mode = 0; s->fuse_zvec = acc ? s->zvec.p : nullptr;
+        int rc = hxv(s, V.ucur, V.w, true, V.uprev);
+        s->fuse_mode = -1; s->fuse_zvec = nullptr;
+        if (rc) return rc;
+        return lz_iter_tail(s, V, k, acc, true);
+    }
     CHK(hxv(s, V.ucur, V.w, true, V.uprev));
     return lz_iter_tail(s, V, k, acc);
+}
+
+// Small sectors are launch bound (an iteration is 4 short kernels, ~4.5 us each on the device side): what helps
+// there is fewer launches (the fused reduce+step kernels above) and fewer host round trips (chunked stopping-rule
+// checks in lanczos_gs).  Replaying three captured iterations as a HIP graph was measured and gave nothing over
+// back-to-back asynchronous launches (200 iterations at N=4900: 3.64 ms vs 3.68 ms) -- not kept.
+static bool lz_small(S *s)
+{
+    return !s->multi && s->nloc <= (int64_t)dbg_int("EDGPU_SMALL_MAXN", 1 << 22);
+}
+static int lz_iters(S *s, LzVecs &V, int k, int count, double *acc)
+{
+    for (const int kend = k + count; k < kend; k++) CHK(lz_iter(s, V, k, acc));
+    return EDGPU_OK;
 }
 
 static int fetch_coeffs(S *s, int k, std::vector<double> &al, std::vector<double> &be)
@@ -160,14 +188,22 @@ static int lanczos_gs(S *s, int nitermax, double threshold, int ncheck, double *
     CHK(lz_start(s, V));
     std::vector<double> al, be;
     int nlanc = 0; double esave = 0.0, e0 = 0.0;
-    for (int k = 0; k < nitermax; k++) {
-        CHK(lz_iter(s, V, k, nullptr));
-        CHK(fetch_coeffs(s, k, al, be));
-        nlanc = k + 1;
-        if (std::fabs(be[k + 1]) < threshold) break;       // invariant subspace reached
-        if (!tridiag_lowest(al.data(), be.data(), nlanc, &e0, nullptr)) return fail(EDGPU_ENOTCONVERGED, "edgpu: tridiagonal QL did not converge");
-        if (nlanc >= ncheck && std::fabs(e0 - esave) <= threshold) break;
-        esave = e0;
+    // The stopping rule of iteration i only involves alpha/beta up to i, so iterations can be issued ahead of
+    // the host check: small (launch-bound) sectors run `chunk` iterations per host round trip and then apply
+    // the rule to each of them in order -- same nlanc and E0, at most chunk-1 surplus iterations.
+    const int chunk = lz_small(s) ? std::max(1, dbg_int("EDGPU_LZ_CHUNK", 6)) : 1;
+    bool done = false;
+    for (int k = 0; k < nitermax && !done;) {
+        const int kend = std::min(nitermax, k + chunk);
+        CHK(lz_iters(s, V, k, kend - k, nullptr));
+        CHK(fetch_coeffs(s, kend - 1, al, be));
+        for (; k < kend; k++) {
+            nlanc = k + 1;
+            if (std::fabs(be[k + 1]) < threshold) { done = true; break; }       // invariant subspace reached
+            if (!tridiag_lowest(al.data(), be.data(), nlanc, &e0, nullptr)) return fail(EDGPU_ENOTCONVERGED, "edgpu: tridiagonal QL did not converge");
+            if (nlanc >= ncheck && std::fabs(e0 - esave) <= threshold) { done = true; break; }
+            esave = e0;
+        }
     }
     std::vector<double> z;
     if (!tridiag_lowest(al.data(), be.data(), nlanc, &e0, &z)) return fail(EDGPU_ENOTCONVERGED, "edgpu: tridiagonal QL did not converge");
@@ -178,7 +214,7 @@ static int lanczos_gs(S *s, int nitermax, double threshold, int ncheck, double *
     V = LzVecs{s->lz[0].p, s->lz[1].p, s->lz[2].p};
     HIPCHK(hipMemcpyAsync(V.ucur, start, (size_t)s->nloc * 8, hipMemcpyDeviceToDevice, s->stream));
     CHK(lz_start(s, V));
-    for (int k = 0; k < nlanc; k++) CHK(lz_iter(s, V, k, acc));
+    CHK(lz_iters(s, V, 0, nlanc, acc));
     CHK(reduce_dot(s, acc, acc));
     hipLaunchKernelGGL(k_scalar_step, dim3(1), dim3(1), 0, s->stream, s->scal.p, s->alphas.p, s->betas.p, (const double *)nullptr, 0, 2);
     int nb = (int)std::max<int64_t>(1, std::min<int64_t>(cdiv(s->nloc, 256 * 4), 4096));
@@ -202,7 +238,7 @@ static int lanczos_tridiag(S *s, const double *vin_dev, int nlanc, double thresh
     const int chunk = 8;  // look at beta on the host every `chunk` iterations
     for (int k = 0; k < nlanc;) {
         int kend = std::min(nlanc, k + chunk);
-        for (; k < kend; k++) CHK(lz_iter(s, V, k, nullptr));
+        CHK(lz_iters(s, V, k, kend - k, nullptr)); k = kend;
         CHK(fetch_coeffs(s, k - 1, al, be));
         bool stop = false;
         for (int i = used; i < k; i++) {

@@ -18,7 +18,8 @@ static int reduce_partials(S *s, int64_t n)
         hipLaunchKernelGGL(k_reduce_chunks, dim3(nb), dim3(256), 0, s->stream, src, n, chunk, s->partial2.p);
         src = s->partial2.p; n = nb;
     }
-    hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(1024), 0, s->stream, src, n, s->scal.p + SC_TMP);
+    if (s->fuse_mode >= 0) hipLaunchKernelGGL(k_reduce_final_step, dim3(1), dim3(1024), 0, s->stream, src, n, s->scal.p, s->alphas.p, s->betas.p, s->fuse_zvec, s->fuse_mode);
+    else hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(1024), 0, s->stream, src, n, s->scal.p + SC_TMP);
     HIPCHK(hipGetLastError());
     return EDGPU_OK;
 }
@@ -60,7 +61,13 @@ static int direct_tables(S *s)
         T.ellc = f.ellc.p; T.ellv = f.ellv.p; T.lin = f.lin.p; T.nlev = H.fac[k].nbits;
         T.pcols = f.packed ? f.pcols.p : nullptr; T.pcodes = f.packed ? f.pcodes.p : nullptr; T.pelem = f.packed_elem ? f.pelem.p : nullptr; T.pelem8 = f.packed_elem8 ? f.pelem8.p : nullptr;
         T.impmask = d.ed_total_ud ? (1 << d.Norb) - 1 : 0; T.pair = d.ed_total_ud ? d.Ust - d.Jh : 0.0; T.E = f.E.p;
-        hipLaunchKernelGGL(k_direct_tables, dim3((unsigned)cdiv(T.dim, 256)), dim3(256), 0, s->stream, T);
+        const auto &tm = H.fac[k].terms;
+        bool wave_ok = tm.size() <= 64 && f.width <= 64;
+        for (size_t a = 0; a < tm.size() && wave_ok; a++)
+            for (size_t b = a + 1; b < tm.size(); b++) if (tm[a].alpha == tm[b].alpha && tm[a].beta == tm[b].beta) { wave_ok = false; break; }
+        if (wave_ok && dbg_int("EDGPU_TABLES_WAVE", 1)) hipLaunchKernelGGL(k_direct_tables_wave, dim3((unsigned)cdiv(T.dim, 4)), dim3(256), 0, s->stream, T);
+        else if (f.width <= 16) hipLaunchKernelGGL(k_direct_tables<16>, dim3((unsigned)cdiv(T.dim, 64)), dim3(64), 0, s->stream, T);
+        else hipLaunchKernelGGL(k_direct_tables<64>, dim3((unsigned)cdiv(T.dim, 64)), dim3(64), 0, s->stream, T);
     }
     HIPCHK(hipGetLastError());
     return EDGPU_OK;

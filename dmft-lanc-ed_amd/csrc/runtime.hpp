@@ -148,6 +148,8 @@ struct edgpu_sector_s {
     std::vector<hipEvent_t> bench_ev; int bench_k = 0; double *bv[3] = {nullptr, nullptr, nullptr};
     int64_t nnz_total = 0, bytes_stored = 0;
     int64_t npartial = 0;
+    // Lanczos iteration fusion (single rank)
+    int fuse_mode = -1; const double *fuse_zvec = nullptr;   // >= 0: the product's final reduction also performs this scalar step
 };
 
 namespace edgpu {
