@@ -241,6 +241,38 @@ def test_c3_full_size_properties(edgpu_mod):
         np.testing.assert_allclose(coeffs[st][1], coeffs["kron"][1], rtol=1e-10, atol=1e-10)
 
 
+def test_c4_full_size_64bit_indexing(edgpu_mod):
+    """BASELINE config 4 (Ns=18, N=2,363,904,400 > 2^31: the reference's int32 row index overflows here,
+    direct_mpi/HxV_local.f90:2-5) on ONE GPU with on-the-fly storage: H symmetric on random vectors, and the
+    first Lanczos coefficients equal to those of the stored (KRON) format, which runs different local kernels."""
+    from edgpu import model
+    m, nu, nd = model.half_filled_c(17)
+    N = 2363904400
+    G = edgpu_mod.HvSector(m, nu, nd, storage="direct")
+    assert G.Dim == N and G.isector == 1 + 9 * 19 + 9 and G.vecDim == N
+    rng = np.random.default_rng(7)
+    du, dv, dh = edgpu_mod.DeviceVector(N), edgpu_mod.DeviceVector(N), edgpu_mod.DeviceVector(N)
+    u = rng.random(N) - 0.5; du.upload(u)
+    v = rng.random(N) - 0.5; dv.upload(v)
+    G.spHtimesV_device(dv, dh); h = dh.download()
+    a = float(u @ h); scale = float(np.abs(u) @ np.abs(h))
+    G.spHtimesV_device(du, dh); h = dh.download()
+    b = float(h @ v)
+    assert abs(a - b) <= 1e-12 * scale
+    del u, v, h
+    du.free(); dv.free(); dh.free()
+    G.bench_begin(5); G.bench_steps(3)
+    _, a_d, b_d = G.bench_result(0, ncoef=3)
+    G.close()
+    G = edgpu_mod.HvSector(m, nu, nd, storage="kron")
+    G.bench_begin(5); G.bench_steps(3)
+    _, a_k, b_k = G.bench_result(0, ncoef=3)
+    G.close()
+    np.testing.assert_allclose(a_d, a_k, rtol=1e-10, atol=1e-10)
+    np.testing.assert_allclose(b_d, b_k, rtol=1e-10, atol=1e-10)
+    assert np.all(np.isfinite(a_d)) and np.all(b_d > 0)
+
+
 def test_edge_sectors(edgpu_mod):
     """Degenerate shapes the reference can meet: one-state sectors, no hopping at all (V=0: empty H_up/H_dw),
     five orbitals, the largest phonon cut-off used in the zoo, and a sector with a single dw column."""
