@@ -21,6 +21,10 @@ program demo_c1
   integer :: N, i, nlanc, isparse
   logical :: sparse_H
   type(sparse_matrix_gpu) :: spA
+  type(sector_gpu) :: Ssrc
+  real(8) :: norm2, hist(4), agf(20), bgf(20), achi(20), bchi(20)
+  real(8), allocatable :: gs(:), tw(:)
+  integer :: nused
   real(8) :: dense(3,3), xv(3), yv(3)
   impHloc = 0d0
   bath_diag(1,1,:) = [-2d0, -1d0, 0d0, 1d0, 2d0]
@@ -52,6 +56,31 @@ program demo_c1
      spHtimesV_p => null()
      call delete_Hv_sector_gpu()
   end do
+  ! callers either side of the product: ground state of (3,3), its impurity weights, one particle (c^+_up -> sector
+  ! (4,3)) Green's-function leg, a spin-susceptibility leg and the twin hand-off, all through the Fortran wrappers
+  call build_Hv_sector_gpu(Norb, Nspin, Nbath, 0, "normal", .true., .true., .true., [3], [3], &
+       Uloc, 0d0, 0d0, 0d0, 0d0, 0d0, 0d0, g_ph, impHloc, diag_hybr, bath_diag)
+  allocate(gs(N), tw(N)); gs = 0d0
+  call sp_lanc_eigh_gpu(egs, gs, min(N, 512), threshold=1d-14)
+  call imp_histogram_gpu(gs, hist)
+  write(*,"(A,ES24.16)") "docc=", hist(4)
+  write(*,"(A,ES24.16)") "hist_sum=", sum(hist)
+  call lanc_chi_leg_gpu([0.5d0], [-0.5d0], gs, achi, bchi, norm2, nused)
+  write(*,"(A,ES24.16)") "chi_norm2=", norm2
+  write(*,"(A,2ES24.16)") "chi_alanc_1_2=", achi(1:2)
+  call twin_reorder_gpu(gs, tw)
+  write(*,"(A,ES24.16)") "twin_overlap=", abs(dot_product(gs, tw))
+  call delete_Hv_sector_gpu()
+  call create_sector_gpu(Ssrc, Norb, Nspin, Nbath, 0, "normal", .true., .false., .true., [3], [3], &
+       Uloc, 0d0, 0d0, 0d0, 0d0, 0d0, 0d0, g_ph, impHloc, diag_hybr, bath_diag)
+  call build_Hv_sector_gpu(Norb, Nspin, Nbath, 0, "normal", .true., .true., .true., [4], [3], &
+       Uloc, 0d0, 0d0, 0d0, 0d0, 0d0, 0d0, g_ph, impHloc, diag_hybr, bath_diag)
+  call lanc_gf_leg_gpu(Ssrc, 1, 1, .true., gs, agf, bgf, norm2, nused)
+  write(*,"(A,ES24.16)") "gf_norm2=", norm2
+  write(*,"(A,2ES24.16)") "gf_alanc_1_2=", agf(1:2)
+  write(*,"(A,ES24.16)") "gf_blanc_2=", bgf(2)
+  call delete_Hv_sector_gpu()
+  call delete_sector_gpu(Ssrc)
   ! sparse container: duplicate-summing insert, dense dump, product on the device
   call sp_init_matrix_gpu(spA, 3)
   call sp_insert_element_gpu(spA, 2d0, 1, 1); call sp_insert_element_gpu(spA, -1d0, 1, 3)

@@ -112,6 +112,79 @@ module EDGPU_C_API
        integer(c_int32_t)        :: nconv, nrestarts, nmatvec
        integer(c_int)            :: rc
      end function edgpu_eigsh
+     function edgpu_gf_lanczos(hfrom, hto, iorb, ispin, dagger, state, nlanc, threshold, norm2, alanc, blanc, nused) &
+          bind(C, name="edgpu_gf_lanczos") result(rc)
+       import :: c_int, c_int32_t, c_double, c_ptr
+       type(c_ptr), value         :: hfrom, hto
+       integer(c_int32_t), value  :: iorb, ispin, dagger, nlanc
+       real(c_double), intent(in) :: state(*)
+       real(c_double), value      :: threshold
+       real(c_double)             :: norm2, alanc(*), blanc(*)
+       integer(c_int32_t)         :: nused
+       integer(c_int)             :: rc
+     end function edgpu_gf_lanczos
+     function edgpu_chi_lanczos(handle, cup, cdw, state, nlanc, threshold, norm2, alanc, blanc, nused) &
+          bind(C, name="edgpu_chi_lanczos") result(rc)
+       import :: c_int, c_int32_t, c_double, c_ptr
+       type(c_ptr), value         :: handle
+       real(c_double), intent(in) :: cup(*), cdw(*), state(*)
+       integer(c_int32_t), value  :: nlanc
+       real(c_double), value      :: threshold
+       real(c_double)             :: norm2, alanc(*), blanc(*)
+       integer(c_int32_t)         :: nused
+       integer(c_int)             :: rc
+     end function edgpu_chi_lanczos
+     function edgpu_phonon_lanczos(handle, state, nlanc, threshold, norm2, alanc, blanc, nused) &
+          bind(C, name="edgpu_phonon_lanczos") result(rc)
+       import :: c_int, c_int32_t, c_double, c_ptr
+       type(c_ptr), value         :: handle
+       real(c_double), intent(in) :: state(*)
+       integer(c_int32_t), value  :: nlanc
+       real(c_double), value      :: threshold
+       real(c_double)             :: norm2, alanc(*), blanc(*)
+       integer(c_int32_t)         :: nused
+       integer(c_int)             :: rc
+     end function edgpu_phonon_lanczos
+     function edgpu_imp_histogram(handle, vec, vec_on_device, hist) bind(C, name="edgpu_imp_histogram") result(rc)
+       import :: c_int, c_int32_t, c_double, c_ptr
+       type(c_ptr), value         :: handle
+       real(c_double), intent(in) :: vec(*)
+       integer(c_int32_t), value  :: vec_on_device
+       real(c_double)             :: hist(*)
+       integer(c_int)             :: rc
+     end function edgpu_imp_histogram
+     function edgpu_imp_density_offdiag(handle, vec, dm) bind(C, name="edgpu_imp_density_offdiag") result(rc)
+       import :: c_int, c_double, c_ptr
+       type(c_ptr), value         :: handle
+       real(c_double), intent(in) :: vec(*)
+       real(c_double)             :: dm(*)
+       integer(c_int)             :: rc
+     end function edgpu_imp_density_offdiag
+     function edgpu_twin_reorder(handle, vin, vout) bind(C, name="edgpu_twin_reorder") result(rc)
+       import :: c_int, c_double, c_ptr
+       type(c_ptr), value         :: handle
+       real(c_double), intent(in) :: vin(*)
+       real(c_double)             :: vout(*)
+       integer(c_int)             :: rc
+     end function edgpu_twin_reorder
+     function edgpu_comm_unique_id(id128) bind(C, name="edgpu_comm_unique_id") result(rc)
+       import :: c_int, c_char
+       character(kind=c_char) :: id128(128)
+       integer(c_int)         :: rc
+     end function edgpu_comm_unique_id
+     function edgpu_comm_init_rccl(handle, id128) bind(C, name="edgpu_comm_init_rccl") result(rc)
+       import :: c_int, c_char, c_ptr
+       type(c_ptr), value                 :: handle
+       character(kind=c_char), intent(in) :: id128(128)
+       integer(c_int)                     :: rc
+     end function edgpu_comm_init_rccl
+     function edgpu_comm_init_callbacks(handle, allgatherv, exchange, allreduce, ctx) bind(C, name="edgpu_comm_init_callbacks") result(rc)
+       import :: c_int, c_ptr, c_funptr
+       type(c_ptr), value    :: handle
+       type(c_funptr), value :: allgatherv, exchange, allreduce    ! bind(C) procedures, see include/edgpu.h
+       type(c_ptr), value    :: ctx
+       integer(c_int)        :: rc
+     end function edgpu_comm_init_callbacks
      function edgpu_last_error() bind(C, name="edgpu_last_error") result(msg)
        import :: c_ptr
        type(c_ptr) :: msg

@@ -40,3 +40,40 @@ def test_fortran_driver_config1_matches_reference_known_answers():
         assert abs(f("E0")[0] - g["E0"]) < 1e-10
         e01 = f("E0E1")
         assert abs(e01[0] - g["E0"]) < 1e-10 and abs(e01[1] - g["E1"]) < 1e-10     # sp_eigh_gpu, 2 pairs
+
+
+@pytest.mark.gpu
+def test_fortran_driver_legs_and_observables():
+    """The Fortran wrappers of the callers either side of the product (lanc_gf_leg_gpu, lanc_chi_leg_gpu,
+    imp_histogram_gpu, twin_reorder_gpu) on config 1, against the oracle's dense ground state."""
+    import numpy as np
+    from oracle import oracle
+    from edgpu import model
+    if not os.path.exists(DEMO):
+        pytest.skip("Fortran demo not built (amdflang absent at build time)")
+    out = subprocess.run([DEMO], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300).stdout.decode()
+    f = lambda key: [float(x) for x in re.findall(r"[-+]?\d+\.\d+(?:[eE][-+]?\d+)?", re.search(key + r"=\s*(.*)", out).group(1))]
+    m, nu, nd = model.half_filled_c(5)
+    S = oracle.Sector(m, nu, nd)
+    w, U = np.linalg.eigh(S.hmat()); gs = U[:, 0]
+    obs = oracle.lanc_observables(S, gs)
+    assert abs(f("docc")[0] - float(np.ravel(obs["docc"])[0])) < 1e-7
+    assert abs(f("hist_sum")[0] - 1.0) < 1e-10
+    assert abs(f("twin_overlap")[0] - 1.0) < 1e-7          # (3,3) is its own twin; the ground state is non-degenerate
+    # Sz leg: vv = (n_up - n_dw)/2 |gs>
+    nup = np.zeros(S.Dim); ndw = np.zeros(S.Dim)
+    mu, md = S.map(0), S.map(1)
+    for i in range(S.Dim):
+        nup[i] = mu[i % S.DimUp] & 1; ndw[i] = md[i // S.DimUp] & 1
+    vv = 0.5 * (nup - ndw) * gs
+    n2 = float(vv @ vv)
+    a_ref, b_ref, _ = oracle.sp_lanc_tridiag(S.spmatvec, vv / np.sqrt(n2), 20)
+    assert abs(f("chi_norm2")[0] - n2) < 1e-7
+    np.testing.assert_allclose(f("chi_alanc_1_2"), a_ref[:2], atol=1e-6)
+    # particle leg c^+_up: sector (4,3)
+    St = oracle.Sector(m, [4], [3])
+    vref, n2ref = oracle.apply_op(S, St, 1, 1, True, gs)
+    a_ref, b_ref, _ = oracle.sp_lanc_tridiag(St.spmatvec, vref, 20)
+    assert abs(f("gf_norm2")[0] - n2ref) < 1e-7
+    np.testing.assert_allclose(f("gf_alanc_1_2"), a_ref[:2], atol=1e-6)
+    assert abs(f("gf_blanc_2")[0] - b_ref[1]) < 1e-6
