@@ -504,12 +504,13 @@ __global__ void __launch_bounds__(256) k_dwpass(DwArgs A)
 // Same pass with two iup per lane (16-byte loads/stores; needs DimUp even) and the Hdw rows of
 // the block staged in LDS once, which removes the per-lane table loads: ~5x fewer vector-memory
 // instructions per element than k_dwpass.
-template <bool EPI, bool NT>
+template <bool EPI, bool NT, bool RAGGED>   // RAGGED: rows have different hop counts (multi-orbital models): skip the ELL padding
 __global__ void __launch_bounds__(256) k_dwpass2(DwArgs A)
 {
     __shared__ double red[4];
     __shared__ double tv[64 * 64];     // [row in block][k]  (<= 64 rows x <= 64 hops)
     __shared__ int32_t tc[64 * 64];
+    __shared__ int32_t tn[64];
     const int xcd = blockIdx.x & 7; const int64_t sidx = blockIdx.x >> 3;
     const int64_t tl = sidx / A.chunks; const int chunk = (int)(sidx - tl * A.chunks);
     const int tile = (int)(tl * 8 + xcd);
@@ -523,6 +524,10 @@ __global__ void __launch_bounds__(256) k_dwpass2(DwArgs A)
             tv[t] = A.dwv[idw * A.dww + k]; tc[t] = A.dwc[idw * A.dww + k];
         }
         __syncthreads();
+        if (RAGGED) {
+            if ((int)threadIdx.x < rb) { int n = A.dww; while (n > 0 && tv[threadIdx.x * A.dww + n - 1] == 0.0) n--; tn[threadIdx.x] = n; }
+            __syncthreads();
+        }
         const int lpr = A.w >> 1;                    // lanes per row
         const int j = threadIdx.x & (lpr - 1), r0 = threadIdx.x >> (A.wshift - 1), rstep = 256 >> (A.wshift - 1);
         const int iup = tile * A.w + 2 * j;
@@ -534,7 +539,8 @@ __global__ void __launch_bounds__(256) k_dwpass2(DwArgs A)
                 const int64_t e = row * A.DimUp + iup, fbase = (int64_t)iph * A.DimDw * A.DimUp + iup;
                 dbl2v acc = {0.0, 0.0};
                 const double *tvr = tv + r * A.dww; const int32_t *tcr = tc + r * A.dww;
-                for (int k = 0; k < A.dww; k++) {
+                const int nk = RAGGED ? tn[r] : A.dww;   // hops of this row (ELL padding sits at the end: not gathered)
+                for (int k = 0; k < nk; k++) {
                     const dbl2v x = *reinterpret_cast<const dbl2v *>(A.vfull + fbase + (int64_t)tcr[k] * A.DimUp);
                     acc += tvr[k] * x;
                 }
@@ -549,6 +555,81 @@ __global__ void __launch_bounds__(256) k_dwpass2(DwArgs A)
             }
     }
     if (EPI) { double rr = block_sum(asum, red); if (threadIdx.x == 0) A.partial[blockIdx.x] = rr; }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Non-local pass of the split product: out += [s_cur *] (spin-exchange Jx + pair-hopping Jp terms),
+// stored/H_non_local.f90:21-83 / direct/HxV_non_local.f90 evaluated on the fly.  Both terms move one
+// impurity electron in EACH spin word, so for a row (idw) the dw word fixes which (a,b) pairs can act and the
+// partner row jdw; rows whose dw impurity bits allow nothing (half of them for two orbitals) are skipped
+// without touching memory, and inside a row only the configurations with the matching up impurity bits
+// gather (from the partner row, at an index that grows with iup) and are written back.
+// Term order per element = that of k_kron2 (a outer, b inner, Jx then Jp).
+// ---------------------------------------------------------------------------------------------
+struct NdArgs {
+    int32_t DimUp, DimDw, DimPh, Norb; int64_t Qdw, dw0;
+    const int32_t *mapup, *mapdw, *rankup, *rankdw;
+    double Jx, Jp;
+    const double *vfull; double *out; const double *scal;
+};
+template <bool EPI>
+__global__ void __launch_bounds__(256) k_ndpass(NdArgs A)
+{
+    __shared__ int32_t s_jdw[2 * EDGPU_MAX_ORB * EDGPU_MAX_ORB];      // partner row, -1: term cannot act on this row
+    __shared__ double s_t[2 * EDGPU_MAX_ORB * EDGPU_MAX_ORB];         // +-J with the sign of the dw word
+    __shared__ int s_any;
+    const int64_t row = blockIdx.x;
+    const int iph = (int)(row / A.Qdw);
+    const int64_t idwl = row - (int64_t)iph * A.Qdw, idw = A.dw0 + idwl;
+    const uint32_t mdw = (uint32_t)A.mapdw[idw];
+    const int nslot = 2 * A.Norb * A.Norb;
+    if (threadIdx.x == 0) s_any = 0;
+    __syncthreads();
+    if ((int)threadIdx.x < nslot) {
+        const int kind = threadIdx.x & 1, ab = threadIdx.x >> 1, a = ab / A.Norb, b = ab - a * A.Norb;
+        const uint32_t ba = 1u << a, bb = 1u << b;
+        int32_t jd = -1; double t = 0.0;
+        if (a != b) {
+            if (kind == 0 && A.Jx != 0.0 && (mdw & ba) && !(mdw & bb)) {
+                const uint32_t k1 = mdw & ~ba, k2 = k1 | bb;
+                const int sg = __popc(mdw & (ba - 1)) + __popc(k1 & (bb - 1));
+                jd = A.rankdw[k2]; t = (sg & 1) ? -A.Jx : A.Jx;
+            }
+            if (kind == 1 && A.Jp != 0.0 && (mdw & bb) && !(mdw & ba)) {
+                const uint32_t k1 = mdw & ~bb, k2 = k1 | ba;
+                const int sg = __popc(mdw & (bb - 1)) + __popc(k1 & (ba - 1));
+                jd = A.rankdw[k2]; t = (sg & 1) ? -A.Jp : A.Jp;
+            }
+        }
+        s_jdw[threadIdx.x] = jd; s_t[threadIdx.x] = t;
+        if (jd >= 0) s_any = 1;
+    }
+    __syncthreads();
+    if (!s_any) return;
+    const int DimUp = A.DimUp;
+    const int64_t rbase = row * DimUp, fbase = (int64_t)iph * A.DimDw * DimUp;
+    const double s_cur = EPI ? A.scal[SC_SCUR] : 1.0;
+    for (int iup = threadIdx.x; iup < DimUp; iup += blockDim.x) {
+        const uint32_t mup = (uint32_t)A.mapup[iup];
+        double acc = 0.0; bool hit = false;
+        for (int a = 0; a < A.Norb; a++)
+            for (int b = 0; b < A.Norb; b++) {
+                const uint32_t ba = 1u << a, bb = 1u << b;
+                if (a == b || !(mup & bb) || (mup & ba)) continue;
+                const uint32_t k3 = mup & ~bb, k4 = k3 | ba;
+                const int sgu = __popc(mup & (bb - 1)) + __popc(k3 & (ba - 1));
+                const int slot = 2 * (a * A.Norb + b);
+#pragma unroll
+                for (int kind = 0; kind < 2; kind++) {
+                    const int32_t jd = s_jdw[slot + kind];
+                    if (jd < 0) continue;
+                    const double t = (sgu & 1) ? -s_t[slot + kind] : s_t[slot + kind];
+                    acc += t * A.vfull[fbase + (int64_t)jd * DimUp + A.rankup[k4]];
+                    hit = true;
+                }
+            }
+        if (hit) A.out[rbase + iup] += s_cur * acc;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------

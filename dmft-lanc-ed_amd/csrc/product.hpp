@@ -129,10 +129,13 @@ static int hxv(S *s, const double *v, double *out, bool epi, const double *uprev
         if (dbg_flags() & 2) A.dww = 0;
         int base = (direct ? KF_DIRECT : 0) | (epi ? KF_EPI : 0) | (s->extra ? (KF_PH | KF_ND) : 0);
         nblocks = H.Qdw * H.DimPh;
-        const bool split = multi || (s->kron_split && !s->extra);
+        // phonon terms live in the fused kernel only; Jx/Jp (without phonons) have their own pass
+        const bool nd_pass = s->has_nd && !s->has_ph && s->nd_split;
+        const bool split = multi || (s->kron_split && (!s->extra || nd_pass));
         if (!split) CHK(dispatch_kron2(s, base | (s->use_lds ? KF_LDS : 0), A, nblocks));
         else {
-            const bool persistent = s->up_persistent && !s->extra && s->fac[0]->packed && s->fac[0]->width <= 16 && s->use_lds && H.DimUp <= 13312 && !direct_tables_dirty(s);
+            const bool plain = !s->extra || nd_pass;      // local pass = stored/on-the-fly diagonal + up hops only
+            const bool persistent = s->up_persistent && plain && s->fac[0]->packed && s->fac[0]->width <= 16 && s->use_lds && H.DimUp <= 13312 && !direct_tables_dirty(s);
             if (persistent && s->up_pairs && s->fac[0]->packed_elem) {
                 UpArgs2 U{};
                 U.DimUp = A.DimUp; U.DimPh = A.DimPh; U.Qdw = A.Qdw; U.dw0 = A.dw0; U.nrows = H.Qdw * H.DimPh;
@@ -182,7 +185,7 @@ static int hxv(S *s, const double *v, double *out, bool epi, const double *uprev
                 }
 #undef UP_LAUNCH
                 HIPCHK(hipGetLastError());
-            } else if (!s->use_lds && !s->extra && s->fac[0]->packed_elem8 && s->up_big) {
+            } else if (!s->use_lds && plain && s->fac[0]->packed_elem8 && s->up_big) {
                 UpBigArgs U{};
                 U.DimUp = A.DimUp; U.DimPh = A.DimPh; U.rsplit = s->row_split; U.Qdw = A.Qdw; U.dw0 = A.dw0; U.nrows = H.Qdw * H.DimPh;
                 U.packed8 = reinterpret_cast<const uint4 *>(s->fac[0]->pelem8.p); U.tval = s->fac[0]->ptval.p; U.nterms = s->fac[0]->pterms;
@@ -198,8 +201,17 @@ static int hxv(S *s, const double *v, double *out, bool epi, const double *uprev
             } else
                 CHK(dispatch_kron2(s, base | KF_NODW | (s->use_lds ? KF_LDS : 0), A, nblocks));
             if (multi) HIPCHK(hipStreamWaitEvent(s->stream, s->ev_gather, 0));
-            if (s->extra) CHK(dispatch_kron2(s, base | KF_NOLOCAL, A, nblocks));   // Jx/Jp and phonon cases: row-wise dw pass
+            if (s->extra && !nd_pass) CHK(dispatch_kron2(s, base | KF_NOLOCAL, A, nblocks));   // phonon cases: row-wise dw pass (+Jx/Jp)
             else {
+                if (nd_pass) {
+                    NdArgs Nd{};
+                    Nd.DimUp = A.DimUp; Nd.DimDw = A.DimDw; Nd.DimPh = A.DimPh; Nd.Norb = A.Norb; Nd.Qdw = A.Qdw; Nd.dw0 = A.dw0;
+                    Nd.mapup = A.mapup; Nd.mapdw = A.mapdw; Nd.rankup = A.rankup; Nd.rankdw = A.rankdw; Nd.Jx = A.Jx; Nd.Jp = A.Jp;
+                    Nd.vfull = A.vfull; Nd.out = out; Nd.scal = s->scal.p;
+                    if (epi) hipLaunchKernelGGL(k_ndpass<true>, dim3((unsigned)(H.Qdw * H.DimPh)), dim3(256), 0, s->stream, Nd);
+                    else hipLaunchKernelGGL(k_ndpass<false>, dim3((unsigned)(H.Qdw * H.DimPh)), dim3(256), 0, s->stream, Nd);
+                    HIPCHK(hipGetLastError());
+                }
                 DwArgs D{};
                 D.DimUp = A.DimUp; D.DimDw = A.DimDw; D.DimPh = A.DimPh; D.Qdw = A.Qdw; D.dw0 = A.dw0;
                 D.dwc = A.dwc; D.dwv = A.dwv; D.dww = A.dww; D.v = v; D.vfull = A.vfull; D.out = out; D.scal = s->scal.p; D.partial = s->partial.p;
@@ -213,12 +225,12 @@ static int hxv(S *s, const double *v, double *out, bool epi, const double *uprev
                 if (!vec2) {
                     if (epi) hipLaunchKernelGGL(k_dwpass<true>, dim3((unsigned)nblocks), dim3(256), 0, s->stream, D);
                     else hipLaunchKernelGGL(k_dwpass<false>, dim3((unsigned)nblocks), dim3(256), 0, s->stream, D);
-                } else if (dv == 2) {
-                    if (epi) hipLaunchKernelGGL((k_dwpass2<true, false>), dim3((unsigned)nblocks), dim3(256), 0, s->stream, D);
-                    else hipLaunchKernelGGL((k_dwpass2<false, false>), dim3((unsigned)nblocks), dim3(256), 0, s->stream, D);
                 } else {
-                    if (epi) hipLaunchKernelGGL((k_dwpass2<true, true>), dim3((unsigned)nblocks), dim3(256), 0, s->stream, D);
-                    else hipLaunchKernelGGL((k_dwpass2<false, true>), dim3((unsigned)nblocks), dim3(256), 0, s->stream, D);
+                    const bool nt = dv != 2, rag = s->fac[1]->ragged;
+#define DW_LAUNCH(E_, N_, R_) hipLaunchKernelGGL((k_dwpass2<E_, N_, R_>), dim3((unsigned)nblocks), dim3(256), 0, s->stream, D)
+                    if (epi) { if (nt) { if (rag) DW_LAUNCH(true, true, true); else DW_LAUNCH(true, true, false); } else { if (rag) DW_LAUNCH(true, false, true); else DW_LAUNCH(true, false, false); } }
+                    else { if (nt) { if (rag) DW_LAUNCH(false, true, true); else DW_LAUNCH(false, true, false); } else { if (rag) DW_LAUNCH(false, false, true); else DW_LAUNCH(false, false, false); } }
+#undef DW_LAUNCH
                 }
                 HIPCHK(hipGetLastError());
             }

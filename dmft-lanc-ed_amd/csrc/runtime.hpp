@@ -112,6 +112,7 @@ struct DevFactor {
     DevBuf<uint32_t> pcols, pcodes, pelem, pelem8; DevBuf<double> ptval; bool packed = false, packed_elem = false, packed_elem8 = false; int32_t pterms = 0;
     DevBuf<double> vals, ellv, E, tval, lin;
     int32_t width = 0;
+    bool ragged = false;     // some row has fewer hops than `width` (ELL padding present)
 };
 
 }  // namespace edgpu
@@ -144,7 +145,7 @@ struct edgpu_sector_s {
     int64_t nloc = 0, nloc_el = 0, vecdim = 0;
     int32_t nmax = 0;
     bool use_lds = false; int kron_threads = 256, kron_threads_override = 0; size_t kron_lds = 0;
-    bool two_factor = false, extra = false, multi = false, kron_split = false; int dw_w = 64, dw_variant = 2, dw_rows = 64; bool up_persistent = true, up_pairs = true; int up_grid = 256, up_threads = 1024, row_split = 4; bool up_big = true;
+    bool two_factor = false, extra = false, has_ph = false, has_nd = false, multi = false, kron_split = false; int dw_w = 64, dw_variant = 2, dw_rows = 64; bool up_persistent = true, up_pairs = true; int up_grid = 256, up_threads = 1024, row_split = 4; bool up_big = true, nd_split = true;
     std::vector<hipEvent_t> bench_ev; int bench_k = 0; double *bv[3] = {nullptr, nullptr, nullptr};
     int64_t nnz_total = 0, bytes_stored = 0;
     int64_t npartial = 0;

@@ -16,6 +16,7 @@ static int upload_factor(S *s, int k)
     CHK(df->rowptr.upload(rp32)); CHK(df->cols.upload(f.cols)); CHK(df->vals.upload(f.vals));
     CHK(df->E.upload(f.E));
     df->width = std::max(f.width, 1);
+    for (int32_t i = 0; i < f.dim; i++) if (f.rowptr[i + 1] - f.rowptr[i] < df->width) { df->ragged = true; break; }
     if (df->width > 64) return fail(EDGPU_EUNSUPPORTED, "edgpu: more than 64 hops per spin configuration");
     if ((int)f.terms.size() > kMaxTerms) return fail(EDGPU_EUNSUPPORTED, "edgpu: too many one-body hop terms");
     // ELL image: up factors transposed [width][dim] (lanes run over rows), dw factors [dim][width]
@@ -258,7 +259,7 @@ static int create(const edgpu_desc *desc, S **out)
     SectorHost &H = s->H;
     s->comm.rank = desc->mpi_rank; s->comm.size = desc->mpi_size;
     s->two_factor = desc->ed_total_ud != 0;
-    s->extra = H.DimPh > 1 || H.Jhflag;
+    s->extra = H.DimPh > 1 || H.Jhflag; s->has_ph = H.DimPh > 1; s->has_nd = H.Jhflag;
     s->nloc_el = H.DimUp * H.Qdw; s->nloc = s->nloc_el * H.DimPh; s->vecdim = s->nloc;
     for (int k = 0; k < 2 * H.Ns_Ud; k++) CHK(upload_factor(s.get(), k));
     CHK(s->cross.upload(H.cross)); CHK(s->gup.upload(H.gph_up)); CHK(s->gdw.upload(H.gph_dw));
@@ -288,6 +289,7 @@ static int create(const edgpu_desc *desc, S **out)
         s->up_pairs = dbg_int("EDGPU_UP_PAIRS", 1) != 0;
         s->row_split = std::max(1, std::min(32, dbg_int("EDGPU_ROW_SPLIT", 4)));
         s->up_big = dbg_int("EDGPU_UP_BIG", 1) != 0;
+        s->nd_split = dbg_int("EDGPU_ND_SPLIT", 1) != 0;
         s->up_threads = dbg_int("EDGPU_UP_THREADS", 1024) == 512 ? 512 : 1024;
         s->dw_rows = std::max(1, std::min(64, dbg_int("EDGPU_DW_ROWS", 64)));
         if (s->dw_w != 8 && s->dw_w != 16 && s->dw_w != 32 && s->dw_w != 64 && s->dw_w != 128 && s->dw_w != 256) s->dw_w = 32;
