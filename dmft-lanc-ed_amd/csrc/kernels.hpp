@@ -569,6 +569,7 @@ __global__ void __launch_bounds__(256) k_dwpass2(DwArgs A)
 struct NdArgs {
     int32_t DimUp, DimDw, DimPh, Norb; int64_t Qdw, dw0;
     const int32_t *mapup, *mapdw, *rankup, *rankdw;
+    const int32_t *xmap;     // needed-rows exchange: global dw row -> row of the compact x-space (else null)
     double Jx, Jp;
     const double *vfull; double *out; const double *scal;
 };
@@ -601,6 +602,7 @@ __global__ void __launch_bounds__(256) k_ndpass(NdArgs A)
                 jd = A.rankdw[k2]; t = (sg & 1) ? -A.Jp : A.Jp;
             }
         }
+        if (jd >= 0 && A.xmap) jd = A.xmap[jd];
         s_jdw[threadIdx.x] = jd; s_t[threadIdx.x] = t;
         if (jd >= 0) s_any = 1;
     }

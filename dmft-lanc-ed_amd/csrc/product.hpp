@@ -207,7 +207,7 @@ static int hxv(S *s, const double *v, double *out, bool epi, const double *uprev
                     NdArgs Nd{};
                     Nd.DimUp = A.DimUp; Nd.DimDw = A.DimDw; Nd.DimPh = A.DimPh; Nd.Norb = A.Norb; Nd.Qdw = A.Qdw; Nd.dw0 = A.dw0;
                     Nd.mapup = A.mapup; Nd.mapdw = A.mapdw; Nd.rankup = A.rankup; Nd.rankdw = A.rankdw; Nd.Jx = A.Jx; Nd.Jp = A.Jp;
-                    Nd.vfull = A.vfull; Nd.out = out; Nd.scal = s->scal.p;
+                    Nd.vfull = A.vfull; Nd.out = out; Nd.scal = s->scal.p; Nd.xmap = s->halo ? s->xmap_dev.p : nullptr;
                     if (epi) hipLaunchKernelGGL(k_ndpass<true>, dim3((unsigned)(H.Qdw * H.DimPh)), dim3(256), 0, s->stream, Nd);
                     else hipLaunchKernelGGL(k_ndpass<false>, dim3((unsigned)(H.Qdw * H.DimPh)), dim3(256), 0, s->stream, Nd);
                     HIPCHK(hipGetLastError());

@@ -138,7 +138,7 @@ struct edgpu_sector_s {
     // [own rows | rows needed from rank 0 | rank 1 | ...] instead of the whole gathered vector
     bool halo = false; int64_t nhalo = 0;
     std::vector<int64_t> send_rows_cnt, recv_rows_cnt, send_rows_off, recv_rows_off;
-    DevBuf<int32_t> send_list, dw_ellc_x, dw_cols_x; DevBuf<double> sendbuf;
+    DevBuf<int32_t> send_list, dw_ellc_x, dw_cols_x, xmap_dev; DevBuf<double> sendbuf;
     hipEvent_t ev_pack = nullptr;
     std::vector<std::unique_ptr<DevBuf<double>>> eigV; DevBuf<double> eig_h, eig_y, eig_partial;
     DevBuf<double> vfull, tmp_in, tmp_out, lz[5], scal, alphas, betas, zvec, partial, partial2;

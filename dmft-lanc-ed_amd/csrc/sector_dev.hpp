@@ -102,7 +102,8 @@ static int upload_factor(S *s, int k)
 }
 
 // Which dw rows does each rank need from each other rank?  Row j of rank r is needed here iff some
-// local row i has H_dw[i,j] != 0.  H_dw is small and known to every rank, so the lists are
+// local row i has H_dw[i,j] != 0 -- or, with Jx/Jp, j is the partner row of i (one impurity electron of the dw
+// word moved to another orbital, stored/H_non_local.f90:21-83).  H_dw is small and known to every rank, so the lists are
 // computed locally on both sides (no set-up communication).  At Ns=16 this is 53 % / 36 % / 24 %
 // of the all-gather volume at 2 / 4 / 8 ranks.
 static int setup_halo(S *s)
@@ -115,16 +116,26 @@ static int setup_halo(S *s)
     std::vector<std::vector<int32_t>> recv_rows(P), send_rows(P);
     {
         std::vector<char> mark(H.DimDw, 0);
-        for (int64_t i = H.dw0; i < H.dw0 + H.Qdw; i++)
+        const edgpu_desc &d = H.desc;
+        auto mark_row = [&](int64_t i) {       // rows that row i reads
             for (int64_t p = dw.rowptr[i]; p < dw.rowptr[i + 1]; p++) mark[dw.cols[p]] = 1;
+            if (!H.Jhflag) return;
+            const uint32_t m = (uint32_t)dw.map[i];
+            for (int a = 0; a < d.Norb; a++)
+                for (int b = 0; b < d.Norb; b++) {
+                    if (a == b) continue;
+                    const uint32_t ba = 1u << a, bb = 1u << b;
+                    if ((m & ba) && !(m & bb)) { const int32_t j = dw.rank[(m & ~ba) | bb]; if (j >= 0) mark[j] = 1; }
+                }
+        };
+        for (int64_t i = H.dw0; i < H.dw0 + H.Qdw; i++) mark_row(i);
         for (int64_t j = 0; j < H.DimDw; j++) if (mark[j] && owner[j] != me) recv_rows[owner[j]].push_back((int32_t)j);
         // what rank r needs from me: rows j of mine that some row i of r couples to
         for (int r = 0; r < P; r++) {
             if (r == me) continue;
             int64_t d0, qd; range_of(r, d0, qd);
             std::fill(mark.begin(), mark.end(), 0);
-            for (int64_t i = d0; i < d0 + qd; i++)
-                for (int64_t p = dw.rowptr[i]; p < dw.rowptr[i + 1]; p++) mark[dw.cols[p]] = 1;
+            for (int64_t i = d0; i < d0 + qd; i++) mark_row(i);
             for (int64_t j = H.dw0; j < H.dw0 + H.Qdw; j++) if (mark[j]) send_rows[r].push_back((int32_t)(j - H.dw0));
         }
     }
@@ -151,6 +162,7 @@ static int setup_halo(S *s)
         for (int64_t p = dw.rowptr[i]; p < dw.rowptr[i + 1]; p++) cc[p] = xmap[dw.cols[p]];
     }
     CHK(s->dw_ellc_x.upload(ec)); CHK(s->dw_cols_x.upload(cc));
+    if (H.Jhflag) CHK(s->xmap_dev.upload(xmap));      // the non-local pass finds its partner rows through this
     HIPCHK(hipEventCreateWithFlags(&s->ev_pack, hipEventDisableTiming));
     s->halo = true;
     return EDGPU_OK;
@@ -306,7 +318,7 @@ static int create(const edgpu_desc *desc, S **out)
     s->nnz_total = (s->nloc_el + nnz_fac) * H.DimPh;
     s->multi = desc->mpi_size > 1 || (desc->reserved & 1);   // reserved bit 0: run the exchange path even on one rank (tests)
     s->nhalo = H.DimDw;
-    if (s->multi && s->two_factor && !s->extra && dbg_int("EDGPU_HALO", 1)) CHK(setup_halo(s.get()));
+    if (s->multi && s->two_factor && (!s->extra || (s->has_nd && !s->has_ph && s->nd_split)) && dbg_int("EDGPU_HALO", 1)) CHK(setup_halo(s.get()));
     if (desc->storage != EDGPU_STORE_DIRECT) { CHK(build_diag(s.get())); s->bytes_stored = s->nloc_el * 8; }
     if (desc->storage == EDGPU_STORE_CSR) {
         CHK(build_csr(s.get()));

@@ -48,7 +48,8 @@ def test_partition_and_staged_exchange_gloo_cpu(case, size):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("case,size", [("c_nb5_half", 2), ("c_nb7_half", 3), ("norb2_normal_JxJp", 2), ("phonons_norb2_JxJp", 2), ("nb5_offhalf_2_4", 4),
-                                       ("orbs_norb2_nb3", 2), ("orbs_norb2_nb3_uneven", 3), ("phonons_orbs", 2)])
+                                       ("orbs_norb2_nb3", 2), ("orbs_norb2_nb3_uneven", 3), ("phonons_orbs", 2),
+                                       ("replica_sz_sx_JxJp", 3), ("norb3_nb1_JxJp", 2), ("norb2_hybrid_JxJp", 4)])
 def test_multirank_on_one_gpu_callback_exchange(edgpu_mod, case, size):
     import cases
     from oracle import oracle
