@@ -60,7 +60,7 @@ def cpu_baseline(seconds_budget=16.0, nbath=13):
         ncpu = len(os.sched_getaffinity(0))
     except AttributeError:
         ncpu = os.cpu_count() or 1
-    ncpu = max(1, min(ncpu, 64))
+    ncpu = max(1, min(ncpu, 16))        # a one-GPU box grants 16 cores' worth of CPU time whatever the affinity mask says
     t1, n1, d1 = run(1, seconds_budget / 2)
     tn, nn, dn = run(ncpu, seconds_budget / 2) if ncpu > 1 else (t1, n1, d1)
     oracle.set_threads(1)

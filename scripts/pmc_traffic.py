@@ -1,0 +1,37 @@
+#!/usr/bin/env python3
+"""HBM-side traffic of one product per storage from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
+(scripts/profile_round.sh): mean counter value per dispatch of every product kernel, corrected as
+MI355X_MICROARCH.md prescribes (units of 1 KiB; FETCH_SIZE tallies 64 B per 128-B request on gfx950 -> x2),
+summed over the kernels that make one product.  Prints a summary and writes pmc_traffic.json next to it."""
+import collections, csv, glob, json, os, sys
+root = sys.argv[1]
+PRODUCT = {"csr": ("k_csr_spmv2",), "kron": ("k_uppass", "k_dwpass"), "direct": ("k_uppass", "k_dwpass", "k_direct_tables")}
+out = []
+for st, prefixes in PRODUCT.items():
+    per = {}
+    for cn in ("FETCH_SIZE", "WRITE_SIZE"):
+        acc = collections.defaultdict(lambda: [0.0, 0])
+        for f in glob.glob(os.path.join(root, "pmc_%s_%s" % (st, cn), "**", "*counter_collection.csv"), recursive=True):
+            for r in csv.DictReader(open(f)):
+                if r["Counter_Name"] != cn:
+                    continue
+                kn = r["Kernel_Name"].split("(")[0].replace("void edgpu::", "").replace("edgpu::", "")
+                if any(p in kn for p in prefixes):
+                    acc[kn][0] += float(r["Counter_Value"]); acc[kn][1] += 1
+        per[cn] = {k: (s / n, n) for k, (s, n) in acc.items()}
+    if not per["FETCH_SIZE"]:
+        continue
+    # a product launches each kernel name once, except the tables kernel (twice: up and dw factor)
+    tot = 0.0
+    print("== storage=%s" % st)
+    for kn in sorted(per["FETCH_SIZE"]):
+        fs, n = per["FETCH_SIZE"][kn]; ws = per["WRITE_SIZE"].get(kn, (0.0, 0))[0]
+        mult = 2 if "k_direct_tables" in kn else 1
+        b = (2 * fs + ws) * 1024 * mult
+        # only the Lanczos-fused (epilogue) instantiations belong to the timed loop
+        print("  %-50s FETCH_SIZE %.4g KiB  WRITE_SIZE %.4g KiB  -> %.3f GB per product (n=%d)" % (kn, fs, ws, b / 1e9, n))
+        tot += b
+    print("  total %.2f GB per product" % (tot / 1e9))
+    out.append({"storage": st, "nbath": 15, "n_gpus": 1, "hbm_bytes_per_launch": tot,
+                "source": "profiles: (2*FETCH_SIZE + WRITE_SIZE)*1024 per dispatch, summed over the kernels of one product (%s); FETCH_SIZE doubled per MI355X_MICROARCH.md (64 B tallied per 128-B request); fabric-side count, Infinity-Cache hits included" % ", ".join(sorted(per["FETCH_SIZE"]))})
+json.dump(out, open(os.path.join(root, "pmc_traffic.json"), "w"), indent=1)
