@@ -19,7 +19,8 @@ using namespace edgpu;
 // duplicate-summing insert in storage order) whose product runs on the GPU.
 // ---------------------------------------------------------------------------------------
 struct edgpu_spmat_s {
-    int64_t nrow = 0, ncol = 0;
+    int64_t nrow = 0, ncol = 0;                  // rows held by this object (the local window in the MPI form)
+    int64_t istart = 1, iend = 0, ishift = 0, nglob = 0; bool mpi = false;   // sp_set_mpi_matrix (ED_SPARSE_MATRIX.f90:574-585)
     std::vector<std::vector<int64_t>> cols;      // 1-based columns, insertion order (ED_SPARSE_MATRIX.f90:13-17)
     std::vector<std::vector<double>> vals;
     bool dirty = true;
@@ -592,14 +593,33 @@ int edgpu_sp_init_matrix(int64_t nrow, int64_t ncol, edgpu_spmat *out)
     auto *m = new edgpu_spmat_s();
     m->nrow = nrow; m->ncol = ncol ? ncol : nrow;
     m->cols.resize((size_t)nrow); m->vals.resize((size_t)nrow);
+    m->istart = 1; m->iend = nrow; m->ishift = 0; m->nglob = nrow;
     *out = m;
+    return EDGPU_OK;
+}
+int edgpu_sp_init_matrix_mpi(int64_t istart, int64_t iend, int64_t ishift, int64_t n, int64_t ncol, edgpu_spmat *out)
+{
+    if (!out || n < 0 || istart < 1 || iend > n || iend < istart - 1 || ishift != istart - 1)
+        return fail(EDGPU_EINVAL, "edgpu_sp_init_matrix_mpi: bad row window (need 1 <= istart, iend <= N, ishift = istart-1)");
+    CHK(edgpu_sp_init_matrix(iend - istart + 1, ncol ? ncol : n, out));     // Nloc = iend-istart+1 rows (ED_SPARSE_MATRIX.f90:167-169)
+    (*out)->istart = istart; (*out)->iend = iend; (*out)->ishift = ishift; (*out)->nglob = n; (*out)->mpi = true;
+    return EDGPU_OK;
+}
+int edgpu_sp_load_matrix(const double *dense, int64_t nrow, int64_t ncol, edgpu_spmat *inout)
+{
+    if (!dense || !inout || nrow < 0 || ncol < 0) return fail(EDGPU_EINVAL, "edgpu_sp_load_matrix: bad argument");
+    if (*inout) { delete *inout; *inout = nullptr; }                        // if(sparse%status)call sp_delete_matrix
+    CHK(edgpu_sp_init_matrix(nrow, ncol, inout));
+    for (int64_t i = 1; i <= nrow; i++)
+        for (int64_t j = 1; j <= ncol; j++) { const double x = dense[(i - 1) + nrow * (j - 1)]; if (x != 0.0) CHK(edgpu_sp_insert_element(*inout, x, i, j)); }
     return EDGPU_OK;
 }
 int edgpu_sp_delete_matrix(edgpu_spmat m) { delete m; return EDGPU_OK; }
 int edgpu_sp_insert_element(edgpu_spmat m, double value, int64_t i, int64_t j)
 {
     if (!m) return fail(EDGPU_EINVAL, "sp_insert_element: matrix not allocated");
-    if (i < 1 || i > m->nrow || j < 1 || j > m->ncol) return fail(EDGPU_EINVAL, "sp_insert_element: index out of range");
+    if (i < m->istart || i > m->iend || j < 1 || j > m->ncol) return fail(EDGPU_EINVAL, "sp_insert_element: index out of range");
+    i -= m->ishift;                                                          // row => sparse%row(i-sparse%Ishift)
     auto &c = m->cols[(size_t)i - 1]; auto &v = m->vals[(size_t)i - 1];
     for (size_t k = 0; k < c.size(); k++) if (c[k] == j) { v[k] += value; m->dirty = true; return EDGPU_OK; }   // column exists: sum it up
     c.push_back(j); v.push_back(value);                                                                       // new column: append
@@ -609,7 +629,8 @@ int edgpu_sp_insert_element(edgpu_spmat m, double value, int64_t i, int64_t j)
 }
 int edgpu_sp_row(edgpu_spmat m, int64_t i, int32_t *size, int64_t *cols, double *vals, int32_t cap)
 {
-    if (!m || !size || i < 1 || i > m->nrow) return fail(EDGPU_EINVAL, "edgpu_sp_row: bad argument");
+    if (!m || !size || i < m->istart || i > m->iend) return fail(EDGPU_EINVAL, "edgpu_sp_row: bad argument");
+    i -= m->ishift;
     const auto &c = m->cols[(size_t)i - 1]; const auto &v = m->vals[(size_t)i - 1];
     *size = (int32_t)c.size();
     if (cols && vals) { if ((int32_t)c.size() > cap) return fail(EDGPU_EINVAL, "edgpu_sp_row: capacity too small"); for (size_t k = 0; k < c.size(); k++) { cols[k] = c[k]; vals[k] = v[k]; } }
@@ -619,7 +640,7 @@ int edgpu_sp_dump_matrix(edgpu_spmat m, double *dense)
 {
     if (!m || !dense) return fail(EDGPU_EINVAL, "edgpu_sp_dump_matrix: null argument");
     for (int64_t i = 0; i < m->nrow; i++)
-        for (size_t k = 0; k < m->cols[(size_t)i].size(); k++) dense[i + m->nrow * (m->cols[(size_t)i][k] - 1)] += m->vals[(size_t)i][k];   // ED_SPARSE_MATRIX.f90:399-405
+        for (size_t k = 0; k < m->cols[(size_t)i].size(); k++) dense[(i + m->ishift) + m->nglob * (m->cols[(size_t)i][k] - 1)] += m->vals[(size_t)i][k];   // ED_SPARSE_MATRIX.f90:399-405, 425-430
     return EDGPU_OK;
 }
 int edgpu_sp_matvec(edgpu_spmat m, const double *v_host, double *hv_host, int32_t accumulate)

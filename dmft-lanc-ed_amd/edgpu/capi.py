@@ -21,7 +21,7 @@ SYMBOLS = [
     "edgpu_lanczos_gs", "edgpu_lanczos_gs_device", "edgpu_lanczos_tridiag", "edgpu_lanczos_tridiag_device",
     "edgpu_lanczos_time", "edgpu_lanczos_bench_begin", "edgpu_lanczos_bench_steps", "edgpu_lanczos_bench_result",
     "edgpu_eigsh", "edgpu_twin_reorder", "edgpu_imp_density_offdiag", "edgpu_imp_histogram", "edgpu_apply_op", "edgpu_gf_lanczos", "edgpu_chi_lanczos", "edgpu_phonon_lanczos",
-    "edgpu_sp_init_matrix", "edgpu_sp_insert_element", "edgpu_sp_delete_matrix", "edgpu_sp_dump_matrix", "edgpu_sp_row", "edgpu_sp_matvec",
+    "edgpu_sp_init_matrix", "edgpu_sp_init_matrix_mpi", "edgpu_sp_load_matrix", "edgpu_sp_insert_element", "edgpu_sp_delete_matrix", "edgpu_sp_dump_matrix", "edgpu_sp_row", "edgpu_sp_matvec",
     "edgpu_comm_unique_id", "edgpu_comm_init_rccl", "edgpu_comm_init_callbacks",
     "edgpu_device_count", "edgpu_malloc", "edgpu_free", "edgpu_memcpy_h2d", "edgpu_memcpy_d2h",
     "edgpu_device_synchronize", "edgpu_last_error", "edgpu_abi_version",
@@ -103,6 +103,8 @@ def lib():
         "edgpu_chi_lanczos": (C.c_int, [vp, vp, vp, vp, i32, dbl, P(dbl), vp, vp, P(i32)]),
         "edgpu_phonon_lanczos": (C.c_int, [vp, vp, i32, dbl, P(dbl), vp, vp, P(i32)]),
         "edgpu_sp_init_matrix": (C.c_int, [i64, i64, P(vp)]),
+        "edgpu_sp_init_matrix_mpi": (C.c_int, [i64, i64, i64, i64, i64, P(vp)]),
+        "edgpu_sp_load_matrix": (C.c_int, [vp, i64, i64, P(vp)]),
         "edgpu_sp_insert_element": (C.c_int, [vp, dbl, i64, i64]),
         "edgpu_sp_delete_matrix": (C.c_int, [vp]),
         "edgpu_sp_dump_matrix": (C.c_int, [vp, vp]),

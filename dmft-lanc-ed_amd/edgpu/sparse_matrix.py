@@ -13,14 +13,34 @@ class sparse_matrix_csr:
         self._h = None
         self.Nrow = self.Ncol = 0
         self.status = False
+        self.istart = self.iend = self.ishift = 0
+        self.mpi = False
+
+
+def sp_set_mpi_matrix(sparse, istart, iend, ishift):
+    """ED_SPARSE_MATRIX.f90:574-585: the object will hold the global rows istart..iend only (call before sp_init_matrix)."""
+    sparse.istart, sparse.iend, sparse.ishift, sparse.mpi = int(istart), int(iend), int(ishift), True
 
 
 def sp_init_matrix(sparse, N, N1=None):
     if sparse.status:
         raise RuntimeError("sp_init_matrix: already allocated can not init")
     h = C.c_void_p()
-    check(capi.lib().edgpu_sp_init_matrix(int(N), int(N1 if N1 is not None else N), C.byref(h)))
-    sparse._h, sparse.Nrow, sparse.Ncol, sparse.status = h, int(N), int(N1 if N1 is not None else N), True
+    ncol = int(N1 if N1 is not None else N)
+    if sparse.mpi:      # mpi_sp_init_matrix: Nloc = iend-istart+1 rows (ED_SPARSE_MATRIX.f90:155-172)
+        check(capi.lib().edgpu_sp_init_matrix_mpi(sparse.istart, sparse.iend, sparse.ishift, int(N), ncol, C.byref(h)))
+        sparse._h, sparse.Nrow, sparse.Ncol, sparse.status, sparse.Nglob = h, sparse.iend - sparse.istart + 1, ncol, True, int(N)
+    else:
+        check(capi.lib().edgpu_sp_init_matrix(int(N), ncol, C.byref(h)))
+        sparse._h, sparse.Nrow, sparse.Ncol, sparse.status, sparse.Nglob = h, int(N), ncol, True, int(N)
+
+
+def sp_load_matrix(matrix, sparse):
+    """ED_SPARSE_MATRIX.f90:325-344: dense -> sparse (an allocated `sparse` is deleted first)."""
+    m = np.asfortranarray(matrix, dtype=np.float64)
+    h = sparse._h if sparse.status else C.c_void_p()
+    check(capi.lib().edgpu_sp_load_matrix(m.ctypes.data, m.shape[0], m.shape[1], C.byref(h)))
+    sparse._h, sparse.Nrow, sparse.Ncol, sparse.status, sparse.Nglob, sparse.mpi = h, m.shape[0], m.shape[1], True, m.shape[0], False
 
 
 def sp_insert_element(sparse, value, i, j):
@@ -31,11 +51,12 @@ def sp_delete_matrix(sparse):
     if sparse.status:
         capi.lib().edgpu_sp_delete_matrix(sparse._h)
     sparse._h, sparse.status, sparse.Nrow, sparse.Ncol = None, False, 0, 0
+    sparse.mpi = False
 
 
 def sp_dump_matrix(sparse, matrix):
     m = np.asfortranarray(matrix, dtype=np.float64)
-    assert m.shape == (sparse.Nrow, sparse.Ncol)
+    assert m.shape == (sparse.Nglob, sparse.Ncol)
     check(capi.lib().edgpu_sp_dump_matrix(sparse._h, m.ctypes.data))
     matrix[...] = m
 

@@ -12,6 +12,9 @@ module ED_SPARSE_MATRIX_GPU
      integer     :: Nrow = 0
      integer     :: Ncol = 0
      logical     :: status = .false.
+     integer     :: istart = 0, iend = 0, ishift = 0     ! sp_set_mpi_matrix (ED_SPARSE_MATRIX.f90:574-585)
+     logical     :: mpi = .false.
+     integer     :: Nglob = 0
   end type sparse_matrix_gpu
 
   interface
@@ -21,6 +24,19 @@ module ED_SPARSE_MATRIX_GPU
        type(c_ptr), intent(out)  :: out
        integer(c_int)            :: rc
      end function edgpu_sp_init_matrix
+     function edgpu_sp_init_matrix_mpi(istart, iend, ishift, n, ncol, out) bind(C, name="edgpu_sp_init_matrix_mpi") result(rc)
+       import :: c_int, c_int64_t, c_ptr
+       integer(c_int64_t), value :: istart, iend, ishift, n, ncol
+       type(c_ptr), intent(out)  :: out
+       integer(c_int)            :: rc
+     end function edgpu_sp_init_matrix_mpi
+     function edgpu_sp_load_matrix(dense, nrow, ncol, inout) bind(C, name="edgpu_sp_load_matrix") result(rc)
+       import :: c_int, c_int64_t, c_double, c_ptr
+       real(c_double), intent(in)  :: dense(*)
+       integer(c_int64_t), value   :: nrow, ncol
+       type(c_ptr), intent(inout)  :: inout
+       integer(c_int)              :: rc
+     end function edgpu_sp_load_matrix
      function edgpu_sp_insert_element(m, value, i, j) bind(C, name="edgpu_sp_insert_element") result(rc)
        import :: c_int, c_int64_t, c_double, c_ptr
        type(c_ptr), value        :: m
@@ -51,6 +67,7 @@ module ED_SPARSE_MATRIX_GPU
 
   public :: sparse_matrix_gpu
   public :: sp_init_matrix_gpu, sp_insert_element_gpu, sp_delete_matrix_gpu, sp_dump_matrix_gpu, sp_matvec_gpu
+  public :: sp_load_matrix_gpu, sp_set_mpi_matrix_gpu
 
 contains
 
@@ -68,11 +85,33 @@ contains
     integer, intent(in)                    :: N
     integer, intent(in), optional          :: N1
     if (sparse%status) stop "sp_init_matrix: already allocated can not init"
-    sparse%Nrow = N; sparse%Ncol = N
+    sparse%Nrow = N; sparse%Ncol = N; sparse%Nglob = N
     if (present(N1)) sparse%Ncol = N1
-    call sp_check(edgpu_sp_init_matrix(int(sparse%Nrow, c_int64_t), int(sparse%Ncol, c_int64_t), sparse%h), "sp_init_matrix")
+    if (sparse%mpi) then                                   ! mpi_sp_init_matrix: Nloc = iend-istart+1 rows (155-172)
+       sparse%Nrow = sparse%iend - sparse%istart + 1
+       call sp_check(edgpu_sp_init_matrix_mpi(int(sparse%istart, c_int64_t), int(sparse%iend, c_int64_t), int(sparse%ishift, c_int64_t), &
+            int(N, c_int64_t), int(sparse%Ncol, c_int64_t), sparse%h), "sp_init_matrix")
+    else
+       call sp_check(edgpu_sp_init_matrix(int(sparse%Nrow, c_int64_t), int(sparse%Ncol, c_int64_t), sparse%h), "sp_init_matrix")
+    end if
     sparse%status = .true.
   end subroutine sp_init_matrix_gpu
+
+  !> sp_set_mpi_matrix(MpiComm,sparse,istart,iend,ishift): call before sp_init_matrix_gpu; insert/dump then take global rows
+  subroutine sp_set_mpi_matrix_gpu(sparse, istart, iend, ishift)   ! ED_SPARSE_MATRIX.f90:574-585
+    type(sparse_matrix_gpu), intent(inout) :: sparse
+    integer, intent(in)                    :: istart, iend, ishift
+    sparse%istart = istart; sparse%iend = iend; sparse%ishift = ishift; sparse%mpi = .true.
+  end subroutine sp_set_mpi_matrix_gpu
+
+  !> sp_load_matrix(matrix,sparse): dense -> sparse, an allocated sparse is deleted first   (325-344)
+  subroutine sp_load_matrix_gpu(matrix, sparse)
+    real(8), intent(in), contiguous        :: matrix(:,:)
+    type(sparse_matrix_gpu), intent(inout) :: sparse
+    if (.not. sparse%status) sparse%h = c_null_ptr
+    call sp_check(edgpu_sp_load_matrix(matrix, int(size(matrix,1), c_int64_t), int(size(matrix,2), c_int64_t), sparse%h), "sp_load_matrix")
+    sparse%Nrow = size(matrix,1); sparse%Ncol = size(matrix,2); sparse%Nglob = sparse%Nrow; sparse%mpi = .false.; sparse%status = .true.
+  end subroutine sp_load_matrix_gpu
 
   subroutine sp_insert_element_gpu(sparse, value, i, j)  ! ED_SPARSE_MATRIX.f90:255-288
     type(sparse_matrix_gpu), intent(inout) :: sparse
@@ -86,13 +125,13 @@ contains
     integer(c_int) :: rc
     if (.not. sparse%status) return
     rc = edgpu_sp_delete_matrix(sparse%h)
-    sparse%h = c_null_ptr; sparse%Nrow = 0; sparse%Ncol = 0; sparse%status = .false.
+    sparse%h = c_null_ptr; sparse%Nrow = 0; sparse%Ncol = 0; sparse%status = .false.; sparse%mpi = .false.
   end subroutine sp_delete_matrix_gpu
 
   subroutine sp_dump_matrix_gpu(sparse, matrix)          ! ED_SPARSE_MATRIX.f90:386-408
     type(sparse_matrix_gpu), intent(in) :: sparse
     real(8), intent(inout), contiguous  :: matrix(:,:)
-    if (size(matrix,1) /= sparse%Nrow .or. size(matrix,2) /= sparse%Ncol) stop "Warning SPARSE/dump_matrix: dimensions error"
+    if (size(matrix,1) /= sparse%Nglob .or. size(matrix,2) /= sparse%Ncol) stop "Warning SPARSE/dump_matrix: dimensions error"
     call sp_check(edgpu_sp_dump_matrix(sparse%h, matrix), "sp_dump_matrix")
   end subroutine sp_dump_matrix_gpu
 

@@ -214,6 +214,14 @@ int edgpu_comm_init_callbacks(edgpu_handle h, edgpu_allgatherv_fn ag, edgpu_exch
  * builds its factors directly); it is provided for host code that assembles other operators. */
 typedef struct edgpu_spmat_s *edgpu_spmat;
 int edgpu_sp_init_matrix(int64_t nrow, int64_t ncol /* 0 -> nrow */, edgpu_spmat *out);
+/* MPI form: sp_set_mpi_matrix(istart,iend,ishift) followed by sp_init_matrix (ED_SPARSE_MATRIX.f90:574-585, 155-172):
+ * the object holds the rows istart..iend (1-based, global) of an N x ncol matrix; insert/row take GLOBAL row
+ * numbers and store at i - ishift (289-323); dump adds the local rows into a dense N x ncol array at their global
+ * position (the reference then all-reduces, 408-438); matvec returns the iend-istart+1 local entries. */
+int edgpu_sp_init_matrix_mpi(int64_t istart, int64_t iend, int64_t ishift, int64_t n, int64_t ncol /* 0 -> n */, edgpu_spmat *out);
+/* sp_load_matrix (325-344): (re)initialise *inout from a dense column-major nrow x ncol array, inserting the
+ * non-zeros row by row, columns ascending.  *inout may be NULL (new object) or an existing matrix (deleted first). */
+int edgpu_sp_load_matrix(const double *dense, int64_t nrow, int64_t ncol, edgpu_spmat *inout);
 int edgpu_sp_insert_element(edgpu_spmat m, double value, int64_t i, int64_t j);
 int edgpu_sp_delete_matrix(edgpu_spmat m);
 int edgpu_sp_dump_matrix(edgpu_spmat m, double *dense);

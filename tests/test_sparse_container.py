@@ -45,6 +45,25 @@ def test_insert_semantics_and_dump_cpu():
         spm.sp_insert_element(A, 1.0, 8, 1)
     spm.sp_delete_matrix(A)
     assert not A.status
+    # sp_load_matrix: non-zeros row by row, columns ascending; reloading replaces the content
+    M = np.zeros((4, 6)); M[0, 5] = 2.0; M[0, 1] = -1.0; M[3, 0] = 4.0
+    B = spm.sparse_matrix_csr(); spm.sp_load_matrix(M, B)
+    c, v = spm.sp_row(B, 1); assert list(c) == [2, 6] and list(v) == [-1.0, 2.0]
+    D = np.zeros((4, 6), order="F"); spm.sp_dump_matrix(B, D); np.testing.assert_array_equal(D, M)
+    spm.sp_load_matrix(2 * M[:, :3], B)
+    D = np.zeros((4, 3), order="F"); spm.sp_dump_matrix(B, D); np.testing.assert_array_equal(D, 2 * M[:, :3])
+    spm.sp_delete_matrix(B)
+    # MPI row window (sp_set_mpi_matrix + sp_init_matrix): global row numbers, local storage, dump at the global position
+    W = spm.sparse_matrix_csr(); spm.sp_set_mpi_matrix(W, 3, 5, 2); spm.sp_init_matrix(W, 7, 4)
+    assert W.Nrow == 3
+    spm.sp_insert_element(W, 1.5, 3, 4); spm.sp_insert_element(W, -2.0, 5, 1); spm.sp_insert_element(W, 0.5, 5, 1)
+    with pytest.raises(capi.EdgpuError):
+        spm.sp_insert_element(W, 1.0, 2, 1)            # row outside the window
+    D = np.zeros((7, 4), order="F"); spm.sp_dump_matrix(W, D)
+    E = np.zeros((7, 4)); E[2, 3] = 1.5; E[4, 0] = -1.5
+    np.testing.assert_array_equal(D, E)
+    c, v = spm.sp_row(W, 5); assert list(c) == [1] and list(v) == [-1.5]
+    spm.sp_delete_matrix(W)
 
 
 @pytest.mark.gpu
@@ -62,6 +81,15 @@ def test_container_matvec_on_gpu_and_reference_insertion_sequence():
         hv2 = spm.sp_matvec(A, v, hv)                              # Hv += A v, as the reference's sweeps do
         np.testing.assert_allclose(hv2, 2 * (D @ v), rtol=0, atol=1e-12 * max(1.0, np.abs(D).sum()))
         spm.sp_delete_matrix(A)
+    # row window: the local product returns the window's rows
+    W = spm.sparse_matrix_csr(); spm.sp_set_mpi_matrix(W, 11, 30, 10); spm.sp_init_matrix(W, 50)
+    Dfull = np.zeros((50, 50))
+    for _ in range(200):
+        i, j, val = int(rng.integers(11, 31)), int(rng.integers(1, 51)), float(rng.uniform(-1, 1))
+        spm.sp_insert_element(W, val, i, j); Dfull[i - 1, j - 1] += val
+    v = rng.uniform(-1, 1, 50)
+    np.testing.assert_allclose(spm.sp_matvec(W, v), (Dfull @ v)[10:30], rtol=0, atol=1e-12)
+    spm.sp_delete_matrix(W)
     # replay the reference's own insertion sequence for H_up of config 1 (column sweep, stored/H_up.f90) and compare
     name, m_, nu, nd = cases.zoo()[3]      # c_nb5_half
     S = oracle.Sector(m_, nu, nd).buildh()
