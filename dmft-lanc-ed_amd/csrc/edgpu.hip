@@ -263,6 +263,13 @@ int edgpu_eigsh(edgpu_handle h, int32_t nev, int32_t ncv, int32_t maxiter, doubl
     return eigsh(h, nev, ncv, maxiter, tol, evals, evecs, nconv, nrestarts, nmatvec);
 }
 
+int edgpu_dvdson(edgpu_handle h, int32_t nev, int32_t maxiter, double tol, double *evals, double *evecs, int32_t *nconv, int32_t *nmatvec)
+{
+    if (!h || !evals) return fail(EDGPU_EINVAL, "edgpu_dvdson: null argument");
+    HIPCHK(hipSetDevice(h->device));
+    return dvdson(h, nev, maxiter, tol, evals, evecs, nconv, nmatvec);
+}
+
 // off-diagonal impurity density matrix of a host state: dm[(s*Norb + a)*Norb + b], s=0 up, 1 dw (diagonal left 0:
 // it follows from the impurity-configuration weights).  ed_total_ud=T, single rank.
 int edgpu_imp_density_offdiag(edgpu_handle h, const double *vec_host, double *dm)

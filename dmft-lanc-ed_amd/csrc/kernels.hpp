@@ -1377,6 +1377,32 @@ __global__ void __launch_bounds__(256) k_basis_rotate(RotArgs R, int64_t n)
     }
 }
 // y = a*x
+// Davidson step (dvdson() in lanczos.hpp): residual of the Ritz pair (theta, V y) and the diagonally preconditioned
+// correction in one pass over the two bases:
+//   r_e = sum_j y_j (W_j[e] - theta V_j[e]) ,  t_e = r_e / (theta - d_e)  (|theta - d_e| kept away from zero),
+//   partial[b] = sum r_e^2 over the block.    d_e = diag[e mod nel] + w0 * (e div nel)  (phonon blocks share the electronic diagonal)
+struct DvdArgs { const double *V[kMaxBasis + 1]; const double *W[kMaxBasis + 1]; int32_t nv; const double *y; double theta; const double *diag; int64_t nel; double w0; };
+__global__ void __launch_bounds__(256) k_dvd_resid(DvdArgs A, double *__restrict__ t, int64_t n, double *__restrict__ partial)
+{
+    __shared__ double red[4];
+    double c[kMaxBasis + 1];
+#pragma unroll
+    for (int i = 0; i <= kMaxBasis; i++) c[i] = i < A.nv ? A.y[i] : 0.0;
+    double rr = 0.0;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
+        double r = 0.0;
+#pragma unroll
+        for (int i = 0; i <= kMaxBasis; i++) if (i < A.nv) r += c[i] * (A.W[i][e] - A.theta * A.V[i][e]);
+        const int64_t iph = e / A.nel;
+        double den = A.theta - (A.diag[e - iph * A.nel] + A.w0 * (double)iph);
+        if (fabs(den) < 1e-8) den = den < 0.0 ? -1e-8 : 1e-8;
+        t[e] = r / den;
+        rr += r * r;
+    }
+    double s = block_sum(rr, red);
+    if (threadIdx.x == 0) partial[blockIdx.x] = s;
+}
+
 __global__ void __launch_bounds__(256) k_scale_copy(double *__restrict__ y, const double *__restrict__ x, double a, int64_t n)
 {
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) y[e] = a * x[e];

@@ -376,4 +376,131 @@ static int eigsh(S *s, int nev, int ncv, int maxiter, double tol, double *evals,
     return EDGPU_OK;
 }
 
+// ---------------------------------------------------------------------------------------
+// Davidson with the diagonal preconditioner: stands in for sp_dvdson_eigh(MatVec,eval,evec,nitermax,tol) of
+// ED_DIAG.f90:189-203 (lanc_method="dvdson"; the routine lives in SciFortran, not in the reference tree, so only
+// its contract -- lowest Neigen pairs to a residual tolerance -- is restated).  Search space V and its image W=HV
+// are kept in HBM (2 x mmax vectors); Rayleigh-Ritz on the host; one new direction per product, aimed at the lowest
+// pair that has not converged yet; thick restart onto the lowest Ritz vectors when the space is full.
+// ---------------------------------------------------------------------------------------
+static int dvdson(S *s, int nev, int maxiter, double tol, double *evals, double *evecs_host, int *nconv_out, int *nmatvec_out)
+{
+    const int64_t Dim = s->H.Dim, n = s->nloc;
+    if (nev < 1) return fail(EDGPU_EINVAL, "edgpu_dvdson: nev < 1");
+    if ((int64_t)nev >= Dim) return fail(EDGPU_EINVAL, "edgpu_dvdson: nev must be smaller than the sector dimension (the reference switches to LAPACK there, ED_DIAG.f90:105-107)");
+    int mmax = std::min<int64_t>(std::min<int64_t>(kMaxBasis, Dim), std::max(2 * nev + 8, 16));
+    if (mmax <= nev) return fail(EDGPU_EINVAL, "edgpu_dvdson: too many eigenpairs requested for the search space");
+    if (maxiter < 1) maxiter = 1;
+    const double tol_eff = std::max(tol, 1e-11);
+    // the diagonal of H: stored formats hold it, the on-the-fly format derives it once here
+    if (s->diag.n != (size_t)s->nloc_el) CHK(build_diag(s));
+    while ((int)s->eigV.size() < 2 * mmax + 1) { auto b = std::make_unique<DevBuf<double>>(); CHK(b->alloc((size_t)n)); s->eigV.push_back(std::move(b)); }
+    auto Vp = [&](int i) { return s->eigV[i]->p; };
+    auto Wp = [&](int i) { return s->eigV[mmax + i]->p; };
+    double *t = s->eigV[2 * mmax]->p;
+    const int nb = (int)std::max<int64_t>(1, std::min<int64_t>(cdiv(n, 256 * 8), 1024));
+    const int gs = (int)std::max<int64_t>(1, std::min<int64_t>(cdiv(n, 256 * 4), 4096));
+    if (s->eig_h.n < (size_t)(mmax + 2)) CHK(s->eig_h.alloc((size_t)mmax + 2));
+    if (s->eig_partial.n < (size_t)nb * (mmax + 1)) CHK(s->eig_partial.alloc((size_t)nb * (mmax + 1)));
+    if (s->eig_y.n < (size_t)mmax * mmax) CHK(s->eig_y.alloc((size_t)mmax * mmax));
+    const SectorHost &H = s->H;
+    auto norm_of = [&](const double *x, double &out) -> int {
+        CHK(reduce_dot(s, x, x));
+        HIPCHK(hipMemcpyAsync(&out, s->scal.p + SC_TMP, 8, hipMemcpyDeviceToHost, s->stream)); HIPCHK(hipStreamSynchronize(s->stream));
+        out = std::sqrt(out);
+        return EDGPU_OK;
+    };
+    // dots of `w` with the first nv basis vectors -> host (one pass over w)
+    std::vector<double> h2(mmax + 1);
+    auto dots = [&](int nv, const double *w, bool with_W) -> int {
+        BasisArgs B{}; B.nv = nv; for (int i = 0; i < nv; i++) B.V[i] = with_W ? Wp(i) : Vp(i);
+        hipLaunchKernelGGL(k_multidot, dim3(nb), dim3(256), 0, s->stream, B, w, n, s->eig_partial.p);
+        hipLaunchKernelGGL(k_multidot_final, dim3(1), dim3(256), 0, s->stream, (const double *)s->eig_partial.p, nb, nv, s->eig_h.p);
+        HIPCHK(hipGetLastError());
+        CHK(allreduce_dev(s, s->eig_h.p, nv));
+        HIPCHK(hipMemcpyAsync(h2.data(), s->eig_h.p, (size_t)nv * 8, hipMemcpyDeviceToHost, s->stream)); HIPCHK(hipStreamSynchronize(s->stream));
+        return EDGPU_OK;
+    };
+    hipLaunchKernelGGL(k_random_start, dim3(2048), dim3(256), 0, s->stream, Vp(0), H.DimUp, H.Qdw, H.dw0, H.DimDw, H.DimPh, (uint64_t)1234567);
+    HIPCHK(hipGetLastError());
+    double nrm; CHK(norm_of(Vp(0), nrm));
+    hipLaunchKernelGGL(k_scale_copy, dim3(gs), dim3(256), 0, s->stream, Vp(0), (const double *)Vp(0), 1.0 / nrm, n);
+    std::vector<double> G((size_t)mmax * mmax, 0.0), theta, Y;
+    int m = 0, nmv = 0, nconv = 0, it = 0;
+    // append V[m] (already orthonormal to the space): W[m] = H V[m], new column of G
+    auto extend = [&]() -> int {
+        CHK(hxv(s, Vp(m), Wp(m), false, nullptr)); nmv++;
+        CHK(dots(m + 1, Wp(m), false));
+        for (int i = 0; i <= m; i++) { G[(size_t)i * mmax + m] = h2[i]; G[(size_t)m * mmax + i] = h2[i]; }
+        m++;
+        return EDGPU_OK;
+    };
+    CHK(extend());
+    for (it = 0; it < maxiter; it++) {
+        std::vector<double> Gs((size_t)m * m);
+        for (int i = 0; i < m; i++) for (int j = 0; j < m; j++) Gs[(size_t)i * m + j] = G[(size_t)i * mmax + j];
+        jacobi_eig(Gs, m, theta, Y);
+        const int k = std::min(nconv, m - 1);                 // target pair
+        // residual of pair k and the preconditioned correction, one pass over V and W
+        HIPCHK(hipMemcpyAsync(s->eig_y.p, Y.data() + (size_t)m * k, (size_t)m * 8, hipMemcpyHostToDevice, s->stream));
+        DvdArgs D{}; D.nv = m; for (int i = 0; i < m; i++) { D.V[i] = Vp(i); D.W[i] = Wp(i); }
+        D.y = s->eig_y.p; D.theta = theta[k]; D.diag = s->diag.p; D.nel = s->nloc_el; D.w0 = H.DimPh > 1 ? H.desc.w0_ph : 0.0;
+        hipLaunchKernelGGL(k_dvd_resid, dim3(nb), dim3(256), 0, s->stream, D, t, n, s->eig_partial.p);
+        hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(1024), 0, s->stream, (const double *)s->eig_partial.p, (int64_t)nb, s->scal.p + SC_TMP);
+        HIPCHK(hipGetLastError());
+        CHK(allreduce_tmp(s));
+        double r2; HIPCHK(hipMemcpyAsync(&r2, s->scal.p + SC_TMP, 8, hipMemcpyDeviceToHost, s->stream)); HIPCHK(hipStreamSynchronize(s->stream));
+        if (std::sqrt(r2) <= tol_eff * std::max(1.0, std::fabs(theta[k]))) {
+            nconv++;
+            if (nconv >= nev || nconv >= m) break;
+            continue;                                          // next pair, same space
+        }
+        if (m == mmax) {     // thick restart: lowest `keep` Ritz vectors, V and W rotated alike, G = diag(theta)
+            const int keep = std::min(mmax - 1, nev + 4);
+            HIPCHK(hipMemcpyAsync(s->eig_y.p, Y.data(), (size_t)m * keep * 8, hipMemcpyHostToDevice, s->stream));
+            for (int half = 0; half < 2; half++) {
+                RotArgs Rt{}; Rt.nv = m; Rt.nout = keep; Rt.Y = s->eig_y.p; for (int i = 0; i < m; i++) Rt.V[i] = half ? Wp(i) : Vp(i);
+                hipLaunchKernelGGL(k_basis_rotate, dim3(gs), dim3(256), (size_t)m * keep * 8, s->stream, Rt, n);
+            }
+            HIPCHK(hipGetLastError());
+            std::fill(G.begin(), G.end(), 0.0);
+            for (int i = 0; i < keep; i++) G[(size_t)i * mmax + i] = theta[i];
+            m = keep;
+            // the correction was computed against the old basis: still a valid new direction
+        }
+        // orthogonalise t against the space (classical Gram-Schmidt, twice), normalise, append
+        BasisArgs B{}; B.nv = m; for (int i = 0; i < m; i++) B.V[i] = Vp(i);
+        for (int pass = 0; pass < 2; pass++) {
+            hipLaunchKernelGGL(k_multidot, dim3(nb), dim3(256), 0, s->stream, B, (const double *)t, n, s->eig_partial.p);
+            hipLaunchKernelGGL(k_multidot_final, dim3(1), dim3(256), 0, s->stream, (const double *)s->eig_partial.p, nb, m, s->eig_h.p);
+            HIPCHK(hipGetLastError());
+            CHK(allreduce_dev(s, s->eig_h.p, m));
+            hipLaunchKernelGGL(k_multiaxpy, dim3(gs), dim3(256), 0, s->stream, B, (const double *)s->eig_h.p, t, n);
+        }
+        double tn; CHK(norm_of(t, tn));
+        if (!(tn > 1e-14)) break;                              // no new direction: the space is invariant
+        hipLaunchKernelGGL(k_scale_copy, dim3(gs), dim3(256), 0, s->stream, Vp(m), (const double *)t, 1.0 / tn, n);
+        HIPCHK(hipGetLastError());
+        CHK(extend());
+    }
+    // Ritz vectors of the lowest nev pairs
+    {
+        std::vector<double> Gs((size_t)m * m);
+        for (int i = 0; i < m; i++) for (int j = 0; j < m; j++) Gs[(size_t)i * m + j] = G[(size_t)i * mmax + j];
+        jacobi_eig(Gs, m, theta, Y);
+    }
+    const int nout = std::min(nev, m);
+    HIPCHK(hipMemcpyAsync(s->eig_y.p, Y.data(), (size_t)m * nout * 8, hipMemcpyHostToDevice, s->stream));
+    RotArgs Rt{}; Rt.nv = m; Rt.nout = nout; Rt.Y = s->eig_y.p; for (int i = 0; i < m; i++) Rt.V[i] = Vp(i);
+    hipLaunchKernelGGL(k_basis_rotate, dim3(gs), dim3(256), (size_t)m * nout * 8, s->stream, Rt, n);
+    HIPCHK(hipGetLastError());
+    for (int i = 0; i < nev; i++) evals[i] = i < nout ? theta[i] : 0.0;
+    if (evecs_host)
+        for (int i = 0; i < nout; i++) HIPCHK(hipMemcpyAsync(evecs_host + (int64_t)i * n, Vp(i), (size_t)n * 8, hipMemcpyDeviceToHost, s->stream));
+    HIPCHK(hipStreamSynchronize(s->stream));
+    if (nconv_out) *nconv_out = std::min(nconv, nout);
+    if (nmatvec_out) *nmatvec_out = nmv;
+    return EDGPU_OK;
+}
+
 }  // namespace edgpu

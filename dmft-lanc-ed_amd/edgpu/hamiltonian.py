@@ -185,6 +185,13 @@ class HvSector:
                                      C.byref(nc), C.byref(nr), C.byref(nm)))
         return ev, vec, {"nconv": nc.value, "restarts": nr.value, "matvecs": nm.value}
 
+    def sp_dvdson_eigh(self, neigen, nitermax=512, tol=1e-12, vectors=True):
+        """sp_dvdson_eigh(MatVec,eval,evec,nitermax,tol): lowest `neigen` pairs by Davidson (ED_DIAG.f90:189-203)."""
+        ev = np.zeros(neigen); vec = np.zeros((self.vecDim, neigen), order="F") if vectors else None
+        nc, nm = C.c_int32(), C.c_int32()
+        check(capi.lib().edgpu_dvdson(self._h, neigen, nitermax, tol, ev.ctypes.data, vec.ctypes.data if vectors else None, C.byref(nc), C.byref(nm)))
+        return ev, vec, {"nconv": nc.value, "matvecs": nm.value}
+
     def twin_reorder(self, vec):
         """State of the twin sector (ndw,nup) from a state of this sector (es_return_cvector, itwin branch)."""
         vec = np.ascontiguousarray(vec, np.float64)

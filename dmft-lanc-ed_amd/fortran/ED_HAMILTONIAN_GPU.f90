@@ -27,6 +27,7 @@ module ED_HAMILTONIAN_GPU
   public :: sp_lanc_eigh_gpu
   public :: sp_lanc_tridiag_gpu
   public :: sp_eigh_gpu
+  public :: sp_dvdson_eigh_gpu
   public :: get_sector_map_gpu
   ! a second, independently owned sector (the source sector of a Green's-function leg: the reference keeps its
   ! maps in a local `HI` next to the global target sector, ED_GF_NORMAL.f90:176-186)
@@ -211,6 +212,21 @@ contains
          eval, evec, nc, nr, nm), "sp_eigh_gpu")
     if (present(nconv)) nconv = nc
   end subroutine sp_eigh_gpu
+
+  !> sp_dvdson_eigh(MatVec,eval,evec,nitermax,tol): ED_DIAG.f90:189-203 (lanc_method="dvdson")
+  subroutine sp_dvdson_eigh_gpu(eval, evec, Nitermax, tol, nconv)
+    real(8), intent(out)           :: eval(:)
+    real(8), intent(out)           :: evec(:,:)        ! (vecDim, Neigen)
+    integer, intent(in)            :: Nitermax
+    real(8), intent(in), optional  :: tol
+    integer, intent(out), optional :: nconv
+    real(c_double)     :: tl
+    integer(c_int32_t) :: nc, nm
+    tl = 0d0; if (present(tol)) tl = tol
+    if (size(evec,1) /= Hinfo%vecDim .or. size(evec,2) /= size(eval)) stop "sp_dvdson_eigh_gpu ERROR: wrong shape of evec"
+    call edgpu_check(edgpu_dvdson(Hhandle, int(size(eval), c_int32_t), int(Nitermax, c_int32_t), tl, eval, evec, nc, nm), "sp_dvdson_eigh_gpu")
+    if (present(nconv)) nconv = nc
+  end subroutine sp_dvdson_eigh_gpu
 
   !> sp_lanc_tridiag(MatVec,vin,alanc,blanc)
   subroutine sp_lanc_tridiag_gpu(vin, alanc, blanc, threshold, nused)

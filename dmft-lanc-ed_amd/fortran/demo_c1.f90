@@ -53,6 +53,8 @@ program demo_c1
      if (.not. allocated(evec2)) allocate(evec2(N,2))
      call sp_eigh_gpu(eval2, evec2, 20, 300, tol=1d-12)
      write(*,"(A,2F20.14)") "E0E1=", eval2
+     call sp_dvdson_eigh_gpu(eval2, evec2, 300, tol=1d-11)
+     write(*,"(A,2F20.14)") "E0E1_dvdson=", eval2
      spHtimesV_p => null()
      call delete_Hv_sector_gpu()
   end do

@@ -112,6 +112,16 @@ module EDGPU_C_API
        integer(c_int32_t)        :: nconv, nrestarts, nmatvec
        integer(c_int)            :: rc
      end function edgpu_eigsh
+     function edgpu_dvdson(handle, nev, maxiter, tol, evals, evecs, nconv, nmatvec) bind(C, name="edgpu_dvdson") result(rc)
+       import :: c_int, c_int32_t, c_double, c_ptr
+       type(c_ptr), value        :: handle
+       integer(c_int32_t), value :: nev, maxiter
+       real(c_double), value     :: tol
+       real(c_double)            :: evals(*)
+       real(c_double)            :: evecs(*)
+       integer(c_int32_t)        :: nconv, nmatvec
+       integer(c_int)            :: rc
+     end function edgpu_dvdson
      function edgpu_gf_lanczos(hfrom, hto, iorb, ispin, dagger, state, nlanc, threshold, norm2, alanc, blanc, nused) &
           bind(C, name="edgpu_gf_lanczos") result(rc)
        import :: c_int, c_int32_t, c_double, c_ptr

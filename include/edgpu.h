@@ -138,6 +138,11 @@ int edgpu_lanczos_time(edgpu_handle h, int32_t nwarm, int32_t niter, float *ms_p
  * NULL).  nconv = number of requested pairs whose residual passed |r| <= tol*max(eps^(2/3),|theta|). */
 int edgpu_eigsh(edgpu_handle h, int32_t nev, int32_t ncv, int32_t maxiter, double tol, double *evals, double *evecs,
                 int32_t *nconv, int32_t *nrestarts, int32_t *nmatvec);
+/* sp_dvdson_eigh(MatVec,eval,evec,nitermax,tol)   ED_DIAG.f90:189-203 (lanc_method="dvdson"): Davidson with the
+ * diagonal of H as preconditioner; search space and its image under H in HBM.  `maxiter` products at most; a pair
+ * counts as converged when |H x - theta x| <= max(tol,1e-11)*max(1,|theta|).  Same outputs as edgpu_eigsh. */
+int edgpu_dvdson(edgpu_handle h, int32_t nev, int32_t maxiter, double tol, double *evals, double *evecs,
+                 int32_t *nconv, int32_t *nmatvec);
 
 /* ---- observables: impurity-configuration weights of a state --------------------
  * hist[(mu*2^Norb + md) + 4^Norb*iph] = sum_i |vec_i|^2 over the states whose impurity up/down

@@ -156,6 +156,12 @@ def main():
             res["e0_" + st] = e0
             a, b, used = G.sp_lanc_tridiag(v0, 20)
             res["a_" + st] = a.tolist(); res["b_" + st] = b.tolist()
+            if S.Dim > 8:      # the multi-eigenpair solvers on the sharded operator
+                wd = np.linalg.eigvalsh(S.hmat())[:2]
+                evd, _, info = G.sp_dvdson_eigh(2, nitermax=400, tol=1e-11)
+                assert info["nconv"] == 2 and np.abs(evd - wd).max() < 1e-9, (st, evd, wd)
+                eva, _, info = G.sp_eigh(2, nblock=min(S.Dim, 20), nitermax=200, tol=1e-12)
+                assert info["nconv"] == 2 and np.abs(eva - wd).max() < 1e-9, (st, eva, wd)
             # eigenvector: gather on the host and check the residual with the oracle
             outs = [None] * size
             dist.all_gather_object(outs, (d0, q, x))

@@ -40,6 +40,8 @@ def test_fortran_driver_config1_matches_reference_known_answers():
         assert abs(f("E0")[0] - g["E0"]) < 1e-10
         e01 = f("E0E1")
         assert abs(e01[0] - g["E0"]) < 1e-10 and abs(e01[1] - g["E1"]) < 1e-10     # sp_eigh_gpu, 2 pairs
+        e01 = f("E0E1_dvdson")
+        assert abs(e01[0] - g["E0"]) < 1e-9 and abs(e01[1] - g["E1"]) < 1e-9       # sp_dvdson_eigh_gpu
 
 
 @pytest.mark.gpu
