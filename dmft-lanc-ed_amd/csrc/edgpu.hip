@@ -28,6 +28,23 @@ struct edgpu_spmat_s {
     int64_t nnz = 0;
 };
 
+// A `state` argument of the leg / observable entry points may live on the host or already in HBM (e.g. the vector
+// edgpu_lanczos_gs_device left there): device pointers are used in place, host pointers are staged once.
+static bool is_device_ptr(const void *p)
+{
+    hipPointerAttribute_t a{};
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }   // plain host memory: not known to HIP
+    return a.type == hipMemoryTypeDevice;
+}
+static int stage_state(S *h, const double *state, const double **dev)
+{
+    if (is_device_ptr(state)) { *dev = state; return EDGPU_OK; }
+    if (h->tmp_in.n != (size_t)h->nloc) { CHK(h->tmp_in.alloc((size_t)h->nloc)); CHK(h->tmp_out.alloc((size_t)h->nloc)); }
+    HIPCHK(hipMemcpy(h->tmp_in.p, state, (size_t)h->nloc * 8, hipMemcpyHostToDevice));
+    *dev = h->tmp_in.p;
+    return EDGPU_OK;
+}
+
 // =========================================================================================
 // C ABI
 // =========================================================================================
@@ -280,18 +297,18 @@ int edgpu_imp_density_offdiag(edgpu_handle h, const double *vec_host, double *dm
     const SectorHost &H = h->H; const int Norb = H.desc.Norb;
     for (int t = 0; t < 2 * Norb * Norb; t++) dm[t] = 0.0;
     if (Norb < 2) return EDGPU_OK;
-    if (h->tmp_in.n != (size_t)h->nloc) { CHK(h->tmp_in.alloc((size_t)h->nloc)); CHK(h->tmp_out.alloc((size_t)h->nloc)); }
-    HIPCHK(hipMemcpy(h->tmp_in.p, vec_host, (size_t)h->nloc * 8, hipMemcpyHostToDevice));
+    const double *st = nullptr;
+    CHK(stage_state(h, vec_host, &st));
     const int64_t nrows = H.Qdw * H.DimPh;
     DevBuf<double> out; CHK(out.alloc((size_t)nrows * 50));
     HIPCHK(hipMemsetAsync(out.p, 0, (size_t)nrows * 50 * 8, h->stream));
     DmArgs A{}; A.DimUp = (int32_t)H.DimUp; A.DimDw = (int32_t)H.DimDw; A.Norb = Norb; A.Qdw = H.Qdw; A.dw0 = H.dw0; A.nrows = nrows;
-    A.mapup = h->fac[0]->map.p; A.mapdw = h->fac[1]->map.p; A.rankup = h->fac[0]->rank.p; A.rankdw = h->fac[1]->rank.p; A.v = h->tmp_in.p; A.out = out.p;
+    A.mapup = h->fac[0]->map.p; A.mapdw = h->fac[1]->map.p; A.rankup = h->fac[0]->rank.p; A.rankdw = h->fac[1]->rank.p; A.v = st; A.out = out.p;
     const bool dist = h->multi && h->comm.size > 1;
     DevBuf<double> full;
     if (dist) {   // the dw-spin partner rows belong to other ranks
         CHK(full.alloc((size_t)(H.DimUp * H.DimDw * H.DimPh)));
-        CHK(gather_full(h, h->tmp_in.p, full.p, h->stream));
+        CHK(gather_full(h, st, full.p, h->stream));
         A.vg = full.p;
     }
     hipLaunchKernelGGL(k_imp_dm_rows, dim3((unsigned)nrows), dim3(256), 0, h->stream, A);
@@ -471,8 +488,9 @@ int edgpu_chi_lanczos(edgpu_handle h, const double *cup, const double *cdw, cons
     if (!h || !cup || !cdw || !state_host || !norm2 || !alanc || !blanc || !nused) return fail(EDGPU_EINVAL, "edgpu_chi_lanczos: null argument");
     HIPCHK(hipSetDevice(h->device));
     const SectorHost &H = h->H;
-    if (h->tmp_in.n != (size_t)h->nloc) { CHK(h->tmp_in.alloc((size_t)h->nloc)); CHK(h->tmp_out.alloc((size_t)h->nloc)); }
-    HIPCHK(hipMemcpy(h->tmp_in.p, state_host, (size_t)h->nloc * 8, hipMemcpyHostToDevice));
+    const double *st = nullptr;
+    if (h->tmp_out.n != (size_t)h->nloc) { CHK(h->tmp_in.alloc((size_t)h->nloc)); CHK(h->tmp_out.alloc((size_t)h->nloc)); }
+    CHK(stage_state(h, state_host, &st));
     CHK(lz_prepare(h, nlanc));
     DiagOpArgs A{};
     A.nfac = 2 * H.Ns_Ud; A.Norb = H.desc.Norb; A.total_ud = H.desc.ed_total_ud; A.Nel = h->nloc_el; A.N = h->nloc;
@@ -480,7 +498,7 @@ int edgpu_chi_lanczos(edgpu_handle h, const double *cup, const double *cdw, cons
     if (h->two_factor) { A.dims[1] = (int32_t)H.Qdw; A.maps[1] = h->fac[1]->map.p + H.dw0; }   // local dw columns
     else A.row0 = H.dw0 * H.DimUp;                                                              // mixed-radix digits are global
     for (int a = 0; a < EDGPU_MAX_ORB; a++) { A.cu[a] = a < A.Norb ? cup[a] : 0.0; A.cd[a] = a < A.Norb ? cdw[a] : 0.0; }
-    A.vin = h->tmp_in.p; A.vout = h->tmp_out.p;
+    A.vin = st; A.vout = h->tmp_out.p;
     const int nb = (int)std::max<int64_t>(1, std::min<int64_t>(cdiv(h->nloc, 256), 8192));
     hipLaunchKernelGGL(k_apply_diagop, dim3(nb), dim3(256), 0, h->stream, A);
     HIPCHK(hipGetLastError());
@@ -497,11 +515,12 @@ int edgpu_phonon_lanczos(edgpu_handle h, const double *state_host, int32_t nlanc
 {
     if (!h || !state_host || !norm2 || !alanc || !blanc || !nused) return fail(EDGPU_EINVAL, "edgpu_phonon_lanczos: null argument");
     HIPCHK(hipSetDevice(h->device));
-    if (h->tmp_in.n != (size_t)h->nloc) { CHK(h->tmp_in.alloc((size_t)h->nloc)); CHK(h->tmp_out.alloc((size_t)h->nloc)); }
-    HIPCHK(hipMemcpy(h->tmp_in.p, state_host, (size_t)h->nloc * 8, hipMemcpyHostToDevice));
+    const double *st = nullptr;
+    if (h->tmp_out.n != (size_t)h->nloc) { CHK(h->tmp_in.alloc((size_t)h->nloc)); CHK(h->tmp_out.alloc((size_t)h->nloc)); }
+    CHK(stage_state(h, state_host, &st));
     CHK(lz_prepare(h, nlanc));
     const int nb = (int)std::max<int64_t>(1, std::min<int64_t>(cdiv(h->nloc, 256), 8192));
-    hipLaunchKernelGGL(k_apply_phonon_x, dim3(nb), dim3(256), 0, h->stream, (const double *)h->tmp_in.p, h->tmp_out.p, h->nloc_el, h->H.DimPh);
+    hipLaunchKernelGGL(k_apply_phonon_x, dim3(nb), dim3(256), 0, h->stream, st, h->tmp_out.p, h->nloc_el, h->H.DimPh);
     HIPCHK(hipGetLastError());
     CHK(normalise_dev(h, h->tmp_out.p, norm2));
     for (int i = 0; i < nlanc; i++) { alanc[i] = 0.0; blanc[i] = 0.0; }
@@ -511,18 +530,18 @@ int edgpu_phonon_lanczos(edgpu_handle h, const double *state_host, int32_t nlanc
 }
 
 // One Green's-function Lanczos leg entirely in HBM: O|state>, normalise, sp_lanc_tridiag.
-// state_host: vecdim(from) doubles on the host.  Returns norm2, alanc/blanc (nlanc) and nused.
+// state_host: vecdim(from) doubles, on the host or already in HBM.  Returns norm2, alanc/blanc (nlanc) and nused.
 int edgpu_gf_lanczos(edgpu_handle from, edgpu_handle to, int32_t iorb, int32_t ispin, int32_t dagger,
                      const double *state_host, int32_t nlanc, double threshold, double *norm2,
                      double *alanc, double *blanc, int32_t *nused)
 {
     if (!from || !to || !state_host || !alanc || !blanc || !nused || !norm2) return fail(EDGPU_EINVAL, "edgpu_gf_lanczos: null argument");
     HIPCHK(hipSetDevice(to->device));
-    if (from->tmp_in.n != (size_t)from->nloc) { CHK(from->tmp_in.alloc((size_t)from->nloc)); CHK(from->tmp_out.alloc((size_t)from->nloc)); }
+    const double *st = nullptr;
+    CHK(stage_state(from, state_host, &st));
     if (to->tmp_in.n != (size_t)to->nloc) { CHK(to->tmp_in.alloc((size_t)to->nloc)); CHK(to->tmp_out.alloc((size_t)to->nloc)); }
-    HIPCHK(hipMemcpy(from->tmp_in.p, state_host, (size_t)from->nloc * 8, hipMemcpyHostToDevice));
     CHK(lz_prepare(to, nlanc));
-    CHK(edgpu_apply_op(from, to, iorb, ispin, dagger, from->tmp_in.p, to->tmp_in.p, norm2));
+    CHK(edgpu_apply_op(from, to, iorb, ispin, dagger, st, to->tmp_in.p, norm2));
     for (int i = 0; i < nlanc; i++) { alanc[i] = 0.0; blanc[i] = 0.0; }
     *nused = 0;
     if (*norm2 <= 0.0) return EDGPU_OK;

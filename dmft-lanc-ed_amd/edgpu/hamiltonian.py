@@ -46,6 +46,14 @@ class DeviceVector:
             pass
 
 
+def _state_ptr(state):
+    """(pointer, keep-alive) of a state given as a numpy array (host) or a DeviceVector (already in HBM)"""
+    if isinstance(state, DeviceVector):
+        return state.ptr, state
+    a = np.ascontiguousarray(state, np.float64)
+    return a.ctypes.data, a
+
+
 def _f64(a):
     return np.asfortranarray(np.asarray(a, dtype=np.float64))
 
@@ -248,17 +256,17 @@ class HvSector:
         sum_a cup[a] n_up,a + cdw[a] n_dw,a applied to `state` (ED_GF_CHISPIN/CHIDENS builders)."""
         Norb = int(self._desc.Norb)
         cu = np.zeros(Norb); cu[:len(cup)] = cup; cd = np.zeros(Norb); cd[:len(cdw)] = cdw
-        state = np.ascontiguousarray(state, np.float64)
+        sp, _keep = _state_ptr(state)
         a = np.zeros(nlanc); b = np.zeros(nlanc); n2 = C.c_double(); nu = C.c_int32()
-        check(capi.lib().edgpu_chi_lanczos(self._h, cu.ctypes.data, cd.ctypes.data, state.ctypes.data, nlanc, threshold,
+        check(capi.lib().edgpu_chi_lanczos(self._h, cu.ctypes.data, cd.ctypes.data, sp, nlanc, threshold,
                                            C.byref(n2), a.ctypes.data, b.ctypes.data, C.byref(nu)))
         return n2.value, a, b, nu.value
 
     def phonon_lanczos(self, state, nlanc, threshold=1e-12):
         """Phonon propagator leg: (norm2, alanc, blanc, nused) for (b+b^+)|state> (ED_GF_PHONON.f90)."""
-        state = np.ascontiguousarray(state, np.float64)
+        sp, _keep = _state_ptr(state)
         a = np.zeros(nlanc); b = np.zeros(nlanc); n2 = C.c_double(); nu = C.c_int32()
-        check(capi.lib().edgpu_phonon_lanczos(self._h, state.ctypes.data, nlanc, threshold, C.byref(n2), a.ctypes.data, b.ctypes.data, C.byref(nu)))
+        check(capi.lib().edgpu_phonon_lanczos(self._h, sp, nlanc, threshold, C.byref(n2), a.ctypes.data, b.ctypes.data, C.byref(nu)))
         return n2.value, a, b, nu.value
 
     def sp_lanc_tridiag(self, vin, nlanc, threshold=1e-12):
@@ -330,9 +338,9 @@ def apply_op(sec_from, sec_to, iorb, ispin, dagger, vin_dev, vout_dev):
 
 def gf_lanczos(sec_from, sec_to, iorb, ispin, dagger, state, nlanc, threshold=1e-12):
     """One leg of lanc_build_gf_normal_main: (norm2, alanc, blanc, nused)."""
-    state = np.ascontiguousarray(state, np.float64)
+    sp, _keep = _state_ptr(state)
     a = np.zeros(nlanc); b = np.zeros(nlanc); n2 = C.c_double(); nu = C.c_int32()
-    check(capi.lib().edgpu_gf_lanczos(sec_from._h, sec_to._h, iorb, ispin, 1 if dagger else 0, state.ctypes.data, nlanc, threshold,
+    check(capi.lib().edgpu_gf_lanczos(sec_from._h, sec_to._h, iorb, ispin, 1 if dagger else 0, sp, nlanc, threshold,
                                       C.byref(n2), a.ctypes.data, b.ctypes.data, C.byref(nu)))
     return n2.value, a, b, nu.value
 

@@ -169,7 +169,9 @@ int edgpu_twin_reorder(edgpu_handle h, const double *vin_host, double *vout_host
  * (the weight passed to add_to_lanczos_gf_normal, ED_GF_NORMAL.f90:239). */
 int edgpu_apply_op(edgpu_handle from, edgpu_handle to, int32_t iorb, int32_t ispin, int32_t dagger,
                    const double *vin_dev, double *vout_dev, double *norm2);
-/* the whole leg: upload state, apply O, normalise, sp_lanc_tridiag in the target sector */
+/* the whole leg: apply O, normalise, sp_lanc_tridiag in the target sector.  `state_host` (here and in the chi /
+ * phonon legs and edgpu_imp_density_offdiag) may be a host pointer or a device pointer (e.g. the eigenvector
+ * edgpu_lanczos_gs_device left in HBM): device memory is used in place, host memory is uploaded once. */
 int edgpu_gf_lanczos(edgpu_handle from, edgpu_handle to, int32_t iorb, int32_t ispin, int32_t dagger,
                      const double *state_host, int32_t nlanc, double threshold, double *norm2,
                      double *alanc, double *blanc, int32_t *nused);

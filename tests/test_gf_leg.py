@@ -126,3 +126,23 @@ def test_phonon_propagator_leg(edgpu_mod, case):
     np.testing.assert_allclose(a[:k], a_ref[:k], rtol=1e-9, atol=1e-9)
     np.testing.assert_allclose(b[1:k], b_ref[1:k], rtol=1e-9, atol=1e-9)
     G.close()
+
+
+def test_legs_take_the_ground_state_straight_from_hbm(edgpu_mod):
+    """sp_lanc_eigh_device leaves the eigenvector in HBM; the GF / chi legs accept that device pointer in place of a
+    host vector (no PCIe round trip of the N-vector between diagonalisation and Green's functions)."""
+    name, m, nu, nd = [z for z in cases.zoo() if z[0] == "c_nb7_half"][0]
+    G0 = edgpu_mod.HvSector(m, nu, nd)
+    dv = edgpu_mod.DeviceVector(G0.Dim).upload(np.zeros(G0.Dim))
+    e0, nl = G0.sp_lanc_eigh_device(dv, nitermax=300, threshold=1e-14)
+    gs = dv.download()
+    Gt = edgpu_mod.HvSector(m, [nu[0] + 1], nd)
+    r_dev = edgpu_mod.gf_lanczos(G0, Gt, 1, 1, True, dv, 40)
+    r_host = edgpu_mod.gf_lanczos(G0, Gt, 1, 1, True, gs, 40)
+    assert r_dev[0] == r_host[0] and r_dev[3] == r_host[3]
+    np.testing.assert_array_equal(r_dev[1], r_host[1]); np.testing.assert_array_equal(r_dev[2], r_host[2])
+    c_dev = G0.chi_lanczos([0.5], [-0.5], dv, 30); c_host = G0.chi_lanczos([0.5], [-0.5], gs, 30)
+    assert c_dev[0] == c_host[0]
+    np.testing.assert_array_equal(c_dev[1], c_host[1])
+    np.testing.assert_array_equal(dv.download(), gs)          # the resident state is left untouched
+    Gt.close(); G0.close()
