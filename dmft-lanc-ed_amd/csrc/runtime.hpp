@@ -151,7 +151,24 @@ struct edgpu_sector_s {
     int64_t npartial = 0;
     // Lanczos iteration fusion (single rank)
     int fuse_mode = -1; const double *fuse_zvec = nullptr;   // >= 0: the product's final reduction also performs this scalar step
+    edgpu_sector_s() = default;
+    edgpu_sector_s(const edgpu_sector_s &) = delete;
+    edgpu_sector_s &operator=(const edgpu_sector_s &) = delete;
+    ~edgpu_sector_s();      // also runs when edgpu_sector_create fails half-way: nothing leaks
 };
+
+inline edgpu_sector_s::~edgpu_sector_s()
+{
+    if (comm.kind == Comm::RCCL && comm.nccl && g_rccl.ok) g_rccl.CommDestroy(comm.nccl);
+    for (auto e : bench_ev) (void)hipEventDestroy(e);
+    if (ev_pack) (void)hipEventDestroy(ev_pack);
+    if (ev_a) (void)hipEventDestroy(ev_a);
+    if (ev_b) (void)hipEventDestroy(ev_b);
+    if (ev_gather) (void)hipEventDestroy(ev_gather);
+    if (ev_ready) (void)hipEventDestroy(ev_ready);
+    if (stream) (void)hipStreamDestroy(stream);
+    if (cstream) (void)hipStreamDestroy(cstream);
+}
 
 namespace edgpu {
 using S = edgpu_sector_s;

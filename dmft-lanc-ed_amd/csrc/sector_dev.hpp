@@ -340,16 +340,7 @@ static void destroy(S *s)
     if (!s) return;
     (void)hipSetDevice(s->device);
     (void)hipDeviceSynchronize();
-    if (s->comm.kind == Comm::RCCL && s->comm.nccl && g_rccl.ok) g_rccl.CommDestroy(s->comm.nccl);
-    for (auto e : s->bench_ev) (void)hipEventDestroy(e);
-    if (s->ev_pack) (void)hipEventDestroy(s->ev_pack);
-    if (s->ev_a) (void)hipEventDestroy(s->ev_a);
-    if (s->ev_b) (void)hipEventDestroy(s->ev_b);
-    if (s->ev_gather) (void)hipEventDestroy(s->ev_gather);
-    if (s->ev_ready) (void)hipEventDestroy(s->ev_ready);
-    if (s->stream) (void)hipStreamDestroy(s->stream);
-    if (s->cstream) (void)hipStreamDestroy(s->cstream);
-    delete s;
+    delete s;      // ~edgpu_sector_s releases the communicator, events, streams and (through DevBuf) device memory
 }
 
 }  // namespace edgpu
