@@ -156,21 +156,24 @@ int edgpu_csr_rows(edgpu_handle h, int64_t row0, int64_t nrows, int64_t *row_ptr
         if (n) { HIPCHK(hipMemcpy(hc.data(), cc.p + hrp[0], (size_t)n * 4, hipMemcpyDeviceToHost)); HIPCHK(hipMemcpy(hv.data(), vv.p + hrp[0], (size_t)n * 8, hipMemcpyDeviceToHost)); }
         return EDGPU_OK;
     };
-    std::vector<int64_t> rl, rd; std::vector<int32_t> cl, cd; std::vector<double> vl, vd;
-    CHK(fetch(h->csr_rowptr, h->csr_cols, h->csr_vals, rl, cl, vl));
-    if (h->csr_split) CHK(fetch(h->csrD_rowptr, h->csrD_cols, h->csrD_vals, rd, cd, vd));
-    // merged view (ascending columns) of the one or two stored blocks
+    // merged view (ascending columns) of the one, two or three stored blocks
+    std::vector<int64_t> rp[3]; std::vector<int32_t> cc[3]; std::vector<double> vv[3];
+    int nblk = 1;
+    CHK(fetch(h->csr_rowptr, h->csr_cols, h->csr_vals, rp[0], cc[0], vv[0]));
+    if (h->csr_split) { CHK(fetch(h->csrD_rowptr, h->csrD_cols, h->csrD_vals, rp[1], cc[1], vv[1])); nblk = 2; }
+    if (h->csr_three) { CHK(fetch(h->csrO_rowptr, h->csrO_cols, h->csrO_vals, rp[2], cc[2], vv[2])); nblk = 3; }
     int64_t n = 0;
     row_ptr[0] = 0;
     for (int64_t r = 0; r < nrows; r++) {
-        int64_t a = rl[r] - rl[0], ae = rl[r + 1] - rl[0], b = 0, be = 0;
-        if (h->csr_split) { b = rd[r] - rd[0]; be = rd[r + 1] - rd[0]; }
-        while (a < ae || b < be) {
-            bool takeL = b >= be || (a < ae && cl[a] < cd[b]);
+        int64_t a[3], ae[3];
+        for (int b = 0; b < nblk; b++) { a[b] = rp[b][r] - rp[b][0]; ae[b] = rp[b][r + 1] - rp[b][0]; }
+        for (;;) {
+            int pick = -1;
+            for (int b = 0; b < nblk; b++) if (a[b] < ae[b] && (pick < 0 || cc[b][a[b]] < cc[pick][a[pick]])) pick = b;
+            if (pick < 0) break;
             if (n >= cap) return fail(EDGPU_EINVAL, "edgpu_csr_rows: capacity too small");
-            if (cols && vals) { cols[n] = takeL ? cl[a] : cd[b]; vals[n] = takeL ? vl[a] : vd[b]; }
-            if (takeL) a++; else b++;
-            n++;
+            if (cols && vals) { cols[n] = cc[pick][a[pick]]; vals[n] = vv[pick][a[pick]]; }
+            a[pick]++; n++;
         }
         row_ptr[r + 1] = n;
     }

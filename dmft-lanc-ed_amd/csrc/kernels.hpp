@@ -866,6 +866,8 @@ struct CsrBuildArgs {
     const int64_t *dwpre;                           // prefix over local idw of row-block nnz, [Qdw+1]
     const double *diag;
     int64_t *rowptr; int32_t *cols; double *vals;
+    int32_t sel; const int64_t *selpre;   // part 2 only: 0 all dw hops; 1 those into the rank's own rows; 2 those into received (halo)
+                                          // rows.  selpre[idwl] = entries of the selected kind in the rows before idwl (times DimUp)
 };
 
 // row (iup, idw) holds, in ascending column order: dw hops to jdw<idw, up hops jup<iup, the
@@ -877,24 +879,29 @@ __global__ void __launch_bounds__(256) k_csr_build(CsrBuildArgs A, int part)
     const int64_t nloc = A.Qdw * A.DimUp;
     if (il > nloc) return;
     const int64_t upall = A.uppre[A.DimUp];
-    if (il == nloc) { A.rowptr[nloc] = part == 0 ? A.dwpre[A.Qdw] : (part == 1 ? A.Qdw * upall : A.dwpre[A.Qdw] - A.Qdw * upall); return; }
+    if (il == nloc) {
+        A.rowptr[nloc] = part == 0 ? A.dwpre[A.Qdw] : (part == 1 ? A.Qdw * upall : (A.sel ? A.selpre[A.Qdw] : A.dwpre[A.Qdw] - A.Qdw * upall));
+        return;
+    }
     const int64_t idwl = il / A.DimUp; const int iup = (int)(il - idwl * A.DimUp); const int64_t idw = A.dw0 + idwl;
-    const int ndw = A.dwrp[idw + 1] - A.dwrp[idw];
+    const int32_t d0 = A.dwrp[idw], d1 = A.dwrp[idw + 1], u0 = A.uprp[iup], u1 = A.uprp[iup + 1];
+    const int ndw = d1 - d0;
+    auto keep = [&](int32_t xr) { return A.sel == 0 || (A.sel == 1) == (xr < A.Qdw); };   // x-space rows [0,Qdw) are the rank's own
     int64_t p;
     if (part == 0) p = A.dwpre[idwl] + (int64_t)iup * ndw + A.uppre[iup];
     else if (part == 1) p = idwl * upall + A.uppre[iup];
-    else p = A.dwpre[idwl] - idwl * upall + (int64_t)iup * ndw;
+    else if (A.sel == 0) p = A.dwpre[idwl] - idwl * upall + (int64_t)iup * ndw;
+    else { int nsel = 0; for (int32_t q = d0; q < d1; q++) nsel += keep(A.dwc[q]) ? 1 : 0; p = A.selpre[idwl] + (int64_t)iup * nsel; }
     A.rowptr[il] = p;
-    const int32_t d0 = A.dwrp[idw], d1 = A.dwrp[idw + 1], u0 = A.uprp[iup], u1 = A.uprp[iup + 1];
     const int64_t xrow = idw - A.rowshift;     // index of this dw row in the column (x) space
-    if (part != 1) for (int32_t q = d0; q < d1; q++) if (A.dwc[q] < xrow) { A.cols[p] = (int32_t)((int64_t)A.dwc[q] * A.DimUp + iup); A.vals[p] = A.dwv[q]; p++; }
+    if (part != 1) for (int32_t q = d0; q < d1; q++) if (A.dwc[q] < xrow && keep(A.dwc[q])) { A.cols[p] = (int32_t)((int64_t)A.dwc[q] * A.DimUp + iup); A.vals[p] = A.dwv[q]; p++; }
     if (part != 2) {
         int32_t r = u0;
         for (; r < u1 && A.upc[r] < iup; r++) { A.cols[p] = (int32_t)(xrow * A.DimUp + A.upc[r]); A.vals[p] = A.upv[r]; p++; }
         A.cols[p] = (int32_t)(xrow * A.DimUp + iup); A.vals[p] = A.diag[il]; p++;
         for (; r < u1; r++) { A.cols[p] = (int32_t)(xrow * A.DimUp + A.upc[r]); A.vals[p] = A.upv[r]; p++; }
     }
-    if (part != 1) for (int32_t q = d0; q < d1; q++) if (A.dwc[q] >= xrow) { A.cols[p] = (int32_t)((int64_t)A.dwc[q] * A.DimUp + iup); A.vals[p] = A.dwv[q]; p++; }
+    if (part != 1) for (int32_t q = d0; q < d1; q++) if (A.dwc[q] >= xrow && keep(A.dwc[q])) { A.cols[p] = (int32_t)((int64_t)A.dwc[q] * A.DimUp + iup); A.vals[p] = A.dwv[q]; p++; }
 }
 
 struct CsrArgs {
@@ -903,7 +910,8 @@ struct CsrArgs {
     const double *x; double *y;
     const double *v_local;  // x restricted to the local rows (== x on one GPU), for the alpha dot
     const double *uprev; const double *scal; double *partial; int32_t epi; int32_t xcd_rows;
-    int32_t pass;      // 0: whole product; 1: first block of a split CSR (no alpha); 2: second block (y +=, alpha)
+    int32_t pass;      // 0: whole product; 1: first block of a split CSR (no alpha); 2: last block (y +=, alpha);
+                       // 3: a block in between (y +=, no alpha)
     int32_t coltiles;  // 1: blocks sweep XCD-affine column tiles (idw fastest) -- the dw block of a split CSR
 };
 
@@ -929,7 +937,7 @@ __global__ void __launch_bounds__(ROWS) k_csr_spmv2(CsrArgs A)
         // x slab x(tile, all idw) that the dw hops gather from stays in its L2
         const int xcd = blockIdx.x & 7; const int64_t sidx = blockIdx.x >> 3;
         const int64_t tl = sidx / A.Qdw; idwl = sidx - tl * A.Qdw; jb = (int)(tl * 8 + xcd);
-        if (jb >= A.blocks_per_row) { if (A.epi && A.pass != 1 && threadIdx.x == 0) A.partial[blockIdx.x] = 0.0; return; }
+        if (jb >= A.blocks_per_row) { if (A.epi && (A.pass == 0 || A.pass == 2) && threadIdx.x == 0) A.partial[blockIdx.x] = 0.0; return; }
     } else {
         const int64_t b = blockIdx.x, per_tile = (int64_t)A.tile * A.Qdw;
         const int nt_full = A.blocks_per_row / A.tile;
@@ -955,9 +963,9 @@ __global__ void __launch_bounds__(ROWS) k_csr_spmv2(CsrArgs A)
     double up_i = 0.0, xl_i = 0.0;   // epilogue operands, requested before the stream so their latency hides under it
     if (tid < nr) {
         ra = (int)(A.rowptr[row0 + tid] - p0) + sh; re = (int)(A.rowptr[row0 + tid + 1] - p0) + sh;
-        if (A.epi && A.pass != 2) up_i = A.uprev[row0 + tid];
-        if (A.epi && A.pass != 1) xl_i = A.v_local[row0 + tid];
-        if (A.pass == 2) up_i = A.y[row0 + tid];        // running value of the first block
+        if (A.epi && A.pass < 2) up_i = A.uprev[row0 + tid];
+        if (A.epi && (A.pass == 0 || A.pass == 2)) xl_i = A.v_local[row0 + tid];
+        if (A.pass >= 2) up_i = A.y[row0 + tid];        // running value of the earlier blocks
     }
     {
         const double *gv = A.vals + (p0 - sh); const int32_t *gc = A.cols + (p0 - sh);   // 4-aligned base
@@ -992,11 +1000,11 @@ __global__ void __launch_bounds__(ROWS) k_csr_spmv2(CsrArgs A)
         for (; k < re; k++) acc0 += sval[k] * A.x[scol[k]];
         const double acc = acc0 + acc1;
         if (A.epi) {
-            const double w = A.pass == 2 ? up_i + s_cur * acc : s_cur * acc - c_prev * up_i;
+            const double w = A.pass >= 2 ? up_i + s_cur * acc : s_cur * acc - c_prev * up_i;
             A.y[row] = w; asum = (s_cur * xl_i) * w;
-        } else A.y[row] = A.pass == 2 ? up_i + acc : acc;
+        } else A.y[row] = A.pass >= 2 ? up_i + acc : acc;
     }
-    if (A.epi && A.pass != 1) { double r = block_sum(asum, red); if (tid == 0) A.partial[blockIdx.x] = r; }
+    if (A.epi && (A.pass == 0 || A.pass == 2)) { double r = block_sum(asum, red); if (tid == 0) A.partial[blockIdx.x] = r; }
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -102,10 +102,19 @@ static int hxv(S *s, const double *v, double *out, bool epi, const double *uprev
         else hipLaunchKernelGGL((k_csr_spmv2<64, 1152, false>), dim3((unsigned)nblocks), dim3(64), 0, s->stream, A);
         HIPCHK(hipGetLastError());
         if (s->csr_split) {
+            A.rows_per_block = s->csrD_rpb; A.blocks_per_row = s->csrD_bpr; A.coltiles = 1; A.xcd_rows = 0;
+            nblocks = 8 * cdiv(s->csrD_bpr, 8) * H.Qdw;
+            if (s->csr_three) {
+                // dw hops into the rank's own rows: their columns are the first Qdw rows of the x-space, i.e. the local
+                // shard itself -- this block too runs while the exchange is in flight
+                A.rowptr = s->csrO_rowptr.p; A.cols = s->csrO_cols.p; A.vals = s->csrO_vals.p; A.pass = 3;
+                if (s->csrD_small) hipLaunchKernelGGL((k_csr_spmv2<64, 640, false>), dim3((unsigned)nblocks), dim3(64), 0, s->stream, A);
+                else hipLaunchKernelGGL((k_csr_spmv2<64, 1152, false>), dim3((unsigned)nblocks), dim3(64), 0, s->stream, A);
+                HIPCHK(hipGetLastError());
+            }
             if (overlap) { HIPCHK(hipStreamWaitEvent(s->stream, s->ev_gather, 0)); A.x = s->vfull.p; }
             A.rowptr = s->csrD_rowptr.p; A.cols = s->csrD_cols.p; A.vals = s->csrD_vals.p;
-            A.rows_per_block = s->csrD_rpb; A.blocks_per_row = s->csrD_bpr; A.pass = 2; A.coltiles = 1; A.xcd_rows = 0;
-            nblocks = 8 * cdiv(s->csrD_bpr, 8) * H.Qdw;
+            A.pass = 2;
             if (s->csrD_small) {
                 if (s->csrD_nt) hipLaunchKernelGGL((k_csr_spmv2<64, 640, true>), dim3((unsigned)nblocks), dim3(64), 0, s->stream, A);
                 else hipLaunchKernelGGL((k_csr_spmv2<64, 640, false>), dim3((unsigned)nblocks), dim3(64), 0, s->stream, A);

@@ -131,6 +131,9 @@ struct edgpu_sector_s {
     // explicit CSR
     DevBuf<int64_t> csr_rowptr, uppre, dwpre; DevBuf<int32_t> csr_cols; DevBuf<double> csr_vals;
     DevBuf<int64_t> csrD_rowptr; DevBuf<int32_t> csrD_cols; DevBuf<double> csrD_vals;   // dw block of the split form
+    // needed-rows exchange: the dw block is stored as two blocks, hops into the rank's own rows (runs while the exchange
+    // is in flight) and hops into received rows (csrD_*: runs after it)
+    DevBuf<int64_t> csrO_rowptr, selpre_own, selpre_halo; DevBuf<int32_t> csrO_cols; DevBuf<double> csrO_vals; bool csr_three = false; int64_t csrO_nnz = 0;
     bool csr_split = false; int64_t csrL_nnz = 0, csrD_nnz = 0; int32_t csrD_rpb = 64, csrD_bpr = 0; int csrD_nt = 1; bool csrL_small = false, csrD_small = false;
     int64_t csr_nnz = 0; int32_t csr_rpb = 0, csr_bpr = 0, csr_tile = 1;
     // work vectors

@@ -220,11 +220,32 @@ static int build_csr(S *s)
         hipLaunchKernelGGL(k_csr_build, dim3(gb), dim3(256), 0, s->stream, A, 0);
     } else {
         CHK(s->csr_rowptr.alloc((size_t)s->nloc_el + 1)); CHK(s->csr_cols.alloc((size_t)s->csrL_nnz)); CHK(s->csr_vals.alloc((size_t)s->csrL_nnz));
-        CHK(s->csrD_rowptr.alloc((size_t)s->nloc_el + 1)); CHK(s->csrD_cols.alloc((size_t)s->csrD_nnz)); CHK(s->csrD_vals.alloc((size_t)s->csrD_nnz));
+        if (!(s->halo && dbg_int("EDGPU_CSR_THREE", 1) != 0)) { CHK(s->csrD_rowptr.alloc((size_t)s->nloc_el + 1)); CHK(s->csrD_cols.alloc((size_t)s->csrD_nnz)); CHK(s->csrD_vals.alloc((size_t)s->csrD_nnz)); }
         A.rowptr = s->csr_rowptr.p; A.cols = s->csr_cols.p; A.vals = s->csr_vals.p;
         hipLaunchKernelGGL(k_csr_build, dim3(gb), dim3(256), 0, s->stream, A, 1);
-        A.rowptr = s->csrD_rowptr.p; A.cols = s->csrD_cols.p; A.vals = s->csrD_vals.p;
-        hipLaunchKernelGGL(k_csr_build, dim3(gb), dim3(256), 0, s->stream, A, 2);
+        s->csr_three = s->halo && dbg_int("EDGPU_CSR_THREE", 1) != 0;
+        if (!s->csr_three) {
+            A.rowptr = s->csrD_rowptr.p; A.cols = s->csrD_cols.p; A.vals = s->csrD_vals.p;
+            hipLaunchKernelGGL(k_csr_build, dim3(gb), dim3(256), 0, s->stream, A, 2);
+        } else {
+            // per local dw row: how many of its hops stay inside the rank's own rows (x-space row < Qdw)
+            std::vector<int64_t> po(H.Qdw + 1, 0), ph(H.Qdw + 1, 0);
+            std::vector<int32_t> xc; { xc.resize(dw.cols.size()); HIPCHK(hipMemcpy(xc.data(), s->dw_cols_x.p, xc.size() * 4, hipMemcpyDeviceToHost)); }
+            for (int64_t q = 0; q < H.Qdw; q++) {
+                int64_t no = 0, nh = 0;
+                for (int64_t pp = dw.rowptr[H.dw0 + q]; pp < dw.rowptr[H.dw0 + q + 1]; pp++) (xc[pp] < H.Qdw ? no : nh)++;
+                po[q + 1] = po[q] + no * up.dim; ph[q + 1] = ph[q] + nh * up.dim;
+            }
+            s->csrO_nnz = po[H.Qdw]; s->csrD_nnz = ph[H.Qdw];
+            CHK(s->selpre_own.upload(po)); CHK(s->selpre_halo.upload(ph));
+            CHK(s->csrD_rowptr.alloc((size_t)s->nloc_el + 1)); CHK(s->csrD_cols.alloc((size_t)std::max<int64_t>(s->csrD_nnz, 1))); CHK(s->csrD_vals.alloc((size_t)std::max<int64_t>(s->csrD_nnz, 1)));
+            CHK(s->csrO_rowptr.alloc((size_t)s->nloc_el + 1)); CHK(s->csrO_cols.alloc((size_t)std::max<int64_t>(s->csrO_nnz, 1))); CHK(s->csrO_vals.alloc((size_t)std::max<int64_t>(s->csrO_nnz, 1)));
+            A.sel = 1; A.selpre = s->selpre_own.p; A.rowptr = s->csrO_rowptr.p; A.cols = s->csrO_cols.p; A.vals = s->csrO_vals.p;
+            hipLaunchKernelGGL(k_csr_build, dim3(gb), dim3(256), 0, s->stream, A, 2);
+            A.sel = 2; A.selpre = s->selpre_halo.p; A.rowptr = s->csrD_rowptr.p; A.cols = s->csrD_cols.p; A.vals = s->csrD_vals.p;
+            hipLaunchKernelGGL(k_csr_build, dim3(gb), dim3(256), 0, s->stream, A, 2);
+            A.sel = 0; A.selpre = nullptr;
+        }
         int64_t ndmax = 0;
         for (int64_t q = 0; q < H.Qdw; q++) ndmax = std::max<int64_t>(ndmax, dw.rowptr[H.dw0 + q + 1] - dw.rowptr[H.dw0 + q]);
         s->csrD_rpb = (int32_t)std::min<int64_t>(dbg_int("EDGPU_CSRD_ROWS", 64), 1152 / std::max<int64_t>(ndmax, 1));
@@ -322,7 +343,7 @@ static int create(const edgpu_desc *desc, S **out)
     if (desc->storage != EDGPU_STORE_DIRECT) { CHK(build_diag(s.get())); s->bytes_stored = s->nloc_el * 8; }
     if (desc->storage == EDGPU_STORE_CSR) {
         CHK(build_csr(s.get()));
-        s->bytes_stored = s->csr_nnz * 12 + (s->nloc_el + 1) * 8 * (s->csr_split ? 2 : 1);
+        s->bytes_stored = s->csr_nnz * 12 + (s->nloc_el + 1) * 8 * (s->csr_three ? 3 : (s->csr_split ? 2 : 1));
     }
     if (s->multi) CHK(s->vfull.alloc((size_t)(H.DimUp * s->nhalo * H.DimPh)));
     s->npartial = max_partials(s.get());

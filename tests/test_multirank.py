@@ -18,12 +18,13 @@ def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
-def _launch(mode, case, size, timeout=600):
+def _launch(mode, case, size, timeout=600, extra_env=None):
     port = _free_port()
     with tempfile.TemporaryDirectory() as d:
         procs = []
         for r in range(size):
             env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(size), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+            env.update(extra_env or {})
             procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "mp_worker.py"), mode, case, d], env=env,
                                           stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
         outs = []
@@ -69,6 +70,21 @@ def test_multirank_on_one_gpu_callback_exchange(edgpu_mod, case, size):
                 np.testing.assert_allclose(v, a1, rtol=1e-9, atol=1e-9)
             if k.startswith("b_"):
                 np.testing.assert_allclose(v, b1, rtol=1e-9, atol=1e-9)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case,size", [("c_nb7_half", 2), ("nb5_offhalf_2_4", 3)])
+def test_multirank_large_sector_forms(edgpu_mod, case, size):
+    """The storage forms that switch on for large sectors, forced on small ones with several ranks: two-pass stored
+    product, and the explicit CSR as three blocks (local | dw hops into own rows | dw hops into received rows)."""
+    res = _launch("gpu", case, size, extra_env={"EDGPU_KRON_SPLIT": "1", "EDGPU_CSR_SPLIT": "1"})
+    name, m, nu, nd = [z for z in __import__("cases").zoo() if z[0] == case][0]
+    from oracle import oracle
+    e_dense = np.linalg.eigvalsh(oracle.Sector(m, nu, nd).hmat())[0]
+    for r in res:
+        for k, v in r.items():
+            if k.startswith("e0_"):
+                assert abs(v - e_dense) < 1e-10, (k, v, e_dense)
 
 
 @pytest.mark.gpu
