@@ -62,7 +62,8 @@ static int halo_exchange(S *s, const double *v_local, hipStream_t st)
     }
     for (int iph = 0; iph < H.DimPh; iph++) {
         double *x = s->vfull.p + (int64_t)iph * s->nhalo * rowlen;
-        HIPCHK(hipMemcpyAsync(x, v_local + (int64_t)iph * s->nloc_el, (size_t)s->nloc_el * 8, hipMemcpyDeviceToDevice, st));
+        // own rows of the x-space: not needed by the three-block CSR (its received-row block never reads them)
+        if (!s->csr_three) HIPCHK(hipMemcpyAsync(x, v_local + (int64_t)iph * s->nloc_el, (size_t)s->nloc_el * 8, hipMemcpyDeviceToDevice, st));
         const double *sb = s->sendbuf.p + (int64_t)iph * nsend_rows * rowlen;
         if (P == 1) continue;
         if (c.kind == Comm::RCCL) {

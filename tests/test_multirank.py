@@ -18,7 +18,7 @@ def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
-def _launch(mode, case, size, timeout=600, extra_env=None):
+def _launch(mode, case, size, timeout=150, extra_env=None):
     port = _free_port()
     with tempfile.TemporaryDirectory() as d:
         procs = []
@@ -27,17 +27,25 @@ def _launch(mode, case, size, timeout=600, extra_env=None):
             env.update(extra_env or {})
             procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "mp_worker.py"), mode, case, d], env=env,
                                           stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
-        outs = []
-        for p in procs:
-            try:
-                o, _ = p.communicate(timeout=timeout)
-            except subprocess.TimeoutExpired:
-                for q in procs:
+        # poll: a rank that dies leaves the others blocked in a collective -- stop them at once and show its output
+        import time
+        t0 = time.time(); failed = None
+        while True:
+            codes = [p.poll() for p in procs]
+            bad = [r for r, c in enumerate(codes) if c not in (None, 0)]
+            if bad:
+                failed = bad[0]; break
+            if all(c == 0 for c in codes):
+                break
+            if time.time() - t0 > timeout:
+                failed = -1; break
+            time.sleep(0.2)
+        if failed is not None:
+            for q in procs:
+                if q.poll() is None:
                     q.kill()
-                raise
-            outs.append(o.decode())
-        for r, p in enumerate(procs):
-            assert p.returncode == 0, "rank %d failed:\n%s" % (r, outs[r][-3000:])
+        outs = [p.communicate()[0].decode() for p in procs]
+        assert failed is None, ("timeout" if failed == -1 else "rank %d failed" % failed) + ":\n" + "\n-----\n".join(o[-2500:] for o in outs)
         return [json.load(open(os.path.join(d, "rank%d.json" % r))) for r in range(size)]
 
 
