@@ -733,7 +733,15 @@ int edgpu_device_count(int32_t *n)
     *n = c;
     return EDGPU_OK;
 }
-int edgpu_malloc(void **dev, size_t bytes) { if (!dev) return fail(EDGPU_EINVAL, "edgpu_malloc: null"); CHK(require_device()); HIPCHK(hipMalloc(dev, bytes)); return EDGPU_OK; }
+int edgpu_malloc(void **dev, size_t bytes)
+{
+    if (!dev) return fail(EDGPU_EINVAL, "edgpu_malloc: null");
+    CHK(require_device());
+    hipError_t e = hipMalloc(dev, bytes);
+    if (e == hipErrorOutOfMemory) { (void)hipGetLastError(); kpool_release(); e = hipMalloc(dev, bytes); }   // cached work vectors go first
+    HIPCHK(e);
+    return EDGPU_OK;
+}
 int edgpu_free(void *dev) { if (dev) HIPCHK(hipFree(dev)); return EDGPU_OK; }
 int edgpu_memcpy_h2d(void *dev, const void *host, size_t bytes) { HIPCHK(hipMemcpy(dev, host, bytes, hipMemcpyHostToDevice)); return EDGPU_OK; }
 int edgpu_memcpy_d2h(void *host, const void *dev, size_t bytes) { HIPCHK(hipMemcpy(host, dev, bytes, hipMemcpyDeviceToHost)); return EDGPU_OK; }

@@ -183,9 +183,45 @@ static int lanczos_gs(S *s, int nitermax, double threshold, int ncheck, double *
         hipLaunchKernelGGL(k_random_start, dim3(2048), dim3(256), 0, s->stream, start, H.DimUp, H.Qdw, H.dw0, H.DimDw, H.DimPh, (uint64_t)1234567);
         HIPCHK(hipGetLastError());
     }
+    // Krylov vectors kept in HBM when they fit (288 GB per GPU: ~90 vectors of 1.3 GB at Ns=16): the eigenvector is
+    // then one weighted sum over the stored vectors instead of SciFortran's second Lanczos pass -- same nlanc, same
+    // E0, same vector up to rounding, half the products.  Buffers are taken on demand; if memory runs out the run
+    // simply continues with three rotating vectors and falls back to the second pass.
+    const int store_max = dbg_int("EDGPU_LZ_STORE_MAX", 1 << 30);               // tests: cap the number of stored vectors
+    bool store = dbg_int("EDGPU_LZ_STORE", 1) != 0 && store_max >= 4;
+    int64_t budget = 0;       // bytes this call may still add to the cache (one driver query: hipMemGetInfo is slow)
+    if (store) {
+        if (g_kpool.device != s->device) { kpool_release(); g_kpool.device = s->device; }
+        size_t fr = 0, tot = 0; HIPCHK(hipMemGetInfo(&fr, &tot));
+        budget = (int64_t)fr - (int64_t)((double)tot * 0.04) - ((int64_t)2 << 30);     // head-room left to everything else
+    }
+    // buffer of u_k: cached from an earlier search when large enough, else (re)allocated within the budget
+    auto ring_get = [&](int k) -> double * {
+        if (k >= store_max) return nullptr;
+        while ((int)g_kpool.buf.size() <= k) { g_kpool.buf.push_back(nullptr); g_kpool.cap.push_back(0); }
+        if (g_kpool.cap[k] >= (size_t)s->nloc) return g_kpool.buf[k];
+        const int64_t need = (int64_t)s->nloc * 8;
+        if (g_kpool.buf[k]) { (void)hipFree(g_kpool.buf[k]); budget += (int64_t)g_kpool.cap[k] * 8; g_kpool.buf[k] = nullptr; g_kpool.cap[k] = 0; }
+        if (budget < need) return nullptr;
+        double *q = nullptr;
+        if (hipMalloc((void **)&q, (size_t)need) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        budget -= need; g_kpool.buf[k] = q; g_kpool.cap[k] = (size_t)s->nloc;
+        return q;
+    };
+    if (store) {
+        // take what a typical search needs before the first kernel is queued (allocation is cheap on an idle device)
+        const int guess = std::min(std::min(nitermax + 2, store_max), dbg_int("EDGPU_LZ_STORE_GUESS", 100));
+        for (int k = 0; k < guess; k++) if (!ring_get(k)) break;
+    }
     LzVecs V{s->lz[0].p, s->lz[1].p, s->lz[2].p};
+    if (store) {
+        double *b0 = ring_get(0), *b1 = ring_get(1);
+        if (b0 && b1) { V.ucur = b0; V.w = b1; } else store = false;
+    }
     HIPCHK(hipMemcpyAsync(V.ucur, start, (size_t)s->nloc * 8, hipMemcpyDeviceToDevice, s->stream));
     CHK(lz_start(s, V));
+    double s0 = 0.0;                                  // scale of the start vector: v_0 = s0 * u_0
+    HIPCHK(hipMemcpyAsync(&s0, s->scal.p + SC_SCUR, 8, hipMemcpyDeviceToHost, s->stream)); HIPCHK(hipStreamSynchronize(s->stream));
     std::vector<double> al, be;
     int nlanc = 0; double esave = 0.0, e0 = 0.0;
     // The stopping rule of iteration i only involves alpha/beta up to i, so iterations can be issued ahead of
@@ -195,7 +231,13 @@ static int lanczos_gs(S *s, int nitermax, double threshold, int ncheck, double *
     bool done = false;
     for (int k = 0; k < nitermax && !done;) {
         const int kend = std::min(nitermax, k + chunk);
-        CHK(lz_iters(s, V, k, kend - k, nullptr));
+        for (int j = k; j < kend; j++) {
+            CHK(lz_iter(s, V, j, nullptr));           // afterwards: uprev = u_j, ucur = u_{j+1}, w = recycled u_{j-1}
+            if (store) {
+                double *nx = ring_get(j + 2);         // u_{j+2} gets a buffer of its own, u_{j-1} stays intact
+                if (nx) V.w = nx; else store = false; // out of memory: keep rotating through the last three
+            }
+        }
         CHK(fetch_coeffs(s, kend - 1, al, be));
         for (; k < kend; k++) {
             nlanc = k + 1;
@@ -208,20 +250,43 @@ static int lanczos_gs(S *s, int nitermax, double threshold, int ncheck, double *
     std::vector<double> z;
     if (!tridiag_lowest(al.data(), be.data(), nlanc, &e0, &z)) return fail(EDGPU_ENOTCONVERGED, "edgpu: tridiagonal QL did not converge");
     *egs = e0; *nlanc_out = nlanc;
-    // second pass: regenerate the Krylov vectors and accumulate vect = sum_k Z(k,1) v_k
-    HIPCHK(hipMemcpyAsync(s->zvec.p, z.data(), (size_t)nlanc * 8, hipMemcpyHostToDevice, s->stream));
+    if (s->multi) {      // every rank must take the same branch below (the second pass contains collectives)
+        DevBuf<double> f; std::vector<double> one(1, store ? 1.0 : 0.0);
+        CHK(f.upload(one)); CHK(allreduce_dev(s, f.p, 1));
+        HIPCHK(hipMemcpyAsync(one.data(), f.p, 8, hipMemcpyDeviceToHost, s->stream)); HIPCHK(hipStreamSynchronize(s->stream));
+        if (one[0] < (double)s->comm.size - 0.5) store = false;
+    }
     HIPCHK(hipMemsetAsync(acc, 0, (size_t)s->nloc * 8, s->stream));
-    V = LzVecs{s->lz[0].p, s->lz[1].p, s->lz[2].p};
-    HIPCHK(hipMemcpyAsync(V.ucur, start, (size_t)s->nloc * 8, hipMemcpyDeviceToDevice, s->stream));
-    CHK(lz_start(s, V));
-    CHK(lz_iters(s, V, 0, nlanc, acc));
+    const int nbk = (int)std::max<int64_t>(1, std::min<int64_t>(cdiv(s->nloc, 256 * 4), 4096));
+    if (store) {
+        // vect = sum_k z_k v_k = sum_k (z_k s_k) u_k over the stored vectors, kMaxBasis of them per pass over acc
+        std::vector<double> coef(nlanc);
+        for (int k = 0; k < nlanc; k++) coef[k] = -z[k] * (k == 0 ? s0 : (be[k] > 0.0 ? 1.0 / be[k] : 0.0));   // k_multiaxpy subtracts
+        if (s->eig_h.n < (size_t)(kMaxBasis + 2)) CHK(s->eig_h.alloc((size_t)kMaxBasis + 2));
+        for (int k0 = 0; k0 < nlanc; k0 += kMaxBasis) {
+            BasisArgs B{}; B.nv = std::min(kMaxBasis, nlanc - k0);
+            for (int i = 0; i < B.nv; i++) B.V[i] = ring_get(k0 + i);
+            HIPCHK(hipMemcpyAsync(s->eig_h.p, coef.data() + k0, (size_t)B.nv * 8, hipMemcpyHostToDevice, s->stream));
+            HIPCHK(hipStreamSynchronize(s->stream));      // coef lives on the host stack of this call
+            hipLaunchKernelGGL(k_multiaxpy, dim3(nbk), dim3(256), 0, s->stream, B, (const double *)s->eig_h.p, acc, s->nloc);
+            HIPCHK(hipGetLastError());
+        }
+    } else {
+        // second pass: regenerate the Krylov vectors and accumulate vect = sum_k Z(k,1) v_k
+        V = LzVecs{s->lz[0].p, s->lz[1].p, s->lz[2].p};
+        HIPCHK(hipMemcpyAsync(s->zvec.p, z.data(), (size_t)nlanc * 8, hipMemcpyHostToDevice, s->stream));
+        V = LzVecs{s->lz[0].p, s->lz[1].p, s->lz[2].p};
+        HIPCHK(hipMemcpyAsync(V.ucur, start, (size_t)s->nloc * 8, hipMemcpyDeviceToDevice, s->stream));
+        CHK(lz_start(s, V));
+        CHK(lz_iters(s, V, 0, nlanc, acc));
+    }
     CHK(reduce_dot(s, acc, acc));
     hipLaunchKernelGGL(k_scalar_step, dim3(1), dim3(1), 0, s->stream, s->scal.p, s->alphas.p, s->betas.p, (const double *)nullptr, 0, 2);
-    int nb = (int)std::max<int64_t>(1, std::min<int64_t>(cdiv(s->nloc, 256 * 4), 4096));
-    hipLaunchKernelGGL(k_scale, dim3(nb), dim3(256), 0, s->stream, acc, s->scal.p, (int)SC_SCUR, s->nloc);
+    hipLaunchKernelGGL(k_scale, dim3(nbk), dim3(256), 0, s->stream, acc, s->scal.p, (int)SC_SCUR, s->nloc);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(vect_dev, acc, (size_t)s->nloc * 8, hipMemcpyDeviceToDevice, s->stream));
     HIPCHK(hipStreamSynchronize(s->stream));
+    if (!dbg_int("EDGPU_LZ_CACHE", 1)) kpool_release();      // default: keep the buffers for the next search
     return EDGPU_OK;
 }
 

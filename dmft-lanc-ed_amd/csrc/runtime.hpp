@@ -99,13 +99,34 @@ struct Comm {
     edgpu_allgatherv_fn ag = nullptr; edgpu_exchange_fn xch = nullptr; edgpu_allreduce_fn ar = nullptr; void *ctx = nullptr;
 };
 
+// Process-wide cache of large work vectors (the stored Krylov basis of edgpu_lanczos_gs): allocating inside a running
+// iteration costs ~30 ms per call on this runtime, so the buffers outlive the call and the sector and are handed to
+// the next ground-state search; any allocation that fails gives them back first (kpool_release) and retries.
+static void kpool_release();
+
 template <class T> struct DevBuf {
     T *p = nullptr; size_t n = 0;
-    int alloc(size_t count) { release(); n = count; if (!count) return EDGPU_OK; HIPCHK(hipMalloc((void **)&p, count * sizeof(T))); return EDGPU_OK; }
+    int alloc(size_t count)
+    {
+        release(); n = count; if (!count) return EDGPU_OK;
+        hipError_t e = hipMalloc((void **)&p, count * sizeof(T));
+        if (e == hipErrorOutOfMemory) { (void)hipGetLastError(); kpool_release(); e = hipMalloc((void **)&p, count * sizeof(T)); }
+        if (e != hipSuccess) { p = nullptr; n = 0; }
+        HIPCHK(e);
+        return EDGPU_OK;
+    }
     int upload(const std::vector<T> &h) { CHK(alloc(h.size())); if (h.size()) HIPCHK(hipMemcpy(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice)); return EDGPU_OK; }
     void release() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
     ~DevBuf() { release(); }
 };
+
+struct KrylovPool { std::vector<double *> buf; std::vector<size_t> cap; int device = -1; };
+static KrylovPool g_kpool;
+static void kpool_release()
+{
+    for (double *q : g_kpool.buf) if (q) (void)hipFree(q);
+    g_kpool.buf.clear(); g_kpool.cap.clear();
+}
 
 struct DevFactor {
     DevBuf<int32_t> map, rank, rowptr, cols, ellc, talpha, tbeta;

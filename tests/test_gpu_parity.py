@@ -320,3 +320,30 @@ def test_bad_descriptors_are_rejected(edgpu_mod):
     assert L.edgpu_sector_create(C.byref(G._desc), C.byref(h)) != 0 and b"abi_version" in L.edgpu_last_error()
     assert L.edgpu_hxv_device(None, None, None) != 0
     G.close()
+
+
+def test_ground_state_with_stored_krylov_vectors(edgpu_mod, monkeypatch):
+    """edgpu_lanczos_gs keeps the Krylov vectors in HBM when they fit and forms the eigenvector as one weighted sum
+    (no second Lanczos pass).  Same nlanc, E0 and vector as the two-pass form, also when memory 'runs out' mid-way."""
+    from edgpu import model
+    for nb, st in ((7, "kron"), (9, "direct"), (11, "csr")):
+        m, nu, nd = model.half_filled_c(nb)
+        res = {}
+        for tag, env in (("stored", {}), ("twopass", {"EDGPU_LZ_STORE": "0"}), ("runs_out", {"EDGPU_LZ_STORE_MAX": "17"})):
+            for k, v in env.items():
+                monkeypatch.setenv(k, v)
+            G = edgpu_mod.HvSector(m, nu, nd, storage=st)
+            v0 = np.random.RandomState(3).uniform(0, 1, G.Dim)
+            e0, x, nl = G.sp_lanc_eigh(v0, nitermax=300, threshold=1e-13)
+            r = np.linalg.norm(G.spHtimesV(x) - e0 * x)
+            res[tag] = (e0, x, nl, r)
+            G.close()
+            for k in env:
+                monkeypatch.delenv(k)
+        e_ref, x_ref, nl_ref, r_ref = res["twopass"]
+        assert nl_ref > 20
+        for tag in ("stored", "runs_out"):
+            e0, x, nl, r = res[tag]
+            assert nl == nl_ref and e0 == e_ref, tag            # the iteration itself is untouched
+            assert abs(np.linalg.norm(x) - 1.0) < 1e-12 and r < max(2 * r_ref, 1e-9), (tag, r, r_ref)
+            assert np.abs(x - x_ref).max() < 1e-10, tag
