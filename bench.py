@@ -206,6 +206,13 @@ def main():
             fb = {"kron": 24 * N, "direct": 16 * N}[st]
             extra[st] = {"ms_per_step": d2 / K * 1e3, "iters_per_sec": K / d2, "hxv_kernel_ms": ms,
                          "format_GBps": fb / (ms * 1e-3) / 1e9, "equivalent_csr_GBps": b_csr(N, nnz) / (ms * 1e-3) / 1e9}
+            if st == "kron":      # the whole ground-state search the iterations serve (device-resident vector, second call: warm cache)
+                dv = edgpu.DeviceVector(N)
+                for _ in range(2):
+                    dv.upload(np.zeros(N))
+                    t0 = time.perf_counter(); e0, nl = g.sp_lanc_eigh_device(dv, nitermax=300, threshold=1e-12); tg = time.perf_counter() - t0
+                dv.free()
+                out["ground_state"] = {"storage": "kron", "E0": e0, "nlanc": nl, "seconds": tg}
             g.close()
         out["other_formats"] = extra
     if world == 1 and rank == 0 and not a.no_cpu:

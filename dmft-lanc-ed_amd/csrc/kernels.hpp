@@ -507,10 +507,13 @@ __global__ void __launch_bounds__(256) k_dwpass(DwArgs A)
 template <bool EPI, bool NT, bool RAGGED>   // RAGGED: rows have different hop counts (multi-orbital models): skip the ELL padding
 __global__ void __launch_bounds__(256) k_dwpass2(DwArgs A)
 {
+    // dynamic LDS sized by the launch to R*dww entries (was a fixed 64x64 image = 48 KB, i.e. 3 workgroups per CU whatever
+    // the factor; 8 hops need 6 KB and leave room for the 8 workgroups a CU can hold)
+    extern __shared__ double dyn_lds[];
     __shared__ double red[4];
-    __shared__ double tv[64 * 64];     // [row in block][k]  (<= 64 rows x <= 64 hops)
-    __shared__ int32_t tc[64 * 64];
     __shared__ int32_t tn[64];
+    double *tv = dyn_lds;                                               // [row in block][k]
+    int32_t *tc = reinterpret_cast<int32_t *>(dyn_lds + A.R * A.dww);
     const int xcd = blockIdx.x & 7; const int64_t sidx = blockIdx.x >> 3;
     const int64_t tl = sidx / A.chunks; const int chunk = (int)(sidx - tl * A.chunks);
     const int tile = (int)(tl * 8 + xcd);

@@ -236,7 +236,14 @@ static int hxv(S *s, const double *v, double *out, bool epi, const double *uprev
                     else hipLaunchKernelGGL(k_dwpass<false>, dim3((unsigned)nblocks), dim3(256), 0, s->stream, D);
                 } else {
                     const bool nt = dv != 2, rag = s->fac[1]->ragged;
-#define DW_LAUNCH(E_, N_, R_) hipLaunchKernelGGL((k_dwpass2<E_, N_, R_>), dim3((unsigned)nblocks), dim3(256), 0, s->stream, D)
+                    // LDS also sets how many workgroups share a CU: fewer residents thrash the tile's L2 slab less (measured best: 48 KB)
+                    const size_t dlds = std::max<size_t>((size_t)D.R * D.dww * 12 + 16, (size_t)dbg_int("EDGPU_DW_LDS_KB", 48) * 1024);
+#define DW_LAUNCH(E_, N_, R_)                                                                                                   \
+    do {                                                                                                                            \
+        static bool attr_ = false;                                                                                                  \
+        if (!attr_) { (void)hipFuncSetAttribute((const void *)k_dwpass2<E_, N_, R_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_ = true; } \
+        hipLaunchKernelGGL((k_dwpass2<E_, N_, R_>), dim3((unsigned)nblocks), dim3(256), dlds, s->stream, D);                        \
+    } while (0)
                     if (epi) { if (nt) { if (rag) DW_LAUNCH(true, true, true); else DW_LAUNCH(true, true, false); } else { if (rag) DW_LAUNCH(true, false, true); else DW_LAUNCH(true, false, false); } }
                     else { if (nt) { if (rag) DW_LAUNCH(false, true, true); else DW_LAUNCH(false, true, false); } else { if (rag) DW_LAUNCH(false, false, true); else DW_LAUNCH(false, false, false); } }
 #undef DW_LAUNCH
