@@ -237,11 +237,14 @@ static int hxv(S *s, const double *v, double *out, bool epi, const double *uprev
                 } else {
                     const bool nt = dv != 2, rag = s->fac[1]->ragged;
                     // LDS also sets how many workgroups share a CU: fewer residents thrash the tile's L2 slab less (measured best: 48 KB)
-                    const size_t dlds = std::max<size_t>((size_t)D.R * D.dww * 12 + 16, (size_t)dbg_int("EDGPU_DW_LDS_KB", 48) * 1024);
+                    const size_t dlds = std::max<size_t>((size_t)D.R * D.dww * 12 + 16, (size_t)std::min(dbg_int("EDGPU_DW_LDS_KB", 48), 150) * 1024);
 #define DW_LAUNCH(E_, N_, R_)                                                                                                   \
     do {                                                                                                                            \
         static bool attr_ = false;                                                                                                  \
-        if (!attr_) { (void)hipFuncSetAttribute((const void *)k_dwpass2<E_, N_, R_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_ = true; } \
+        if (!attr_ && dlds > 60 * 1024) {      /* static LDS of the kernel comes on top: stay below the 160 KB of a CU */           \
+            if (hipFuncSetAttribute((const void *)k_dwpass2<E_, N_, R_>, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024) != hipSuccess) (void)hipGetLastError(); \
+            attr_ = true;                                                                                                           \
+        }                                                                                                                           \
         hipLaunchKernelGGL((k_dwpass2<E_, N_, R_>), dim3((unsigned)nblocks), dim3(256), dlds, s->stream, D);                        \
     } while (0)
                     if (epi) { if (nt) { if (rag) DW_LAUNCH(true, true, true); else DW_LAUNCH(true, true, false); } else { if (rag) DW_LAUNCH(true, false, true); else DW_LAUNCH(true, false, false); } }
