@@ -48,8 +48,6 @@ static int dispatch_kron2(S *s, int flags, const Kron2Args &A, int64_t rows)
     return EDGPU_OK;
 }
 
-static bool direct_tables_dirty(S *) { return false; }
-static bool epi_partials_needed(int flags) { return (flags & KF_EPI) && !(flags & KF_NODW); }
 static int direct_tables(S *s)
 {
     const SectorHost &H = s->H; const edgpu_desc &d = H.desc;
@@ -144,7 +142,7 @@ static int hxv(S *s, const double *v, double *out, bool epi, const double *uprev
         if (!split) CHK(dispatch_kron2(s, base | (s->use_lds ? KF_LDS : 0), A, nblocks));
         else {
             const bool plain = !s->extra || nd_pass;      // local pass = stored/on-the-fly diagonal + up hops only
-            const bool persistent = s->up_persistent && plain && s->fac[0]->packed && s->fac[0]->width <= 16 && s->use_lds && H.DimUp <= 13312 && !direct_tables_dirty(s);
+            const bool persistent = s->up_persistent && plain && s->fac[0]->packed && s->fac[0]->width <= 16 && s->use_lds && H.DimUp <= 13312;
             if (persistent && s->up_pairs && s->fac[0]->packed_elem) {
                 UpArgs2 U{};
                 U.DimUp = A.DimUp; U.DimPh = A.DimPh; U.Qdw = A.Qdw; U.dw0 = A.dw0; U.nrows = H.Qdw * H.DimPh;
@@ -204,11 +202,11 @@ static int hxv(S *s, const double *v, double *out, bool epi, const double *uprev
                 if (direct) { if (epi) hipLaunchKernelGGL((k_uppass_big<true, true>), dim3(grid), dim3(512), 0, s->stream, U); else hipLaunchKernelGGL((k_uppass_big<true, false>), dim3(grid), dim3(512), 0, s->stream, U); }
                 else { if (epi) hipLaunchKernelGGL((k_uppass_big<false, true>), dim3(grid), dim3(512), 0, s->stream, U); else hipLaunchKernelGGL((k_uppass_big<false, false>), dim3(grid), dim3(512), 0, s->stream, U); }
                 HIPCHK(hipGetLastError());
-            } else if (!s->use_lds && !epi_partials_needed(base | KF_NODW)) {
+            } else if (!s->use_lds) {
                 Kron2Args A2 = A; A2.rsplit = s->row_split;
                 CHK(dispatch_kron2(s, base | KF_NODW, A2, s->row_split > 1 ? cdiv(nblocks, 8) * 8 * s->row_split : nblocks));
             } else
-                CHK(dispatch_kron2(s, base | KF_NODW | (s->use_lds ? KF_LDS : 0), A, nblocks));
+                CHK(dispatch_kron2(s, base | KF_NODW | KF_LDS, A, nblocks));
             if (multi) HIPCHK(hipStreamWaitEvent(s->stream, s->ev_gather, 0));
             if (s->extra && !nd_pass) CHK(dispatch_kron2(s, base | KF_NOLOCAL, A, nblocks));   // phonon cases: row-wise dw pass (+Jx/Jp)
             else {
