@@ -55,6 +55,15 @@ module ED_SPARSE_MATRIX_GPU
        real(c_double)     :: dense(*)
        integer(c_int)     :: rc
      end function edgpu_sp_dump_matrix
+     function edgpu_sp_row(m, i, size, cols, vals, cap) bind(C, name="edgpu_sp_row") result(rc)
+       import :: c_int, c_int32_t, c_int64_t, c_double, c_ptr
+       type(c_ptr), value        :: m
+       integer(c_int64_t), value :: i
+       integer(c_int32_t)        :: size
+       type(c_ptr), value        :: cols, vals          ! null: only the size is returned
+       integer(c_int32_t), value :: cap
+       integer(c_int)            :: rc
+     end function edgpu_sp_row
      function edgpu_sp_matvec(m, v, hv, accumulate) bind(C, name="edgpu_sp_matvec") result(rc)
        import :: c_int, c_int32_t, c_double, c_ptr
        type(c_ptr), value         :: m
@@ -67,7 +76,7 @@ module ED_SPARSE_MATRIX_GPU
 
   public :: sparse_matrix_gpu
   public :: sp_init_matrix_gpu, sp_insert_element_gpu, sp_delete_matrix_gpu, sp_dump_matrix_gpu, sp_matvec_gpu
-  public :: sp_load_matrix_gpu, sp_set_mpi_matrix_gpu
+  public :: sp_load_matrix_gpu, sp_set_mpi_matrix_gpu, sp_row_gpu
 
 contains
 
@@ -134,6 +143,20 @@ contains
     if (size(matrix,1) /= sparse%Nglob .or. size(matrix,2) /= sparse%Ncol) stop "Warning SPARSE/dump_matrix: dimensions error"
     call sp_check(edgpu_sp_dump_matrix(sparse%h, matrix), "sp_dump_matrix")
   end subroutine sp_dump_matrix_gpu
+
+  !> row i (global numbering): its stored columns and values in insertion order
+  subroutine sp_row_gpu(sparse, i, n, cols, vals)
+    type(sparse_matrix_gpu), intent(in)                   :: sparse
+    integer, intent(in)                                   :: i
+    integer, intent(out)                                  :: n
+    integer(c_int64_t), allocatable, intent(out), target  :: cols(:)
+    real(8), allocatable, intent(out), target             :: vals(:)
+    integer(c_int32_t) :: sz
+    call sp_check(edgpu_sp_row(sparse%h, int(i, c_int64_t), sz, c_null_ptr, c_null_ptr, 0_c_int32_t), "sp_row")
+    n = sz
+    allocate(cols(max(n,1)), vals(max(n,1)))
+    if (n > 0) call sp_check(edgpu_sp_row(sparse%h, int(i, c_int64_t), sz, c_loc(cols), c_loc(vals), sz), "sp_row")
+  end subroutine sp_row_gpu
 
   !> Hv = A v (or Hv = Hv + A v when accumulate is true), computed on the device
   subroutine sp_matvec_gpu(sparse, v, Hv, accumulate)

@@ -11,4 +11,7 @@ cd "$HERE/_build"
 "$FC" -O2 -c "$HERE/ED_HAMILTONIAN_GPU.f90" -o ED_HAMILTONIAN_GPU.o
 "$FC" -O2 -c "$HERE/ED_SPARSE_MATRIX_GPU.f90" -o ED_SPARSE_MATRIX_GPU.o
 "$FC" -O2 "$HERE/demo_c1.f90" edgpu_c_api.o ED_HAMILTONIAN_GPU.o ED_SPARSE_MATRIX_GPU.o -L"$HERE/../edgpu" -ledgpu -Wl,-rpath,'$ORIGIN/../../edgpu' -o demo_c1
+# same-name drop-in of the reference module ED_SPARSE_MATRIX and a host-only demo of it
+"$FC" -O2 -c "$HERE/dropin/ED_SPARSE_MATRIX.f90" -o ED_SPARSE_MATRIX.o
+"$FC" -O2 "$HERE/dropin/demo_sparse_dropin.f90" edgpu_c_api.o ED_SPARSE_MATRIX_GPU.o ED_SPARSE_MATRIX.o -L"$HERE/../edgpu" -ledgpu -Wl,-rpath,'$ORIGIN/../../edgpu' -o demo_sparse_dropin
 echo "built $HERE/_build/demo_c1"

@@ -79,3 +79,21 @@ def test_fortran_driver_legs_and_observables():
     assert abs(f("gf_norm2")[0] - n2ref) < 1e-7
     np.testing.assert_allclose(f("gf_alanc_1_2"), a_ref[:2], atol=1e-6)
     assert abs(f("gf_blanc_2")[0] - b_ref[1]) < 1e-6
+
+
+def test_same_name_sparse_matrix_module_cpu(tmp_path):
+    """dropin/ED_SPARSE_MATRIX.f90: the reference's module and procedure names (incl. the MpiComm-first forms) over the
+    C-ABI container.  Insert / dump / load / spy / row window are host-side: runs without a GPU."""
+    exe = os.path.join(ROOT, "dmft-lanc-ed_amd", "fortran", "_build", "demo_sparse_dropin")
+    if not os.path.exists(exe):
+        pytest.skip("Fortran demo not built (amdflang absent at build time)")
+    out = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=120, cwd=str(tmp_path)).stdout.decode()
+    assert re.search(r"row1=\s+2\.000\s+0\.000\s+-0\.500\s+0\.000", out), out           # duplicate-summing insert
+    assert re.search(r"row3=\s+0\.000\s+4\.000\s+0\.000\s+0\.000", out), out
+    assert re.search(r"shape_status=\s+3\s+4\s+T", out), out
+    assert re.search(r"loaded_row2=\s+-3\.000\s+0\.000\s+0\.000\s+7\.000", out), out     # sp_load_matrix
+    assert re.search(r"deleted=\s+F", out), out
+    assert re.search(r"window=\s+3\s+1\.500\s+-1\.500", out), out                        # global rows, local storage
+    data = open(os.path.join(str(tmp_path), "dropinB_data.dat")).read().split()
+    assert data == ["1", "2", "4", "2"]                                                   # "column row" per stored entry
+    assert os.path.exists(os.path.join(str(tmp_path), "plot_dropinB_commands.gp"))
