@@ -1368,6 +1368,24 @@ __global__ void __launch_bounds__(256) k_multiaxpy(BasisArgs B, const double *__
         w[e] = x;
     }
 }
+// the same update with |w_new|^2 accumulated on the way (block partials, fixed order): saves the separate norm pass
+__global__ void __launch_bounds__(256) k_multiaxpy_norm(BasisArgs B, const double *__restrict__ h, double *__restrict__ w, int64_t n, double *__restrict__ partial)
+{
+    __shared__ double red[4];
+    double c[kMaxBasis + 1];
+#pragma unroll
+    for (int i = 0; i <= kMaxBasis; i++) c[i] = i < B.nv ? h[i] : 0.0;
+    double ss = 0.0;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
+        double x = w[e];
+#pragma unroll
+        for (int i = 0; i <= kMaxBasis; i++) if (i < B.nv) x -= c[i] * B.V[i][e];
+        w[e] = x;
+        ss += x * x;
+    }
+    double r = block_sum(ss, red);
+    if (threadIdx.x == 0) partial[blockIdx.x] = r;
+}
 // in-place rotation of the basis: V_j <- sum_i V_i Y[i + nv*j], j < nout  (row by row)
 struct RotArgs { double *V[kMaxBasis + 1]; int32_t nv, nout; const double *Y; };
 __global__ void __launch_bounds__(256) k_basis_rotate(RotArgs R, int64_t n)

@@ -317,6 +317,42 @@ static int lanczos_tridiag(S *s, const double *vin_dev, int nlanc, double thresh
     return EDGPU_OK;
 }
 
+// Orthogonalise w against the first nv vectors of a basis (classical Gram-Schmidt).  One pass gives the coefficients
+// h_i = V_i.w AND |w|^2 (w rides along as an extra "basis vector" of the multi-dot); the update pass returns |w'|^2.
+// One pass leaves an orthogonality error of about eps*|w|/|w'|; a second pass follows only when the first one removed
+// more than 90 % of the norm (|w'| < 0.1|w|, error bound ~1e-15 otherwise) -- the Daniel/DGKS idea with a threshold
+// that does not fire on the large diagonal component every H*v carries.  About half the memory traffic of
+// unconditional double Gram-Schmidt plus a separate norm pass.
+// hh (host, nv entries) receives the summed coefficients, wnorm the final |w|.
+static int orthogonalise_dgks(S *s, double *const *basis, int nv, double *w, int64_t n, int nb, int gs, std::vector<double> &hh, double &wnorm)
+{
+    std::vector<double> h2((size_t)nv + 1);
+    hh.assign((size_t)nv, 0.0);
+    BasisArgs B{}; B.nv = nv + 1; for (int i = 0; i < nv; i++) B.V[i] = basis[i];
+    B.V[nv] = w;
+    BasisArgs Bu = B; Bu.nv = nv;
+    double before = 0.0, after = 0.0;
+    for (int pass = 0; pass < 2; pass++) {
+        hipLaunchKernelGGL(k_multidot, dim3(nb), dim3(256), 0, s->stream, B, (const double *)w, n, s->eig_partial.p);
+        hipLaunchKernelGGL(k_multidot_final, dim3(1), dim3(256), 0, s->stream, (const double *)s->eig_partial.p, nb, B.nv, s->eig_h.p);
+        HIPCHK(hipGetLastError());
+        CHK(allreduce_dev(s, s->eig_h.p, B.nv));
+        hipLaunchKernelGGL(k_multiaxpy_norm, dim3(nb), dim3(256), 0, s->stream, Bu, (const double *)s->eig_h.p, w, n, s->eig_partial.p);
+        hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(1024), 0, s->stream, (const double *)s->eig_partial.p, (int64_t)nb, s->scal.p + SC_TMP);
+        HIPCHK(hipGetLastError());
+        CHK(allreduce_tmp(s));
+        HIPCHK(hipMemcpyAsync(h2.data(), s->eig_h.p, (size_t)(nv + 1) * 8, hipMemcpyDeviceToHost, s->stream));
+        HIPCHK(hipMemcpyAsync(&after, s->scal.p + SC_TMP, 8, hipMemcpyDeviceToHost, s->stream));
+        HIPCHK(hipStreamSynchronize(s->stream));
+        for (int i = 0; i < nv; i++) hh[i] += h2[i];
+        before = h2[nv];
+        if (after >= 0.01 * before) break;         // |w'| >= 0.1 |w|: one pass was enough
+    }
+    (void)gs;
+    wnorm = std::sqrt(after > 0.0 ? after : 0.0);
+    return EDGPU_OK;
+}
+
 // ---------------------------------------------------------------------------------------
 // Lowest `nev` eigenpairs: thick-restart Lanczos with full re-orthogonalisation in a basis of
 // `ncv` vectors held in HBM, explicit Rayleigh-Ritz on the host.  Stands in for the ARPACK call
@@ -364,8 +400,8 @@ static int eigsh(S *s, int nev, int ncv, int maxiter, double tol, double *evals,
     const int m = ncv;
     while ((int)s->eigV.size() < m + 1) { auto b = std::make_unique<DevBuf<double>>(); CHK(b->alloc((size_t)n)); s->eigV.push_back(std::move(b)); }
     const int nb = (int)std::max<int64_t>(1, std::min<int64_t>(cdiv(n, 256 * 8), 1024));
-    if (s->eig_h.n < (size_t)(m + 2)) CHK(s->eig_h.alloc((size_t)m + 2));
-    if (s->eig_partial.n < (size_t)nb * (m + 1)) CHK(s->eig_partial.alloc((size_t)nb * (m + 1)));
+    if (s->eig_h.n < (size_t)(m + 3)) CHK(s->eig_h.alloc((size_t)m + 3));
+    if (s->eig_partial.n < (size_t)nb * (m + 2)) CHK(s->eig_partial.alloc((size_t)nb * (m + 2)));
     if (s->eig_y.n < (size_t)m * m) CHK(s->eig_y.alloc((size_t)m * m));
     auto Vp = [&](int i) { return s->eigV[i]->p; };
     const SectorHost &H = s->H;
@@ -387,19 +423,10 @@ static int eigsh(S *s, int nev, int ncv, int maxiter, double tol, double *evals,
         for (int j = l; j < m; j++) {
             double *w = Vp(j + 1);
             CHK(hxv(s, Vp(j), w, false, nullptr)); nmv++;
-            BasisArgs B{}; B.nv = j + 1; for (int i = 0; i <= j; i++) B.V[i] = Vp(i);
-            std::fill(hh.begin(), hh.end(), 0.0);
-            for (int pass = 0; pass < 2; pass++) {      // classical Gram-Schmidt, twice
-                hipLaunchKernelGGL(k_multidot, dim3(nb), dim3(256), 0, s->stream, B, (const double *)w, n, s->eig_partial.p);
-                hipLaunchKernelGGL(k_multidot_final, dim3(1), dim3(256), 0, s->stream, (const double *)s->eig_partial.p, nb, B.nv, s->eig_h.p);
-                HIPCHK(hipGetLastError());
-                CHK(allreduce_dev(s, s->eig_h.p, B.nv));
-                hipLaunchKernelGGL(k_multiaxpy, dim3(gs), dim3(256), 0, s->stream, B, (const double *)s->eig_h.p, w, n);
-                HIPCHK(hipMemcpyAsync(h2.data(), s->eig_h.p, (size_t)B.nv * 8, hipMemcpyDeviceToHost, s->stream)); HIPCHK(hipStreamSynchronize(s->stream));
-                for (int i = 0; i <= j; i++) hh[i] += h2[i];
-            }
-            for (int i = 0; i <= j; i++) { Hm[(size_t)i * m + j] = hh[i]; Hm[(size_t)j * m + i] = hh[i]; }
-            double beta; CHK(norm_of(w, beta));
+            std::vector<double *> bas(j + 1); for (int i = 0; i <= j; i++) bas[i] = Vp(i);
+            std::vector<double> hj; double beta;
+            CHK(orthogonalise_dgks(s, bas.data(), j + 1, w, n, nb, gs, hj, beta));
+            for (int i = 0; i <= j; i++) { hh[i] = hj[i]; Hm[(size_t)i * m + j] = hh[i]; Hm[(size_t)j * m + i] = hh[i]; }
             beta_last = beta;
             if (j + 1 < m) { Hm[(size_t)(j + 1) * m + j] = beta; Hm[(size_t)j * m + (j + 1)] = beta; }
             if (beta <= 1e-13 * std::max(1.0, std::fabs(hh[j]))) { meff = j + 1; break; }   // invariant subspace
@@ -465,8 +492,8 @@ static int dvdson(S *s, int nev, int maxiter, double tol, double *evals, double 
     double *t = s->eigV[2 * mmax]->p;
     const int nb = (int)std::max<int64_t>(1, std::min<int64_t>(cdiv(n, 256 * 8), 1024));
     const int gs = (int)std::max<int64_t>(1, std::min<int64_t>(cdiv(n, 256 * 4), 4096));
-    if (s->eig_h.n < (size_t)(mmax + 2)) CHK(s->eig_h.alloc((size_t)mmax + 2));
-    if (s->eig_partial.n < (size_t)nb * (mmax + 1)) CHK(s->eig_partial.alloc((size_t)nb * (mmax + 1)));
+    if (s->eig_h.n < (size_t)(mmax + 3)) CHK(s->eig_h.alloc((size_t)mmax + 3));
+    if (s->eig_partial.n < (size_t)nb * (mmax + 2)) CHK(s->eig_partial.alloc((size_t)nb * (mmax + 2)));
     if (s->eig_y.n < (size_t)mmax * mmax) CHK(s->eig_y.alloc((size_t)mmax * mmax));
     const SectorHost &H = s->H;
     auto norm_of = [&](const double *x, double &out) -> int {
@@ -534,15 +561,9 @@ static int dvdson(S *s, int nev, int maxiter, double tol, double *evals, double 
             // the correction was computed against the old basis: still a valid new direction
         }
         // orthogonalise t against the space (classical Gram-Schmidt, twice), normalise, append
-        BasisArgs B{}; B.nv = m; for (int i = 0; i < m; i++) B.V[i] = Vp(i);
-        for (int pass = 0; pass < 2; pass++) {
-            hipLaunchKernelGGL(k_multidot, dim3(nb), dim3(256), 0, s->stream, B, (const double *)t, n, s->eig_partial.p);
-            hipLaunchKernelGGL(k_multidot_final, dim3(1), dim3(256), 0, s->stream, (const double *)s->eig_partial.p, nb, m, s->eig_h.p);
-            HIPCHK(hipGetLastError());
-            CHK(allreduce_dev(s, s->eig_h.p, m));
-            hipLaunchKernelGGL(k_multiaxpy, dim3(gs), dim3(256), 0, s->stream, B, (const double *)s->eig_h.p, t, n);
-        }
-        double tn; CHK(norm_of(t, tn));
+        std::vector<double *> bas(m); for (int i = 0; i < m; i++) bas[i] = Vp(i);
+        std::vector<double> hj; double tn;
+        CHK(orthogonalise_dgks(s, bas.data(), m, t, n, nb, gs, hj, tn));
         if (!(tn > 1e-14)) break;                              // no new direction: the space is invariant
         hipLaunchKernelGGL(k_scale_copy, dim3(gs), dim3(256), 0, s->stream, Vp(m), (const double *)t, 1.0 / tn, n);
         HIPCHK(hipGetLastError());
