@@ -317,22 +317,26 @@ static int lanczos_tridiag(S *s, const double *vin_dev, int nlanc, double thresh
     return EDGPU_OK;
 }
 
-// Orthogonalise w against the first nv vectors of a basis (classical Gram-Schmidt).  One pass gives the coefficients
-// h_i = V_i.w AND |w|^2 (w rides along as an extra "basis vector" of the multi-dot); the update pass returns |w'|^2.
-// One pass leaves an orthogonality error of about eps*|w|/|w'|; a second pass follows only when the first one removed
-// more than 90 % of the norm (|w'| < 0.1|w|, error bound ~1e-15 otherwise) -- the Daniel/DGKS idea with a threshold
-// that does not fire on the large diagonal component every H*v carries.  About half the memory traffic of
-// unconditional double Gram-Schmidt plus a separate norm pass.
-// hh (host, nv entries) receives the summed coefficients, wnorm the final |w|.
-static int orthogonalise_dgks(S *s, double *const *basis, int nv, double *w, int64_t n, int nb, int gs, std::vector<double> &hh, double &wnorm)
+// Orthogonalise w against the first nv vectors of a basis by classical Gram-Schmidt in at most two passes.
+// A single pass against a basis that is orthonormal to delta leaves w orthogonal only to about delta*|w|/|w'|, so the
+// error is multiplied by |w|/|w'| at every step: harmless when that ratio is ~1, exponentially unstable when it is
+// ~10 (H*v carries a large component along v itself).  Hence:
+//   pass 1 runs over basis[first_from .. nv) -- the caller names the vectors that carry the bulk of w (for a Lanczos
+//          vector the last two: the three-term recurrence), or all of them (first_from = 0);
+//   pass 2 runs over the whole basis, always after a partial pass 1, else only if pass 1 removed more than half of
+//          |w|^2 (the DGKS test).  After pass 2 the ratio is ~1 and the result is orthogonal to rounding.
+// Every multi-dot also returns |w|^2 (w rides along as one more "basis vector") and every update pass |w'|^2, so
+// no separate norm pass is needed.  hh (host, nv entries) receives the summed coefficients, wnorm the final |w|.
+static int orthogonalise_cgs(S *s, double *const *basis, int nv, int first_from, double *w, int64_t n, int nb, std::vector<double> &hh, double &wnorm)
 {
     std::vector<double> h2((size_t)nv + 1);
     hh.assign((size_t)nv, 0.0);
-    BasisArgs B{}; B.nv = nv + 1; for (int i = 0; i < nv; i++) B.V[i] = basis[i];
-    B.V[nv] = w;
-    BasisArgs Bu = B; Bu.nv = nv;
     double before = 0.0, after = 0.0;
     for (int pass = 0; pass < 2; pass++) {
+        const int from = pass == 0 ? first_from : 0, cnt = nv - from;
+        BasisArgs B{}; B.nv = cnt + 1; for (int i = 0; i < cnt; i++) B.V[i] = basis[from + i];
+        B.V[cnt] = w;
+        BasisArgs Bu = B; Bu.nv = cnt;
         hipLaunchKernelGGL(k_multidot, dim3(nb), dim3(256), 0, s->stream, B, (const double *)w, n, s->eig_partial.p);
         hipLaunchKernelGGL(k_multidot_final, dim3(1), dim3(256), 0, s->stream, (const double *)s->eig_partial.p, nb, B.nv, s->eig_h.p);
         HIPCHK(hipGetLastError());
@@ -341,14 +345,13 @@ static int orthogonalise_dgks(S *s, double *const *basis, int nv, double *w, int
         hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(1024), 0, s->stream, (const double *)s->eig_partial.p, (int64_t)nb, s->scal.p + SC_TMP);
         HIPCHK(hipGetLastError());
         CHK(allreduce_tmp(s));
-        HIPCHK(hipMemcpyAsync(h2.data(), s->eig_h.p, (size_t)(nv + 1) * 8, hipMemcpyDeviceToHost, s->stream));
+        HIPCHK(hipMemcpyAsync(h2.data(), s->eig_h.p, (size_t)(cnt + 1) * 8, hipMemcpyDeviceToHost, s->stream));
         HIPCHK(hipMemcpyAsync(&after, s->scal.p + SC_TMP, 8, hipMemcpyDeviceToHost, s->stream));
         HIPCHK(hipStreamSynchronize(s->stream));
-        for (int i = 0; i < nv; i++) hh[i] += h2[i];
-        before = h2[nv];
-        if (after >= 0.01 * before) break;         // |w'| >= 0.1 |w|: one pass was enough
+        for (int i = 0; i < cnt; i++) hh[from + i] += h2[i];
+        before = h2[cnt];
+        if (pass == 0 && first_from == 0 && after >= 0.5 * before) break;      // DGKS: one full pass was enough
     }
-    (void)gs;
     wnorm = std::sqrt(after > 0.0 ? after : 0.0);
     return EDGPU_OK;
 }
@@ -425,7 +428,8 @@ static int eigsh(S *s, int nev, int ncv, int maxiter, double tol, double *evals,
             CHK(hxv(s, Vp(j), w, false, nullptr)); nmv++;
             std::vector<double *> bas(j + 1); for (int i = 0; i <= j; i++) bas[i] = Vp(i);
             std::vector<double> hj; double beta;
-            CHK(orthogonalise_dgks(s, bas.data(), j + 1, w, n, nb, gs, hj, beta));
+            // a Lanczos vector: the bulk of H v_j lies along v_j and v_{j-1}; right after a restart it couples to every kept Ritz vector
+            CHK(orthogonalise_cgs(s, bas.data(), j + 1, j > l ? std::max(j - 1, 0) : 0, w, n, nb, hj, beta));
             for (int i = 0; i <= j; i++) { hh[i] = hj[i]; Hm[(size_t)i * m + j] = hh[i]; Hm[(size_t)j * m + i] = hh[i]; }
             beta_last = beta;
             if (j + 1 < m) { Hm[(size_t)(j + 1) * m + j] = beta; Hm[(size_t)j * m + (j + 1)] = beta; }
@@ -563,7 +567,7 @@ static int dvdson(S *s, int nev, int maxiter, double tol, double *evals, double 
         // orthogonalise t against the space (classical Gram-Schmidt, twice), normalise, append
         std::vector<double *> bas(m); for (int i = 0; i < m; i++) bas[i] = Vp(i);
         std::vector<double> hj; double tn;
-        CHK(orthogonalise_dgks(s, bas.data(), m, t, n, nb, gs, hj, tn));
+        CHK(orthogonalise_cgs(s, bas.data(), m, 0, t, n, nb, hj, tn));
         if (!(tn > 1e-14)) break;                              // no new direction: the space is invariant
         hipLaunchKernelGGL(k_scale_copy, dim3(gs), dim3(256), 0, s->stream, Vp(m), (const double *)t, 1.0 / tn, n);
         HIPCHK(hipGetLastError());

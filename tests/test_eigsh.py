@@ -8,7 +8,7 @@ from oracle import oracle
 
 pytestmark = pytest.mark.gpu
 SEL = [z for z in cases.zoo() if z[0] in ("c_nb5_half", "c_nb7_half", "nb5_offhalf_2_4", "norb2_normal_JxJp", "replica_sz_sx_JxJp",
-                                         "orbs_norb2_nb3", "phonons_nb3_nph3", "nspin2_random_bath")]
+                                         "orbs_norb2_nb3", "phonons_nb3_nph3", "nspin2_random_bath", "norb3_nb1_JxJp", "norb2_hybrid_JxJp")]
 
 
 @pytest.mark.parametrize("name,m,nu,nd", SEL, ids=[z[0] for z in SEL])
