@@ -725,6 +725,8 @@ int edgpu_comm_init_callbacks(edgpu_handle h, edgpu_allgatherv_fn ag, edgpu_exch
     return EDGPU_OK;
 }
 
+int edgpu_cache_release(void) { kpool_release(); return EDGPU_OK; }
+
 int edgpu_device_count(int32_t *n)
 {
     if (!n) return fail(EDGPU_EINVAL, "edgpu_device_count: null argument");

@@ -345,6 +345,11 @@ def gf_lanczos(sec_from, sec_to, iorb, ispin, dagger, state, nlanc, threshold=1e
     return n2.value, a, b, nu.value
 
 
+def cache_release():
+    """Return the cached work vectors (stored Krylov basis) to the device."""
+    check(capi.lib().edgpu_cache_release())
+
+
 def rccl_unique_id():
     buf = C.create_string_buffer(128)
     check(capi.lib().edgpu_comm_unique_id(buf))

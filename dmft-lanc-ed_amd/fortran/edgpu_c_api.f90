@@ -195,6 +195,10 @@ module EDGPU_C_API
        type(c_ptr), value    :: ctx
        integer(c_int)        :: rc
      end function edgpu_comm_init_callbacks
+     function edgpu_cache_release() bind(C, name="edgpu_cache_release") result(rc)
+       import :: c_int
+       integer(c_int) :: rc
+     end function edgpu_cache_release
      function edgpu_last_error() bind(C, name="edgpu_last_error") result(msg)
        import :: c_ptr
        type(c_ptr) :: msg

@@ -236,6 +236,11 @@ int edgpu_sp_row(edgpu_spmat m, int64_t i, int32_t *size, int64_t *cols, double 
 /* Hv = A v (accumulate=0) or Hv += A v (accumulate=1); host vectors, product on the device */
 int edgpu_sp_matvec(edgpu_spmat m, const double *v_host, double *hv_host, int32_t accumulate);
 
+/* The library keeps large work vectors (the stored Krylov basis of edgpu_lanczos_gs) in a process-wide cache between
+ * calls and sectors; it gives them back by itself when one of its allocations fails.  Call this to return the memory
+ * to the device at once (e.g. before another library needs it). */
+int edgpu_cache_release(void);
+
 /* ---- device memory helpers for hosts without a HIP binding (Fortran) ---------------------- */
 int edgpu_device_count(int32_t *n);
 int edgpu_malloc(void **dev, size_t bytes);
