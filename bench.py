@@ -151,6 +151,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     hxv_ms, alphas, betas = G.bench_result(K, ncoef=W + K)
+    comm_ms = G.bench_comm_ms(K) if multi else 0.0
 
     N = int(G.Dim); Ns = m["Ns"]
     nnz = N * (1 + Ns)                   # 1 diag + Ns/2 up + Ns/2 dw per row at half filling, all V != 0
@@ -171,7 +172,8 @@ def main():
                      "achieved": bytes_fmt / (hxv_ms * 1e-3) / 1e9 if hxv_ms > 0 else None, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": (bytes_fmt / (hxv_ms * 1e-3) / 1e9) / HBM_PEAK_GBPS if hxv_ms > 0 else None,
                      "algorithmic_bytes_per_launch": bytes_fmt, "kernel_ms": hxv_ms, "traffic": None},
-        "time_split_ms": {"hxv_product": hxv_ms, "axpy_norm_reductions_scalars": ms_step - hxv_ms},
+        "time_split_ms": dict({"hxv_product": hxv_ms, "axpy_norm_reductions_scalars": ms_step - hxv_ms},
+                              **({"exchange_on_comm_stream_overlapped_with_local_blocks": comm_ms} if multi else {})),
         "build_s": t_build,
         "lanczos_alpha_first_last": [float(alphas[0]), float(alphas[-1])] if len(alphas) else None,
     }

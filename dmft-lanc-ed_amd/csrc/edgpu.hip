@@ -414,6 +414,18 @@ int edgpu_imp_histogram(edgpu_handle h, const double *vec, int32_t vec_on_device
     return EDGPU_OK;
 }
 
+// mean duration (ms) of the exchange step over the last timed batch (multi-rank; 0 on one rank): HIP events on the comm stream
+int edgpu_lanczos_bench_comm_ms(edgpu_handle h, int32_t nsteps_timed, float *ms_mean)
+{
+    if (!h || !ms_mean) return fail(EDGPU_EINVAL, "edgpu_lanczos_bench_comm_ms: null argument");
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipStreamSynchronize(h->stream)); HIPCHK(hipStreamSynchronize(h->cstream));
+    double tot = 0.0; int cnt = 0;
+    for (int i = 0; i < nsteps_timed && 2 * i + 1 < (int)h->comm_ev.size(); i++) { float ms = 0.f; if (hipEventElapsedTime(&ms, h->comm_ev[2 * i], h->comm_ev[2 * i + 1]) == hipSuccess) { tot += ms; cnt++; } else (void)hipGetLastError(); }
+    *ms_mean = cnt ? (float)(tot / cnt) : 0.f;
+    return EDGPU_OK;
+}
+
 // ---- O|state> between two live sectors (GF builders, ED_GF_NORMAL.f90:190-213, 264-283) ------
 int edgpu_apply_op(edgpu_handle from, edgpu_handle to, int32_t iorb, int32_t ispin, int32_t dagger,
                    const double *vin_dev, double *vout_dev, double *norm2)
@@ -565,6 +577,7 @@ int edgpu_lanczos_bench_begin(edgpu_handle h, int32_t max_steps)
     CHK(lz_start(h, V));
     h->bench_k = 0;
     while ((int)h->bench_ev.size() < 2 * max_steps) { hipEvent_t e; HIPCHK(hipEventCreate(&e)); h->bench_ev.push_back(e); }
+    if (h->multi) while ((int)h->comm_ev.size() < 2 * max_steps) { hipEvent_t e; HIPCHK(hipEventCreate(&e)); h->comm_ev.push_back(e); }
     HIPCHK(hipStreamSynchronize(h->stream));
     return EDGPU_OK;
 }
@@ -582,8 +595,9 @@ int edgpu_lanczos_bench_steps(edgpu_handle h, int32_t nsteps, int32_t timed)
         if (timed) {   // lz_iter with the product bracketed by events
             HIPCHK(hipEventRecord(h->bench_ev[2 * i], h->stream));
             if (!h->multi) h->fuse_mode = 0;          // as lz_iter: the alpha step rides on the product's final reduction
+            h->comm_slot = i;
             const int rc = hxv(h, V.ucur, V.w, true, V.uprev);
-            h->fuse_mode = -1;
+            h->fuse_mode = -1; h->comm_slot = -1;
             if (rc) return rc;
             HIPCHK(hipEventRecord(h->bench_ev[2 * i + 1], h->stream));
             CHK(lz_iter_tail(h, V, k, nullptr, !h->multi));

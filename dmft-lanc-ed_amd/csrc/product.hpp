@@ -80,7 +80,10 @@ static int hxv(S *s, const double *v, double *out, bool epi, const double *uprev
     if (multi) {  // start the exchange on the comm stream; local work overlaps it
         HIPCHK(hipEventRecord(s->ev_ready, s->stream));
         HIPCHK(hipStreamWaitEvent(s->cstream, s->ev_ready, 0));
+        const bool timed = s->comm_slot >= 0 && 2 * s->comm_slot + 1 < (int)s->comm_ev.size();
+        if (timed) HIPCHK(hipEventRecord(s->comm_ev[2 * s->comm_slot], s->cstream));
         CHK(gather_vector(s, v, s->cstream));
+        if (timed) HIPCHK(hipEventRecord(s->comm_ev[2 * s->comm_slot + 1], s->cstream));
         HIPCHK(hipEventRecord(s->ev_gather, s->cstream));
     }
     int64_t nblocks = 0;

@@ -171,6 +171,7 @@ struct edgpu_sector_s {
     bool use_lds = false; int kron_threads = 256, kron_threads_override = 0; size_t kron_lds = 0;
     bool two_factor = false, extra = false, has_ph = false, has_nd = false, multi = false, kron_split = false; int dw_w = 64, dw_variant = 2, dw_rows = 64; bool up_persistent = true, up_pairs = true; int up_grid = 256, up_threads = 1024, row_split = 4; bool up_big = true, nd_split = true;
     std::vector<hipEvent_t> bench_ev; int bench_k = 0; double *bv[3] = {nullptr, nullptr, nullptr};
+    std::vector<hipEvent_t> comm_ev; int comm_slot = -1;     // timed bench steps: events around the exchange on the comm stream
     int64_t nnz_total = 0, bytes_stored = 0;
     int64_t npartial = 0;
     // Lanczos iteration fusion (single rank)
@@ -185,6 +186,7 @@ inline edgpu_sector_s::~edgpu_sector_s()
 {
     if (comm.kind == Comm::RCCL && comm.nccl && g_rccl.ok) g_rccl.CommDestroy(comm.nccl);
     for (auto e : bench_ev) (void)hipEventDestroy(e);
+    for (auto e : comm_ev) (void)hipEventDestroy(e);
     if (ev_pack) (void)hipEventDestroy(ev_pack);
     if (ev_a) (void)hipEventDestroy(ev_a);
     if (ev_b) (void)hipEventDestroy(ev_b);

@@ -19,7 +19,7 @@ SYMBOLS = [
     "edgpu_sector_map", "edgpu_factor_size", "edgpu_factor_export", "edgpu_diag_export", "edgpu_csr_rows",
     "edgpu_hxv", "edgpu_hxv64", "edgpu_hxv_device", "edgpu_hxv_time",
     "edgpu_lanczos_gs", "edgpu_lanczos_gs_device", "edgpu_lanczos_tridiag", "edgpu_lanczos_tridiag_device",
-    "edgpu_lanczos_time", "edgpu_lanczos_bench_begin", "edgpu_lanczos_bench_steps", "edgpu_lanczos_bench_result",
+    "edgpu_lanczos_time", "edgpu_lanczos_bench_begin", "edgpu_lanczos_bench_steps", "edgpu_lanczos_bench_result", "edgpu_lanczos_bench_comm_ms",
     "edgpu_eigsh", "edgpu_dvdson", "edgpu_cache_release", "edgpu_twin_reorder", "edgpu_imp_density_offdiag", "edgpu_imp_histogram", "edgpu_apply_op", "edgpu_gf_lanczos", "edgpu_chi_lanczos", "edgpu_phonon_lanczos",
     "edgpu_sp_init_matrix", "edgpu_sp_init_matrix_mpi", "edgpu_sp_load_matrix", "edgpu_sp_insert_element", "edgpu_sp_delete_matrix", "edgpu_sp_dump_matrix", "edgpu_sp_row", "edgpu_sp_matvec",
     "edgpu_comm_unique_id", "edgpu_comm_init_rccl", "edgpu_comm_init_callbacks",
@@ -93,6 +93,7 @@ def lib():
         "edgpu_lanczos_time": (C.c_int, [vp, i32, i32, P(C.c_float)]),
         "edgpu_lanczos_bench_begin": (C.c_int, [vp, i32]),
         "edgpu_lanczos_bench_steps": (C.c_int, [vp, i32, i32]),
+        "edgpu_lanczos_bench_comm_ms": (C.c_int, [vp, i32, P(C.c_float)]),
         "edgpu_lanczos_bench_result": (C.c_int, [vp, i32, P(C.c_float), vp, vp, i32]),
         "edgpu_eigsh": (C.c_int, [vp, i32, i32, i32, dbl, vp, vp, P(i32), P(i32), P(i32)]),
         "edgpu_dvdson": (C.c_int, [vp, i32, i32, dbl, vp, vp, P(i32), P(i32)]),

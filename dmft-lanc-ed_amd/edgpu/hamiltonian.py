@@ -293,6 +293,11 @@ class HvSector:
         return ms.value, a[:ncoef], b[:ncoef]
 
     # ---- exchange -------------------------------------------------------------------
+    def bench_comm_ms(self, ntimed):
+        ms = C.c_float()
+        check(capi.lib().edgpu_lanczos_bench_comm_ms(self._h, ntimed, C.byref(ms)))
+        return ms.value
+
     def comm_init_rccl(self, uid_bytes):
         buf = C.create_string_buffer(bytes(uid_bytes), 128)
         check(capi.lib().edgpu_comm_init_rccl(self._h, buf))

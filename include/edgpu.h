@@ -194,6 +194,8 @@ int edgpu_phonon_lanczos(edgpu_handle h, const double *state_host, int32_t nlanc
 int edgpu_lanczos_bench_begin(edgpu_handle h, int32_t max_steps);
 int edgpu_lanczos_bench_steps(edgpu_handle h, int32_t nsteps, int32_t timed);
 int edgpu_lanczos_bench_result(edgpu_handle h, int32_t nsteps_timed, float *hxv_ms_mean, double *alphas, double *betas, int32_t ncoef);
+/* mean duration of the exchange step (pack + send/recv, or the callback) of the last timed batch; 0 on one rank */
+int edgpu_lanczos_bench_comm_ms(edgpu_handle h, int32_t nsteps_timed, float *ms_mean);
 
 /* ---- multi-GPU exchange (replaces MPI_AllGatherv/MPI_AllReduce of the MPI matvecs,
  * ED_SETUP.f90:689-733, ED_HAMILTONIAN_SPARSE_HxV.f90:674-692) --------------------------
