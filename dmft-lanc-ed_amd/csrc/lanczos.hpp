@@ -195,9 +195,19 @@ static int lanczos_gs(S *s, int nitermax, double threshold, int ncheck, double *
         size_t fr = 0, tot = 0; HIPCHK(hipMemGetInfo(&fr, &tot));
         budget = (int64_t)fr - (int64_t)((double)tot * 0.04) - ((int64_t)2 << 30);     // head-room left to everything else
     }
+    // small sectors: every vector of the search in ONE cached allocation (grown geometrically), so that a run over many
+    // small sectors of growing size does not pay a hundred allocations each time
+    const int64_t want_all = (int64_t)std::min(nitermax + 2, store_max) * s->nloc;
+    const bool slab_mode = store && want_all * 8 <= ((int64_t)512 << 20);
+    if (slab_mode && g_kpool.slab_cap < (size_t)want_all) {
+        if (g_kpool.slab) { (void)hipFree(g_kpool.slab); g_kpool.slab = nullptr; }
+        const size_t cap = std::max<size_t>((size_t)want_all, 2 * g_kpool.slab_cap);
+        if (hipMalloc((void **)&g_kpool.slab, cap * 8) == hipSuccess) g_kpool.slab_cap = cap; else { (void)hipGetLastError(); g_kpool.slab = nullptr; g_kpool.slab_cap = 0; }
+    }
     // buffer of u_k: cached from an earlier search when large enough, else (re)allocated within the budget
     auto ring_get = [&](int k) -> double * {
         if (k >= store_max) return nullptr;
+        if (slab_mode) return (g_kpool.slab && (size_t)(k + 1) * (size_t)s->nloc <= g_kpool.slab_cap) ? g_kpool.slab + (int64_t)k * s->nloc : nullptr;
         while ((int)g_kpool.buf.size() <= k) { g_kpool.buf.push_back(nullptr); g_kpool.cap.push_back(0); }
         if (g_kpool.cap[k] >= (size_t)s->nloc) return g_kpool.buf[k];
         const int64_t need = (int64_t)s->nloc * 8;
@@ -211,7 +221,7 @@ static int lanczos_gs(S *s, int nitermax, double threshold, int ncheck, double *
     if (store) {
         // take what a typical search needs before the first kernel is queued (allocation is cheap on an idle device)
         const int guess = std::min(std::min(nitermax + 2, store_max), dbg_int("EDGPU_LZ_STORE_GUESS", 100));
-        for (int k = 0; k < guess; k++) if (!ring_get(k)) break;
+        if (!slab_mode) for (int k = 0; k < guess; k++) if (!ring_get(k)) break;
     }
     LzVecs V{s->lz[0].p, s->lz[1].p, s->lz[2].p};
     if (store) {

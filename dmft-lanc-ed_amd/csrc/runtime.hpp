@@ -120,12 +120,14 @@ template <class T> struct DevBuf {
     ~DevBuf() { release(); }
 };
 
-struct KrylovPool { std::vector<double *> buf; std::vector<size_t> cap; int device = -1; };
+struct KrylovPool { std::vector<double *> buf; std::vector<size_t> cap; int device = -1; double *slab = nullptr; size_t slab_cap = 0; };   // slab: all vectors of a small sector in one allocation
 static KrylovPool g_kpool;
 static void kpool_release()
 {
     for (double *q : g_kpool.buf) if (q) (void)hipFree(q);
     g_kpool.buf.clear(); g_kpool.cap.clear();
+    if (g_kpool.slab) (void)hipFree(g_kpool.slab);
+    g_kpool.slab = nullptr; g_kpool.slab_cap = 0;
 }
 
 struct DevFactor {
