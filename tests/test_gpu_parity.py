@@ -347,3 +347,26 @@ def test_ground_state_with_stored_krylov_vectors(edgpu_mod, monkeypatch):
             assert nl == nl_ref and e0 == e_ref, tag            # the iteration itself is untouched
             assert abs(np.linalg.norm(x) - 1.0) < 1e-12 and r < max(2 * r_ref, 1e-9), (tag, r, r_ref)
             assert np.abs(x - x_ref).max() < 1e-10, tag
+
+
+def test_sweep_over_all_sectors_of_a_small_model(edgpu_mod):
+    """What a DMFT iteration does: every (Nup,Ndw) sector of the Ns=6 model in turn (dimensions 1 ... 400), ground state of
+    each against dense diagonalisation.  Exercises the work-vector cache across sectors of changing size."""
+    from edgpu import model
+    m, _, _ = model.half_filled_c(5)
+    Ns = m["Ns"]
+    order = [(a, b) for a in range(Ns + 1) for b in range(Ns + 1)]
+    rng = np.random.default_rng(11); rng.shuffle(order)          # sizes go up and down
+    for nup, ndw in order:
+        S = oracle.Sector(m, [nup], [ndw])
+        w = np.linalg.eigvalsh(S.hmat())
+        G = edgpu_mod.HvSector(m, [nup], [ndw], storage="kron" if (nup + ndw) % 2 else "direct")
+        assert G.Dim == S.Dim and G.isector == 1 + nup * (Ns + 1) + ndw
+        e0, x, nl = G.sp_lanc_eigh(nitermax=min(300, S.Dim), threshold=1e-14)
+        assert abs(e0 - w[0]) < 1e-9, (nup, ndw, e0, w[0])
+        assert abs(np.linalg.norm(x) - 1.0) < 1e-10
+        if S.Dim > 1:
+            deg = np.sum(np.abs(w - w[0]) < 1e-9)
+            r = np.linalg.norm(S.spmatvec(x) - e0 * x)
+            assert r < 1e-5 or deg > 1, (nup, ndw, r)
+        G.close()
