@@ -194,6 +194,10 @@ static int lanczos_gs(S *s, int nitermax, double threshold, int ncheck, double *
         if (g_kpool.device != s->device) { kpool_release(); g_kpool.device = s->device; }
         size_t fr = 0, tot = 0; HIPCHK(hipMemGetInfo(&fr, &tot));
         budget = (int64_t)fr - (int64_t)((double)tot * 0.04) - ((int64_t)2 << 30);     // head-room left to everything else
+        for (size_t k = 0; k < g_kpool.cap.size(); k++) if (g_kpool.cap[k] >= (size_t)s->nloc) budget += (int64_t)s->nloc * 8;   // already ours
+        // a search rarely ends before ~50 iterations: when not even that many vectors fit (Ns=18: 19 GB each) do not
+        // tie the memory up for nothing, go straight to the two-pass form
+        if (budget < (int64_t)std::min(nitermax, 48) * s->nloc * 8) store = false;
     }
     // small sectors: every vector of the search in ONE cached allocation (grown geometrically), so that a run over many
     // small sectors of growing size does not pay a hundred allocations each time
