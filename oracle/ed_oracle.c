@@ -697,7 +697,7 @@ static void emit_orb_apply(void *c, int irow, double val)
     x->Hv[i - 1] += val * x->vj;
 }
 
-/* directMatVec_orbs: ED_HAMILTONIAN_DIRECT_HxV.f90:100-171 + direct/Orbs/*.f90 */
+/* directMatVec_orbs: ED_HAMILTONIAN_DIRECT_HxV.f90:100-171 + direct/Orbs/ (all files) */
 static void direct_orbs(orc_sector *S, const double *vin, double *Hv)
 {
     const orc_params *p = &S->p;
