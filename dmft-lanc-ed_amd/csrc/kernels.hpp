@@ -307,7 +307,7 @@ __global__ void __launch_bounds__(NT) k_uppass(UpArgs A)
             double acc = dval * x;
 #pragma unroll
             for (int c = 0; c < MAXC; c++)
-                if (c < ndw) {
+                if (c < ndw && __any(cur.codes[c] != 0x7f7f7f7fu)) {   // ragged factors: a group of 4 slots that is padding in all 64 lanes is skipped
 #pragma unroll
                     for (int e = 0; e < 4; e++) {
                         const uint32_t code = (cur.codes[c] >> (8 * e)) & 0xffu;
