@@ -84,6 +84,11 @@ def main():
     ap.add_argument("--force-dist", action="store_true", help="run the N>1 code path (process group, communicator, exchange) even with one rank (self-test)")
     a = ap.parse_args()
 
+    # exactly ONE line on stdout: libraries that chat on fd 1 (RCCL prints a version banner at communicator set-up)
+    # are sent to stderr for the duration of the run; the JSON goes to the saved descriptor at the end
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     import torch
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -220,7 +225,8 @@ def main():
     if world == 1 and rank == 0 and not a.no_cpu:
         out["cpu_baseline"] = cpu_baseline()
     if rank == 0:
-        print(json.dumps(out))
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
     if dist:
         dist.barrier()
         dist.destroy_process_group()

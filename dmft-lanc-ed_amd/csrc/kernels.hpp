@@ -638,6 +638,74 @@ __global__ void __launch_bounds__(256) k_ndpass(NdArgs A)
 }
 
 // ---------------------------------------------------------------------------------------------
+// Distributed-transpose form of the dw hops (the reference's own MPI scheme: vector_transpose_MPI,
+// ED_HAMILTONIAN_COMMON.f90:53-125, used by spMatVec_mpi_main 621-692): every rank turns its (Qdw x DimUp)
+// shard into (DimUp x Qdw), an all-to-all hands rank r the rows iup in its up-block from everybody, so that
+// it holds vt(iup_local, all idw); there the dw hops are a LOCAL pass along contiguous rows; the result goes
+// back the same way.  Volume per rank and product: 2 x (P-1)/P shards, spread evenly over all peers -- against
+// ~(log2 P)/2 shards concentrated on log2 P peers for the needed-rows exchange (better from 8 ranks on).
+// ---------------------------------------------------------------------------------------------
+// out[c*R + r] = in[r*C + c]   (R x C row-major -> C x R), 32x32 tiles through LDS
+__global__ void __launch_bounds__(256) k_transpose2d(const double *__restrict__ in, double *__restrict__ out, int64_t R, int64_t C)
+{
+    __shared__ double tile[32][33];
+    const int64_t tc = (C + 31) / 32, t = blockIdx.x, tr0 = (t / tc) * 32, tc0 = (t % tc) * 32;
+    const int lx = threadIdx.x & 31, ly = threadIdx.x >> 5;
+    for (int y = ly; y < 32; y += 8) { const int64_t r = tr0 + y, c = tc0 + lx; if (r < R && c < C) tile[y][lx] = in[r * C + c]; }
+    __syncthreads();
+    for (int y = ly; y < 32; y += 8) { const int64_t c = tc0 + y, r = tr0 + lx; if (r < R && c < C) out[c * R + r] = tile[lx][y]; }
+}
+// received blocks (sender s: [Qup][Qdw_s] at offset Qup*dw0_s) <-> vt[Qup][DimDw]; dir 0: blocks -> vt, 1: vt -> blocks
+struct TBlkArgs { int32_t P; int64_t Qup, DimDw; int64_t dw0[65]; double *blocks; double *vt; int32_t dir; };
+__global__ void __launch_bounds__(256) k_tblocks(TBlkArgs A)
+{
+    const int64_t n = A.Qup * A.DimDw;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t il = e / A.DimDw, idw = e - il * A.DimDw;
+        int sl = 0; while (sl + 1 < A.P && A.dw0[sl + 1] <= idw) sl++;            // owner of this dw column
+        const int64_t q = A.dw0[sl + 1] - A.dw0[sl], b = A.Qup * A.dw0[sl] + il * q + (idw - A.dw0[sl]);
+        if (A.dir == 0) A.vt[e] = A.blocks[b]; else A.blocks[b] = A.vt[e];
+    }
+}
+// dw hops in the transposed space: hvt(row, i) = sum_k Hdw[i,k] vt(row, j_k); ELL of H_dw in [k][i] layout
+struct TdwArgs { int32_t DimDw, dww, use_lds; const int32_t *ellc; const double *ellv; const double *vt; double *hvt; };
+__global__ void __launch_bounds__(1024) k_tdw(TdwArgs A)
+{
+    extern __shared__ double lds[];
+    const double *r = A.vt + (int64_t)blockIdx.x * A.DimDw;
+    if (A.use_lds) { for (int i = threadIdx.x; i < A.DimDw; i += blockDim.x) lds[i] = r[i]; __syncthreads(); }
+    for (int i = threadIdx.x; i < A.DimDw; i += blockDim.x) {
+        double acc = 0.0;
+        for (int k = 0; k < A.dww; k++) { const int32_t j = A.ellc[(int64_t)k * A.DimDw + i]; acc += A.ellv[(int64_t)k * A.DimDw + i] * (A.use_lds ? lds[j] : r[j]); }
+        A.hvt[(int64_t)blockIdx.x * A.DimDw + i] = acc;
+    }
+}
+// out(idw_l, iup) += [s_cur *] back(iup, idw_l)  (back: DimUp x Qdw), with the Lanczos alpha partials
+template <bool EPI>
+__global__ void __launch_bounds__(256) k_tadd(const double *__restrict__ back, double *__restrict__ out, const double *__restrict__ v,
+                                              int64_t Qdw, int64_t DimUp, const double *__restrict__ scal, double *__restrict__ partial)
+{
+    __shared__ double tile[32][33];
+    __shared__ double red[4];
+    const int64_t tc = (Qdw + 31) / 32, t = blockIdx.x, tr0 = (t / tc) * 32, tc0 = (t % tc) * 32;     // back is DimUp x Qdw
+    const int lx = threadIdx.x & 31, ly = threadIdx.x >> 5;
+    for (int y = ly; y < 32; y += 8) { const int64_t iu = tr0 + y, id = tc0 + lx; if (iu < DimUp && id < Qdw) tile[y][lx] = back[iu * Qdw + id]; }
+    __syncthreads();
+    const double s_cur = EPI ? scal[SC_SCUR] : 1.0;
+    double asum = 0.0;
+    for (int y = ly; y < 32; y += 8) {
+        const int64_t id = tc0 + y, iu = tr0 + lx;
+        if (iu < DimUp && id < Qdw) {
+            const int64_t e = id * DimUp + iu;
+            const double w = out[e] + s_cur * tile[lx][y];
+            out[e] = w;
+            if (EPI) asum += (s_cur * v[e]) * w;
+        }
+    }
+    if (EPI) { double r = block_sum(asum, red); if (threadIdx.x == 0) partial[blockIdx.x] = r; }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Generic multi-factor operator (ed_total_ud=F: spMatVec_orbs / directMatVec_orbs,
 // ED_HAMILTONIAN_SPARSE_HxV.f90:487-564, ED_HAMILTONIAN_DIRECT_HxV.f90:100-171).
 // State index is the mixed-radix number over [DimUps..., DimDws...]; factor k acts on digit k.

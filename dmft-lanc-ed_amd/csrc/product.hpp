@@ -54,7 +54,7 @@ static int direct_tables(S *s)
     for (int k = 0; k < 2 * H.Ns_Ud; k++) {
         DevFactor &f = *s->fac[k];
         TabArgs T{};
-        T.dim = H.fac[k].dim; T.nterms = (int32_t)H.fac[k].terms.size(); T.width = f.width; T.transposed = k < H.Ns_Ud;
+        T.dim = H.fac[k].dim; T.nterms = (int32_t)H.fac[k].terms.size(); T.width = f.width; T.transposed = (k < H.Ns_Ud || s->tr_on) ? 1 : 0;
         T.map = f.map.p; T.rank = f.rank.p; T.talpha = f.talpha.p; T.tbeta = f.tbeta.p; T.tval = f.tval.p;
         T.ellc = f.ellc.p; T.ellv = f.ellv.p; T.lin = f.lin.p; T.nlev = H.fac[k].nbits;
         T.pcols = f.packed ? f.pcols.p : nullptr; T.pcodes = f.packed ? f.pcodes.p : nullptr; T.pelem = f.packed_elem ? f.pelem.p : nullptr; T.pelem8 = f.packed_elem8 ? f.pelem8.p : nullptr;
@@ -71,6 +71,64 @@ static int direct_tables(S *s)
     return EDGPU_OK;
 }
 
+// dw hops through the distributed transpose (see k_transpose2d): v (local shard) -> ... -> s->tA = (H_dw (x) 1) v, transposed
+static int transposed_dw_pass(S *s, const double *v, hipStream_t st)
+{
+    const SectorHost &H = s->H; Comm &c = s->comm;
+    const int P = c.size;
+    auto split = [&](int64_t D, int r, int64_t &q, int64_t &d0) { const int64_t qq = D / P, rem = D % P; q = r < rem ? qq + 1 : qq; d0 = r < rem ? r * (qq + 1) : r * qq + rem; };
+    std::vector<int64_t> sc(P), sd(P), rc(P), rd(P);
+    TBlkArgs Bk{}; Bk.P = P; Bk.Qup = s->Qup; Bk.DimDw = H.DimDw;
+    if (P > 64) return fail(EDGPU_EUNSUPPORTED, "edgpu: transpose exchange supports up to 64 ranks");
+    for (int r = 0; r < P; r++) {
+        int64_t qu, u0, qd, d0; split(H.DimUp, r, qu, u0); split(H.DimDw, r, qd, d0);
+        sc[r] = qu * H.Qdw; sd[r] = H.Qdw * u0;          // rows iup of rank r's up-block out of my transposed shard
+        rc[r] = s->Qup * qd; rd[r] = s->Qup * d0;        // my up-block out of rank r's dw columns
+        Bk.dw0[r] = d0; Bk.dw0[r + 1] = d0 + qd;
+    }
+    auto a2a = [&](const double *send, const std::vector<int64_t> &scn, const std::vector<int64_t> &sdp, double *recv, const std::vector<int64_t> &rcn, const std::vector<int64_t> &rdp) -> int {
+        HIPCHK(hipMemcpyAsync(recv + rdp[c.rank], send + sdp[c.rank], (size_t)scn[c.rank] * 8, hipMemcpyDeviceToDevice, st));
+        if (P == 1) return EDGPU_OK;
+        if (c.kind == Comm::RCCL) {
+            int rc2 = g_rccl.GroupStart();
+            for (int r = 0; r < P && rc2 == 0; r++) {
+                if (r == c.rank) continue;
+                if (scn[r]) rc2 = g_rccl.Send(send + sdp[r], (size_t)scn[r], kNcclDouble, r, c.nccl, st);
+                if (rc2 == 0 && rcn[r]) rc2 = g_rccl.Recv(recv + rdp[r], (size_t)rcn[r], kNcclDouble, r, c.nccl, st);
+            }
+            int rc3 = g_rccl.GroupEnd();
+            if (rc2 || rc3) return fail(EDGPU_ECOMM, std::string("edgpu: RCCL send/recv failed: ") + g_rccl.GetErrorString(rc2 ? rc2 : rc3));
+        } else if (c.kind == Comm::CALLBACK) {
+            if (!c.xch) return fail(EDGPU_ECOMM, "edgpu: the callback exchange needs an all-to-all-v callback");
+            std::vector<int64_t> s2 = scn, r2 = rcn; s2[c.rank] = 0; r2[c.rank] = 0;       // own block already copied
+            HIPCHK(hipStreamSynchronize(st));
+            if (c.xch(c.ctx, send, s2.data(), sdp.data(), recv, r2.data(), rdp.data(), P)) return fail(EDGPU_ECOMM, "edgpu: exchange callback failed");
+        } else
+            return fail(EDGPU_ECOMM, "edgpu: mpi_size>1 but no communicator attached (edgpu_comm_init_*)");
+        return EDGPU_OK;
+    };
+    const unsigned tgrid = (unsigned)(cdiv(H.Qdw, 32) * cdiv(H.DimUp, 32));
+    hipLaunchKernelGGL(k_transpose2d, dim3(tgrid), dim3(256), 0, st, v, s->tA.p, H.Qdw, H.DimUp);     // tA: DimUp x Qdw
+    HIPCHK(hipGetLastError());
+    CHK(a2a(s->tA.p, sc, sd, s->tB.p, rc, rd));                                                       // tB: blocks by sender
+    const unsigned bgrid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(cdiv(s->Qup * H.DimDw, 256), 65536));
+    Bk.blocks = s->tB.p; Bk.vt = s->tVT.p; Bk.dir = 0;
+    hipLaunchKernelGGL(k_tblocks, dim3(bgrid), dim3(256), 0, st, Bk);
+    TdwArgs D{}; D.DimDw = (int32_t)H.DimDw; D.dww = s->fac[1]->width; D.use_lds = s->tr_lds ? 1 : 0;
+    D.ellc = s->fac[1]->ellc.p; D.ellv = s->fac[1]->ellv.p; D.vt = s->tVT.p; D.hvt = s->tHVT.p;
+    if (dbg_flags() & 2) D.dww = 0;
+    if (s->Qup > 0) {
+        static bool attr = false;
+        if (!attr) { if (hipFuncSetAttribute((const void *)k_tdw, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024) != hipSuccess) (void)hipGetLastError(); attr = true; }
+        hipLaunchKernelGGL(k_tdw, dim3((unsigned)s->Qup), dim3(H.DimDw >= 4096 ? 1024 : 256), s->tr_lds ? (size_t)H.DimDw * 8 : 0, st, D);
+    }
+    Bk.vt = s->tHVT.p; Bk.dir = 1;
+    hipLaunchKernelGGL(k_tblocks, dim3(bgrid), dim3(256), 0, st, Bk);                                  // tB: blocks by destination
+    HIPCHK(hipGetLastError());
+    CHK(a2a(s->tB.p, rc, rd, s->tA.p, sc, sd));                                                       // tA: DimUp x Qdw again
+    return EDGPU_OK;
+}
+
 static int hxv(S *s, const double *v, double *out, bool epi, const double *uprev)
 {
     const SectorHost &H = s->H; const edgpu_desc &d = H.desc;
@@ -82,7 +140,8 @@ static int hxv(S *s, const double *v, double *out, bool epi, const double *uprev
         HIPCHK(hipStreamWaitEvent(s->cstream, s->ev_ready, 0));
         const bool timed = s->comm_slot >= 0 && 2 * s->comm_slot + 1 < (int)s->comm_ev.size();
         if (timed) HIPCHK(hipEventRecord(s->comm_ev[2 * s->comm_slot], s->cstream));
-        CHK(gather_vector(s, v, s->cstream));
+        if (s->tr_on) CHK(transposed_dw_pass(s, v, s->cstream));      // whole dw part, on the comm stream
+        else CHK(gather_vector(s, v, s->cstream));
         if (timed) HIPCHK(hipEventRecord(s->comm_ev[2 * s->comm_slot + 1], s->cstream));
         HIPCHK(hipEventRecord(s->ev_gather, s->cstream));
     }
@@ -211,7 +270,12 @@ static int hxv(S *s, const double *v, double *out, bool epi, const double *uprev
             } else
                 CHK(dispatch_kron2(s, base | KF_NODW | KF_LDS, A, nblocks));
             if (multi) HIPCHK(hipStreamWaitEvent(s->stream, s->ev_gather, 0));
-            if (s->extra && !nd_pass) CHK(dispatch_kron2(s, base | KF_NOLOCAL, A, nblocks));   // phonon cases: row-wise dw pass (+Jx/Jp)
+            if (s->tr_on) {      // the dw part came back transposed in tA (DimUp x Qdw): add it, scale, alpha partials
+                nblocks = cdiv(H.DimUp, 32) * cdiv(H.Qdw, 32);
+                if (epi) hipLaunchKernelGGL(k_tadd<true>, dim3((unsigned)nblocks), dim3(256), 0, s->stream, (const double *)s->tA.p, out, v, H.Qdw, H.DimUp, (const double *)s->scal.p, s->partial.p);
+                else hipLaunchKernelGGL(k_tadd<false>, dim3((unsigned)nblocks), dim3(256), 0, s->stream, (const double *)s->tA.p, out, v, H.Qdw, H.DimUp, (const double *)s->scal.p, s->partial.p);
+                HIPCHK(hipGetLastError());
+            } else if (s->extra && !nd_pass) CHK(dispatch_kron2(s, base | KF_NOLOCAL, A, nblocks));   // phonon cases: row-wise dw pass (+Jx/Jp)
             else {
                 if (nd_pass) {
                     NdArgs Nd{};

@@ -20,7 +20,7 @@ static int upload_factor(S *s, int k)
     if (df->width > 64) return fail(EDGPU_EUNSUPPORTED, "edgpu: more than 64 hops per spin configuration");
     if ((int)f.terms.size() > kMaxTerms) return fail(EDGPU_EUNSUPPORTED, "edgpu: too many one-body hop terms");
     // ELL image: up factors transposed [width][dim] (lanes run over rows), dw factors [dim][width]
-    const bool transposed = k < s->H.Ns_Ud;
+    const bool transposed = k < s->H.Ns_Ud || s->tr_on;     // transpose mode: H_dw is applied along rows too
     std::vector<int32_t> ec((size_t)df->width * f.dim); std::vector<double> ev((size_t)df->width * f.dim);
     for (int32_t i = 0; i < f.dim; i++)
         for (int32_t q = 0; q < df->width; q++) {
@@ -31,7 +31,7 @@ static int upload_factor(S *s, int k)
     CHK(df->ellc.upload(ec)); CHK(df->ellv.upload(ev));
     // packed image for the persistent local pass: 16-bit column + (sign | term index) byte per hop;
     // padded slots use code 127 -> amplitude 0.  Only when every entry is a single hop term.
-    if (transposed && f.dim <= 65536 && f.terms.size() < 127) {
+    if (k < s->H.Ns_Ud && f.dim <= 65536 && f.terms.size() < 127) {
         const int W = df->width, ncw = (W + 1) / 2, ndw = (W + 3) / 4;
         std::vector<uint32_t> pc((size_t)ncw * f.dim, 0u), pd((size_t)ndw * f.dim, 0u);
         std::vector<double> tvl(128, 0.0);
@@ -271,6 +271,7 @@ static int64_t max_partials(const S *s)
         const int w = s->dw_w, R = std::min(256 / w, s->dw_rows);
         n = std::max<int64_t>(n, 8 * cdiv(cdiv(s->H.DimUp, w), 8) * cdiv(s->H.Qdw * s->H.DimPh, std::max(R, 1)));
     }
+    if (s->tr_on) n = std::max<int64_t>(n, cdiv(s->H.DimUp, 32) * cdiv(s->H.Qdw, 32));      // k_tadd: one partial per 32x32 tile
     if (s->csr_bpr) n = std::max<int64_t>(n, (int64_t)s->csr_bpr * s->H.Qdw);
     if (s->csrD_bpr) n = std::max<int64_t>(n, 8 * cdiv(s->csrD_bpr, 8) * s->H.Qdw);
     return n;
@@ -294,6 +295,8 @@ static int create(const edgpu_desc *desc, S **out)
     s->two_factor = desc->ed_total_ud != 0;
     s->extra = H.DimPh > 1 || H.Jhflag; s->has_ph = H.DimPh > 1; s->has_nd = H.Jhflag;
     s->nloc_el = H.DimUp * H.Qdw; s->nloc = s->nloc_el * H.DimPh; s->vecdim = s->nloc;
+    s->multi = desc->mpi_size > 1 || (desc->reserved & 1);   // reserved bit 0: run the exchange path even on one rank (tests)
+    s->tr_on = s->multi && s->two_factor && !s->extra && desc->storage != EDGPU_STORE_CSR && dbg_int("EDGPU_DW_TRANSPOSE", 0) != 0 && H.DimUp >= desc->mpi_size;
     for (int k = 0; k < 2 * H.Ns_Ud; k++) CHK(upload_factor(s.get(), k));
     CHK(s->cross.upload(H.cross)); CHK(s->gup.upload(H.gph_up)); CHK(s->gdw.upload(H.gph_dw));
     {
@@ -339,13 +342,20 @@ static int create(const edgpu_desc *desc, S **out)
     s->nnz_total = (s->nloc_el + nnz_fac) * H.DimPh;
     s->multi = desc->mpi_size > 1 || (desc->reserved & 1);   // reserved bit 0: run the exchange path even on one rank (tests)
     s->nhalo = H.DimDw;
-    if (s->multi && s->two_factor && (!s->extra || (s->has_nd && !s->has_ph && s->nd_split)) && dbg_int("EDGPU_HALO", 1)) CHK(setup_halo(s.get()));
+    if (s->multi && !s->tr_on && s->two_factor && (!s->extra || (s->has_nd && !s->has_ph && s->nd_split)) && dbg_int("EDGPU_HALO", 1)) CHK(setup_halo(s.get()));
+    if (s->tr_on) {     // up-block of this rank in the transposed space (same rule as the dw split)
+        const int64_t P = s->comm.size, r = s->comm.rank, q = H.DimUp / P, rem = H.DimUp % P;
+        s->Qup = r < rem ? q + 1 : q; s->up0 = r < rem ? r * (q + 1) : r * q + rem;
+        CHK(s->tA.alloc((size_t)s->nloc_el)); CHK(s->tB.alloc((size_t)(s->Qup * H.DimDw)));
+        CHK(s->tVT.alloc((size_t)(s->Qup * H.DimDw))); CHK(s->tHVT.alloc((size_t)(s->Qup * H.DimDw)));
+        s->tr_lds = (size_t)H.DimDw * 8 + 128 <= 150 * 1024 && !(dbg_flags() & 4);
+    }
     if (desc->storage != EDGPU_STORE_DIRECT) { CHK(build_diag(s.get())); s->bytes_stored = s->nloc_el * 8; }
     if (desc->storage == EDGPU_STORE_CSR) {
         CHK(build_csr(s.get()));
         s->bytes_stored = s->csr_nnz * 12 + (s->nloc_el + 1) * 8 * (s->csr_three ? 3 : (s->csr_split ? 2 : 1));
     }
-    if (s->multi) CHK(s->vfull.alloc((size_t)(H.DimUp * s->nhalo * H.DimPh)));
+    if (s->multi && !s->tr_on) CHK(s->vfull.alloc((size_t)(H.DimUp * s->nhalo * H.DimPh)));
     s->npartial = max_partials(s.get());
     CHK(s->partial.alloc((size_t)s->npartial));
     CHK(s->partial2.alloc(1024));

@@ -96,6 +96,22 @@ def test_multirank_large_sector_forms(edgpu_mod, case, size):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("case,size,env", [("c_nb7_half", 3, {}), ("nb5_offhalf_2_4", 4, {}), ("nb6_even", 2, {"EDGPU_DEBUG": "4"}),
+                                           ("nspin2_random_bath", 3, {}), ("norb2_normal_offdiag_hloc", 2, {})])
+def test_multirank_distributed_transpose(edgpu_mod, case, size, env):
+    """EDGPU_DW_TRANSPOSE=1: the dw hops through the reference's own scheme (transpose, all-to-all, local pass along
+    rows, transpose back) instead of the needed-rows exchange; uneven up/dw splits, rows with and without LDS staging."""
+    res = _launch("gpu", case, size, extra_env=dict({"EDGPU_DW_TRANSPOSE": "1"}, **env))
+    name, m, nu, nd = [z for z in __import__("cases").zoo() if z[0] == case][0]
+    from oracle import oracle
+    e_dense = np.linalg.eigvalsh(oracle.Sector(m, nu, nd).hmat())[0]
+    for r in res:
+        for k, v in r.items():
+            if k.startswith("e0_"):
+                assert abs(v - e_dense) < 1e-10, (k, v, e_dense)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("case,size", [("c_nb5_half", 2), ("norb2_normal_JxJp", 3), ("orbs_norb2_nb3", 2), ("phonons_nb3_nph3", 2), ("phonons_orbs", 2)])
 def test_multirank_legs_observables_twin(edgpu_mod, case, size):
     """GF / chi / phonon legs, impurity histogram + density matrix and the twin-sector hand-off with the
