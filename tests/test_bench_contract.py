@@ -15,8 +15,8 @@ def _run(extra):
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--nbath", "9", "--steps", "3", "--warmup", "1", "--no-cpu"] + extra
     out = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600, cwd=ROOT)
     assert out.returncode == 0, out.stderr.decode()[-2000:]
-    lines = [l for l in out.stdout.decode().splitlines() if l.strip().startswith("{")]
-    assert len(lines) == 1, out.stdout.decode()
+    lines = [l for l in out.stdout.decode().splitlines() if l.strip()]
+    assert len(lines) == 1 and lines[0].startswith("{"), out.stdout.decode()      # ONE line on stdout, nothing else (library banners go to stderr)
     return json.loads(lines[0])
 
 
