@@ -680,6 +680,26 @@ __global__ void __launch_bounds__(1024) k_tdw(TdwArgs A)
         A.hvt[(int64_t)blockIdx.x * A.DimDw + i] = acc;
     }
 }
+// the same pass reading and writing the all-to-all block layout directly (rows that fit LDS): row il of vt is the
+// concatenation of one contiguous segment per sender, staged into LDS in place of the k_tblocks pass; the result is
+// written straight into the block layout of the way back -- two passes over the shard less
+struct TdwFusedArgs { int32_t DimDw, dww, P; int64_t Qup; int64_t dw0[65]; const int32_t *ellc; const double *ellv; const double *blk_in; double *blk_out; };
+__global__ void __launch_bounds__(1024) k_tdw_blocks(TdwFusedArgs A)
+{
+    extern __shared__ double lds[];
+    const int64_t il = blockIdx.x;
+    for (int i = threadIdx.x; i < A.DimDw; i += blockDim.x) {
+        int sl = 0; while (sl + 1 < A.P && A.dw0[sl + 1] <= i) sl++;
+        lds[i] = A.blk_in[A.Qup * A.dw0[sl] + il * (A.dw0[sl + 1] - A.dw0[sl]) + (i - A.dw0[sl])];
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < A.DimDw; i += blockDim.x) {
+        double acc = 0.0;
+        for (int k = 0; k < A.dww; k++) acc += A.ellv[(int64_t)k * A.DimDw + i] * lds[A.ellc[(int64_t)k * A.DimDw + i]];
+        int sl = 0; while (sl + 1 < A.P && A.dw0[sl + 1] <= i) sl++;
+        A.blk_out[A.Qup * A.dw0[sl] + il * (A.dw0[sl + 1] - A.dw0[sl]) + (i - A.dw0[sl])] = acc;
+    }
+}
 // out(idw_l, iup) += [s_cur *] back(iup, idw_l)  (back: DimUp x Qdw), with the Lanczos alpha partials
 template <bool EPI>
 __global__ void __launch_bounds__(256) k_tadd(const double *__restrict__ back, double *__restrict__ out, const double *__restrict__ v,

@@ -111,17 +111,28 @@ static int transposed_dw_pass(S *s, const double *v, hipStream_t st)
     hipLaunchKernelGGL(k_transpose2d, dim3(tgrid), dim3(256), 0, st, v, s->tA.p, H.Qdw, H.DimUp);     // tA: DimUp x Qdw
     HIPCHK(hipGetLastError());
     CHK(a2a(s->tA.p, sc, sd, s->tB.p, rc, rd));                                                       // tB: blocks by sender
+    if (s->tr_lds) {
+        // rows fit LDS: read the received blocks and write the blocks of the way back directly (tVT is the out buffer)
+        TdwFusedArgs F{}; F.DimDw = (int32_t)H.DimDw; F.dww = s->fac[1]->width; F.P = P; F.Qup = s->Qup;
+        for (int r = 0; r <= P; r++) F.dw0[r] = Bk.dw0[r];
+        F.ellc = s->fac[1]->ellc.p; F.ellv = s->fac[1]->ellv.p; F.blk_in = s->tB.p; F.blk_out = s->tVT.p;
+        if (dbg_flags() & 2) F.dww = 0;
+        if (s->Qup > 0) {
+            static bool attr = false;
+            if (!attr) { if (hipFuncSetAttribute((const void *)k_tdw_blocks, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024) != hipSuccess) (void)hipGetLastError(); attr = true; }
+            hipLaunchKernelGGL(k_tdw_blocks, dim3((unsigned)s->Qup), dim3(H.DimDw >= 4096 ? 1024 : 256), (size_t)H.DimDw * 8, st, F);
+        }
+        HIPCHK(hipGetLastError());
+        CHK(a2a(s->tVT.p, rc, rd, s->tA.p, sc, sd));                                                  // tA: DimUp x Qdw again
+        return EDGPU_OK;
+    }
     const unsigned bgrid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(cdiv(s->Qup * H.DimDw, 256), 65536));
     Bk.blocks = s->tB.p; Bk.vt = s->tVT.p; Bk.dir = 0;
     hipLaunchKernelGGL(k_tblocks, dim3(bgrid), dim3(256), 0, st, Bk);
-    TdwArgs D{}; D.DimDw = (int32_t)H.DimDw; D.dww = s->fac[1]->width; D.use_lds = s->tr_lds ? 1 : 0;
+    TdwArgs D{}; D.DimDw = (int32_t)H.DimDw; D.dww = s->fac[1]->width; D.use_lds = 0;
     D.ellc = s->fac[1]->ellc.p; D.ellv = s->fac[1]->ellv.p; D.vt = s->tVT.p; D.hvt = s->tHVT.p;
     if (dbg_flags() & 2) D.dww = 0;
-    if (s->Qup > 0) {
-        static bool attr = false;
-        if (!attr) { if (hipFuncSetAttribute((const void *)k_tdw, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024) != hipSuccess) (void)hipGetLastError(); attr = true; }
-        hipLaunchKernelGGL(k_tdw, dim3((unsigned)s->Qup), dim3(H.DimDw >= 4096 ? 1024 : 256), s->tr_lds ? (size_t)H.DimDw * 8 : 0, st, D);
-    }
+    if (s->Qup > 0) hipLaunchKernelGGL(k_tdw, dim3((unsigned)s->Qup), dim3(H.DimDw >= 4096 ? 1024 : 256), 0, st, D);
     Bk.vt = s->tHVT.p; Bk.dir = 1;
     hipLaunchKernelGGL(k_tblocks, dim3(bgrid), dim3(256), 0, st, Bk);                                  // tB: blocks by destination
     HIPCHK(hipGetLastError());
