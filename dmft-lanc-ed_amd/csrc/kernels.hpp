@@ -419,6 +419,7 @@ struct UpBigArgs {
     const double *tval; int32_t nterms;
     const double *diag, *Eup, *Edw, *cross; const int32_t *mapup, *mapdw; int32_t impmask, nI; double econst;
     const double *v; double *out; const double *uprev; const double *scal;
+    int32_t nodiag;           // 1: hops only (the transposed dw pass re-uses this kernel with H_dw's image)
 };
 template <bool DIRECT, bool EPI>
 __global__ void __launch_bounds__(512) k_uppass_big(UpBigArgs A)
@@ -442,7 +443,7 @@ __global__ void __launch_bounds__(512) k_uppass_big(UpBigArgs A)
         const double x = vrow[i];
         double dval;
         if (DIRECT) dval = edw + A.Eup[i] + A.cross[((uint32_t)A.mapup[i] & A.impmask) * A.nI + mdw];
-        else dval = A.diag[idwl * DimUp + i];
+        else dval = A.nodiag ? 0.0 : A.diag[idwl * DimUp + i];
         double up = 0.0;
         if (EPI) up = A.uprev[rbase + i];
         const uint32_t c[5] = {p0.x, p0.y, p0.z, p0.w, p1.x}, k[3] = {p1.y, p1.z, p1.w};

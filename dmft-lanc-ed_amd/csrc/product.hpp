@@ -132,7 +132,14 @@ static int transposed_dw_pass(S *s, const double *v, hipStream_t st)
     TdwArgs D{}; D.DimDw = (int32_t)H.DimDw; D.dww = s->fac[1]->width; D.use_lds = 0;
     D.ellc = s->fac[1]->ellc.p; D.ellv = s->fac[1]->ellv.p; D.vt = s->tVT.p; D.hvt = s->tHVT.p;
     if (dbg_flags() & 2) D.dww = 0;
-    if (s->Qup > 0) hipLaunchKernelGGL(k_tdw, dim3((unsigned)s->Qup), dim3(H.DimDw >= 4096 ? 1024 : 256), 0, st, D);
+    if (s->Qup > 0 && s->fac[1]->packed_elem8 && s->up_big && D.dww > 0) {
+        // long rows: the packed-image gather kernel of the local pass, applied to H_dw (no diagonal)
+        UpBigArgs U{};
+        U.DimUp = (int32_t)H.DimDw; U.DimPh = 1; U.rsplit = s->row_split; U.Qdw = s->Qup; U.dw0 = 0; U.nrows = s->Qup;
+        U.packed8 = reinterpret_cast<const uint4 *>(s->fac[1]->pelem8.p); U.tval = s->fac[1]->ptval.p; U.nterms = s->fac[1]->pterms;
+        U.v = s->tVT.p; U.out = s->tHVT.p; U.nodiag = 1;
+        hipLaunchKernelGGL((k_uppass_big<false, false>), dim3((unsigned)(cdiv(U.nrows, 8) * 8 * s->row_split)), dim3(512), 0, st, U);
+    } else if (s->Qup > 0) hipLaunchKernelGGL(k_tdw, dim3((unsigned)s->Qup), dim3(H.DimDw >= 4096 ? 1024 : 256), 0, st, D);
     Bk.vt = s->tHVT.p; Bk.dir = 1;
     hipLaunchKernelGGL(k_tblocks, dim3(bgrid), dim3(256), 0, st, Bk);                                  // tB: blocks by destination
     HIPCHK(hipGetLastError());

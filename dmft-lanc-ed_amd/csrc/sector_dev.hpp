@@ -31,7 +31,7 @@ static int upload_factor(S *s, int k)
     CHK(df->ellc.upload(ec)); CHK(df->ellv.upload(ev));
     // packed image for the persistent local pass: 16-bit column + (sign | term index) byte per hop;
     // padded slots use code 127 -> amplitude 0.  Only when every entry is a single hop term.
-    if (k < s->H.Ns_Ud && f.dim <= 65536 && f.terms.size() < 127) {
+    if ((k < s->H.Ns_Ud || s->tr_on) && f.dim <= 65536 && f.terms.size() < 127) {      // transpose mode: H_dw is applied along rows too
         const int W = df->width, ncw = (W + 1) / 2, ndw = (W + 3) / 4;
         std::vector<uint32_t> pc((size_t)ncw * f.dim, 0u), pd((size_t)ndw * f.dim, 0u);
         std::vector<double> tvl(128, 0.0);
