@@ -59,6 +59,39 @@ def main():
         ex.allreduce(part)
         assert abs(part[0] - vglob @ ref) <= 1e-10 * abs(vglob @ ref) + 1e-12
         res["ok"] = True
+    elif mode == "cpu_transpose":
+        # the distributed-transpose scheme of the dw hops (csrc/product.hpp: transposed_dw_pass) restated with numpy on
+        # the same block arithmetic (counts / displacements of both all-to-alls), through the staged gloo exchange
+        ex = exchange.StagedExchange(dist)
+        P = size
+        split = lambda D, r: model.dw_partition(D, P, r)
+        qup, up0 = split(DimUp, rank)
+        rng2 = np.random.RandomState(7)
+        Hdw = rng2.uniform(-1, 1, (DimDw, DimDw)); Hdw = Hdw + Hdw.T             # any symmetric dw factor
+        want = (Hdw @ vglob.reshape(DimPh, DimDw, DimUp)[0])[d0:d0 + q, :]        # (H_dw x 1) v, my dw rows
+        vl = vloc[:nel_loc].reshape(q, DimUp)
+        tA = np.ascontiguousarray(vl.T).reshape(-1)                              # DimUp x Qdw
+        sc = [split(DimUp, r)[0] * q for r in range(P)]; sd = [q * split(DimUp, r)[1] for r in range(P)]
+        rc = [qup * split(DimDw, r)[0] for r in range(P)]; rd = [qup * split(DimDw, r)[1] for r in range(P)]
+        tB = np.zeros(qup * DimDw + 1)
+        tB[rd[rank]:rd[rank] + rc[rank]] = tA[sd[rank]:sd[rank] + sc[rank]]
+        s2, r2 = list(sc), list(rc); s2[rank] = 0; r2[rank] = 0
+        ex.exchange(tA.ctypes.data, s2, sd, tB.ctypes.data, r2, rd)
+        vt = np.zeros((qup, DimDw))
+        for s_ in range(P):
+            qs, ds = split(DimDw, s_)
+            vt[:, ds:ds + qs] = tB[rd[s_]:rd[s_] + rc[s_]].reshape(qup, qs)
+        hvt = vt @ Hdw.T                                                         # row pass: hvt(il, i) = sum_j Hdw[i,j] vt(il, j)
+        back = np.zeros(qup * DimDw + 1)
+        for s_ in range(P):
+            qs, ds = split(DimDw, s_)
+            back[rd[s_]:rd[s_] + rc[s_]] = np.ascontiguousarray(hvt[:, ds:ds + qs]).reshape(-1)
+        tA2 = np.zeros(DimUp * q + 1)
+        tA2[sd[rank]:sd[rank] + sc[rank]] = back[rd[rank]:rd[rank] + rc[rank]]
+        ex.exchange(back.ctypes.data, r2, rd, tA2.ctypes.data, s2, sd)
+        got = tA2[:DimUp * q].reshape(DimUp, q).T
+        assert np.abs(got - want).max() <= 1e-12 * max(1.0, np.abs(want).max())
+        res["ok"] = True
     elif mode == "torchdev":
         import torch  # noqa: F401  (before libedgpu.so, as in bench.py)
         import edgpu

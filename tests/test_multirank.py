@@ -55,6 +55,13 @@ def test_partition_and_staged_exchange_gloo_cpu(case, size):
     assert all(r["ok"] for r in res)
 
 
+@pytest.mark.parametrize("case,size", [("c_nb5_half", 2), ("nb5_offhalf_2_4", 3)])
+def test_transpose_scheme_block_arithmetic_gloo_cpu(case, size):
+    """world_size 2 and 3 on CPU: the two all-to-alls of the distributed-transpose dw pass with uneven up/dw splits."""
+    res = _launch("cpu_transpose", case, size)
+    assert all(r["ok"] for r in res)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("case,size", [("c_nb5_half", 2), ("c_nb7_half", 3), ("norb2_normal_JxJp", 2), ("phonons_norb2_JxJp", 2), ("nb5_offhalf_2_4", 4),
                                        ("orbs_norb2_nb3", 2), ("orbs_norb2_nb3_uneven", 3), ("phonons_orbs", 2),
