@@ -59,6 +59,32 @@ def main():
         ex.allreduce(part)
         assert abs(part[0] - vglob @ ref) <= 1e-10 * abs(vglob @ ref) + 1e-12
         res["ok"] = True
+    elif mode == "cpu_halo":
+        # the needed-rows exchange (csrc/sector_dev.hpp: setup_halo) restated on the oracle's H_dw: every rank derives BOTH
+        # its receive lists and what every peer needs from it without communication; the lists must match pairwise and the
+        # exchanged rows must be exactly the dw rows the rank's own rows couple to
+        ex = exchange.StagedExchange(dist)
+        rp, cols, vals = S.sp("dw")
+        nbr = [set(int(c) - 1 for c in cols[rp[i]:rp[i + 1]]) for i in range(DimDw)]
+        own = lambda r: range(model.dw_partition(DimDw, size, r)[1], model.dw_partition(DimDw, size, r)[1] + model.dw_partition(DimDw, size, r)[0])
+        owner = {}
+        for r in range(size):
+            for j in own(r):
+                owner[j] = r
+        need = lambda r: sorted(set().union(*[nbr[i] for i in own(r)]) - set(own(r))) if len(own(r)) else []
+        recv_rows = [[j for j in need(rank) if owner[j] == r] for r in range(size)]
+        send_rows = [[j for j in need(r) if owner[j] == rank] for r in range(size)]
+        X = vglob.reshape(DimPh, DimDw, DimUp)[0]
+        sbuf = np.concatenate([X[j] for r in range(size) for j in send_rows[r]] + [np.zeros(1)])
+        sc = [len(send_rows[r]) * DimUp for r in range(size)]; sd = [int(x) for x in np.cumsum([0] + sc[:-1])]
+        rc = [len(recv_rows[r]) * DimUp for r in range(size)]; rd = [int(x) for x in np.cumsum([0] + rc[:-1])]
+        rbuf = np.full(sum(rc) + 1, np.nan)
+        ex.exchange(sbuf.ctypes.data, sc, sd, rbuf.ctypes.data, rc, rd)
+        k = 0
+        for r in range(size):
+            for j in recv_rows[r]:
+                assert np.array_equal(rbuf[k:k + DimUp], X[j]); k += DimUp
+        res["ok"] = True; res["halo_rows"] = sum(len(x) for x in recv_rows); res["allgather_rows"] = DimDw - q
     elif mode == "cpu_transpose":
         # the distributed-transpose scheme of the dw hops (csrc/product.hpp: transposed_dw_pass) restated with numpy on
         # the same block arithmetic (counts / displacements of both all-to-alls), through the staged gloo exchange

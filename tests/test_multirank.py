@@ -55,6 +55,15 @@ def test_partition_and_staged_exchange_gloo_cpu(case, size):
     assert all(r["ok"] for r in res)
 
 
+@pytest.mark.parametrize("case,size", [("c_nb5_half", 2), ("c_nb7_half", 3), ("nb5_offhalf_2_4", 4)])
+def test_needed_rows_exchange_lists_gloo_cpu(case, size):
+    """world_size 2-4 on CPU: send/receive row lists derived independently on both sides from H_dw are consistent, and the
+    exchange delivers exactly the rows a rank's dw hops read (and fewer than an all-gather would)."""
+    res = _launch("cpu_halo", case, size)
+    assert all(r["ok"] for r in res)
+    assert all(r["halo_rows"] <= r["allgather_rows"] for r in res)
+
+
 @pytest.mark.parametrize("case,size", [("c_nb5_half", 2), ("nb5_offhalf_2_4", 3)])
 def test_transpose_scheme_block_arithmetic_gloo_cpu(case, size):
     """world_size 2 and 3 on CPU: the two all-to-alls of the distributed-transpose dw pass with uneven up/dw splits."""
