@@ -370,3 +370,35 @@ def test_sweep_over_all_sectors_of_a_small_model(edgpu_mod):
             r = np.linalg.norm(S.spmatvec(x) - e0 * x)
             assert r < 1e-5 or deg > 1, (nup, ndw, r)
         G.close()
+
+
+def test_c5_full_size_properties(edgpu_mod):
+    """BASELINE config 5 at full size (2-orbital impurity, replica bath with H_basis={sigma_z}, Ns=16, N=165,636,900,
+    Jx=Jp=Jh): stored and on-the-fly formats agree, H is symmetric, and the non-local pass (k_ndpass) equals the fused
+    row-wise form of the same terms."""
+    import os
+    from edgpu import model
+    m = model.make_model(Norb=2, Nbath=7, bath_type="replica", H_basis=[cases.sigma_z()], lambda_imp=[1.0],
+                         Uloc=(2.0, 2.0), Jh=0.25, Ust=1.5, Jx=0.25, Jp=0.25)
+    N = 165636900
+    rng = np.random.default_rng(9)
+    u = rng.random(N) - 0.5; v = rng.random(N) - 0.5
+    du, dv, dh = edgpu_mod.DeviceVector(N).upload(u), edgpu_mod.DeviceVector(N).upload(v), edgpu_mod.DeviceVector(N)
+    ref = None
+    for st, env in (("kron", {}), ("direct", {}), ("kron", {"EDGPU_ND_SPLIT": "0"})):
+        os.environ.update(env)
+        try:
+            G = edgpu_mod.HvSector(m, [8], [8], storage=st)
+        finally:
+            for k in env:
+                os.environ.pop(k, None)
+        assert G.Dim == N
+        G.spHtimesV_device(dv, dh); hv = dh.download()
+        if ref is None:
+            G.spHtimesV_device(du, dh); hu = dh.download()
+            scale = float(np.abs(u) @ np.abs(hv))
+            assert abs(float(u @ hv) - float(hu @ v)) <= 1e-12 * scale
+            ref = hv; del hu
+        else:
+            assert np.abs(hv - ref).max() <= 1e-12 * np.abs(ref).max(), (st, env)
+        G.close()
