@@ -742,6 +742,122 @@ void orc_directmatvec(orc_sector *S, const double *vin, double *Hv)
     if (S->p.ed_total_ud) direct_main(S, vin, Hv); else direct_orbs(S, vin, Hv);
 }
 
+/* ---- single rows of the operator, gather form ---------------------------------------------------------
+ * orc_rows: Hv(i) for a list of rows i, evaluated from the bit patterns alone -- no N-sized matrix is built,
+ * so it runs at Ns=16 and Ns=18 where orc_buildh cannot (spH0d alone is 2N heap blocks) and 64-bit row numbers
+ * are used throughout (the reference's int32 `i` overflows at Ns=18, direct_mpi/HxV_local.f90:2-5).
+ * Per row the accumulation order is that of spMatVec_main (ED_HAMILTONIAN_SPARSE_HxV.f90:399-483) /
+ * spMatVec_orbs (487-564): spH0d, the spH0dws row, the spH0ups row, phonon terms, the spH0nd row.
+ * Row i of spH0ups holds one entry (i, j) per source pattern j with a hop ONTO i (stored/H_up.f90: the outer
+ * loop runs over the source jup and inserts at (iup=target, jup)), in ascending j with duplicates summed in
+ * statement order (sp_insert).  Here each hop statement of stored/H_up.f90:8-81 is inverted -- target pattern
+ * -> the one source pattern it can come from -- and the reference's own c/cdg calls are then replayed on that
+ * source, so signs and values are the reference's; no symmetry of H_sigma is assumed. */
+typedef struct { int64_t j; double val; } row_ent;
+typedef struct { row_ent e[256]; int n; } row_list;
+static void rl_add(row_list *L, int64_t j, double val)
+{
+    for (int k = 0; k < L->n; k++) if (L->e[k].j == j) { L->e[k].val += val; return; }     /* sp_insert: column exists -> sum */
+    if (L->n >= 256) die("orc_rows: more than 256 entries in one factor row");
+    L->e[L->n].j = j; L->e[L->n].val = val; L->n++;
+}
+static void rl_sort(row_list *L)      /* storage order of a factor row = ascending source index (stable insertion sort) */
+{
+    for (int a = 1; a < L->n; a++) { row_ent t = L->e[a]; int b = a; while (b > 0 && L->e[b - 1].j > t.j) { L->e[b] = L->e[b - 1]; b--; } L->e[b] = t; }
+}
+/* hop statement "amplitude t, c^+_alpha c_beta" arriving at target pattern mt: source = mt with alpha emptied, beta filled */
+static void inv_hop(const int *map, int dim, int mt, int alpha, int beta, double t, row_list *L)
+{
+    int k1, k2; double sg1, sg2;
+    if (alpha == beta || t == 0.0) return;
+    if (!((mt >> (alpha - 1)) & 1) || ((mt >> (beta - 1)) & 1)) return;
+    int src = (mt & ~(1 << (alpha - 1))) | (1 << (beta - 1));
+    op_c(beta, src, &k1, &sg1); op_cdg(alpha, k1, &k2, &sg2);          /* as the reference applies them to the source */
+    if (k2 != mt) die("orc_rows: inverted hop does not land on the row");
+    rl_add(L, binary_search_rec(map, dim, src), t * sg1 * sg2);
+}
+/* stored/H_up.f90:8-81 / H_dw.f90 read backwards: every entry of row `mt` of H_sigma */
+static void row_main(const orc_sector *S, int spin, const int *map, int dim, int mt, row_list *L)
+{
+    const orc_params *p = &S->p;
+    L->n = 0;
+    for (int iorb = 1; iorb <= p->Norb; iorb++)
+        for (int jorb = 1; jorb <= p->Norb; jorb++) inv_hop(map, dim, mt, iorb, jorb, IMPHLOC(spin, spin, iorb, jorb), L);
+    if (p->bath_type == 2)
+        for (int kp = 1; kp <= p->Nbath; kp++)
+            for (int iorb = 1; iorb <= p->Norb; iorb++)
+                for (int jorb = 1; jorb <= p->Norb; jorb++)
+                    inv_hop(map, dim, mt, S->getBathStride[iorb - 1][kp - 1], S->getBathStride[jorb - 1][kp - 1], HBATH(spin, spin, iorb, jorb, kp), L);
+    for (int iorb = 1; iorb <= p->Norb; iorb++)
+        for (int kp = 1; kp <= p->Nbath; kp++) {
+            int ialfa = S->getBathStride[iorb - 1][kp - 1];
+            inv_hop(map, dim, mt, ialfa, iorb, DIAG_HYBR(spin, iorb, kp), L);
+            inv_hop(map, dim, mt, iorb, ialfa, DIAG_HYBR(spin, iorb, kp), L);
+        }
+    rl_sort(L);
+}
+/* stored/Orbs/H_up.f90:7-30 read backwards */
+static void row_orbs(const orc_sector *S, int spin, int iorb, const int *map, int dim, int mt, row_list *L)
+{
+    const orc_params *p = &S->p;
+    L->n = 0;
+    for (int kp = 1; kp <= p->Nbath; kp++) {
+        inv_hop(map, dim, mt, 1 + kp, 1, DIAG_HYBR(spin, iorb, kp), L);
+        inv_hop(map, dim, mt, 1, 1 + kp, DIAG_HYBR(spin, iorb, kp), L);
+    }
+    rl_sort(L);
+}
+typedef struct { const orc_sector *S; row_list *L; } nl_row_ctx;
+static void emit_nl_row(void *c, int jup, int jdw, double val) { nl_row_ctx *x = (nl_row_ctx *)c; rl_add(x->L, jup + (int64_t)(jdw - 1) * x->S->DimUp, val); }
+
+/* idx: n global row numbers, 1-based (1..Dim); v: the whole input vector (Dim); out[r] = (H v)(idx[r]) */
+void orc_rows(orc_sector *S, int64_t n, const int64_t *idx, const double *v, double *out)
+{
+    const orc_params *p = &S->p;
+    const int64_t DimUp = S->DimUp, Nel = S->DimUp * S->DimDw;
+    int Nvec[2 * ORC_MAX_UD], Ind[2 * ORC_MAX_UD], Jnd[2 * ORC_MAX_UD], n2 = 2 * S->Ns_Ud;
+    for (int k = 0; k < S->Ns_Ud; k++) { Nvec[k] = S->DimUps[k]; Nvec[k + S->Ns_Ud] = S->DimDws[k]; }
+    for (int64_t r = 0; r < n; r++) {
+        const int64_t i = idx[r];
+        if (i < 1 || i > S->Dim) die("orc_rows: row out of range");
+        const int64_t iph = (i - 1) / Nel + 1, i_el = (i - 1) % Nel + 1, phoff = (iph - 1) * Nel;
+        int nup[64], ndw[64], mup = 0, mdw = 0;
+        row_list L;
+        double hv = 0.0;
+        occupations(S, i_el, nup, ndw, &mup, &mdw);
+        hv = hv + h_local(S, nup, ndw) * V(i);                                            /* spH0d */
+        if (p->ed_total_ud) {
+            const int64_t iup = iup_index(i_el, DimUp), idw = idw_index(i_el, DimUp);
+            row_main(S, p->Nspin, S->map[1], (int)S->DimDw, mdw, &L);                      /* 413-427: dw first */
+            for (int k = 0; k < L.n; k++) { int64_t j = iup + (L.e[k].j - 1) * DimUp + phoff; hv = hv + L.e[k].val * V(j); }
+            row_main(S, 1, S->map[0], (int)DimUp, mup, &L);                                /* 429-443 */
+            for (int k = 0; k < L.n; k++) { int64_t j = L.e[k].j + (idw - 1) * DimUp + phoff; hv = hv + L.e[k].val * V(j); }
+        } else {
+            state2indices(i_el, Nvec, n2, Ind);
+            for (int iud = 0; iud < S->Ns_Ud; iud++) {                                     /* 512-533 */
+                row_orbs(S, 1, iud + 1, S->map[iud], S->DimUps[iud], S->map[iud][Ind[iud] - 1], &L);
+                for (int k = 0; k < L.n; k++) { memcpy(Jnd, Ind, sizeof(int) * (size_t)n2); Jnd[iud] = (int)L.e[k].j; hv = hv + L.e[k].val * V(indices2state(Jnd, Nvec, n2) + phoff); }
+                row_orbs(S, p->Nspin, iud + 1, S->map[iud + S->Ns_Ud], S->DimDws[iud], S->map[iud + S->Ns_Ud][Ind[iud + S->Ns_Ud] - 1], &L);
+                for (int k = 0; k < L.n; k++) { memcpy(Jnd, Ind, sizeof(int) * (size_t)n2); Jnd[iud + S->Ns_Ud] = (int)L.e[k].j; hv = hv + L.e[k].val * V(indices2state(Jnd, Nvec, n2) + phoff); }
+            }
+        }
+        if (S->DimPh > 1) {                                                               /* 445-470 / 535-562 */
+            double htmp = 0.0;
+            hv = hv + p->w0_ph * (iph - 1) * V(i);
+            for (int iorb = 1; iorb <= p->Norb; iorb++) htmp = htmp + p->g_ph[iorb - 1] * (nup[iorb - 1] + ndw[iorb - 1] - 1.0);
+            if (iph + 1 <= S->DimPh) { double val = htmp * sqrt((double)iph); hv = hv + val * V(i_el + iph * Nel); }
+            if (iph - 1 > 0) { double val = htmp * sqrt((double)(iph - 1)); hv = hv + val * V(i_el + (iph - 2) * Nel); }
+        }
+        if (S->Jhflag) {                                                                  /* 473-483: row i of spH0nd (insertion order) */
+            nl_row_ctx c = { S, &L };
+            L.n = 0;
+            nonlocal_terms(S, mup, mdw, nup, ndw, emit_nl_row, &c);
+            for (int k = 0; k < L.n; k++) hv = hv + L.e[k].val * V(L.e[k].j + phoff);
+        }
+        out[r] = hv;
+    }
+}
+
 /* dense Hmat of ed_buildh_main/orbs: ED_HAMILTONIAN_SPARSE_HxV.f90:132-195, 304-363.
  * Column-major Dim x Dim. */
 void orc_hmat(orc_sector *S, double *Hmat)

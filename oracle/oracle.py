@@ -65,6 +65,7 @@ def lib():
         L.orc_spmatvec.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_directmatvec.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_hmat.argtypes = [C.c_void_p, C.c_void_p]
+        L.orc_rows.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_sector_map.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         L.orc_sector_info.argtypes = [C.c_void_p] + [C.POINTER(C.c_int)] * 5 + [C.c_void_p, C.c_void_p, C.POINTER(C.c_int64)]
         L.orc_binomial.restype = C.c_int
@@ -203,6 +204,16 @@ class Sector:
         hv = np.empty_like(v)
         lib().orc_directmatvec(self._h, v.ctypes.data, hv.ctypes.data)
         return hv
+
+    def rows(self, idx, v):
+        """(H v)[idx] for 0-based global row numbers `idx`, evaluated row by row from the bit patterns (orc_rows):
+        needs no stored matrix, so it also runs on the Ns=16/18 sectors.  Same per-row accumulation order as
+        spmatvec()."""
+        v = np.ascontiguousarray(v, np.float64); assert v.shape == (self.Dim,)
+        ix = np.ascontiguousarray(np.asarray(idx, dtype=np.int64) + 1)
+        out = np.empty(ix.size, np.float64)
+        lib().orc_rows(self._h, ix.size, ix.ctypes.data, v.ctypes.data, out.ctypes.data)
+        return out
 
     def hmat(self):
         """dense Hmat of build_Hv_sector(isector,Hmat)."""

@@ -18,6 +18,8 @@ def test_oracle_reproduces_reference_known_answers(g):
     v = cases.sinvec(S.Dim)
     hv = S.spmatvec(v)
     scale = np.abs(hv).sum()
+    if g.get("unpinned"):      # parameters of this record were fitted to its sums (see its _note): not a known answer
+        return
     assert abs(hv.sum() - g["sum_Hv"]) <= RTOL * scale
     if "v_Hv" in g:
         assert abs(v @ hv - g["v_Hv"]) <= RTOL * scale
