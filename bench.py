@@ -1,22 +1,27 @@
 #!/usr/bin/env python3
-"""bench.py -- Lanczos HxV throughput of the Ns=16 half-filled sector on N MI355X.
+"""bench.py -- Lanczos HxV throughput of the Ns=16 half-filled sector on 1/2/4/8 MI355X.
 
 A "step" is one full Lanczos iteration on the device-resident sector operator: the product
 w = H v (fused with the beta*v_prev subtraction and the alpha dot), the axpy+norm pass and the
 two single-workgroup reductions.  Default workload = BASELINE config 3: 1 orbital, Nbath=15
 (Ns=16), Nup=Ndw=8, N=165,636,900, operator held as an explicit CSR in HBM.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W]
-  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+  python bench.py [--gpus N] [--steps K] [--warmup W]        # N>1: bench.py starts its own N rank processes
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...   # or an external launcher
+  python bench.py --gpus 8 --nbath 17 --storage direct       # the Ns=18 run (BASELINE config 4, on-the-fly operator)
 
 Rank 0 prints ONE JSON line.  `value` = equivalent-CSR bytes of one product (B_csr of the whole
 sector) divided by the wall time of one Lanczos step (max over ranks): GB/s of HxV
 sustained inside the Lanczos loop.  N>1 is strong scaling (same sector, dw columns split over
-the ranks, RCCL exchange of the input vector every product).
+the ranks as ED_HAMILTONIAN.f90:96-110 does, RCCL exchange of the needed rows of the input vector every product).
+If the world that comes up differs from --gpus the run exits non-zero instead of reporting fewer GPUs.
 """
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -25,11 +30,24 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "dmft-lanc-ed_amd"))
 
 HBM_PEAK_GBPS = 8000.0  # MI355X spec, /opt/skills/guides/MI355X_MICROARCH.md
+KERNELS = {"csr": "k_csr_spmv2<64,640,false> (local block) + k_csr_spmv2<64,640,true> (dw block): one product of the split explicit CSR",
+           "kron": "k_uppass2 + k_dwpass2 (two-pass stored product)", "direct": "k_direct_tables_wave + k_uppass2<DIRECT> + k_dwpass2"}
 
 
 def b_csr(N, nnz):
     """explicit CSR algorithmic bytes of one product: 12*nnz + 8*(N+1) + 16*N  """
     return 12 * nnz + 8 * (N + 1) + 16 * N
+
+
+def source_stamp():
+    """sha256 over the kernel sources: the PMC traffic summary under profiles/ is stamped with it, and bench.py only
+    reports that traffic while the stamp still matches the code that is running (there is no .git on the GPU box)."""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "dmft-lanc-ed_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".hpp")):
+            h.update(f.encode()); h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
 
 
 def cpu_baseline(seconds_budget=16.0, nbath=13):
@@ -68,78 +86,60 @@ def cpu_baseline(seconds_budget=16.0, nbath=13):
     return {"value": b_csr(N, nnz) / best / 1e9, "unit": "GB/s", "cores": cores, "kind": "port",
             "sample": "oracle restatement of spMatVec_main (reference's stored format), Ns=%d half-filled sector (N=%d): %d products in %.1f s on 1 thread, %d products in %.1f s on %d threads (+%.1f s build); equivalent-CSR bytes / time"
                       % (m["Ns"], N, n1, d1, nn, dn, ncpu, tb),
-            "s_per_hxv": best, "single_thread_value": b_csr(N, nnz) / t1 / 1e9, "single_thread_s_per_hxv": t1}
+            "s_per_hxv": best, "single_thread_value": b_csr(N, nnz) / t1 / 1e9, "single_thread_s_per_hxv": t1,
+            "reference_code_recorded": {"s_per_hxv": 0.272, "config": "Ns=12 half-filled sector (BASELINE config 2), stored spMatVec_main, 1 core of the survey container",
+                                        "equivalent_csr_GBps": 0.56, "source": "BASELINE.md section 2 (survey probe of the reference's own code; not re-measured here: the reference is not buildable in this repository)"}}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--nbath", type=int, default=15, help="Ns = nbath+1 (15 -> BASELINE config 3)")
-    ap.add_argument("--storage", default="csr", choices=["csr", "kron", "direct"])
-    ap.add_argument("--no-extra", action="store_true", help="skip the kron/direct side measurements")
-    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
-    ap.add_argument("--comm", default="rccl", choices=["rccl", "torch"], help="N>1: communicator owned by libedgpu.so (rccl) or torch.distributed device callbacks")
-    ap.add_argument("--force-dist", action="store_true", help="run the N>1 code path (process group, communicator, exchange) even with one rank (self-test)")
-    a = ap.parse_args()
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
-    # exactly ONE line on stdout: libraries that chat on fd 1 (RCCL prints a version banner at communicator set-up)
-    # are sent to stderr for the duration of the run; the JSON goes to the saved descriptor at the end
-    sys.stdout.flush()
-    real_stdout = os.dup(1)
-    os.dup2(2, 1)
-    import torch
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != a.gpus and world > 1:
-        a.gpus = world
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU (libedgpu.so has no CPU path)")
-    torch.cuda.set_device(local_rank)
-    dist = None
-    multi = world > 1 or a.force_dist
-    if multi:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29533")
-        os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
-    import numpy as np
-    import edgpu
-    from edgpu import model
+def launch_ranks(a, argv):
+    """`python bench.py --gpus N` with no launcher around it: start N rank processes (one per GPU) and relay rank 0's
+    line.  The parent never touches the GPU (children are fork+exec'ed; a process that has initialised HIP must not exec)."""
+    import torch                                           # device_count() does not initialise the GPU runtime
+    ndev = torch.cuda.device_count()
+    if ndev < 1:
+        sys.stderr.write("bench.py needs a GPU (libedgpu.so has no CPU path)\n"); return 2
+    if ndev < a.gpus and not a.share_gpus:
+        sys.stderr.write("bench.py: --gpus %d but only %d device(s) visible; refusing to report fewer GPUs than asked "
+                         "(--share-gpus maps several ranks onto one device for functional tests)\n" % (a.gpus, ndev))
+        return 2
+    port = _free_port()
+    procs = []
+    for r in range(a.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r % ndev), WORLD_SIZE=str(a.gpus), LOCAL_WORLD_SIZE=str(a.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, stderr=sys.stderr))
+    t0 = time.time(); failed = None
+    while True:                                            # a rank that dies leaves the others inside a collective: stop them at once
+        codes = [p.poll() for p in procs]
+        bad = [r for r, c in enumerate(codes) if c not in (None, 0)]
+        if bad:
+            failed = bad[0]; break
+        if all(c == 0 for c in codes):
+            break
+        if time.time() - t0 > a.launch_timeout:
+            failed = -1; break
+        time.sleep(0.2)
+    if failed is not None:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()                                   # exact children only
+    out0 = procs[0].communicate()[0]
+    for p in procs[1:]:
+        p.wait()
+    if failed is not None:
+        sys.stderr.write("bench.py: %s\n" % ("timed out after %d s" % a.launch_timeout if failed == -1 else "rank %d exited with code %s" % (failed, procs[failed].returncode)))
+        return 3
+    sys.stdout.write(out0.decode()); sys.stdout.flush()
+    return 0
 
-    m, nu, nd = model.half_filled_c(a.nbath)
-    t_build = time.perf_counter()
-    G = edgpu.HvSector(m, nu, nd, storage=a.storage, rank=rank, size=world, device=local_rank, force_exchange=a.force_dist)
-    comm_used = "none"
-    if multi:
-        ok = torch.ones(1, device="cuda")
-        if a.comm == "rccl":
-            # libedgpu.so opens its own RCCL communicator (id broadcast by torch.distributed)
-            try:
-                uid = torch.zeros(128, dtype=torch.uint8, device="cuda")
-                if rank == 0:
-                    uid.copy_(torch.frombuffer(bytearray(edgpu.rccl_unique_id()), dtype=torch.uint8))
-                dist.broadcast(uid, 0)
-                G.comm_init_rccl(bytes(uid.cpu().numpy().tobytes()))
-            except Exception as e:  # keep the job alive: every rank must take the same branch
-                print("rank %d: native RCCL communicator failed (%s)" % (rank, e), file=sys.stderr)
-                ok.zero_()
-            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-        if a.comm == "torch" or ok.item() == 0:
-            from edgpu import exchange
-            ex = exchange.TorchDeviceExchange(dist)
-            G.comm_init_callbacks(ex.allgatherv, ex.exchange, ex.allreduce)
-            comm_used = "torch.distributed(nccl) device callbacks"
-        else:
-            comm_used = "native RCCL communicator (ncclSend/ncclRecv group + ncclAllReduce)"
-    torch.cuda.synchronize()
-    t_build = time.perf_counter() - t_build
 
-    K, W = a.steps, a.warmup
+def timed_steps(G, K, W, torch, dist):
+    """W untimed + K timed Lanczos steps, barrier + synchronize on both sides, max over ranks"""
     G.bench_begin(W + K + 2)
     G.bench_steps(W, timed=False)
     torch.cuda.synchronize()
@@ -152,28 +152,134 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     if dist:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    return dt
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--nbath", type=int, default=15, help="Ns = nbath+1 (15 -> BASELINE config 3; 17 -> config 4, use --storage direct)")
+    ap.add_argument("--storage", default="csr", choices=["csr", "kron", "direct"])
+    ap.add_argument("--no-extra", action="store_true", help="skip the kron/direct side measurements")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--no-ref1", action="store_true", help="N>1: skip the one-GPU reference timing of the same sector on rank 0")
+    ap.add_argument("--comm", default="rccl", choices=["rccl", "torch", "gloo"], help="N>1: communicator owned by libedgpu.so (rccl), torch.distributed device callbacks (torch), or host-staged gloo callbacks (gloo: functional tests, several ranks on one GPU)")
+    ap.add_argument("--force-dist", action="store_true", help="run the N>1 code path (process group, communicator, exchange) even with one rank (self-test)")
+    ap.add_argument("--share-gpus", action="store_true", help="allow more ranks than devices (ranks share devices; implies --comm gloo)")
+    ap.add_argument("--launch-timeout", type=int, default=1500)
+    a = ap.parse_args()
+    if a.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if a.share_gpus:
+        a.comm = "gloo"
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:      # no launcher: be the launcher
+        raise SystemExit(launch_ranks(a, sys.argv[1:]))
+
+    # exactly ONE line on stdout: libraries that chat on fd 1 (RCCL prints a version banner at communicator set-up)
+    # are sent to stderr for the duration of the run; the JSON goes to the saved descriptor at the end
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+    import torch
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        sys.stderr.write("bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks; refusing to report a different GPU count\n" % (a.gpus, world))
+        raise SystemExit(2)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (libedgpu.so has no CPU path)")
+    ndev = torch.cuda.device_count()
+    if local_rank >= ndev:
+        if not a.share_gpus:
+            raise SystemExit("bench.py: LOCAL_RANK %d but only %d device(s) visible" % (local_rank, ndev))
+        local_rank %= ndev
+    torch.cuda.set_device(local_rank)
+    dist = None
+    multi = world > 1 or a.force_dist
+    if multi:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
+        if a.comm == "gloo":
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    import numpy as np
+    import edgpu
+    from edgpu import model
+
+    m, nu, nd = model.half_filled_c(a.nbath)
+    t_build = time.perf_counter()
+    G = edgpu.HvSector(m, nu, nd, storage=a.storage, rank=rank, size=world, device=local_rank, force_exchange=a.force_dist)
+    comm_used = "none"; comm = None; n_ranks_seen = 1
+    if multi:
+        ok = torch.ones(1, device="cuda")
+        if a.comm == "rccl":
+            # ONE RCCL communicator per process, owned by libedgpu.so (id broadcast by torch.distributed), attached to the sector
+            try:
+                uid = torch.zeros(128, dtype=torch.uint8, device="cuda")
+                if rank == 0:
+                    uid.copy_(torch.frombuffer(bytearray(edgpu.rccl_unique_id()), dtype=torch.uint8))
+                dist.broadcast(uid, 0)
+                comm = edgpu.Communicator.rccl(bytes(uid.cpu().numpy().tobytes()), rank, world, device=local_rank)
+            except Exception as e:  # keep the job alive: every rank must take the same branch
+                print("rank %d: native RCCL communicator failed (%s)" % (rank, e), file=sys.stderr)
+                ok.zero_()
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if a.comm == "gloo":
+            from edgpu import exchange
+            ex = exchange.device_staged(dist)
+            comm = edgpu.Communicator.callbacks(rank, world, ex.allgatherv, ex.exchange, ex.allreduce)
+            comm_used = "host-staged gloo callbacks (functional test path)"
+        elif a.comm == "torch" or ok.item() == 0:
+            from edgpu import exchange
+            ex = exchange.TorchDeviceExchange(dist)
+            comm = edgpu.Communicator.callbacks(rank, world, ex.allgatherv, ex.exchange, ex.allreduce)
+            comm_used = "torch.distributed(nccl) device callbacks"
+        else:
+            comm_used = "native RCCL communicator (ncclSend/ncclRecv group + ncclAllReduce)"
+        G.attach_comm(comm)
+        n_ranks_seen = int(round(float(comm.allreduce_sum(np.ones(1))[0])))     # every rank adds 1 through the communicator the products use
+        if n_ranks_seen != world:
+            sys.stderr.write("bench.py: the communicator sums %d ranks, WORLD_SIZE is %d\n" % (n_ranks_seen, world))
+            raise SystemExit(4)
+    torch.cuda.synchronize()
+    t_build = time.perf_counter() - t_build
+
+    K, W = a.steps, a.warmup
+    dt = timed_steps(G, K, W, torch, dist)
     hxv_ms, alphas, betas = G.bench_result(K, ncoef=W + K)
     comm_ms = G.bench_comm_ms(K) if multi else 0.0
+    xmode, sendb, recvb = G.exchange_info()
 
     N = int(G.Dim); Ns = m["Ns"]
     nnz = N * (1 + Ns)                   # 1 diag + Ns/2 up + Ns/2 dw per row at half filling, all V != 0
     Nloc = int(G.vecDim); nnz_loc = int(G.info.nnz_total)
     ms_step = dt / K * 1e3
     bytes_fmt = {"csr": b_csr(Nloc, nnz_loc), "kron": 24 * Nloc, "direct": 16 * Nloc}[a.storage]
+    par = "single GPU"
+    if multi:
+        par = "dw-column split x%d (ED_HAMILTONIAN.f90:96-110), %s exchange per product over %s" % (
+            world, {"needed-rows": "needed-rows (send/recv pairs)", "all-gather": "all-gather of the input vector",
+                    "transpose": "distributed-transpose (two all-to-alls)", "none": "no"}[xmode], comm_used)
     out = {
         "metric": "Lanczos HxV GB/s (equivalent-CSR bytes of one product / Lanczos-iteration time), Ns=%d half-filled sector" % Ns,
         "value": b_csr(N, nnz) / (dt / K) / 1e9, "unit": "GB/s",
-        "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": ms_step, "higher_is_better": True,
+        "n_gpus": world, "n_ranks_seen": n_ranks_seen, "steps": K, "warmup": W, "ms_per_step": ms_step, "higher_is_better": True,
         "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "iters_per_sec": K / dt,
         "config": {"workload": "1-orbital Anderson impurity, Nbath=%d (Ns=%d), sector Nup=Ndw=%d, N=%d, default initial bath, operator storage=%s, one Lanczos iteration per step"
                                % (a.nbath, Ns, nu[0], N, a.storage),
-                   "storage": a.storage, "N": N, "nnz": nnz, "parallelism": ("dw-column split x%d, needed-rows exchange per product over %s" % (world, comm_used)) if multi else "single GPU"},
-        "roofline": {"bound": "hbm", "kernel": {"csr": "k_csr_spmv2<64,640,false> (local block) + k_csr_spmv2<64,640,true> (dw block): one product of the split explicit CSR",
-                                "kron": "k_uppass + k_dwpass2 (two-pass stored product)", "direct": "k_direct_tables + k_uppass + k_dwpass2"}[a.storage],
+                   "storage": a.storage, "N": N, "nnz": nnz, "parallelism": par},
+        "roofline": {"bound": "hbm", "kernel": KERNELS[a.storage],
                      "achieved": bytes_fmt / (hxv_ms * 1e-3) / 1e9 if hxv_ms > 0 else None, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": (bytes_fmt / (hxv_ms * 1e-3) / 1e9) / HBM_PEAK_GBPS if hxv_ms > 0 else None,
                      "algorithmic_bytes_per_launch": bytes_fmt, "kernel_ms": hxv_ms, "traffic": None},
@@ -182,15 +288,45 @@ def main():
         "build_s": t_build,
         "lanczos_alpha_first_last": [float(alphas[0]), float(alphas[-1])] if len(alphas) else None,
     }
+    if multi:      # who sends how much to whom per product (row r = bytes rank r sends to every peer): link balance at a glance
+        mat = torch.zeros(world, world, dtype=torch.float64, device="cuda" if a.comm != "gloo" else "cpu")
+        mat[rank] = torch.as_tensor(sendb.astype(np.float64), device=mat.device)
+        dist.all_reduce(mat)
+        out["exchange_bytes_per_product"] = {"mode": xmode, "send_matrix_MB": [[round(float(x) / 1e6, 2) for x in row] for row in mat.cpu().tolist()],
+                                             "busiest_pair_MB": round(float(mat.max()) / 1e6, 2), "per_rank_received_MB": [round(float(x) / 1e6, 2) for x in mat.sum(0).cpu().tolist()]}
+    # HBM traffic from the counter passes committed under profiles/: only while it was measured on THIS code
     pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(pmc):
         try:
+            stamp = source_stamp()
             for rec in json.load(open(pmc)):
                 if rec.get("storage") == a.storage and rec.get("nbath") == a.nbath and rec.get("n_gpus") == world:
-                    out["roofline"]["traffic"] = rec["hbm_bytes_per_launch"]
-                    out["roofline"]["traffic_source"] = rec.get("source")
+                    if rec.get("source_stamp") == stamp:
+                        out["roofline"]["traffic"] = rec["hbm_bytes_per_launch"]
+                        out["roofline"]["traffic_source"] = rec.get("source")
+                        out["roofline"]["traffic_kernels"] = rec.get("kernels")
+                    else:
+                        out["roofline"]["traffic_source"] = "null: the committed counter summary (%s) was measured on source stamp %s, the running code is %s" % (
+                            rec.get("file", "profiles/"), rec.get("source_stamp"), stamp)
         except Exception:
             pass
+    if world > 1 and not a.no_ref1:
+        # the same sector on ONE GPU (rank 0 alone, the others wait): the reference point of the strong-scaling ratio
+        ref = None
+        if rank == 0:
+            try:
+                G.close(); G = None
+                g1 = edgpu.HvSector(m, nu, nd, storage=a.storage, device=local_rank)
+                d1 = timed_steps(g1, K, W, torch, None)
+                g1.close()
+                ref = {"ms_per_step_1gpu": d1 / K * 1e3, "speedup_vs_1gpu": (d1 / K) / (dt / K)}
+                if Ns == 18:
+                    ref["ns18_ref_ms_1gpu"] = d1 / K * 1e3
+            except Exception as e:
+                ref = {"error": "one-GPU reference run failed: %s" % e}
+        dist.barrier()
+        if rank == 0:
+            out["strong_scaling_reference"] = ref
     if world == 1 and rank == 0 and not a.no_extra:
         extra = {}
         G.close()
@@ -227,6 +363,10 @@ def main():
     if rank == 0:
         sys.stdout.flush()
         os.write(real_stdout, (json.dumps(out) + "\n").encode())
+    if G is not None:
+        G.close()
+    if comm is not None:
+        comm.close()
     if dist:
         dist.barrier()
         dist.destroy_process_group()

@@ -729,7 +729,111 @@ int edgpu_comm_init_rccl(edgpu_handle h, const void *id128)
     NcclUid uid; memcpy(&uid, id128, sizeof(uid));
     int rc = g_rccl.CommInitRank(&h->comm.nccl, h->comm.size, uid, h->comm.rank);
     if (rc) return fail(EDGPU_ECOMM, std::string("ncclCommInitRank: ") + g_rccl.GetErrorString(rc));
-    h->comm.kind = Comm::RCCL;
+    h->comm.kind = Comm::RCCL; h->comm.owned = true; g_comm_created++;
+    return EDGPU_OK;
+}
+
+// ---- the process-wide communicator: created once, attached to every sector -----------------------------
+int edgpu_comm_create_rccl(const void *id128, int32_t rank, int32_t size, int32_t device, edgpu_comm *out)
+{
+    if (!id128 || !out || size < 1 || rank < 0 || rank >= size) return fail(EDGPU_EINVAL, "edgpu_comm_create_rccl: bad argument");
+    *out = nullptr;
+    CHK(require_device());
+    if (!g_rccl.load()) return fail(EDGPU_ECOMM, "edgpu: RCCL (librccl.so) could not be loaded");
+    if (device >= 0) HIPCHK(hipSetDevice(device));
+    auto c = std::unique_ptr<edgpu_comm_s>(new edgpu_comm_s());
+    HIPCHK(hipGetDevice(&c->device));
+    NcclUid uid; memcpy(&uid, id128, sizeof(uid));
+    int rc = g_rccl.CommInitRank(&c->c.nccl, size, uid, rank);
+    if (rc) return fail(EDGPU_ECOMM, std::string("ncclCommInitRank: ") + g_rccl.GetErrorString(rc));
+    c->c.kind = Comm::RCCL; c->c.rank = rank; c->c.size = size; g_comm_created++;
+    *out = c.release();
+    return EDGPU_OK;
+}
+int edgpu_comm_create_callbacks(int32_t rank, int32_t size, edgpu_allgatherv_fn ag, edgpu_exchange_fn xch, edgpu_allreduce_fn ar, void *ctx, edgpu_comm *out)
+{
+    if (!out || !ag || !xch || !ar || size < 1 || rank < 0 || rank >= size) return fail(EDGPU_EINVAL, "edgpu_comm_create_callbacks: bad argument");
+    auto *c = new edgpu_comm_s();
+    c->c.kind = Comm::CALLBACK; c->c.rank = rank; c->c.size = size; c->c.ag = ag; c->c.xch = xch; c->c.ar = ar; c->c.ctx = ctx;
+    (void)hipGetDevice(&c->device); (void)hipGetLastError();
+    *out = c;
+    return EDGPU_OK;
+}
+// Sub-communicator of the first `nranks` ranks (ED_HAMILTONIAN.f90:65-93: sectors with DimDw < MpiSize run on the first
+// DimDw ranks).  COLLECTIVE over the parent: every rank calls it; *is_member = 0 and *out = NULL on the ranks left out.
+// The result is cached in the parent: one split per distinct size, however many sectors use it.
+int edgpu_comm_sub(edgpu_comm parent, int32_t nranks, edgpu_comm *out, int32_t *is_member)
+{
+    if (!parent || !out || nranks < 1 || nranks > parent->c.size) return fail(EDGPU_EINVAL, "edgpu_comm_sub: bad argument");
+    *out = nullptr;
+    if (is_member) *is_member = parent->c.rank < nranks ? 1 : 0;
+    if (nranks == parent->c.size) { *out = parent; return EDGPU_OK; }
+    auto it = parent->subs.find(nranks);
+    if (it != parent->subs.end()) { *out = it->second->member ? it->second : nullptr; return EDGPU_OK; }
+    if (parent->c.kind != Comm::RCCL) return fail(EDGPU_EUNSUPPORTED, "edgpu_comm_sub: a callback communicator is split by the host that owns it (create one per group with edgpu_comm_create_callbacks)");
+    if (!g_rccl.CommSplit) return fail(EDGPU_EUNSUPPORTED, "edgpu_comm_sub: this RCCL has no ncclCommSplit");
+    HIPCHK(hipSetDevice(parent->device));
+    auto *s = new edgpu_comm_s();
+    s->device = parent->device; s->member = parent->c.rank < nranks;
+    int rc = g_rccl.CommSplit(parent->c.nccl, s->member ? 0 : -1 /* NCCL_SPLIT_NOCOLOR */, parent->c.rank, &s->c.nccl, nullptr);
+    if (rc) { delete s; return fail(EDGPU_ECOMM, std::string("ncclCommSplit: ") + g_rccl.GetErrorString(rc)); }
+    s->c.kind = Comm::RCCL; s->c.rank = parent->c.rank; s->c.size = nranks;
+    if (s->member) g_comm_created++;
+    parent->subs[nranks] = s;
+    *out = s->member ? s : nullptr;
+    return EDGPU_OK;
+}
+int edgpu_comm_destroy(edgpu_comm c)
+{
+    if (!c) return EDGPU_OK;
+    for (auto &kv : c->subs) { if (kv.second->c.nccl && g_rccl.ok) g_rccl.CommDestroy(kv.second->c.nccl); delete kv.second; }
+    if (c->c.kind == Comm::RCCL && c->c.nccl && g_rccl.ok) g_rccl.CommDestroy(c->c.nccl);
+    delete c;
+    return EDGPU_OK;
+}
+int edgpu_comm_count(int32_t *n) { if (!n) return fail(EDGPU_EINVAL, "edgpu_comm_count: null argument"); *n = g_comm_created; return EDGPU_OK; }
+// attach: the sector uses the communicator (which must outlive it); rank and size must be those of the descriptor
+int edgpu_sector_attach_comm(edgpu_handle h, edgpu_comm c)
+{
+    if (!h || !c) return fail(EDGPU_EINVAL, "edgpu_sector_attach_comm: null argument");
+    if (c->c.size != h->comm.size || c->c.rank != h->comm.rank) return fail(EDGPU_EINVAL, "edgpu_sector_attach_comm: rank/size of the communicator differ from the sector's mpi_rank/mpi_size (shrunk sectors take edgpu_comm_sub)");
+    if (h->comm.kind == Comm::RCCL && h->comm.owned && h->comm.nccl && g_rccl.ok) g_rccl.CommDestroy(h->comm.nccl);
+    h->comm = c->c; h->comm.owned = false;
+    return EDGPU_OK;
+}
+// in-place sum of n host doubles over the ranks of the communicator (diagnostics: bench.py counts its ranks with it)
+int edgpu_comm_allreduce_sum(edgpu_comm c, double *buf_host, int32_t n)
+{
+    if (!c || !buf_host || n < 1) return fail(EDGPU_EINVAL, "edgpu_comm_allreduce_sum: bad argument");
+    if (c->c.kind == Comm::CALLBACK) { if (c->c.ar(c->c.ctx, buf_host, n)) return fail(EDGPU_ECOMM, "edgpu: allreduce callback failed"); return EDGPU_OK; }
+    if (c->c.kind != Comm::RCCL) return fail(EDGPU_ECOMM, "edgpu_comm_allreduce_sum: no communicator");
+    HIPCHK(hipSetDevice(c->device));
+    DevBuf<double> d; CHK(d.alloc((size_t)n));
+    HIPCHK(hipMemcpy(d.p, buf_host, (size_t)n * 8, hipMemcpyHostToDevice));
+    int rc = g_rccl.AllReduce(d.p, d.p, (size_t)n, kNcclDouble, kNcclSum, c->c.nccl, (hipStream_t)0);
+    if (rc) return fail(EDGPU_ECOMM, std::string("edgpu: RCCL allreduce failed: ") + g_rccl.GetErrorString(rc));
+    HIPCHK(hipStreamSynchronize((hipStream_t)0));
+    HIPCHK(hipMemcpy(buf_host, d.p, (size_t)n * 8, hipMemcpyDeviceToHost));
+    return EDGPU_OK;
+}
+// What one product exchanges: mode 0 none (one rank), 1 needed dw rows only, 2 all-gather of the vector, 3 distributed
+// transpose (two all-to-alls); send_bytes[r] / recv_bytes[r] = bytes this rank sends to / receives from rank r per product.
+int edgpu_sector_exchange_info(edgpu_handle h, int32_t *mode, int64_t *send_bytes, int64_t *recv_bytes)
+{
+    if (!h || !mode) return fail(EDGPU_EINVAL, "edgpu_sector_exchange_info: null argument");
+    const SectorHost &H = h->H; const int P = h->comm.size, me = h->comm.rank;
+    *mode = !h->multi ? 0 : (h->tr_on ? 3 : (h->halo ? 1 : 2));
+    if (!send_bytes || !recv_bytes) return EDGPU_OK;
+    auto split = [&](int64_t D, int r, int64_t &q) { const int64_t qq = D / P, rem = D % P; q = r < rem ? qq + 1 : qq; };
+    for (int r = 0; r < P; r++) {
+        int64_t sb = 0, rb = 0;
+        if (r != me && h->multi) {
+            if (h->tr_on) { int64_t qu, qd; split(H.DimUp, r, qu); split(H.DimDw, r, qd); sb = 2 * qu * H.Qdw * 8; rb = 2 * h->Qup * qd * 8; }
+            else if (h->halo) { sb = h->send_rows_cnt[r] * H.DimUp * H.DimPh * 8; rb = h->recv_rows_cnt[r] * H.DimUp * H.DimPh * 8; }
+            else { int64_t qd; split(H.DimDw, r, qd); sb = h->nloc * 8; rb = qd * H.DimUp * H.DimPh * 8; }
+        }
+        send_bytes[r] = sb; recv_bytes[r] = rb;
+    }
     return EDGPU_OK;
 }
 int edgpu_comm_init_callbacks(edgpu_handle h, edgpu_allgatherv_fn ag, edgpu_exchange_fn xch, edgpu_allreduce_fn ar, void *ctx)

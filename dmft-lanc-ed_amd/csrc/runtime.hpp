@@ -7,6 +7,7 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <map>
 #include <memory>
 #include <string>
 #include <vector>
@@ -53,6 +54,7 @@ struct Rccl {
     int (*AllReduce)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
     int (*GroupStart)() = nullptr;
     int (*GroupEnd)() = nullptr;
+    int (*CommSplit)(void *, int, int, void **, void *) = nullptr;     // optional (sub-communicators)
     const char *(*GetErrorString)(int) = nullptr;
     bool ok = false;
     bool load()
@@ -85,6 +87,7 @@ struct Rccl {
 #define L(name) *(void **)(&name) = dlsym(h, "nccl" #name); if (!name) return false
         L(GetUniqueId); L(CommInitRank); L(CommDestroy); L(Send); L(Recv); L(AllReduce); L(GroupStart); L(GroupEnd); L(GetErrorString);
 #undef L
+        *(void **)(&CommSplit) = dlsym(h, "ncclCommSplit");
         ok = true;
         return true;
     }
@@ -96,8 +99,10 @@ struct Comm {
     enum Kind { NONE, RCCL, CALLBACK } kind = NONE;
     int rank = 0, size = 1;
     void *nccl = nullptr;
+    bool owned = false;      // the sector created `nccl` itself (edgpu_comm_init_rccl) and destroys it; attached communicators are not owned
     edgpu_allgatherv_fn ag = nullptr; edgpu_exchange_fn xch = nullptr; edgpu_allreduce_fn ar = nullptr; void *ctx = nullptr;
 };
+static int g_comm_created = 0;      // native (RCCL) communicators this process has created so far
 
 // Process-wide cache of large work vectors (the stored Krylov basis of edgpu_lanczos_gs): allocating inside a running
 // iteration costs ~30 ms per call on this runtime, so the buffers outlive the call and the sector and are handed to
@@ -186,9 +191,19 @@ struct edgpu_sector_s {
     ~edgpu_sector_s();      // also runs when edgpu_sector_create fails half-way: nothing leaks
 };
 
+// The process-wide communicator of the host (the reference sets MpiComm once, ED_VARS_GLOBAL.f90:332-347): created once,
+// attached to every sector (edgpu_sector_attach_comm).  `subs` caches the shrunk communicators of sectors with fewer dw
+// columns than ranks (ED_HAMILTONIAN.f90:65-93), keyed by their size.
+struct edgpu_comm_s {
+    edgpu::Comm c;
+    int device = 0;
+    std::map<int, edgpu_comm_s *> subs;
+    bool member = true;      // false: this rank is outside the (sub-)communicator
+};
+
 inline edgpu_sector_s::~edgpu_sector_s()
 {
-    if (comm.kind == Comm::RCCL && comm.nccl && g_rccl.ok) g_rccl.CommDestroy(comm.nccl);
+    if (comm.kind == Comm::RCCL && comm.nccl && comm.owned && g_rccl.ok) g_rccl.CommDestroy(comm.nccl);
     for (auto e : bench_ev) (void)hipEventDestroy(e);
     for (auto e : comm_ev) (void)hipEventDestroy(e);
     if (ev_pack) (void)hipEventDestroy(ev_pack);

@@ -5,4 +5,4 @@ declared in include/edgpu.h.  Importing this package does not load the library; 
 call that needs it does, and fails loudly if it has not been built.
 """
 from . import model  # noqa: F401
-from .hamiltonian import HvSector, DeviceVector, build_Hv_sector, device_count, rccl_unique_id, apply_op, gf_lanczos, cache_release  # noqa: F401
+from .hamiltonian import HvSector, DeviceVector, Communicator, comm_count, build_Hv_sector, device_count, rccl_unique_id, apply_op, gf_lanczos, cache_release  # noqa: F401

@@ -23,6 +23,8 @@ SYMBOLS = [
     "edgpu_eigsh", "edgpu_dvdson", "edgpu_cache_release", "edgpu_twin_reorder", "edgpu_imp_density_offdiag", "edgpu_imp_histogram", "edgpu_apply_op", "edgpu_gf_lanczos", "edgpu_chi_lanczos", "edgpu_phonon_lanczos",
     "edgpu_sp_init_matrix", "edgpu_sp_init_matrix_mpi", "edgpu_sp_load_matrix", "edgpu_sp_insert_element", "edgpu_sp_delete_matrix", "edgpu_sp_dump_matrix", "edgpu_sp_row", "edgpu_sp_matvec",
     "edgpu_comm_unique_id", "edgpu_comm_init_rccl", "edgpu_comm_init_callbacks",
+    "edgpu_comm_create_rccl", "edgpu_comm_create_callbacks", "edgpu_comm_sub", "edgpu_comm_destroy", "edgpu_sector_attach_comm",
+    "edgpu_comm_count", "edgpu_comm_allreduce_sum", "edgpu_sector_exchange_info",
     "edgpu_device_count", "edgpu_malloc", "edgpu_free", "edgpu_memcpy_h2d", "edgpu_memcpy_d2h",
     "edgpu_device_synchronize", "edgpu_last_error", "edgpu_abi_version",
 ]
@@ -116,6 +118,14 @@ def lib():
         "edgpu_comm_unique_id": (C.c_int, [vp]),
         "edgpu_comm_init_rccl": (C.c_int, [vp, vp]),
         "edgpu_comm_init_callbacks": (C.c_int, [vp, ALLGATHERV_FN, EXCHANGE_FN, ALLREDUCE_FN, vp]),
+        "edgpu_comm_create_rccl": (C.c_int, [vp, i32, i32, i32, P(vp)]),
+        "edgpu_comm_create_callbacks": (C.c_int, [i32, i32, ALLGATHERV_FN, EXCHANGE_FN, ALLREDUCE_FN, vp, P(vp)]),
+        "edgpu_comm_sub": (C.c_int, [vp, i32, P(vp), P(i32)]),
+        "edgpu_comm_destroy": (C.c_int, [vp]),
+        "edgpu_sector_attach_comm": (C.c_int, [vp, vp]),
+        "edgpu_comm_count": (C.c_int, [P(i32)]),
+        "edgpu_comm_allreduce_sum": (C.c_int, [vp, vp, i32]),
+        "edgpu_sector_exchange_info": (C.c_int, [vp, P(i32), vp, vp]),
         "edgpu_device_count": (C.c_int, [P(i32)]),
         "edgpu_malloc": (C.c_int, [P(vp), C.c_size_t]),
         "edgpu_free": (C.c_int, [vp]),

@@ -298,6 +298,18 @@ class HvSector:
         check(capi.lib().edgpu_lanczos_bench_comm_ms(self._h, ntimed, C.byref(ms)))
         return ms.value
 
+    def attach_comm(self, comm):
+        """Use the process-wide communicator (Communicator) for this sector's exchanges."""
+        check(capi.lib().edgpu_sector_attach_comm(self._h, comm._c))
+        self._comm = comm          # keep it alive as long as the sector
+
+    def exchange_info(self):
+        """(mode, send_bytes[size], recv_bytes[size]) of one product: mode 'none' | 'needed-rows' | 'all-gather' | 'transpose'."""
+        P = int(self._desc.mpi_size)
+        mode = C.c_int32(); sb = np.zeros(P, np.int64); rb = np.zeros(P, np.int64)
+        check(capi.lib().edgpu_sector_exchange_info(self._h, C.byref(mode), sb.ctypes.data, rb.ctypes.data))
+        return ("none", "needed-rows", "all-gather", "transpose")[mode.value], sb, rb
+
     def comm_init_rccl(self, uid_bytes):
         buf = C.create_string_buffer(bytes(uid_bytes), 128)
         check(capi.lib().edgpu_comm_init_rccl(self._h, buf))
@@ -305,33 +317,93 @@ class HvSector:
     def comm_init_callbacks(self, allgatherv, exchange, allreduce):
         """allgatherv(send_ptr, nsend, recv_ptr, counts, displs) / exchange(send_ptr, scounts, sdispls,
         recv_ptr, rcounts, rdispls) / allreduce(np_array) in Python."""
-        def _ag(ctx, send, nsend, recv, counts, displs, nr):
-            try:
-                allgatherv(send, nsend, recv, [counts[i] for i in range(nr)], [displs[i] for i in range(nr)])
-                return 0
-            except Exception as e:  # pragma: no cover
-                print("allgatherv callback failed:", e)
-                return 1
-
-        def _xc(ctx, send, sc, sd, recv, rc, rd, nr):
-            try:
-                exchange(send, [sc[i] for i in range(nr)], [sd[i] for i in range(nr)], recv, [rc[i] for i in range(nr)], [rd[i] for i in range(nr)])
-                return 0
-            except Exception as e:  # pragma: no cover
-                print("exchange callback failed:", e)
-                return 1
-
-        def _ar(ctx, buf, n):
-            try:
-                a = np.ctypeslib.as_array(buf, shape=(n,))
-                allreduce(a)
-                return 0
-            except Exception as e:  # pragma: no cover
-                print("allreduce callback failed:", e)
-                return 1
-
-        self._cb = (capi.ALLGATHERV_FN(_ag), capi.EXCHANGE_FN(_xc), capi.ALLREDUCE_FN(_ar))
+        self._cb = _wrap_callbacks(allgatherv, exchange, allreduce)
         check(capi.lib().edgpu_comm_init_callbacks(self._h, self._cb[0], self._cb[1], self._cb[2], None))
+
+
+def _wrap_callbacks(allgatherv, exchange, allreduce):
+    def _ag(ctx, send, nsend, recv, counts, displs, nr):
+        try:
+            allgatherv(send, nsend, recv, [counts[i] for i in range(nr)], [displs[i] for i in range(nr)])
+            return 0
+        except Exception as e:  # pragma: no cover
+            print("allgatherv callback failed:", e)
+            return 1
+
+    def _xc(ctx, send, sc, sd, recv, rc, rd, nr):
+        try:
+            exchange(send, [sc[i] for i in range(nr)], [sd[i] for i in range(nr)], recv, [rc[i] for i in range(nr)], [rd[i] for i in range(nr)])
+            return 0
+        except Exception as e:  # pragma: no cover
+            print("exchange callback failed:", e)
+            return 1
+
+    def _ar(ctx, buf, n):
+        try:
+            a = np.ctypeslib.as_array(buf, shape=(n,))
+            allreduce(a)
+            return 0
+        except Exception as e:  # pragma: no cover
+            print("allreduce callback failed:", e)
+            return 1
+
+    return capi.ALLGATHERV_FN(_ag), capi.EXCHANGE_FN(_xc), capi.ALLREDUCE_FN(_ar)
+
+
+class Communicator:
+    """The process-wide communicator (the reference's MpiComm, set once: ED_VARS_GLOBAL.f90:332-347): create it once,
+    attach it to every sector (HvSector.attach_comm), close it at the end."""
+
+    def __init__(self, c, rank, size, cb=None, owner=True):
+        self._c, self.rank, self.size, self._cb, self._owner = c, rank, size, cb, owner
+        self._subs = {}
+
+    @classmethod
+    def rccl(cls, uid_bytes, rank, size, device=-1):
+        buf = C.create_string_buffer(bytes(uid_bytes), 128)
+        c = C.c_void_p()
+        check(capi.lib().edgpu_comm_create_rccl(buf, rank, size, device, C.byref(c)))
+        return cls(c, rank, size)
+
+    @classmethod
+    def callbacks(cls, rank, size, allgatherv, exchange, allreduce):
+        cb = _wrap_callbacks(allgatherv, exchange, allreduce)
+        c = C.c_void_p()
+        check(capi.lib().edgpu_comm_create_callbacks(rank, size, cb[0], cb[1], cb[2], None, C.byref(c)))
+        return cls(c, rank, size, cb)
+
+    def sub(self, nranks):
+        """Communicator of the first `nranks` ranks (collective; cached); None on the ranks left out."""
+        if nranks == self.size:
+            return self
+        if nranks not in self._subs:
+            c = C.c_void_p(); mem = C.c_int32()
+            check(capi.lib().edgpu_comm_sub(self._c, nranks, C.byref(c), C.byref(mem)))
+            self._subs[nranks] = Communicator(c, self.rank, nranks, owner=False) if mem.value else None
+        return self._subs[nranks]
+
+    def allreduce_sum(self, arr):
+        a = np.ascontiguousarray(arr, np.float64)
+        check(capi.lib().edgpu_comm_allreduce_sum(self._c, a.ctypes.data, a.size))
+        return a
+
+    def close(self):
+        if self._c and self._owner:
+            capi.lib().edgpu_comm_destroy(self._c)
+        self._c = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def comm_count():
+    """native (RCCL) communicators created by this process so far"""
+    n = C.c_int32()
+    check(capi.lib().edgpu_comm_count(C.byref(n)))
+    return n.value
 
 
 def apply_op(sec_from, sec_to, iorb, ispin, dagger, vin_dev, vout_dev):

@@ -216,6 +216,31 @@ typedef int (*edgpu_exchange_fn)(void *ctx, const double *send_dev, const int64_
                                  double *recv_dev, const int64_t *recvcounts, const int64_t *rdispls, int32_t nranks);
 int edgpu_comm_init_callbacks(edgpu_handle h, edgpu_allgatherv_fn ag, edgpu_exchange_fn xch, edgpu_allreduce_fn ar, void *ctx);
 
+/* ---- the process-wide communicator ----------------------------------------------------------------------
+ * The reference sets MpiComm ONCE (ed_set_MpiComm, ED_VARS_GLOBAL.f90:332-347) and every sector uses it; a DMFT
+ * iteration builds O(Ns^2) sectors plus the GF target sectors.  Accordingly: create the communicator once per
+ * process (RCCL: id from edgpu_comm_unique_id on rank 0, broadcast by the host; or host callbacks), attach it to
+ * every sector after edgpu_sector_create, destroy it at the end.  The communicator must outlive the sectors it is
+ * attached to.  edgpu_comm_init_rccl/_callbacks above remain as the one-communicator-per-sector convenience form. */
+typedef struct edgpu_comm_s *edgpu_comm;
+int edgpu_comm_create_rccl(const void *id128, int32_t rank, int32_t size, int32_t device /* -1: current */, edgpu_comm *out);
+int edgpu_comm_create_callbacks(int32_t rank, int32_t size, edgpu_allgatherv_fn ag, edgpu_exchange_fn xch, edgpu_allreduce_fn ar,
+                                void *ctx, edgpu_comm *out);
+/* Sectors with fewer dw columns than ranks run on the first DimDw ranks (ED_HAMILTONIAN.f90:65-93: MPI_Group_incl +
+ * MPI_Comm_create).  edgpu_comm_sub is that shrunk communicator: COLLECTIVE over `parent` (every rank calls it),
+ * cached inside the parent (one split per distinct size); ranks outside get *out = NULL, *is_member = 0 and do not
+ * create the sector.  RCCL communicators only; a host that owns its groups makes one callback communicator per group. */
+int edgpu_comm_sub(edgpu_comm parent, int32_t nranks, edgpu_comm *out, int32_t *is_member);
+int edgpu_comm_destroy(edgpu_comm c);
+int edgpu_sector_attach_comm(edgpu_handle h, edgpu_comm c);
+/* number of native (RCCL) communicators this process has created so far (tests: one per process, not per sector) */
+int edgpu_comm_count(int32_t *n);
+/* in-place sum of n host doubles over the ranks of the communicator */
+int edgpu_comm_allreduce_sum(edgpu_comm c, double *buf_host, int32_t n);
+/* what one product of this sector exchanges: mode 0 none, 1 needed dw rows (send/recv pairs), 2 all-gather, 3 distributed
+ * transpose; send_bytes/recv_bytes (mpi_size entries each, may be NULL): bytes to / from every peer per product */
+int edgpu_sector_exchange_info(edgpu_handle h, int32_t *mode, int64_t *send_bytes, int64_t *recv_bytes);
+
 /* ---- sparse-matrix container (ED_SPARSE_MATRIX.f90): same semantics, product on the GPU ------------------
  * sp_init_matrix (127-172), sp_insert_element = duplicate-summing append in storage order (255-323),
  * sp_delete_matrix (184-237), sp_dump_matrix adds into a dense column-major Nrow x Ncol array (386-438).

@@ -118,6 +118,39 @@ def main():
         got = tA2[:DimUp * q].reshape(DimUp, q).T
         assert np.abs(got - want).max() <= 1e-12 * max(1.0, np.abs(want).max())
         res["ok"] = True
+    elif mode == "sweep":
+        # one communicator object per rank for the whole sweep (callback form: the host owns the groups, so the shrunk
+        # communicator of a sector with DimDw < size is a callback communicator over dist.new_group(first DimDw ranks))
+        import edgpu
+        ex = exchange.device_staged(dist)
+        world = edgpu.Communicator.callbacks(rank, size, ex.allgatherv, ex.exchange, ex.allreduce)
+        groups = {n: dist.new_group(list(range(n))) for n in range(1, size)}          # collective: every rank creates every group
+        subs = {}
+        Nso = m["Ns"]
+        nsec = shrunk = skipped = 0
+        for nup in range(Nso + 1):
+            for ndw in range(Nso + 1):
+                St = oracle.Sector(m, [nup], [ndw])
+                wd = np.linalg.eigvalsh(St.hmat())
+                nsec += 1
+                P = min(size, St.DimDw)                                               # ED_HAMILTONIAN.f90:65-93
+                if P < size:
+                    shrunk += 1
+                    if rank >= P:
+                        skipped += 1
+                        continue
+                    if P not in subs:
+                        exs = exchange.device_staged(dist, group=groups[P])
+                        subs[P] = edgpu.Communicator.callbacks(rank, P, exs.allgatherv, exs.exchange, exs.allreduce)
+                    c = subs[P]
+                else:
+                    c = world
+                G = edgpu.HvSector(m, [nup], [ndw], storage="kron" if (nup + ndw) % 2 else "direct", rank=rank, size=P)
+                G.attach_comm(c)
+                e0, x, nl = G.sp_lanc_eigh(nitermax=min(300, St.Dim), threshold=1e-14)
+                assert abs(e0 - wd[0]) < 1e-9, (nup, ndw, e0, wd[0])
+                G.close()
+        res.update(ok=True, nsectors=nsec, shrunk=shrunk, skipped=skipped)
     elif mode == "torchdev":
         import torch  # noqa: F401  (before libedgpu.so, as in bench.py)
         import edgpu

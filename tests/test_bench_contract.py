@@ -11,9 +11,14 @@ KEYS = ["metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "
         "dtype", "data", "config", "roofline"]
 
 
-def _run(extra):
+def _run(extra, env=None, expect_fail=False):
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--nbath", "9", "--steps", "3", "--warmup", "1", "--no-cpu"] + extra
-    out = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600, cwd=ROOT)
+    e = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    e.update(env or {})
+    out = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600, cwd=ROOT, env=e)
+    if expect_fail:
+        assert out.returncode != 0 and not out.stdout.strip(), (out.returncode, out.stdout.decode())
+        return out.stderr.decode()
     assert out.returncode == 0, out.stderr.decode()[-2000:]
     lines = [l for l in out.stdout.decode().splitlines() if l.strip()]
     assert len(lines) == 1 and lines[0].startswith("{"), out.stdout.decode()      # ONE line on stdout, nothing else (library banners go to stderr)
@@ -28,7 +33,7 @@ def test_bench_line(extra):
     for k in KEYS:
         assert k in d, k
     assert d["unit"] == "GB/s" and d["dtype"] == "f64" and d["data"] == "synthetic" and d["vs_baseline"] is None
-    assert d["steps"] == 3 and d["warmup"] == 1 and d["n_gpus"] == 1 and d["higher_is_better"] is True
+    assert d["steps"] == 3 and d["warmup"] == 1 and d["n_gpus"] == 1 and d["n_ranks_seen"] == 1 and d["higher_is_better"] is True
     assert d["value"] > 0 and d["ms_per_step"] > 0
     r = d["roofline"]
     assert r["bound"] == "hbm" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
@@ -39,3 +44,36 @@ def test_bench_line(extra):
     if not extra:
         assert set(d["other_formats"]) == {"kron", "direct"}
         assert d["ground_state"]["nlanc"] > 10 and d["ground_state"]["seconds"] > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("storage", ["csr", "kron"])
+def test_bench_starts_its_own_ranks(storage):
+    """`python bench.py --gpus 2` with NO launcher around it: two rank processes come up (sharing the one GPU of the test
+    box through the host-staged exchange), rank 0 prints the line, and the line counts two ranks -- through an all-reduce
+    over the communicator the products use."""
+    d = _run(["--gpus", "2", "--share-gpus", "--no-extra", "--storage", storage])
+    assert d["n_gpus"] == 2 and d["n_ranks_seen"] == 2 and d["scaling"] == "strong"
+    assert "x2" in d["config"]["parallelism"] and "needed-rows" in d["config"]["parallelism"]
+    x = d["exchange_bytes_per_product"]
+    assert x["mode"] == "needed-rows" and len(x["send_matrix_MB"]) == 2 and x["send_matrix_MB"][0][0] == 0 and x["send_matrix_MB"][0][1] > 0
+    r = d["strong_scaling_reference"]
+    assert r["ms_per_step_1gpu"] > 0 and r["speedup_vs_1gpu"] > 0
+    assert d["time_split_ms"]["exchange_on_comm_stream_overlapped_with_local_blocks"] >= 0.0
+
+
+@pytest.mark.gpu
+def test_bench_refuses_to_report_fewer_gpus_than_asked():
+    import torch
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("needs a box with fewer devices than ranks")
+    err = _run(["--gpus", "2", "--no-extra"], expect_fail=True)
+    assert "only 1 device" in err
+    err = _run(["--gpus", "2", "--no-extra"], env={"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"}, expect_fail=True)
+    assert "refusing to report a different GPU count" in err
+
+
+def test_bench_launcher_needs_no_gpu_to_refuse():
+    """CPU: with no device visible the launcher path exits non-zero without a line (it never reports n_gpus < --gpus)."""
+    err = _run(["--gpus", "2", "--no-extra"], expect_fail=True)
+    assert "GPU" in err or "device" in err

@@ -163,3 +163,41 @@ def test_torch_device_exchange_single_process():
     a child process that imports torch before libedgpu.so, as bench.py does."""
     res = _launch("torchdev", "c_nb5_half", 1)
     assert res[0]["ok"]
+
+
+@pytest.mark.gpu
+def test_one_communicator_per_process_not_per_sector(edgpu_mod):
+    """The reference sets MpiComm once (ED_VARS_GLOBAL.f90:332-347); a DMFT iteration then builds every (Nup,Ndw) sector.
+    Here: ONE RCCL communicator, attached to all 49 sectors of the Ns=6 model run through the exchange code path
+    (ground state of each against dense diagonalisation); the process has created exactly one communicator at the end."""
+    from edgpu import model
+    from oracle import oracle
+    m, _, _ = model.half_filled_c(5)
+    Ns = m["Ns"]
+    n0 = edgpu_mod.comm_count()
+    comm = edgpu_mod.Communicator.rccl(edgpu_mod.rccl_unique_id(), 0, 1)
+    assert comm.allreduce_sum(np.ones(3)).tolist() == [1.0, 1.0, 1.0]
+    for nup in range(Ns + 1):
+        for ndw in range(Ns + 1):
+            S = oracle.Sector(m, [nup], [ndw])
+            w = np.linalg.eigvalsh(S.hmat())
+            G = edgpu_mod.HvSector(m, [nup], [ndw], storage=("kron", "direct", "csr")[(nup + ndw) % 3], force_exchange=True)
+            G.attach_comm(comm)
+            assert G.exchange_info()[0] in ("needed-rows", "all-gather")
+            e0, x, nl = G.sp_lanc_eigh(nitermax=min(300, S.Dim), threshold=1e-14)
+            assert abs(e0 - w[0]) < 1e-9, (nup, ndw, e0, w[0])
+            G.close()
+    assert edgpu_mod.comm_count() == n0 + 1
+    assert comm.sub(1) is comm
+    comm.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("size", [2, 3])
+def test_multirank_sweep_with_one_communicator_and_shrunk_sectors(edgpu_mod, size):
+    """world_size 2 and 3 on the one GPU: every rank creates ONE communicator object and sweeps over all sectors of a small
+    model, including those with fewer dw columns than ranks, which run on the first DimDw ranks through a
+    sub-communicator (ED_HAMILTONIAN.f90:65-93) while the other ranks sit the sector out."""
+    res = _launch("sweep", "c_nb3_half", size, timeout=300)
+    assert all(r["ok"] for r in res)
+    assert res[0]["nsectors"] == 25 and res[0]["shrunk"] >= 2 and res[-1]["skipped"] >= 2
