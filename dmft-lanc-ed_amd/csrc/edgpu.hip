@@ -142,6 +142,72 @@ int edgpu_diag_export(edgpu_handle h, double *d_host)
     return EDGPU_OK;
 }
 
+// dense Hmat of build_Hv_sector(isector,Hmat) (ED_HAMILTONIAN.f90:128-137 -> ed_buildh_main/orbs with Hmat,
+// ED_HAMILTONIAN_SPARSE_HxV.f90:132-195, 304-363): what the reference hands to LAPACK for every sector with
+// dim <= lanc_dim_threshold (ED_DIAG.f90:105-107, 212-237).  Column-major Dim x Dim on the host.  The diagonal comes from
+// the device kernel (k_build_diag, the reference's statement order); the factors are expanded as sp_dump_matrix +
+// kronecker_product do.  With several ranks every rank fills its own rows and the matrix is summed over the ranks
+// (the reference's mpi_sp_dump_matrix all-reduce, ED_SPARSE_MATRIX.f90:408-437), so every rank returns the full matrix.
+int edgpu_sector_hmat(edgpu_handle h, double *hmat)
+{
+    if (!h || !hmat) return fail(EDGPU_EINVAL, "edgpu_sector_hmat: null argument");
+    const SectorHost &H = h->H; const edgpu_desc &d = H.desc;
+    if (H.Dim > 46340) return fail(EDGPU_EUNSUPPORTED, "edgpu_sector_hmat: the dense form is for sectors up to lanc_dim_threshold (Dim*Dim must fit an int32 count)");
+    HIPCHK(hipSetDevice(h->device));
+    if (!h->diag.p) CHK(build_diag(h));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    std::vector<double> dg((size_t)h->nloc_el);
+    if (h->nloc_el) HIPCHK(hipMemcpy(dg.data(), h->diag.p, dg.size() * 8, hipMemcpyDeviceToHost));
+    const int64_t Dim = H.Dim, Nel = H.DimUp * H.DimDw, DimUp = H.DimUp;
+    memset(hmat, 0, sizeof(double) * (size_t)Dim * (size_t)Dim);
+#define HM(i, j) hmat[(size_t)(i) + (size_t)Dim * (size_t)(j)]
+    const int nf = 2 * H.Ns_Ud;
+    std::vector<int64_t> dims(nf), strd(nf); { int64_t st = 1; for (int k = 0; k < nf; k++) { dims[k] = H.fac[k].dim; strd[k] = st; st *= H.fac[k].dim; } }
+    std::vector<int64_t> ncol; std::vector<double> nval;
+    const int nI = 1 << d.Norb;
+    for (int iph = 0; iph < H.DimPh; iph++) {
+        const int64_t off = (int64_t)iph * Nel;
+        for (int64_t il = 0; il < h->nloc_el; il++) {
+            const int64_t ie = il + H.dw0 * DimUp, i = ie + off;          // global electronic row, global row
+            HM(i, i) += dg[(size_t)il];                                   // spH0d
+            // digits of the row
+            int64_t c = ie; std::vector<int32_t> dgt(nf);
+            for (int k = 0; k < nf; k++) { dgt[k] = (int32_t)(c % dims[k]); c /= dims[k]; }
+            if (d.ed_total_ud && H.Jhflag) {                              // spH0nd (stored transposed, dumped as stored)
+                H.nonlocal_row(dgt[0], dgt[1], ncol, nval);
+                for (size_t q = 0; q < ncol.size(); q++) HM(i, ncol[q] + off) += nval[q];
+            }
+            for (int k = 0; k < nf; k++) {                                // I (x) ... H_k ... (x) I
+                const Factor &f = H.fac[k];
+                for (int64_t p = f.rowptr[dgt[k]]; p < f.rowptr[dgt[k] + 1]; p++) HM(i, ie + (int64_t)(f.cols[p] - dgt[k]) * strd[k] + off) += f.vals[p];
+            }
+            if (H.DimPh > 1) {                                            // stored/H_ph.f90:2-5, H_e_ph.f90:2-39
+                HM(i, i) += d.w0_ph * iph;
+                uint32_t mu = 0, md = 0;
+                if (d.ed_total_ud) { mu = (uint32_t)H.fac[0].map[dgt[0]] & (nI - 1); md = (uint32_t)H.fac[1].map[dgt[1]] & (nI - 1); }
+                else for (int a = 0; a < H.Ns_Ud; a++) { mu |= ((uint32_t)H.fac[a].map[dgt[a]] & 1u) << a; md |= ((uint32_t)H.fac[a + H.Ns_Ud].map[dgt[a + H.Ns_Ud]] & 1u) << a; }
+                double g = 0.0;
+                for (int a = 0; a < d.Norb; a++) g = g + d.g_ph[a] * ((double)(((mu >> a) & 1) + ((md >> a) & 1)) - 1.0);
+                if (iph + 1 < H.DimPh) HM(i, ie + (int64_t)(iph + 1) * Nel) += g * sqrt((double)(iph + 1));
+                if (iph > 0) HM(i, ie + (int64_t)(iph - 1) * Nel) += g * sqrt((double)iph);
+            }
+        }
+    }
+#undef HM
+    if (h->multi && h->comm.size > 1) {
+        const int64_t n2 = Dim * Dim;
+        if (h->comm.kind == Comm::CALLBACK) { if (h->comm.ar(h->comm.ctx, hmat, (int32_t)n2)) return fail(EDGPU_ECOMM, "edgpu: allreduce callback failed"); }
+        else {
+            DevBuf<double> b; CHK(b.alloc((size_t)n2));
+            HIPCHK(hipMemcpy(b.p, hmat, (size_t)n2 * 8, hipMemcpyHostToDevice));
+            CHK(allreduce_dev(h, b.p, (int)n2));
+            HIPCHK(hipStreamSynchronize(h->stream));
+            HIPCHK(hipMemcpy(hmat, b.p, (size_t)n2 * 8, hipMemcpyDeviceToHost));
+        }
+    }
+    return EDGPU_OK;
+}
+
 int edgpu_csr_rows(edgpu_handle h, int64_t row0, int64_t nrows, int64_t *row_ptr, int32_t *cols, double *vals, int64_t cap)
 {
     if (!h || !row_ptr) return fail(EDGPU_EINVAL, "edgpu_csr_rows: null argument");

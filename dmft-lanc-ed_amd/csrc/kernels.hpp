@@ -1100,6 +1100,177 @@ __global__ void __launch_bounds__(ROWS) k_csr_spmv2(CsrArgs A)
 }
 
 // ---------------------------------------------------------------------------------------------
+// Persistent, software-pipelined form of the row-block CSR product with an LDS-staged vector tile.
+//
+// k_csr_spmv2 above is one wave per launch-time block: rowptr -> stream -> gathers -> store is a serial chain per
+// block, and the up-hop gathers (8 of the 9 entries of a local-block row) are 64 uncoalesced 8-byte loads each:
+// counters showed the address/data path of the vector memory unit busy 90-100 % with the HBM stream waiting behind
+// it.  Here
+//   * WIN: a workgroup owns one dw row (DimUp matrix rows) at a time and keeps that row of x -- the column window
+//     [xrow*DimUp, (xrow+1)*DimUp) that every up hop and the diagonal read -- in LDS (103 KB at Ns=16); in-window
+//     columns are LDS reads, anything else (dw hops of an unsplit CSR) a global gather.  The next window is already on
+//     its way into registers while the current one is in use.
+//   * every wave walks its own chunks of `rb` consecutive rows in a three-stage pipeline: row pointers of chunk t+2
+//     and the (value, column) stream of chunk t+1 are requested before chunk t is computed, so a CU always has
+//     ~56 KB of the HBM stream in flight however long the gathers take;
+//   * rows shorter than the wave is wide share their lanes: 64/rb lanes split the entries of one row and are summed
+//     by a segmented wave reduction (xor shuffles over the lane bits above log2 rb).
+// !WIN: no window, chunks are dealt in XCD-owned column-tile order (the dw block of the split form; see k_dwpass).
+// ---------------------------------------------------------------------------------------------
+struct CsrLdsArgs {
+    int64_t Qdw; int32_t DimUp; int32_t rb, rbshift; int32_t cpr;      // rows per chunk (power of two <= 64), chunks per dw row
+    const int64_t *rowptr; const int32_t *cols; const double *vals;
+    const double *x; int64_t xrow0;        // WIN: window of local dw row idwl starts at x[(xrow0 + idwl) * DimUp]
+    double *y; const double *v_local, *uprev, *scal; double *partial; int32_t epi, pass;
+};
+
+template <int NT, int CAP, bool WIN>
+__global__ void __launch_bounds__(NT) k_csr_lds(CsrLdsArgs A)
+{
+    extern __shared__ __attribute__((aligned(32))) unsigned char csr_smem[];
+    constexpr int NW = NT / 64;
+    constexpr int NG = (CAP + 4 + 3) / 4;                  // 4-entry groups of a staged chunk (shift of up to 3 included)
+    constexpr int NC = (NG + 63) / 64;                     // groups per lane
+    constexpr int STAGE = (CAP + 8) * 12;                  // bytes of one wave's staging area
+    constexpr int MAXQ = WIN ? (13312 / 2 + NT - 1) / NT : 1;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int DimUp = A.DimUp, npair = DimUp >> 1;
+    const int xwbytes = WIN ? ((DimUp * 8 + 31) & ~31) : 0;
+    double *xw = reinterpret_cast<double *>(csr_smem);
+    double *sval = reinterpret_cast<double *>(csr_smem + xwbytes + wv * STAGE);
+    int32_t *scol = reinterpret_cast<int32_t *>(sval + CAP + 8);
+    double *red = reinterpret_cast<double *>(csr_smem + xwbytes + NW * STAGE);
+    dbl2_t *sv2 = reinterpret_cast<dbl2_t *>(sval); int4_t *sc4 = reinterpret_cast<int4_t *>(scol);
+    const int rb = A.rb, r = lane & (rb - 1), sub = lane >> A.rbshift, L = 64 >> A.rbshift;
+    const int cpw = (A.cpr + NW - 1) / NW;                 // chunk slots per wave and dw row (WIN)
+    // task t of this wave -> (idwl, first row of the chunk, rows in it); nr = 0: empty slot / past the end
+    int64_t ntask;
+    if (WIN) { const int64_t rows_here = A.Qdw > blockIdx.x ? (A.Qdw - blockIdx.x + gridDim.x - 1) / gridDim.x : 0; ntask = rows_here * cpw; }
+    else {
+        // XCD x = blockIdx % 8 owns the column tiles x, x+8, ...; its wave slots walk (tile, idwl) with idwl fastest
+        const int xcd = blockIdx.x & 7; const int64_t slots = (int64_t)(gridDim.x >> 3) * NW;
+        const int64_t ntile = A.cpr > xcd ? (A.cpr - xcd + 7) / 8 : 0, tot = ntile * A.Qdw, me = (int64_t)(blockIdx.x >> 3) * NW + wv;
+        ntask = tot > me ? (tot - me + slots - 1) / slots : 0;
+    }
+    auto locate = [&](int64_t t, int64_t &idwl, int &iup0, int &nr) {
+        if (t >= ntask) { nr = 0; idwl = 0; iup0 = 0; return; }
+        int c;
+        if (WIN) { idwl = blockIdx.x + (t / cpw) * gridDim.x; c = wv + (int)(t % cpw) * NW; }
+        else {
+            const int xcd = blockIdx.x & 7; const int64_t slots = (int64_t)(gridDim.x >> 3) * NW;
+            const int64_t u = (int64_t)(blockIdx.x >> 3) * NW + wv + t * slots;
+            const int64_t tl = u / A.Qdw; idwl = u - tl * A.Qdw; c = (int)(tl * 8 + xcd);
+        }
+        iup0 = c * rb; nr = DimUp - iup0; if (nr > rb) nr = rb; if (c >= A.cpr || nr < 0) nr = 0;
+    };
+    struct RP { int64_t ra, re; int64_t idwl; int iup0, nr; };
+    struct ST { dbl2_t v[2 * NC]; int4_t c[NC]; int64_t idwl; int iup0, nr, sh, ra, re; double up, xl; };
+    auto load_rp = [&](int64_t t, RP &o) {
+        locate(t, o.idwl, o.iup0, o.nr);
+        o.ra = 0; o.re = 0;
+        if (sub == 0 && r < o.nr) { const int64_t row = o.idwl * DimUp + o.iup0 + r; o.ra = A.rowptr[row]; o.re = A.rowptr[row + 1]; }
+    };
+    auto load_st = [&](const RP &p, ST &o) {
+        o.idwl = p.idwl; o.iup0 = p.iup0; o.nr = p.nr; o.sh = 0; o.ra = 0; o.re = 0; o.up = 0.0; o.xl = 0.0;
+        if (p.nr == 0) return;
+        const int64_t p0 = __shfl(p.ra, 0, 64), p1 = __shfl(p.re, p.nr - 1, 64);
+        const int sh = (int)(p0 & 3); o.sh = sh;
+        // every lane of a row group needs the row's range: broadcast from the sub==0 lanes
+        const int64_t ra64 = __shfl(p.ra, r, 64), re64 = __shfl(p.re, r, 64);
+        o.ra = (int)(ra64 - p0) + sh; o.re = (int)(re64 - p0) + sh;
+        if (r >= p.nr) { o.ra = 0; o.re = 0; }
+        const int ng = (sh + (int)(p1 - p0) + 3) >> 2;
+        const dbl2_t *pv = reinterpret_cast<const dbl2_t *>(A.vals + (p0 - sh)); const int4_t *pc = reinterpret_cast<const int4_t *>(A.cols + (p0 - sh));
+#pragma unroll
+        for (int j = 0; j < NC; j++) {
+            const int g = lane + 64 * j;
+            if (g < ng) { o.c[j] = __builtin_nontemporal_load(pc + g); o.v[2 * j] = __builtin_nontemporal_load(pv + 2 * g); o.v[2 * j + 1] = __builtin_nontemporal_load(pv + 2 * g + 1); }
+        }
+        if (sub == 0 && r < p.nr) {
+            const int64_t row = p.idwl * DimUp + p.iup0 + r;
+            if (A.epi && A.pass < 2) o.up = A.uprev[row];
+            if (A.epi && (A.pass == 0 || A.pass == 2)) o.xl = A.v_local[row];
+            if (A.pass >= 2) o.up = A.y[row];                 // running value of the earlier blocks
+        }
+    };
+    double s_cur = 1.0, c_prev = 0.0, asum = 0.0;
+    if (A.epi) { s_cur = A.scal[SC_SCUR]; c_prev = A.scal[SC_BETA] * A.scal[SC_SPREV]; }
+    // window prefetch registers (WIN)
+    dbl2_t xr[MAXQ];
+    const int nq = WIN ? (npair + NT - 1) / NT : 0;
+    auto load_win = [&](int64_t idwl) {
+        const dbl2_t *src = reinterpret_cast<const dbl2_t *>(A.x + (A.xrow0 + idwl) * DimUp);
+#pragma unroll
+        for (int q = 0; q < MAXQ; q++) { const int p = tid + q * NT; if (q < nq && p < npair) xr[q] = src[p]; }
+    };
+    if (WIN && blockIdx.x < A.Qdw) load_win(blockIdx.x);
+    RP rp1, rp2; ST st;
+    load_rp(0, rp1);
+    load_st(rp1, st);
+    load_rp(1, rp1);
+    int64_t cur_idwl = -1;
+    for (int64_t t = 0; t < ntask; t++) {
+        if (WIN && st.idwl != cur_idwl) {
+            // all waves of the workgroup change dw row at the same task index (every wave has cpw slots per row)
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < MAXQ; q++) { const int p = tid + q * NT; if (q < nq && p < npair) reinterpret_cast<dbl2_t *>(xw)[p] = xr[q]; }
+            if ((DimUp & 1) && tid == 0) xw[DimUp - 1] = A.x[(A.xrow0 + st.idwl) * DimUp + DimUp - 1];
+            cur_idwl = st.idwl;
+            const int64_t nxt = cur_idwl + gridDim.x;
+            if (nxt < A.Qdw) load_win(nxt);
+            __syncthreads();
+        }
+        // stage the chunk of task t from registers into this wave's LDS area
+        const int nr = st.nr, ra = st.ra, re = st.re; const int64_t idwl = st.idwl; const int iup0 = st.iup0; const double up_i = st.up, xl_i = st.xl;
+        if (nr > 0) {
+            const int last = __shfl(st.re, nr - 1, 64);
+            const int ng = (last + 3) >> 2;
+#pragma unroll
+            for (int j = 0; j < NC; j++) { const int g = lane + 64 * j; if (g < ng) { sc4[g] = st.c[j]; sv2[2 * g] = st.v[2 * j]; sv2[2 * g + 1] = st.v[2 * j + 1]; } }
+        }
+        // keep the pipeline full: stream of task t+1, row pointers of task t+2
+        load_st(rp1, st);
+        load_rp(t + 2, rp2); rp1 = rp2;
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (nr > 0) {
+            const int32_t base = WIN ? (int32_t)((A.xrow0 + idwl) * DimUp) : 0;
+            double acc0 = 0.0, acc1 = 0.0;
+            int k = ra + sub;
+            for (; k + L < re; k += 2 * L) {
+                const int32_t c0 = scol[k], c1 = scol[k + L];
+                const double v0 = sval[k], v1 = sval[k + L];
+                double x0, x1;
+                if (WIN) {
+                    const uint32_t o0 = (uint32_t)(c0 - base), o1 = (uint32_t)(c1 - base);
+                    x0 = o0 < (uint32_t)DimUp ? xw[o0] : A.x[c0];
+                    x1 = o1 < (uint32_t)DimUp ? xw[o1] : A.x[c1];
+                } else { x0 = A.x[c0]; x1 = A.x[c1]; }
+                acc0 += v0 * x0; acc1 += v1 * x1;
+            }
+            if (k < re) {
+                const int32_t c0 = scol[k]; const double v0 = sval[k];
+                double x0;
+                if (WIN) { const uint32_t o0 = (uint32_t)(c0 - base); x0 = o0 < (uint32_t)DimUp ? xw[o0] : A.x[c0]; } else x0 = A.x[c0];
+                acc0 += v0 * x0;
+            }
+            double acc = acc0 + acc1;
+            for (int msk = rb; msk < 64; msk <<= 1) acc += __shfl_xor(acc, msk, 64);      // segmented sum over the lanes of a row
+            if (sub == 0 && r < nr) {
+                const int64_t row = idwl * DimUp + iup0 + r;
+                if (A.epi) {
+                    const double w = A.pass >= 2 ? up_i + s_cur * acc : s_cur * acc - c_prev * up_i;
+                    A.y[row] = w; asum += (s_cur * xl_i) * w;
+                } else A.y[row] = A.pass >= 2 ? up_i + acc : acc;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (A.epi && (A.pass == 0 || A.pass == 2)) { double rr = block_sum(asum, red); if (tid == 0) A.partial[blockIdx.x] = rr; }
+}
+
+// ---------------------------------------------------------------------------------------------
 // |out> = c^+_{orb,spin} |in>  or  c_{orb,spin} |in>  between two sectors, gather form over the
 // target index (ED_GF_NORMAL.f90:190-213 and 264-283 loop over the source and scatter).
 // The sign involves only the spin string that changes (cdg/c of ED_SETUP.f90:805-831).

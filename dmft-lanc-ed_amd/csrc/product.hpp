@@ -172,13 +172,48 @@ static int hxv(S *s, const double *v, double *out, bool epi, const double *uprev
         CsrArgs A{};
         A.nrows = s->nloc_el; A.rows_per_block = s->csr_rpb; A.DimUp = (int32_t)H.DimUp; A.blocks_per_row = s->csr_bpr; A.Qdw = H.Qdw; A.tile = s->csr_tile;
         A.rowptr = s->csr_rowptr.p; A.cols = s->csr_cols.p; A.vals = s->csr_vals.p;
-        A.x = overlap ? (s->halo ? v : v - H.dw0 * H.DimUp) : (multi ? s->vfull.p : v); A.y = out; A.v_local = v; A.uprev = uprev; A.scal = s->scal.p; A.partial = s->partial.p; A.epi = epi; A.xcd_rows = dbg_int("EDGPU_CSR_XCD", 0);
+        A.x = overlap ? (s->halo ? v : v - H.dw0 * H.DimUp) : (multi ? s->vfull.p : v); A.y = out; A.v_local = v; A.uprev = uprev; A.scal = s->scal.p; A.partial = s->partial.p; A.epi = epi; A.xcd_rows = s->csr_xcd_rows;
         // the column index is global; on one GPU local == global
+        // persistent pipelined kernels (k_csr_lds): x window of the dw row in LDS for the local block (or the whole unsplit
+        // matrix), XCD-owned column tiles without a window for the dw block(s)
+        auto launch_lds = [&](bool win, const int64_t *rp, const int32_t *cc, const double *vv, int pass, int rb, const double *xptr) -> int {
+            CsrLdsArgs L{};
+            L.Qdw = H.Qdw; L.DimUp = (int32_t)H.DimUp; L.rb = rb; L.rbshift = 0; while ((1 << L.rbshift) < rb) L.rbshift++;
+            L.cpr = (int32_t)cdiv(H.DimUp, rb);
+            L.rowptr = rp; L.cols = cc; L.vals = vv; L.x = xptr; L.xrow0 = s->halo ? 0 : H.dw0;     // x-space row of local dw row 0 (columns are x-space: build_csr's rowshift)
+            L.y = out; L.v_local = v; L.uprev = uprev; L.scal = s->scal.p; L.partial = s->partial.p; L.epi = epi; L.pass = pass;
+            if (win) {
+                const int grid = (int)std::min<int64_t>(H.Qdw, s->csr_lds_grid);
+                const size_t xw = (((size_t)H.DimUp * 8 + 31) & ~(size_t)31);
+                if (s->csr_lds_nt == 512) {
+                    const size_t lds = xw + 8 * (size_t)((576 + 8) * 12) + 128;
+                    static bool attr = false;
+                    if (!attr) { HIPCHK(hipFuncSetAttribute((const void *)k_csr_lds<512, 576, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr = true; }
+                    hipLaunchKernelGGL((k_csr_lds<512, 576, true>), dim3(grid), dim3(512), lds, s->stream, L);
+                } else {
+                    const size_t lds = xw + 16 * (size_t)((288 + 8) * 12) + 128;
+                    static bool attr = false;
+                    if (!attr) { HIPCHK(hipFuncSetAttribute((const void *)k_csr_lds<1024, 288, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr = true; }
+                    hipLaunchKernelGGL((k_csr_lds<1024, 288, true>), dim3(grid), dim3(1024), lds, s->stream, L);
+                }
+                nblocks = grid;
+            } else {
+                const int grid = s->csrD_pipe_grid;                                 // multiple of 8: XCD-owned column tiles
+                const size_t lds = 4 * (size_t)((576 + 8) * 12) + 128;
+                hipLaunchKernelGGL((k_csr_lds<256, 576, false>), dim3(grid), dim3(256), lds, s->stream, L);
+                nblocks = grid;
+            }
+            HIPCHK(hipGetLastError());
+            return EDGPU_OK;
+        };
         nblocks = (int64_t)s->csr_bpr * H.Qdw;
         A.pass = s->csr_split ? 1 : 0; A.coltiles = 0;
-        if (s->csr_split && s->csrL_small) hipLaunchKernelGGL((k_csr_spmv2<64, 640, false>), dim3((unsigned)nblocks), dim3(64), 0, s->stream, A);
-        else hipLaunchKernelGGL((k_csr_spmv2<64, 1152, false>), dim3((unsigned)nblocks), dim3(64), 0, s->stream, A);
-        HIPCHK(hipGetLastError());
+        if (s->csr_lds) CHK(launch_lds(true, s->csr_rowptr.p, s->csr_cols.p, s->csr_vals.p, A.pass, s->csr_lds_rb, A.x));
+        else {
+            if (s->csr_split && s->csrL_small) hipLaunchKernelGGL((k_csr_spmv2<64, 640, false>), dim3((unsigned)nblocks), dim3(64), 0, s->stream, A);
+            else hipLaunchKernelGGL((k_csr_spmv2<64, 1152, false>), dim3((unsigned)nblocks), dim3(64), 0, s->stream, A);
+            HIPCHK(hipGetLastError());
+        }
         if (s->csr_split) {
             A.rows_per_block = s->csrD_rpb; A.blocks_per_row = s->csrD_bpr; A.coltiles = 1; A.xcd_rows = 0;
             nblocks = 8 * cdiv(s->csrD_bpr, 8) * H.Qdw;
@@ -186,21 +221,28 @@ static int hxv(S *s, const double *v, double *out, bool epi, const double *uprev
                 // dw hops into the rank's own rows: their columns are the first Qdw rows of the x-space, i.e. the local
                 // shard itself -- this block too runs while the exchange is in flight
                 A.rowptr = s->csrO_rowptr.p; A.cols = s->csrO_cols.p; A.vals = s->csrO_vals.p; A.pass = 3;
-                if (s->csrD_small) hipLaunchKernelGGL((k_csr_spmv2<64, 640, false>), dim3((unsigned)nblocks), dim3(64), 0, s->stream, A);
-                else hipLaunchKernelGGL((k_csr_spmv2<64, 1152, false>), dim3((unsigned)nblocks), dim3(64), 0, s->stream, A);
-                HIPCHK(hipGetLastError());
+                if (s->csrD_pipe) CHK(launch_lds(false, A.rowptr, A.cols, A.vals, 3, s->csrD_pipe_rb, A.x));
+                else {
+                    if (s->csrD_small) hipLaunchKernelGGL((k_csr_spmv2<64, 640, false>), dim3((unsigned)nblocks), dim3(64), 0, s->stream, A);
+                    else hipLaunchKernelGGL((k_csr_spmv2<64, 1152, false>), dim3((unsigned)nblocks), dim3(64), 0, s->stream, A);
+                    HIPCHK(hipGetLastError());
+                }
             }
             if (overlap) { HIPCHK(hipStreamWaitEvent(s->stream, s->ev_gather, 0)); A.x = s->vfull.p; }
             A.rowptr = s->csrD_rowptr.p; A.cols = s->csrD_cols.p; A.vals = s->csrD_vals.p;
             A.pass = 2;
-            if (s->csrD_small) {
-                if (s->csrD_nt) hipLaunchKernelGGL((k_csr_spmv2<64, 640, true>), dim3((unsigned)nblocks), dim3(64), 0, s->stream, A);
-                else hipLaunchKernelGGL((k_csr_spmv2<64, 640, false>), dim3((unsigned)nblocks), dim3(64), 0, s->stream, A);
-            } else {
-                if (s->csrD_nt) hipLaunchKernelGGL((k_csr_spmv2<64, 1152, true>), dim3((unsigned)nblocks), dim3(64), 0, s->stream, A);
-                else hipLaunchKernelGGL((k_csr_spmv2<64, 1152, false>), dim3((unsigned)nblocks), dim3(64), 0, s->stream, A);
+            if (s->csrD_pipe) CHK(launch_lds(false, A.rowptr, A.cols, A.vals, 2, s->csrD_pipe_rb, A.x));
+            else {
+                nblocks = 8 * cdiv(s->csrD_bpr, 8) * H.Qdw;
+                if (s->csrD_small) {
+                    if (s->csrD_nt) hipLaunchKernelGGL((k_csr_spmv2<64, 640, true>), dim3((unsigned)nblocks), dim3(64), 0, s->stream, A);
+                    else hipLaunchKernelGGL((k_csr_spmv2<64, 640, false>), dim3((unsigned)nblocks), dim3(64), 0, s->stream, A);
+                } else {
+                    if (s->csrD_nt) hipLaunchKernelGGL((k_csr_spmv2<64, 1152, true>), dim3((unsigned)nblocks), dim3(64), 0, s->stream, A);
+                    else hipLaunchKernelGGL((k_csr_spmv2<64, 1152, false>), dim3((unsigned)nblocks), dim3(64), 0, s->stream, A);
+                }
+                HIPCHK(hipGetLastError());
             }
-            HIPCHK(hipGetLastError());
         }
     } else if (s->two_factor) {
         Kron2Args A{};

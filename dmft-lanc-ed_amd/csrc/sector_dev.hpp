@@ -215,12 +215,12 @@ static int build_csr(S *s)
     A.uppre = s->uppre.p; A.dwpre = s->dwpre.p; A.diag = s->diag.p;
     const unsigned gb = (unsigned)cdiv(s->nloc_el + 1, 256);
     if (!s->csr_split) {
-        CHK(s->csr_rowptr.alloc((size_t)s->nloc_el + 1)); CHK(s->csr_cols.alloc((size_t)s->csr_nnz)); CHK(s->csr_vals.alloc((size_t)s->csr_nnz));
+        CHK(s->csr_rowptr.alloc((size_t)s->nloc_el + 1)); CHK(s->csr_cols.alloc((size_t)s->csr_nnz + 8)); CHK(s->csr_vals.alloc((size_t)s->csr_nnz + 8));
         A.rowptr = s->csr_rowptr.p; A.cols = s->csr_cols.p; A.vals = s->csr_vals.p;
         hipLaunchKernelGGL(k_csr_build, dim3(gb), dim3(256), 0, s->stream, A, 0);
     } else {
-        CHK(s->csr_rowptr.alloc((size_t)s->nloc_el + 1)); CHK(s->csr_cols.alloc((size_t)s->csrL_nnz)); CHK(s->csr_vals.alloc((size_t)s->csrL_nnz));
-        if (!(s->halo && dbg_int("EDGPU_CSR_THREE", 1) != 0)) { CHK(s->csrD_rowptr.alloc((size_t)s->nloc_el + 1)); CHK(s->csrD_cols.alloc((size_t)s->csrD_nnz)); CHK(s->csrD_vals.alloc((size_t)s->csrD_nnz)); }
+        CHK(s->csr_rowptr.alloc((size_t)s->nloc_el + 1)); CHK(s->csr_cols.alloc((size_t)s->csrL_nnz + 8)); CHK(s->csr_vals.alloc((size_t)s->csrL_nnz + 8));
+        if (!(s->halo && dbg_int("EDGPU_CSR_THREE", 1) != 0)) { CHK(s->csrD_rowptr.alloc((size_t)s->nloc_el + 1)); CHK(s->csrD_cols.alloc((size_t)s->csrD_nnz + 8)); CHK(s->csrD_vals.alloc((size_t)s->csrD_nnz + 8)); }
         A.rowptr = s->csr_rowptr.p; A.cols = s->csr_cols.p; A.vals = s->csr_vals.p;
         hipLaunchKernelGGL(k_csr_build, dim3(gb), dim3(256), 0, s->stream, A, 1);
         s->csr_three = s->halo && dbg_int("EDGPU_CSR_THREE", 1) != 0;
@@ -238,8 +238,8 @@ static int build_csr(S *s)
             }
             s->csrO_nnz = po[H.Qdw]; s->csrD_nnz = ph[H.Qdw];
             CHK(s->selpre_own.upload(po)); CHK(s->selpre_halo.upload(ph));
-            CHK(s->csrD_rowptr.alloc((size_t)s->nloc_el + 1)); CHK(s->csrD_cols.alloc((size_t)std::max<int64_t>(s->csrD_nnz, 1))); CHK(s->csrD_vals.alloc((size_t)std::max<int64_t>(s->csrD_nnz, 1)));
-            CHK(s->csrO_rowptr.alloc((size_t)s->nloc_el + 1)); CHK(s->csrO_cols.alloc((size_t)std::max<int64_t>(s->csrO_nnz, 1))); CHK(s->csrO_vals.alloc((size_t)std::max<int64_t>(s->csrO_nnz, 1)));
+            CHK(s->csrD_rowptr.alloc((size_t)s->nloc_el + 1)); CHK(s->csrD_cols.alloc((size_t)s->csrD_nnz + 8)); CHK(s->csrD_vals.alloc((size_t)s->csrD_nnz + 8));
+            CHK(s->csrO_rowptr.alloc((size_t)s->nloc_el + 1)); CHK(s->csrO_cols.alloc((size_t)s->csrO_nnz + 8)); CHK(s->csrO_vals.alloc((size_t)s->csrO_nnz + 8));
             A.sel = 1; A.selpre = s->selpre_own.p; A.rowptr = s->csrO_rowptr.p; A.cols = s->csrO_cols.p; A.vals = s->csrO_vals.p;
             hipLaunchKernelGGL(k_csr_build, dim3(gb), dim3(256), 0, s->stream, A, 2);
             A.sel = 2; A.selpre = s->selpre_halo.p; A.rowptr = s->csrD_rowptr.p; A.cols = s->csrD_cols.p; A.vals = s->csrD_vals.p;
@@ -257,6 +257,25 @@ static int build_csr(S *s)
         s->csrD_small = ndmax * s->csrD_rpb <= 640 && dbg_int("EDGPU_CSR_SMALL", 1);
     }
     HIPCHK(hipGetLastError());
+    // persistent pipelined kernels: chunk = largest power-of-two row count whose entries fit a wave's staging area
+    {
+        auto pow2_rows = [](int64_t cap, int64_t rowmax) { int rb = 64; while (rb > 1 && (int64_t)rb * rowmax > cap) rb >>= 1; return rb; };
+        s->csr_xcd_rows = dbg_int("EDGPU_CSR_XCD", 0);
+        s->csr_lds_nt = dbg_int("EDGPU_CSR_LDS_NT", 1024) == 512 ? 512 : 1024;
+        const int64_t cap = s->csr_lds_nt == 512 ? 576 : 288;
+        const int64_t rowmax = s->csr_split ? 1 + upmax : maxrow;
+        const bool fits = (((size_t)H.DimUp * 8 + 31) & ~(size_t)31) + (s->csr_lds_nt / 64) * (size_t)((cap + 8) * 12) + 128 <= 160 * 1024;
+        // worth it once a dw row is long enough to keep a 16-wave workgroup busy; small sectors stay with one wave per block
+        s->csr_lds = fits && rowmax <= cap && dbg_int("EDGPU_CSR_LDS", (s->csr_split && H.DimUp >= 2048) ? 1 : 0) != 0;
+        s->csr_lds_rb = pow2_rows(cap, rowmax);
+        int ncu = 256; { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, s->device) == hipSuccess) ncu = pr.multiProcessorCount; else (void)hipGetLastError(); }
+        s->csr_lds_grid = std::max(1, dbg_int("EDGPU_CSR_LDS_GRID", ncu));
+        int64_t ndmax2 = 1;
+        for (int64_t q = 0; q < H.Qdw; q++) ndmax2 = std::max<int64_t>(ndmax2, dw.rowptr[H.dw0 + q + 1] - dw.rowptr[H.dw0 + q]);
+        s->csrD_pipe = s->csr_split && ndmax2 <= 576 && dbg_int("EDGPU_CSRD_PIPE", H.DimUp >= 2048 ? 1 : 0) != 0;
+        s->csrD_pipe_rb = std::min(pow2_rows(576, ndmax2), std::max(1, dbg_int("EDGPU_CSRD_PIPE_ROWS", 64)));
+        s->csrD_pipe_grid = 8 * std::max(1, dbg_int("EDGPU_CSRD_PIPE_GRID", ncu * 5) / 8);      // 4-wave workgroups, 5 per CU by LDS
+    }
     s->csr_rpb = (int32_t)std::min<int64_t>(64, 1152 / std::max<int64_t>(maxrow, 1));      // one wave per row block
     if (s->csr_rpb < 1) return fail(EDGPU_EUNSUPPORTED, "edgpu: a CSR row exceeds the LDS tile");
     s->csr_bpr = (int32_t)cdiv(H.DimUp, s->csr_rpb);
@@ -274,6 +293,7 @@ static int64_t max_partials(const S *s)
     if (s->tr_on) n = std::max<int64_t>(n, cdiv(s->H.DimUp, 32) * cdiv(s->H.Qdw, 32));      // k_tadd: one partial per 32x32 tile
     if (s->csr_bpr) n = std::max<int64_t>(n, (int64_t)s->csr_bpr * s->H.Qdw);
     if (s->csrD_bpr) n = std::max<int64_t>(n, 8 * cdiv(s->csrD_bpr, 8) * s->H.Qdw);
+    n = std::max<int64_t>(n, std::max(s->csr_lds_grid, s->csrD_pipe_grid));
     return n;
 }
 

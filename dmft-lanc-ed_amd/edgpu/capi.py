@@ -16,7 +16,7 @@ ENODEVICE = -2
 # every symbol include/edgpu.h declares
 SYMBOLS = [
     "edgpu_sector_create", "edgpu_sector_destroy", "edgpu_sector_vecdim", "edgpu_sector_info",
-    "edgpu_sector_map", "edgpu_factor_size", "edgpu_factor_export", "edgpu_diag_export", "edgpu_csr_rows",
+    "edgpu_sector_map", "edgpu_factor_size", "edgpu_factor_export", "edgpu_diag_export", "edgpu_sector_hmat", "edgpu_csr_rows",
     "edgpu_hxv", "edgpu_hxv64", "edgpu_hxv_device", "edgpu_hxv_time",
     "edgpu_lanczos_gs", "edgpu_lanczos_gs_device", "edgpu_lanczos_tridiag", "edgpu_lanczos_tridiag_device",
     "edgpu_lanczos_time", "edgpu_lanczos_bench_begin", "edgpu_lanczos_bench_steps", "edgpu_lanczos_bench_result", "edgpu_lanczos_bench_comm_ms",
@@ -83,6 +83,7 @@ def lib():
         "edgpu_factor_size": (C.c_int, [vp, i32, i32, P(i64), P(i64)]),
         "edgpu_factor_export": (C.c_int, [vp, i32, i32, vp, vp, vp]),
         "edgpu_diag_export": (C.c_int, [vp, vp]),
+        "edgpu_sector_hmat": (C.c_int, [vp, vp]),
         "edgpu_csr_rows": (C.c_int, [vp, i64, i64, vp, vp, vp, i64]),
         "edgpu_hxv": (C.c_int, [vp, P(i32), vp, vp]),
         "edgpu_hxv64": (C.c_int, [vp, i64, vp, vp]),

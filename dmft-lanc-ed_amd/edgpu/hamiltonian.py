@@ -139,6 +139,12 @@ class HvSector:
         check(capi.lib().edgpu_diag_export(self._h, out.ctypes.data))
         return out
 
+    def hmat(self):
+        """Dense Hmat of build_Hv_sector(isector,Hmat) (ED_HAMILTONIAN.f90:128-137), Dim x Dim, Fortran order."""
+        H = np.zeros((int(self.Dim), int(self.Dim)), np.float64, order="F")
+        check(capi.lib().edgpu_sector_hmat(self._h, H.ctypes.data))
+        return H
+
     def csr_rows(self, row0, nrows, cap=None):
         cap = cap or nrows * 256
         rp = np.zeros(nrows + 1, np.int64); cols = np.zeros(cap, np.int32); vals = np.zeros(cap, np.float64)

@@ -100,6 +100,12 @@ int edgpu_factor_size(edgpu_handle h, int32_t which, int32_t iud, int64_t *nrow,
 int edgpu_factor_export(edgpu_handle h, int32_t which, int32_t iud, int64_t *row_ptr, int64_t *cols, double *vals);
 /* spH0d: the local diagonal d(1:DimUp*mpiQdw) (stored/H_local.f90:13-71), computed on the device */
 int edgpu_diag_export(edgpu_handle h, double *d_host);
+/* dense Hmat of build_Hv_sector(isector,Hmat) (ED_HAMILTONIAN.f90:128-137; ed_buildh_main/orbs with Hmat,
+ * ED_HAMILTONIAN_SPARSE_HxV.f90:132-195, 304-363): the form the reference diagonalises with LAPACK for every sector
+ * with dim <= lanc_dim_threshold (ED_DIAG.f90:105-107, 212-237).  hmat: host, Dim x Dim column-major, overwritten.
+ * With more than one rank the rows are summed over the ranks (mpi_sp_dump_matrix, ED_SPARSE_MATRIX.f90:408-437):
+ * every rank gets the full matrix. */
+int edgpu_sector_hmat(edgpu_handle h, double *hmat);
 /* explicit CSR (storage=CSR only): sizes and a window of rows [row0,row0+nrows) copied to the host */
 int edgpu_csr_rows(edgpu_handle h, int64_t row0, int64_t nrows, int64_t *row_ptr, int32_t *cols, double *vals, int64_t cap);
 

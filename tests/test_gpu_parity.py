@@ -104,6 +104,19 @@ def test_hxv_against_reference_known_answers(edgpu_mod, g):
         G.close()
 
 
+@pytest.mark.parametrize("name,m,nu,nd", [z for z in ZOO if z[0] not in ("c_nb7_half",)], ids=[z[0] for z in ZOO if z[0] not in ("c_nb7_half",)])
+def test_dense_hmat_matches_oracle(edgpu_mod, name, m, nu, nd):
+    """build_Hv_sector(isector,Hmat): the dense form every sector with dim <= lanc_dim_threshold takes
+    (ED_DIAG.f90:105-107) against the oracle's restatement of ed_buildh_main/orbs with Hmat -- element by element."""
+    S = oracle.Sector(m, nu, nd)
+    Href = S.hmat()
+    for st in ("kron", "direct"):
+        G = edgpu_mod.HvSector(m, nu, nd, storage=st)
+        H = G.hmat()
+        assert np.abs(H - Href).max() <= 1e-15 * max(1.0, np.abs(Href).max()), (st, np.abs(H - Href).max())
+        G.close()
+
+
 def test_explicit_csr_rows_equal_dense(edgpu_mod):
     from edgpu import model
     m, nu, nd = model.half_filled_c(5)
@@ -211,6 +224,10 @@ def test_large_sector_code_paths_on_small_sectors(edgpu_mod, monkeypatch, name, 
     tol = HXV_RTOL * np.abs(ref).max()
     w = np.linalg.eigvalsh(S.hmat())
     for env in ({"EDGPU_KRON_SPLIT": "1", "EDGPU_CSR_SPLIT": "1"},
+                # persistent pipelined CSR kernels (x window in LDS / XCD-owned tiles), which small sectors do not pick by themselves
+                {"EDGPU_CSR_SPLIT": "1", "EDGPU_CSR_LDS": "1", "EDGPU_CSRD_PIPE": "1"},
+                {"EDGPU_CSR_SPLIT": "1", "EDGPU_CSR_LDS": "1", "EDGPU_CSRD_PIPE": "1", "EDGPU_CSR_LDS_NT": "512", "EDGPU_CSR_LDS_GRID": "3", "EDGPU_CSRD_PIPE_GRID": "16", "EDGPU_CSRD_PIPE_ROWS": "16"},
+                {"EDGPU_CSR_SPLIT": "0", "EDGPU_CSR_LDS": "1", "EDGPU_CSR_LDS_GRID": "2"},      # unsplit matrix: dw hops gather outside the window
                 {"EDGPU_KRON_SPLIT": "1", "EDGPU_CSR_SPLIT": "1", "EDGPU_DW_W": "8", "EDGPU_DW_ROWS": "16", "EDGPU_CSRD_ROWS": "16", "EDGPU_UP_GRID": "3"},
                 {"EDGPU_KRON_SPLIT": "1", "EDGPU_DW_VARIANT": "1", "EDGPU_UP_PERSISTENT": "0", "EDGPU_CSR_SPLIT": "1", "EDGPU_CSRD_NT": "0"},
                 {"EDGPU_CSR_SPLIT": "0", "EDGPU_KRON_SPLIT": "1", "EDGPU_UP_THREADS": "512", "EDGPU_UP_PAIRS": "0"},
