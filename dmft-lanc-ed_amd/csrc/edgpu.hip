@@ -349,6 +349,9 @@ int edgpu_eigsh(edgpu_handle h, int32_t nev, int32_t ncv, int32_t maxiter, doubl
     return eigsh(h, nev, ncv, maxiter, tol, evals, evecs, nconv, nrestarts, nmatvec);
 }
 
+int32_t edgpu_eigsh_ncv_cap(void) { return kMaxBasisBig; }
+int32_t edgpu_eigsh_ncv_used(edgpu_handle h) { return h ? h->eig_ncv_used : 0; }
+
 int edgpu_dvdson(edgpu_handle h, int32_t nev, int32_t maxiter, double tol, double *evals, double *evecs, int32_t *nconv, int32_t *nmatvec)
 {
     if (!h || !evals) return fail(EDGPU_EINVAL, "edgpu_dvdson: null argument");

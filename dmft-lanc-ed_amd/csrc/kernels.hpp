@@ -1770,21 +1770,25 @@ __global__ void __launch_bounds__(256) k_multiaxpy_norm(BasisArgs B, const doubl
     double r = block_sum(ss, red);
     if (threadIdx.x == 0) partial[blockIdx.x] = r;
 }
-// in-place rotation of the basis: V_j <- sum_i V_i Y[i + nv*j], j < nout  (row by row)
-struct RotArgs { double *V[kMaxBasis + 1]; int32_t nv, nout; const double *Y; };
-__global__ void __launch_bounds__(256) k_basis_rotate(RotArgs R, int64_t n)
+// in-place rotation of the basis: V_j <- sum_i V_i Y[i + nv*j], j < nout  (row by row: all nv values of an element sit in
+// registers, so the capacity is a template parameter: 48 for the usual bases, 96 for the large ones of finite-T runs)
+constexpr int kMaxBasisBig = 96;
+template <int MAXB> struct RotArgsT { double *V[MAXB + 1]; int32_t nv, nout; const double *Y; };
+using RotArgs = RotArgsT<kMaxBasis>;
+template <int MAXB>
+__global__ void __launch_bounds__(256) k_basis_rotate(RotArgsT<MAXB> R, int64_t n)
 {
     extern __shared__ double ysh[];     // nv*nout
     for (int t = threadIdx.x; t < R.nv * R.nout; t += blockDim.x) ysh[t] = R.Y[t];
     __syncthreads();
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
-        double x[kMaxBasis + 1];
+        double x[MAXB + 1];
 #pragma unroll
-        for (int i = 0; i <= kMaxBasis; i++) x[i] = i < R.nv ? R.V[i][e] : 0.0;
+        for (int i = 0; i <= MAXB; i++) x[i] = i < R.nv ? R.V[i][e] : 0.0;
         for (int j = 0; j < R.nout; j++) {
             double s = 0.0;
 #pragma unroll
-            for (int i = 0; i <= kMaxBasis; i++) if (i < R.nv) s += x[i] * ysh[i + R.nv * j];
+            for (int i = 0; i <= MAXB; i++) if (i < R.nv) s += x[i] * ysh[i + R.nv * j];
             R.V[j][e] = s;
         }
     }

@@ -343,27 +343,43 @@ static int lanczos_tridiag(S *s, const double *vin_dev, int nlanc, double thresh
 // no separate norm pass is needed.  hh (host, nv entries) receives the summed coefficients, wnorm the final |w|.
 static int orthogonalise_cgs(S *s, double *const *basis, int nv, int first_from, double *w, int64_t n, int nb, std::vector<double> &hh, double &wnorm)
 {
-    std::vector<double> h2((size_t)nv + 1);
+    std::vector<double> h2((size_t)kMaxBasis + 1);
     hh.assign((size_t)nv, 0.0);
     double before = 0.0, after = 0.0;
     for (int pass = 0; pass < 2; pass++) {
         const int from = pass == 0 ? first_from : 0, cnt = nv - from;
-        BasisArgs B{}; B.nv = cnt + 1; for (int i = 0; i < cnt; i++) B.V[i] = basis[from + i];
-        B.V[cnt] = w;
-        BasisArgs Bu = B; Bu.nv = cnt;
-        hipLaunchKernelGGL(k_multidot, dim3(nb), dim3(256), 0, s->stream, B, (const double *)w, n, s->eig_partial.p);
-        hipLaunchKernelGGL(k_multidot_final, dim3(1), dim3(256), 0, s->stream, (const double *)s->eig_partial.p, nb, B.nv, s->eig_h.p);
-        HIPCHK(hipGetLastError());
-        CHK(allreduce_dev(s, s->eig_h.p, B.nv));
-        hipLaunchKernelGGL(k_multiaxpy_norm, dim3(nb), dim3(256), 0, s->stream, Bu, (const double *)s->eig_h.p, w, n, s->eig_partial.p);
+        // bases beyond the capacity of one kernel argument block go in groups of kMaxBasis vectors: all dots are taken
+        // against the SAME w (classical Gram-Schmidt), then the groups are subtracted one after the other
+        const int ngroups = std::max(1, (int)cdiv(cnt, kMaxBasis));
+        std::vector<double> hpass((size_t)std::max(cnt, 1), 0.0);
+        for (int g = 0; g < ngroups; g++) {
+            const int g0 = g * kMaxBasis, gc = std::min(kMaxBasis, cnt - g0);
+            const bool lastg = g == ngroups - 1;
+            BasisArgs B{}; B.nv = gc + (lastg ? 1 : 0);
+            for (int i = 0; i < gc; i++) B.V[i] = basis[from + g0 + i];
+            if (lastg) B.V[gc] = w;                           // w rides along once: |w|^2 before the update
+            hipLaunchKernelGGL(k_multidot, dim3(nb), dim3(256), 0, s->stream, B, (const double *)w, n, s->eig_partial.p);
+            hipLaunchKernelGGL(k_multidot_final, dim3(1), dim3(256), 0, s->stream, (const double *)s->eig_partial.p, nb, B.nv, s->eig_h.p + g0);
+            HIPCHK(hipGetLastError());
+        }
+        CHK(allreduce_dev(s, s->eig_h.p, cnt + 1));
+        for (int g = 0; g < ngroups; g++) {
+            const int g0 = g * kMaxBasis, gc = std::min(kMaxBasis, cnt - g0);
+            BasisArgs Bu{}; Bu.nv = gc;
+            for (int i = 0; i < gc; i++) Bu.V[i] = basis[from + g0 + i];
+            if (g == ngroups - 1) hipLaunchKernelGGL(k_multiaxpy_norm, dim3(nb), dim3(256), 0, s->stream, Bu, (const double *)(s->eig_h.p + g0), w, n, s->eig_partial.p);
+            else hipLaunchKernelGGL(k_multiaxpy, dim3(nb), dim3(256), 0, s->stream, Bu, (const double *)(s->eig_h.p + g0), w, n);
+            HIPCHK(hipGetLastError());
+        }
         hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(1024), 0, s->stream, (const double *)s->eig_partial.p, (int64_t)nb, s->scal.p + SC_TMP);
         HIPCHK(hipGetLastError());
         CHK(allreduce_tmp(s));
-        HIPCHK(hipMemcpyAsync(h2.data(), s->eig_h.p, (size_t)(cnt + 1) * 8, hipMemcpyDeviceToHost, s->stream));
+        std::vector<double> hall((size_t)cnt + 1);
+        HIPCHK(hipMemcpyAsync(hall.data(), s->eig_h.p, (size_t)(cnt + 1) * 8, hipMemcpyDeviceToHost, s->stream));
         HIPCHK(hipMemcpyAsync(&after, s->scal.p + SC_TMP, 8, hipMemcpyDeviceToHost, s->stream));
         HIPCHK(hipStreamSynchronize(s->stream));
-        for (int i = 0; i < cnt; i++) hh[from + i] += h2[i];
-        before = h2[cnt];
+        for (int i = 0; i < cnt; i++) hh[from + i] += hall[i];
+        before = hall[cnt];
         if (pass == 0 && first_from == 0 && after >= 0.5 * before) break;      // DGKS: one full pass was enough
     }
     wnorm = std::sqrt(after > 0.0 ? after : 0.0);
@@ -408,20 +424,34 @@ static int eigsh(S *s, int nev, int ncv, int maxiter, double tol, double *evals,
     const int64_t Dim = s->H.Dim, n = s->nloc;
     if (nev < 1) return fail(EDGPU_EINVAL, "edgpu_eigsh: nev < 1");
     if ((int64_t)nev >= Dim) return fail(EDGPU_EINVAL, "edgpu_eigsh: nev must be smaller than the sector dimension (the reference switches to LAPACK there, ED_DIAG.f90:105-107)");
-    if (ncv > kMaxBasis) ncv = kMaxBasis;
+    if (nev >= kMaxBasisBig) return fail(EDGPU_EUNSUPPORTED, "edgpu_eigsh: nev must be below the basis capacity (edgpu_eigsh_ncv_cap)");
+    if (ncv > kMaxBasisBig) ncv = kMaxBasisBig;         // documented cap (edgpu_eigsh_ncv_cap): a smaller thick-restart basis costs restarts, not accuracy
     if ((int64_t)ncv > Dim) ncv = (int)Dim;
-    if (ncv <= nev) ncv = (int)std::min<int64_t>(std::min<int64_t>(2 * nev + 1, kMaxBasis), Dim);
+    if (ncv <= nev) ncv = (int)std::min<int64_t>(std::min<int64_t>(2 * nev + 1, kMaxBasisBig), Dim);
     if (ncv <= nev) return fail(EDGPU_EINVAL, "edgpu_eigsh: ncv must exceed nev");
+    s->eig_ncv_used = ncv;
     if (maxiter < 1) maxiter = 1;
     const double tol_eff = std::max(tol, 1e-12), eps23 = std::pow(2.220446049250313e-16, 2.0 / 3.0);
     const int m = ncv;
     while ((int)s->eigV.size() < m + 1) { auto b = std::make_unique<DevBuf<double>>(); CHK(b->alloc((size_t)n)); s->eigV.push_back(std::move(b)); }
     const int nb = (int)std::max<int64_t>(1, std::min<int64_t>(cdiv(n, 256 * 8), 1024));
     if (s->eig_h.n < (size_t)(m + 3)) CHK(s->eig_h.alloc((size_t)m + 3));
-    if (s->eig_partial.n < (size_t)nb * (m + 2)) CHK(s->eig_partial.alloc((size_t)nb * (m + 2)));
+    if (s->eig_partial.n < (size_t)nb * (kMaxBasis + 2)) CHK(s->eig_partial.alloc((size_t)nb * (kMaxBasis + 2)));
     if (s->eig_y.n < (size_t)m * m) CHK(s->eig_y.alloc((size_t)m * m));
     auto Vp = [&](int i) { return s->eigV[i]->p; };
     const SectorHost &H = s->H;
+    const int gsr = (int)std::max<int64_t>(1, std::min<int64_t>(cdiv(n, 256 * 4), 4096));
+    // V_j <- sum_i V_i Y_ij in place; bases above 48 vectors take the 96-capacity instantiation
+    auto rotate = [&](int nv, int nout) -> int {
+        if (nv <= kMaxBasis) { RotArgs R{}; R.nv = nv; R.nout = nout; R.Y = s->eig_y.p; for (int i = 0; i < nv; i++) R.V[i] = Vp(i);
+            hipLaunchKernelGGL(k_basis_rotate<kMaxBasis>, dim3(gsr), dim3(256), (size_t)nv * nout * 8, s->stream, R, n); }
+        else { RotArgsT<kMaxBasisBig> R{}; R.nv = nv; R.nout = nout; R.Y = s->eig_y.p; for (int i = 0; i < nv; i++) R.V[i] = Vp(i);
+            static bool attr = false;
+            if (!attr) { HIPCHK(hipFuncSetAttribute((const void *)k_basis_rotate<kMaxBasisBig>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 96 * 8)); attr = true; }
+            hipLaunchKernelGGL(k_basis_rotate<kMaxBasisBig>, dim3(gsr), dim3(256), (size_t)nv * nout * 8, s->stream, R, n); }
+        HIPCHK(hipGetLastError());
+        return EDGPU_OK;
+    };
     hipLaunchKernelGGL(k_random_start, dim3(2048), dim3(256), 0, s->stream, Vp(0), H.DimUp, H.Qdw, H.dw0, H.DimDw, H.DimPh, (uint64_t)1234567);
     HIPCHK(hipGetLastError());
     auto norm_of = [&](const double *x, double &out) -> int {
@@ -464,18 +494,14 @@ static int eigsh(S *s, int nev, int ncv, int maxiter, double tol, double *evals,
         // thick restart: keep the lowest l Ritz vectors, append the residual direction
         l = std::min(m - 1, nev + std::max(1, (m - nev) / 2));
         HIPCHK(hipMemcpyAsync(s->eig_y.p, Y.data(), (size_t)m * l * 8, hipMemcpyHostToDevice, s->stream));
-        RotArgs R{}; R.nv = m; R.nout = l; R.Y = s->eig_y.p; for (int i = 0; i < m; i++) R.V[i] = Vp(i);
-        hipLaunchKernelGGL(k_basis_rotate, dim3(gs), dim3(256), (size_t)m * l * 8, s->stream, R, n);
-        HIPCHK(hipGetLastError());
+        CHK(rotate(m, l));
         HIPCHK(hipMemcpyAsync(Vp(l), Vp(m), (size_t)n * 8, hipMemcpyDeviceToDevice, s->stream));
         std::fill(Hm.begin(), Hm.end(), 0.0);
         for (int i = 0; i < l; i++) Hm[(size_t)i * m + i] = theta[i];
     }
     const int nout = std::min(nev, meff);
     HIPCHK(hipMemcpyAsync(s->eig_y.p, Y.data(), (size_t)meff * nout * 8, hipMemcpyHostToDevice, s->stream));
-    RotArgs R{}; R.nv = meff; R.nout = nout; R.Y = s->eig_y.p; for (int i = 0; i < meff; i++) R.V[i] = Vp(i);
-    hipLaunchKernelGGL(k_basis_rotate, dim3(gs), dim3(256), (size_t)meff * nout * 8, s->stream, R, n);
-    HIPCHK(hipGetLastError());
+    CHK(rotate(meff, nout));
     for (int i = 0; i < nev; i++) evals[i] = i < nout ? theta[i] : 0.0;
     if (evecs_host)
         for (int i = 0; i < nout; i++) HIPCHK(hipMemcpyAsync(evecs_host + (int64_t)i * n, Vp(i), (size_t)n * 8, hipMemcpyDeviceToHost, s->stream));
@@ -483,6 +509,9 @@ static int eigsh(S *s, int nev, int ncv, int maxiter, double tol, double *evals,
     if (nconv_out) *nconv_out = nconv;
     if (nrestart_out) *nrestart_out = it + 1;
     if (nmatvec_out) *nmatvec_out = nmv;
+    // fewer converged pairs than asked for is an ERROR the caller must see (evals / evecs / nconv are filled all the same):
+    // sp_eigh's callers take every returned pair for an eigenpair (ED_DIAG.f90:240-280)
+    if (nconv < nev) return fail(EDGPU_ENOTCONVERGED, "edgpu_eigsh: " + std::to_string(nconv) + " of " + std::to_string(nev) + " pairs converged within maxiter restarts");
     return EDGPU_OK;
 }
 
@@ -570,7 +599,7 @@ static int dvdson(S *s, int nev, int maxiter, double tol, double *evals, double 
             HIPCHK(hipMemcpyAsync(s->eig_y.p, Y.data(), (size_t)m * keep * 8, hipMemcpyHostToDevice, s->stream));
             for (int half = 0; half < 2; half++) {
                 RotArgs Rt{}; Rt.nv = m; Rt.nout = keep; Rt.Y = s->eig_y.p; for (int i = 0; i < m; i++) Rt.V[i] = half ? Wp(i) : Vp(i);
-                hipLaunchKernelGGL(k_basis_rotate, dim3(gs), dim3(256), (size_t)m * keep * 8, s->stream, Rt, n);
+                hipLaunchKernelGGL(k_basis_rotate<kMaxBasis>, dim3(gs), dim3(256), (size_t)m * keep * 8, s->stream, Rt, n);
             }
             HIPCHK(hipGetLastError());
             std::fill(G.begin(), G.end(), 0.0);
@@ -596,7 +625,7 @@ static int dvdson(S *s, int nev, int maxiter, double tol, double *evals, double 
     const int nout = std::min(nev, m);
     HIPCHK(hipMemcpyAsync(s->eig_y.p, Y.data(), (size_t)m * nout * 8, hipMemcpyHostToDevice, s->stream));
     RotArgs Rt{}; Rt.nv = m; Rt.nout = nout; Rt.Y = s->eig_y.p; for (int i = 0; i < m; i++) Rt.V[i] = Vp(i);
-    hipLaunchKernelGGL(k_basis_rotate, dim3(gs), dim3(256), (size_t)m * nout * 8, s->stream, Rt, n);
+    hipLaunchKernelGGL(k_basis_rotate<kMaxBasis>, dim3(gs), dim3(256), (size_t)m * nout * 8, s->stream, Rt, n);
     HIPCHK(hipGetLastError());
     for (int i = 0; i < nev; i++) evals[i] = i < nout ? theta[i] : 0.0;
     if (evecs_host)
@@ -604,6 +633,7 @@ static int dvdson(S *s, int nev, int maxiter, double tol, double *evals, double 
     HIPCHK(hipStreamSynchronize(s->stream));
     if (nconv_out) *nconv_out = std::min(nconv, nout);
     if (nmatvec_out) *nmatvec_out = nmv;
+    if (std::min(nconv, nout) < nev) return fail(EDGPU_ENOTCONVERGED, "edgpu_dvdson: " + std::to_string(std::min(nconv, nout)) + " of " + std::to_string(nev) + " pairs converged within maxiter products");
     return EDGPU_OK;
 }
 

@@ -185,6 +185,7 @@ struct edgpu_sector_s {
     std::vector<hipEvent_t> comm_ev; int comm_slot = -1;     // timed bench steps: events around the exchange on the comm stream
     int64_t nnz_total = 0, bytes_stored = 0;
     int64_t npartial = 0;
+    int eig_ncv_used = 0;     // basis size the last edgpu_eigsh call actually ran with
     // Lanczos iteration fusion (single rank)
     int fuse_mode = -1; const double *fuse_zvec = nullptr;   // >= 0: the product's final reduction also performs this scalar step
     edgpu_sector_s() = default;

@@ -189,21 +189,27 @@ class HvSector:
         check(capi.lib().edgpu_lanczos_gs_device(self._h, nitermax, threshold, ncheck, C.byref(e), vect_dev.ptr, C.byref(n)))
         return e.value, n.value
 
-    def sp_eigh(self, neigen, nblock=None, nitermax=512, tol=1e-12, vectors=True):
+    def sp_eigh(self, neigen, nblock=None, nitermax=512, tol=1e-12, vectors=True, allow_unconverged=False):
         """sp_eigh(MatVec,eval,evec,Nblock,Nitermax,tol): lowest `neigen` pairs (ED_DIAG.f90:153-170).
-        Returns (evals, evecs[vecDim, neigen] or None, info dict)."""
+        Returns (evals, evecs[vecDim, neigen] or None, info dict).  Fewer converged pairs than asked for raises
+        (EDGPU_ENOTCONVERGED) unless allow_unconverged: then info["nconv"] tells how many can be trusted."""
         nblock = nblock or min(int(self.Dim), 10 * max(neigen, 2))
         ev = np.zeros(neigen); vec = np.zeros((self.vecDim, neigen), order="F") if vectors else None
         nc, nr, nm = C.c_int32(), C.c_int32(), C.c_int32()
-        check(capi.lib().edgpu_eigsh(self._h, neigen, nblock, nitermax, tol, ev.ctypes.data, vec.ctypes.data if vectors else None,
-                                     C.byref(nc), C.byref(nr), C.byref(nm)))
-        return ev, vec, {"nconv": nc.value, "restarts": nr.value, "matvecs": nm.value}
+        rc = capi.lib().edgpu_eigsh(self._h, neigen, nblock, nitermax, tol, ev.ctypes.data, vec.ctypes.data if vectors else None,
+                                    C.byref(nc), C.byref(nr), C.byref(nm))
+        if not (rc == capi.ENOTCONVERGED and allow_unconverged):
+            check(rc)
+        return ev, vec, {"nconv": nc.value, "restarts": nr.value, "matvecs": nm.value, "ncv_used": int(capi.lib().edgpu_eigsh_ncv_used(self._h))}
 
-    def sp_dvdson_eigh(self, neigen, nitermax=512, tol=1e-12, vectors=True):
-        """sp_dvdson_eigh(MatVec,eval,evec,nitermax,tol): lowest `neigen` pairs by Davidson (ED_DIAG.f90:189-203)."""
+    def sp_dvdson_eigh(self, neigen, nitermax=512, tol=1e-12, vectors=True, allow_unconverged=False):
+        """sp_dvdson_eigh(MatVec,eval,evec,nitermax,tol): lowest `neigen` pairs by Davidson (ED_DIAG.f90:189-203).
+        Raises when fewer pairs converged than asked for, unless allow_unconverged."""
         ev = np.zeros(neigen); vec = np.zeros((self.vecDim, neigen), order="F") if vectors else None
         nc, nm = C.c_int32(), C.c_int32()
-        check(capi.lib().edgpu_dvdson(self._h, neigen, nitermax, tol, ev.ctypes.data, vec.ctypes.data if vectors else None, C.byref(nc), C.byref(nm)))
+        rc = capi.lib().edgpu_dvdson(self._h, neigen, nitermax, tol, ev.ctypes.data, vec.ctypes.data if vectors else None, C.byref(nc), C.byref(nm))
+        if not (rc == capi.ENOTCONVERGED and allow_unconverged):
+            check(rc)
         return ev, vec, {"nconv": nc.value, "matvecs": nm.value}
 
     def twin_reorder(self, vec):

@@ -50,14 +50,6 @@ module ED_HAMILTONIAN_GPU
 
 contains
 
-  subroutine edgpu_check(rc, where)
-    integer(c_int), intent(in) :: rc
-    character(len=*), intent(in) :: where
-    if (rc /= 0) then
-       write(*,"(A)") trim(where)//": "//edgpu_error_message()
-       stop "edgpu error"                       ! the reference aborts with `stop "<msg>"`
-    end if
-  end subroutine edgpu_check
 
   !> build_Hv_sector(isector): ED_HAMILTONIAN.f90:43-168.  Arrays are the reference's own
   !  (column-major, same index order); Nups/Ndws are get_Nup/get_Ndw of the sector.

@@ -3,7 +3,7 @@
 !  with the reference's abstract interface and prints the SURVEY 8c known-answer quantities.
 program demo_c1
   use ED_HAMILTONIAN_GPU
-  use ED_SPARSE_MATRIX_GPU
+  use ED_SPARSE_MATRIX
   implicit none
   abstract interface
      subroutine dd_sparse_HxV(Nloc, v, Hv)      ! ED_VARS_GLOBAL.f90:75-81
@@ -20,7 +20,7 @@ program demo_c1
   real(8), allocatable :: v(:), Hv(:), vect(:), alanc(:), blanc(:)
   integer :: N, i, nlanc, isparse
   logical :: sparse_H
-  type(sparse_matrix_gpu) :: spA
+  type(sparse_matrix_csr) :: spA
   type(sector_gpu) :: Ssrc
   real(8) :: norm2, hist(4), agf(20), bgf(20), achi(20), bchi(20)
   real(8), allocatable :: gs(:), tw(:)
@@ -84,12 +84,12 @@ program demo_c1
   call delete_Hv_sector_gpu()
   call delete_sector_gpu(Ssrc)
   ! sparse container: duplicate-summing insert, dense dump, product on the device
-  call sp_init_matrix_gpu(spA, 3)
-  call sp_insert_element_gpu(spA, 2d0, 1, 1); call sp_insert_element_gpu(spA, -1d0, 1, 3)
-  call sp_insert_element_gpu(spA, 0.5d0, 1, 3); call sp_insert_element_gpu(spA, 4d0, 3, 2)
-  dense = 0d0; call sp_dump_matrix_gpu(spA, dense)
-  xv = [1d0, 2d0, 3d0]; yv = 0d0; call sp_matvec_gpu(spA, xv, yv)
+  call sp_init_matrix(spA, 3)
+  call sp_insert_element(spA, 2d0, 1, 1); call sp_insert_element(spA, -1d0, 1, 3)
+  call sp_insert_element(spA, 0.5d0, 1, 3); call sp_insert_element(spA, 4d0, 3, 2)
+  dense = 0d0; call sp_dump_matrix(spA, dense)
+  xv = [1d0, 2d0, 3d0]; yv = 0d0; call sp_matvec(spA, xv, yv)
   write(*,"(A,3F10.5)") "sp_dense_row1=", dense(1,:)
   write(*,"(A,3F10.5)") "sp_matvec=", yv
-  call sp_delete_matrix_gpu(spA)
+  call sp_delete_matrix(spA)
 end program demo_c1

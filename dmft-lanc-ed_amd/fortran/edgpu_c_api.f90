@@ -195,6 +195,109 @@ module EDGPU_C_API
        type(c_ptr), value    :: ctx
        integer(c_int)        :: rc
      end function edgpu_comm_init_callbacks
+     !> dense Hmat of build_Hv_sector(isector,Hmat): ED_HAMILTONIAN.f90:128-137
+     function edgpu_sector_hmat(handle, hmat) bind(C, name="edgpu_sector_hmat") result(rc)
+       import :: c_int, c_double, c_ptr
+       type(c_ptr), value :: handle
+       real(c_double)     :: hmat(*)
+       integer(c_int)     :: rc
+     end function edgpu_sector_hmat
+     !> the process-wide communicator (MpiComm of ed_set_MpiComm, ED_VARS_GLOBAL.f90:332-347)
+     function edgpu_comm_create_rccl(id128, rank, nranks, device, comm) bind(C, name="edgpu_comm_create_rccl") result(rc)
+       import :: c_int, c_int32_t, c_char, c_ptr
+       character(kind=c_char), intent(in) :: id128(128)
+       integer(c_int32_t), value          :: rank, nranks, device
+       type(c_ptr), intent(out)           :: comm
+       integer(c_int)                     :: rc
+     end function edgpu_comm_create_rccl
+     function edgpu_comm_create_callbacks(rank, nranks, allgatherv, exchange, allreduce, ctx, comm) bind(C, name="edgpu_comm_create_callbacks") result(rc)
+       import :: c_int, c_int32_t, c_ptr, c_funptr
+       integer(c_int32_t), value :: rank, nranks
+       type(c_funptr), value     :: allgatherv, exchange, allreduce
+       type(c_ptr), value        :: ctx
+       type(c_ptr), intent(out)  :: comm
+       integer(c_int)            :: rc
+     end function edgpu_comm_create_callbacks
+     function edgpu_comm_sub(parent, nranks, comm, is_member) bind(C, name="edgpu_comm_sub") result(rc)
+       import :: c_int, c_int32_t, c_ptr
+       type(c_ptr), value        :: parent
+       integer(c_int32_t), value :: nranks
+       type(c_ptr), intent(out)  :: comm
+       integer(c_int32_t)        :: is_member
+       integer(c_int)            :: rc
+     end function edgpu_comm_sub
+     function edgpu_comm_destroy(comm) bind(C, name="edgpu_comm_destroy") result(rc)
+       import :: c_int, c_ptr
+       type(c_ptr), value :: comm
+       integer(c_int)     :: rc
+     end function edgpu_comm_destroy
+     function edgpu_sector_attach_comm(handle, comm) bind(C, name="edgpu_sector_attach_comm") result(rc)
+       import :: c_int, c_ptr
+       type(c_ptr), value :: handle, comm
+       integer(c_int)     :: rc
+     end function edgpu_sector_attach_comm
+     function edgpu_comm_allreduce_sum(comm, buf, n) bind(C, name="edgpu_comm_allreduce_sum") result(rc)
+       import :: c_int, c_int32_t, c_double, c_ptr
+       type(c_ptr), value        :: comm
+       real(c_double)            :: buf(*)
+       integer(c_int32_t), value :: n
+       integer(c_int)            :: rc
+     end function edgpu_comm_allreduce_sum
+     !> sparse container (ED_SPARSE_MATRIX.f90): see include/edgpu.h
+     function edgpu_sp_init_matrix(nrow, ncol, out) bind(C, name="edgpu_sp_init_matrix") result(rc)
+       import :: c_int, c_int64_t, c_ptr
+       integer(c_int64_t), value :: nrow, ncol
+       type(c_ptr), intent(out)  :: out
+       integer(c_int)            :: rc
+     end function edgpu_sp_init_matrix
+     function edgpu_sp_init_matrix_mpi(istart, iend, ishift, n, ncol, out) bind(C, name="edgpu_sp_init_matrix_mpi") result(rc)
+       import :: c_int, c_int64_t, c_ptr
+       integer(c_int64_t), value :: istart, iend, ishift, n, ncol
+       type(c_ptr), intent(out)  :: out
+       integer(c_int)            :: rc
+     end function edgpu_sp_init_matrix_mpi
+     function edgpu_sp_load_matrix(dense, nrow, ncol, inout) bind(C, name="edgpu_sp_load_matrix") result(rc)
+       import :: c_int, c_int64_t, c_double, c_ptr
+       real(c_double), intent(in)  :: dense(*)
+       integer(c_int64_t), value   :: nrow, ncol
+       type(c_ptr), intent(inout)  :: inout
+       integer(c_int)              :: rc
+     end function edgpu_sp_load_matrix
+     function edgpu_sp_insert_element(m, value, i, j) bind(C, name="edgpu_sp_insert_element") result(rc)
+       import :: c_int, c_int64_t, c_double, c_ptr
+       type(c_ptr), value        :: m
+       real(c_double), value     :: value
+       integer(c_int64_t), value :: i, j
+       integer(c_int)            :: rc
+     end function edgpu_sp_insert_element
+     function edgpu_sp_delete_matrix(m) bind(C, name="edgpu_sp_delete_matrix") result(rc)
+       import :: c_int, c_ptr
+       type(c_ptr), value :: m
+       integer(c_int)     :: rc
+     end function edgpu_sp_delete_matrix
+     function edgpu_sp_dump_matrix(m, dense) bind(C, name="edgpu_sp_dump_matrix") result(rc)
+       import :: c_int, c_double, c_ptr
+       type(c_ptr), value :: m
+       real(c_double)     :: dense(*)
+       integer(c_int)     :: rc
+     end function edgpu_sp_dump_matrix
+     function edgpu_sp_row(m, i, size, cols, vals, cap) bind(C, name="edgpu_sp_row") result(rc)
+       import :: c_int, c_int32_t, c_int64_t, c_ptr
+       type(c_ptr), value        :: m
+       integer(c_int64_t), value :: i
+       integer(c_int32_t)        :: size
+       type(c_ptr), value        :: cols, vals          ! null: only the size is returned
+       integer(c_int32_t), value :: cap
+       integer(c_int)            :: rc
+     end function edgpu_sp_row
+     function edgpu_sp_matvec(m, v, hv, accumulate) bind(C, name="edgpu_sp_matvec") result(rc)
+       import :: c_int, c_int32_t, c_double, c_ptr
+       type(c_ptr), value         :: m
+       real(c_double), intent(in) :: v(*)
+       real(c_double)             :: hv(*)
+       integer(c_int32_t), value  :: accumulate
+       integer(c_int)             :: rc
+     end function edgpu_sp_matvec
      function edgpu_cache_release() bind(C, name="edgpu_cache_release") result(rc)
        import :: c_int
        integer(c_int) :: rc
@@ -211,6 +314,16 @@ module EDGPU_C_API
   end interface
 
 contains
+
+  !> the reference aborts with `stop "<msg>"`: non-zero status -> print the library's message and stop
+  subroutine edgpu_check(rc, where)
+    integer(c_int), intent(in)   :: rc
+    character(len=*), intent(in) :: where
+    if (rc /= 0) then
+       write(*,"(A)") trim(where)//": "//edgpu_error_message()
+       stop "edgpu error"
+    end if
+  end subroutine edgpu_check
 
   !> message of the last failed call as a Fortran string
   function edgpu_error_message() result(s)

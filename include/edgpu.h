@@ -144,11 +144,17 @@ int edgpu_lanczos_time(edgpu_handle h, int32_t nwarm, int32_t niter, float *ms_p
  * NULL).  nconv = number of requested pairs whose residual passed |r| <= tol*max(eps^(2/3),|theta|). */
 int edgpu_eigsh(edgpu_handle h, int32_t nev, int32_t ncv, int32_t maxiter, double tol, double *evals, double *evecs,
                 int32_t *nconv, int32_t *nrestarts, int32_t *nmatvec);
+/* Returns EDGPU_ENOTCONVERGED (outputs still filled) when fewer than nev pairs converged.  The basis holds at most
+ * edgpu_eigsh_ncv_cap() vectors (96; the reference's Nblock = 10*max(Neigen,lanc_nstates_sector)+lanc_ncv_add,
+ * ED_DIAG.f90:95-98, exceeds that only for lanc_nstates_sector > 9): a larger ncv is reduced to the cap -- a smaller
+ * thick-restart basis costs restarts, not accuracy -- and edgpu_eigsh_ncv_used() tells what the last call ran with. */
+int32_t edgpu_eigsh_ncv_cap(void);
+int32_t edgpu_eigsh_ncv_used(edgpu_handle h);
 /* sp_dvdson_eigh(MatVec,eval,evec,nitermax,tol)   ED_DIAG.f90:189-203 (lanc_method="dvdson"): Davidson with the
  * diagonal of H as preconditioner; search space and its image under H in HBM.  `maxiter` products at most; a pair
  * counts as converged when |H x - theta x| <= max(tol,1e-11)*max(1,|theta|).  Same outputs as edgpu_eigsh. */
 int edgpu_dvdson(edgpu_handle h, int32_t nev, int32_t maxiter, double tol, double *evals, double *evecs,
-                 int32_t *nconv, int32_t *nmatvec);
+                 int32_t *nconv, int32_t *nmatvec);      /* EDGPU_ENOTCONVERGED as edgpu_eigsh */
 
 /* ---- observables: impurity-configuration weights of a state --------------------
  * hist[(mu*2^Norb + md) + 4^Norb*iph] = sum_i |vec_i|^2 over the states whose impurity up/down

@@ -40,6 +40,34 @@ def test_eigsh_agrees_with_plain_lanczos_on_c2(edgpu_mod):
     G.close()
 
 
+def test_eigsh_large_basis_and_unconverged_is_an_error(edgpu_mod):
+    """Nblock = 10*max(Neigen,lanc_nstates_sector)+lanc_ncv_add (ED_DIAG.f90:95-98) exceeds 48 as soon as lanc_nstates_sector
+    does 5 (finite temperature): bases up to 96 vectors run as asked, larger requests run with 96 and say so; and a run that
+    ends before all requested pairs converged raises instead of handing back Ritz values as eigenvalues."""
+    from edgpu import model, capi
+    m, nu, nd = model.half_filled_c(7)           # N = 4900
+    S = oracle.Sector(m, nu, nd)
+    w = np.linalg.eigvalsh(S.hmat())
+    G = edgpu_mod.HvSector(m, nu, nd)
+    assert capi.lib().edgpu_eigsh_ncv_cap() == 96
+    for nblock, used in ((70, 70), (200, 96)):
+        ev, X, info = G.sp_eigh(6, nblock=nblock, nitermax=300, tol=1e-12)
+        assert info["ncv_used"] == used and info["nconv"] == 6
+        np.testing.assert_allclose(ev, w[:6], rtol=0, atol=1e-10)
+        assert np.abs(X.T @ X - np.eye(6)).max() < 1e-10
+        for i in range(6):
+            assert np.linalg.norm(S.spmatvec(X[:, i]) - ev[i] * X[:, i]) < 1e-8
+    with pytest.raises(capi.EdgpuError) as e:     # one restart of a 8-vector basis cannot converge 3 pairs of a 4900-state sector
+        G.sp_eigh(3, nblock=8, nitermax=1, tol=1e-13)
+    assert e.value.code == capi.ENOTCONVERGED
+    ev, X, info = G.sp_eigh(3, nblock=8, nitermax=1, tol=1e-13, allow_unconverged=True)
+    assert info["nconv"] < 3 and np.all(np.isfinite(ev))
+    with pytest.raises(capi.EdgpuError) as e:
+        G.sp_dvdson_eigh(3, nitermax=3, tol=1e-13)
+    assert e.value.code == capi.ENOTCONVERGED
+    G.close()
+
+
 def test_eigsh_argument_errors(edgpu_mod):
     from edgpu import model, capi
     m, nu, nd = model.half_filled_c(1)           # N = 4
