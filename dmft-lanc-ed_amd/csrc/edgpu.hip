@@ -483,6 +483,80 @@ int edgpu_imp_histogram(edgpu_handle h, const double *vec, int32_t vec_on_device
     return EDGPU_OK;
 }
 
+// Local energy terms of one state (lanc_local_energy, ED_OBSERVABLES.f90:372-616), weight 1 (the host applies
+// peso = exp(-beta(Ei-Egs))/Z and sums over its state list):
+//   out[0] ed_Epot (interaction energy INCLUDING the Hartree shift, as the routine leaves it at 589)   out[1] ed_Ehartree
+//   out[2] ed_Eknot   out[3] ed_Dust   out[4] ed_Dund   out[5] ed_Dse   out[6] ed_Dph
+// The density terms are sums over the impurity-configuration weights (edgpu_imp_histogram), the off-diagonal impHloc part
+// of Eknot over the impurity density matrix (edgpu_imp_density_offdiag), Dse / Dph one more pass over the state
+// (k_nd_expect).  ed_total_ud=F: density terms only, as in the reference (the other blocks sit under if(ed_total_ud)).
+int edgpu_local_energy(edgpu_handle h, const double *state_host, double *out7)
+{
+    if (!h || !state_host || !out7) return fail(EDGPU_EINVAL, "edgpu_local_energy: null argument");
+    HIPCHK(hipSetDevice(h->device));
+    const SectorHost &H = h->H; const edgpu_desc &d = H.desc;
+    const int Norb = d.Norb, nI = 1 << Norb;
+    const double *st = nullptr;
+    CHK(stage_state(h, state_host, &st));
+    std::vector<double> hist((size_t)nI * nI * H.DimPh);
+    CHK(edgpu_imp_histogram(h, st, 1, hist.data()));
+    double Epot = 0.0, Ehar = 0.0, Eknot = 0.0, Dust = 0.0, Dund = 0.0, Dse = 0.0, Dph = 0.0;
+    for (int iph = 0; iph < H.DimPh; iph++)
+        for (int mu = 0; mu < nI; mu++)
+            for (int md = 0; md < nI; md++) {
+                const double w = hist[(size_t)(mu * nI + md) + (size_t)nI * nI * iph];
+                if (w == 0.0) continue;
+                auto nu = [&](int a) { return (double)((mu >> a) & 1); };
+                auto nd = [&](int a) { return (double)((md >> a) & 1); };
+                for (int a = 0; a < Norb; a++) {
+                    Eknot += H.imp(1, 1, a + 1, a + 1) * nu(a) * w + H.imp(d.Nspin, d.Nspin, a + 1, a + 1) * nd(a) * w;
+                    Epot += d.Uloc[a] * nu(a) * nd(a) * w;
+                    if (d.hfmode) Ehar += (-0.5 * d.Uloc[a] * (nu(a) + nd(a)) + 0.25 * d.Uloc[a]) * w;
+                }
+                for (int a = 0; a < Norb; a++)
+                    for (int b = a + 1; b < Norb; b++) {
+                        const double ust = nu(a) * nd(b) + nu(b) * nd(a), und = nu(a) * nu(b) + nd(a) * nd(b), n4 = nu(a) + nd(a) + nu(b) + nd(b);
+                        Epot += d.Ust * ust * w + (d.Ust - d.Jh) * und * w;
+                        Dust += ust * w; Dund += und * w;
+                        if (d.hfmode) Ehar += (-0.5 * d.Ust * n4 + 0.25 * d.Ust - 0.5 * (d.Ust - d.Jh) * n4 + 0.25 * (d.Ust - d.Jh)) * w;
+                    }
+            }
+    if (h->two_factor && Norb > 1) {
+        bool offd = false;
+        for (int a = 1; a <= Norb; a++) for (int b = 1; b <= Norb; b++) if (a != b && (H.imp(1, 1, a, b) != 0.0 || H.imp(d.Nspin, d.Nspin, a, b) != 0.0)) offd = true;
+        if (offd) {
+            std::vector<double> dm((size_t)2 * Norb * Norb);
+            CHK(edgpu_imp_density_offdiag(h, st, dm.data()));
+            for (int a = 0; a < Norb; a++) for (int b = 0; b < Norb; b++) if (a != b)
+                Eknot += H.imp(1, 1, a + 1, b + 1) * dm[(size_t)(0 * Norb + a) * Norb + b] + H.imp(d.Nspin, d.Nspin, a + 1, b + 1) * dm[(size_t)(1 * Norb + a) * Norb + b];
+        }
+        if (H.Jhflag && (d.Jx != 0.0 || d.Jp != 0.0)) {
+            const int64_t nrows = H.Qdw * H.DimPh;
+            DevBuf<double> o; CHK(o.alloc((size_t)nrows * 2));
+            NdExpArgs A{}; A.DimUp = (int32_t)H.DimUp; A.DimDw = (int32_t)H.DimDw; A.Norb = Norb; A.Qdw = H.Qdw; A.dw0 = H.dw0;
+            A.mapup = h->fac[0]->map.p; A.mapdw = h->fac[1]->map.p; A.rankup = h->fac[0]->rank.p; A.rankdw = h->fac[1]->rank.p;
+            A.do_se = d.Jx != 0.0; A.do_ph = d.Jp != 0.0; A.v = st; A.vfull = st; A.full_rows = H.DimDw; A.out = o.p;
+            const bool dist = h->multi && h->comm.size > 1;
+            DevBuf<double> full;
+            if (dist) { CHK(full.alloc((size_t)(H.DimUp * H.DimDw * H.DimPh))); CHK(gather_full(h, st, full.p, h->stream)); A.vfull = full.p; }
+            hipLaunchKernelGGL(k_nd_expect, dim3((unsigned)nrows), dim3(256), 0, h->stream, A);
+            HIPCHK(hipGetLastError());
+            std::vector<double> part((size_t)nrows * 2);
+            HIPCHK(hipMemcpyAsync(part.data(), o.p, part.size() * 8, hipMemcpyDeviceToHost, h->stream)); HIPCHK(hipStreamSynchronize(h->stream));
+            double acc[2] = {0.0, 0.0};
+            for (int64_t r = 0; r < nrows; r++) { acc[0] += part[(size_t)r * 2]; acc[1] += part[(size_t)r * 2 + 1]; }
+            if (dist) {
+                std::vector<double> a2(acc, acc + 2); DevBuf<double> dd; CHK(dd.upload(a2)); CHK(allreduce_dev(h, dd.p, 2));
+                HIPCHK(hipMemcpyAsync(acc, dd.p, 16, hipMemcpyDeviceToHost, h->stream)); HIPCHK(hipStreamSynchronize(h->stream));
+            }
+            Dse = acc[0]; Dph = acc[1];
+            Epot += d.Jx * Dse + d.Jp * Dph;
+        }
+    }
+    out7[0] = Epot + Ehar; out7[1] = Ehar; out7[2] = Eknot; out7[3] = Dust; out7[4] = Dund; out7[5] = Dse; out7[6] = Dph;
+    return EDGPU_OK;
+}
+
 // mean duration (ms) of the exchange step over the last timed batch (multi-rank; 0 on one rank): HIP events on the comm stream
 int edgpu_lanczos_bench_comm_ms(edgpu_handle h, int32_t nsteps_timed, float *ms_mean)
 {

@@ -638,6 +638,69 @@ __global__ void __launch_bounds__(256) k_ndpass(NdArgs A)
     }
 }
 
+// Expectation values of the spin-exchange and pair-hopping operators in a state (lanc_local_energy, ED_OBSERVABLES.f90:
+// 470-527: ed_Dse, ed_Dph): sum_i sgn * v_i * v_j over the same (a,b) terms as k_ndpass, with unit amplitude and the two
+// kinds kept apart.  out[row*2 + kind]: partial sums per (idw,iph) row in a fixed order.
+struct NdExpArgs {
+    int32_t DimUp, DimDw, Norb; int64_t Qdw, dw0;
+    const int32_t *mapup, *mapdw, *rankup, *rankdw;
+    int32_t do_se, do_ph;
+    const double *v; const double *vfull; int64_t full_rows;   // vfull: gathered vector (global rows) with several ranks, else the shard itself
+    double *out;
+};
+__global__ void __launch_bounds__(256) k_nd_expect(NdExpArgs A)
+{
+    __shared__ int32_t s_jdw[2 * EDGPU_MAX_ORB * EDGPU_MAX_ORB];
+    __shared__ double s_sg[2 * EDGPU_MAX_ORB * EDGPU_MAX_ORB];
+    __shared__ double red[4];
+    const int64_t row = blockIdx.x;
+    const int iph = (int)(row / A.Qdw);
+    const int64_t idwl = row - (int64_t)iph * A.Qdw, idw = A.dw0 + idwl;
+    const uint32_t mdw = (uint32_t)A.mapdw[idw];
+    const int nslot = 2 * A.Norb * A.Norb;
+    if ((int)threadIdx.x < nslot) {
+        const int kind = threadIdx.x & 1, ab = threadIdx.x >> 1, a = ab / A.Norb, b = ab - a * A.Norb;
+        const uint32_t ba = 1u << a, bb = 1u << b;
+        int32_t jd = -1; double sg = 0.0;
+        if (a != b) {
+            if (kind == 0 && A.do_se && (mdw & ba) && !(mdw & bb)) {
+                const uint32_t k1 = mdw & ~ba, k2 = k1 | bb;
+                jd = A.rankdw[k2]; sg = ((__popc(mdw & (ba - 1)) + __popc(k1 & (bb - 1))) & 1) ? -1.0 : 1.0;
+            }
+            if (kind == 1 && A.do_ph && (mdw & bb) && !(mdw & ba)) {
+                const uint32_t k1 = mdw & ~bb, k2 = k1 | ba;
+                jd = A.rankdw[k2]; sg = ((__popc(mdw & (bb - 1)) + __popc(k1 & (ba - 1))) & 1) ? -1.0 : 1.0;
+            }
+        }
+        s_jdw[threadIdx.x] = jd; s_sg[threadIdx.x] = sg;
+    }
+    __syncthreads();
+    const int DimUp = A.DimUp;
+    const double *vrow = A.v + row * DimUp;
+    double acc[2] = {0.0, 0.0};
+    for (int iup = threadIdx.x; iup < DimUp; iup += blockDim.x) {
+        const uint32_t mup = (uint32_t)A.mapup[iup];
+        const double vi = vrow[iup];
+        for (int a = 0; a < A.Norb; a++)
+            for (int b = 0; b < A.Norb; b++) {
+                const uint32_t ba = 1u << a, bb = 1u << b;
+                if (a == b || !(mup & bb) || (mup & ba)) continue;
+                const uint32_t k3 = mup & ~bb, k4 = k3 | ba;
+                const double sgu = ((__popc(mup & (bb - 1)) + __popc(k3 & (ba - 1))) & 1) ? -1.0 : 1.0;
+                const int slot = 2 * (a * A.Norb + b);
+#pragma unroll
+                for (int kind = 0; kind < 2; kind++) {
+                    const int32_t jd = s_jdw[slot + kind];
+                    if (jd < 0) continue;
+                    const int64_t jrow = A.vfull == A.v ? (int64_t)iph * A.Qdw + (jd - A.dw0) : (int64_t)iph * A.full_rows + jd;
+                    acc[kind] += sgu * s_sg[slot + kind] * vi * A.vfull[jrow * DimUp + A.rankup[k4]];
+                }
+            }
+    }
+#pragma unroll
+    for (int kind = 0; kind < 2; kind++) { const double t = block_sum(acc[kind], red); if (threadIdx.x == 0) A.out[row * 2 + kind] = t; __syncthreads(); }
+}
+
 // ---------------------------------------------------------------------------------------------
 // Distributed-transpose form of the dw hops (the reference's own MPI scheme: vector_transpose_MPI,
 // ED_HAMILTONIAN_COMMON.f90:53-125, used by spMatVec_mpi_main 621-692): every rank turns its (Qdw x DimUp)

@@ -165,7 +165,17 @@ static int fetch_coeffs(S *s, int k, std::vector<double> &al, std::vector<double
     return EDGPU_OK;
 }
 
+static int lanczos_gs_impl(S *s, int nitermax, double threshold, int ncheck, double *egs, double *vect_dev, int *nlanc_out);
 static int lanczos_gs(S *s, int nitermax, double threshold, int ncheck, double *egs, double *vect_dev, int *nlanc_out)
+{
+    // the cached Krylov vectors must survive an out-of-memory retry of any allocation made while the search runs
+    g_kpool.in_use = true;
+    const int rc = lanczos_gs_impl(s, nitermax, threshold, ncheck, egs, vect_dev, nlanc_out);
+    g_kpool.in_use = false;
+    if (rc == EDGPU_OK && !dbg_int("EDGPU_LZ_CACHE", 1)) kpool_release();      // default: keep the buffers for the next search
+    return rc;
+}
+static int lanczos_gs_impl(S *s, int nitermax, double threshold, int ncheck, double *egs, double *vect_dev, int *nlanc_out)
 {
     if (nitermax < 1) return fail(EDGPU_EINVAL, "edgpu_lanczos_gs: nitermax < 1");
     if (ncheck < 1) ncheck = 10;
@@ -191,7 +201,7 @@ static int lanczos_gs(S *s, int nitermax, double threshold, int ncheck, double *
     bool store = dbg_int("EDGPU_LZ_STORE", 1) != 0 && store_max >= 4;
     int64_t budget = 0;       // bytes this call may still add to the cache (one driver query: hipMemGetInfo is slow)
     if (store) {
-        if (g_kpool.device != s->device) { kpool_release(); g_kpool.device = s->device; }
+        if (g_kpool.device != s->device) { g_kpool.in_use = false; kpool_release(); g_kpool.in_use = true; g_kpool.device = s->device; }
         size_t fr = 0, tot = 0; HIPCHK(hipMemGetInfo(&fr, &tot));
         budget = (int64_t)fr - (int64_t)((double)tot * 0.04) - ((int64_t)2 << 30);     // head-room left to everything else
         for (size_t k = 0; k < g_kpool.cap.size(); k++) if (g_kpool.cap[k] >= (size_t)s->nloc) budget += (int64_t)s->nloc * 8;   // already ours
@@ -300,7 +310,6 @@ static int lanczos_gs(S *s, int nitermax, double threshold, int ncheck, double *
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(vect_dev, acc, (size_t)s->nloc * 8, hipMemcpyDeviceToDevice, s->stream));
     HIPCHK(hipStreamSynchronize(s->stream));
-    if (!dbg_int("EDGPU_LZ_CACHE", 1)) kpool_release();      // default: keep the buffers for the next search
     return EDGPU_OK;
 }
 
@@ -446,8 +455,8 @@ static int eigsh(S *s, int nev, int ncv, int maxiter, double tol, double *evals,
         if (nv <= kMaxBasis) { RotArgs R{}; R.nv = nv; R.nout = nout; R.Y = s->eig_y.p; for (int i = 0; i < nv; i++) R.V[i] = Vp(i);
             hipLaunchKernelGGL(k_basis_rotate<kMaxBasis>, dim3(gsr), dim3(256), (size_t)nv * nout * 8, s->stream, R, n); }
         else { RotArgsT<kMaxBasisBig> R{}; R.nv = nv; R.nout = nout; R.Y = s->eig_y.p; for (int i = 0; i < nv; i++) R.V[i] = Vp(i);
-            static bool attr = false;
-            if (!attr) { HIPCHK(hipFuncSetAttribute((const void *)k_basis_rotate<kMaxBasisBig>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 96 * 8)); attr = true; }
+            static OncePerDevice once;
+            if (once.first(s->device)) HIPCHK(hipFuncSetAttribute((const void *)k_basis_rotate<kMaxBasisBig>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 96 * 8));
             hipLaunchKernelGGL(k_basis_rotate<kMaxBasisBig>, dim3(gsr), dim3(256), (size_t)nv * nout * 8, s->stream, R, n); }
         HIPCHK(hipGetLastError());
         return EDGPU_OK;

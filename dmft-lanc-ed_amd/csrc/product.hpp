@@ -27,8 +27,8 @@ static int reduce_partials(S *s, int64_t n)
 template <int F> static void launch_kron2(S *s, const Kron2Args &A, int64_t rows)
 {
     size_t lds = (F & KF_LDS) ? s->kron_lds : 16 * sizeof(double);
-    static bool attr_set = false;
-    if (!attr_set && lds > 64 * 1024) { (void)hipFuncSetAttribute((const void *)k_kron2<F>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; }
+    static OncePerDevice once;
+    if (lds > 64 * 1024 && once.first(s->device)) (void)hipFuncSetAttribute((const void *)k_kron2<F>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipLaunchKernelGGL(k_kron2<F>, dim3((unsigned)rows), dim3(s->kron_threads), lds, s->stream, A);
 }
 
@@ -63,7 +63,7 @@ static int direct_tables(S *s)
         bool wave_ok = tm.size() <= 64 && f.width <= 64;
         for (size_t a = 0; a < tm.size() && wave_ok; a++)
             for (size_t b = a + 1; b < tm.size(); b++) if (tm[a].alpha == tm[b].alpha && tm[a].beta == tm[b].beta) { wave_ok = false; break; }
-        if (wave_ok && dbg_int("EDGPU_TABLES_WAVE", 1)) hipLaunchKernelGGL(k_direct_tables_wave, dim3((unsigned)cdiv(T.dim, 4)), dim3(256), 0, s->stream, T);
+        if (wave_ok && s->tables_wave) hipLaunchKernelGGL(k_direct_tables_wave, dim3((unsigned)cdiv(T.dim, 4)), dim3(256), 0, s->stream, T);
         else if (f.width <= 16) hipLaunchKernelGGL(k_direct_tables<16>, dim3((unsigned)cdiv(T.dim, 64)), dim3(64), 0, s->stream, T);
         else hipLaunchKernelGGL(k_direct_tables<64>, dim3((unsigned)cdiv(T.dim, 64)), dim3(64), 0, s->stream, T);
     }
@@ -116,10 +116,10 @@ static int transposed_dw_pass(S *s, const double *v, hipStream_t st)
         TdwFusedArgs F{}; F.DimDw = (int32_t)H.DimDw; F.dww = s->fac[1]->width; F.P = P; F.Qup = s->Qup;
         for (int r = 0; r <= P; r++) F.dw0[r] = Bk.dw0[r];
         F.ellc = s->fac[1]->ellc.p; F.ellv = s->fac[1]->ellv.p; F.blk_in = s->tB.p; F.blk_out = s->tVT.p;
-        if (dbg_flags() & 2) F.dww = 0;
+        if (s->dbg & 2) F.dww = 0;
         if (s->Qup > 0) {
-            static bool attr = false;
-            if (!attr) { if (hipFuncSetAttribute((const void *)k_tdw_blocks, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024) != hipSuccess) (void)hipGetLastError(); attr = true; }
+            static OncePerDevice once;
+            if (once.first(s->device)) { if (hipFuncSetAttribute((const void *)k_tdw_blocks, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024) != hipSuccess) (void)hipGetLastError(); }
             hipLaunchKernelGGL(k_tdw_blocks, dim3((unsigned)s->Qup), dim3(H.DimDw >= 4096 ? 1024 : 256), (size_t)H.DimDw * 8, st, F);
         }
         HIPCHK(hipGetLastError());
@@ -131,7 +131,7 @@ static int transposed_dw_pass(S *s, const double *v, hipStream_t st)
     hipLaunchKernelGGL(k_tblocks, dim3(bgrid), dim3(256), 0, st, Bk);
     TdwArgs D{}; D.DimDw = (int32_t)H.DimDw; D.dww = s->fac[1]->width; D.use_lds = 0;
     D.ellc = s->fac[1]->ellc.p; D.ellv = s->fac[1]->ellv.p; D.vt = s->tVT.p; D.hvt = s->tHVT.p;
-    if (dbg_flags() & 2) D.dww = 0;
+    if (s->dbg & 2) D.dww = 0;
     if (s->Qup > 0 && s->fac[1]->packed_elem8 && s->up_big && D.dww > 0) {
         // long rows: the packed-image gather kernel of the local pass, applied to H_dw (no diagonal)
         UpBigArgs U{};
@@ -181,18 +181,17 @@ static int hxv(S *s, const double *v, double *out, bool epi, const double *uprev
             L.Qdw = H.Qdw; L.DimUp = (int32_t)H.DimUp; L.rb = rb; L.rbshift = 0; while ((1 << L.rbshift) < rb) L.rbshift++;
             L.cpr = (int32_t)cdiv(H.DimUp, rb);
             L.rowptr = rp; L.cols = cc; L.vals = vv; L.x = xptr; L.xrow0 = s->halo ? 0 : H.dw0;     // x-space row of local dw row 0 (columns are x-space: build_csr's rowshift)
-            L.y = out; L.v_local = v; L.uprev = uprev; L.scal = s->scal.p; L.partial = s->partial.p; L.epi = epi; L.pass = pass; L.dbg = (dbg_flags() >> 3) & 3;
+            L.y = out; L.v_local = v; L.uprev = uprev; L.scal = s->scal.p; L.partial = s->partial.p; L.epi = epi; L.pass = pass; L.dbg = (s->dbg >> 3) & 3;
             if (win) {
                 const int grid = (int)std::min<int64_t>(H.Qdw, s->csr_lds_grid);
                 const size_t xw = (((size_t)H.DimUp * 8 + 31) & ~(size_t)31);
 #define CSRW_LAUNCH(NT_, CAP_, D_)                                                                                           \
     do {                                                                                                                         \
         const size_t lds = xw + (NT_ / 64) * (size_t)((CAP_ + 8) * 12) + 128;                                                    \
-        static bool attr = false;                                                                                                \
-        if (!attr) {                                                                                                             \
+        static OncePerDevice once_;                                                                                              \
+        if (once_.first(s->device)) {                                                                                            \
             HIPCHK(hipFuncSetAttribute((const void *)k_csr_lds<NT_, CAP_, true, D_, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));  \
             HIPCHK(hipFuncSetAttribute((const void *)k_csr_lds<NT_, CAP_, true, D_, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
-            attr = true;                                                                                                         \
         }                                                                                                                        \
         if (pass != 0) hipLaunchKernelGGL((k_csr_lds<NT_, CAP_, true, D_, true>), dim3(grid), dim3(NT_), lds, s->stream, L);     /* local block of the split form: every column lies in the window */ \
         else hipLaunchKernelGGL((k_csr_lds<NT_, CAP_, true, D_, false>), dim3(grid), dim3(NT_), lds, s->stream, L);              \
@@ -274,8 +273,8 @@ static int hxv(S *s, const double *v, double *out, bool epi, const double *uprev
         A.impmask = (1 << d.Norb) - 1; A.nI = 1 << d.Norb; A.econst = H.econst; A.w0 = d.w0_ph; A.gsum = H.gph_sum; A.Jx = d.Jx; A.Jp = d.Jp;
         A.gup = s->gup.p; A.gdw = s->gdw.p;
         A.v = v; A.vfull = multi ? s->vfull.p : v; A.out = out; A.uprev = uprev; A.scal = s->scal.p; A.partial = s->partial.p;
-        if (dbg_flags() & 1) A.upw = 0;
-        if (dbg_flags() & 2) A.dww = 0;
+        if (s->dbg & 1) A.upw = 0;
+        if (s->dbg & 2) A.dww = 0;
         int base = (direct ? KF_DIRECT : 0) | (epi ? KF_EPI : 0) | (s->extra ? (KF_PH | KF_ND) : 0);
         nblocks = H.Qdw * H.DimPh;
         // phonon terms live in the fused kernel only; Jx/Jp (without phonons) have their own pass
@@ -293,18 +292,16 @@ static int hxv(S *s, const double *v, double *out, bool epi, const double *uprev
                 U.v = v; U.out = out; U.uprev = uprev; U.scal = s->scal.p;
                 const size_t lds = (size_t)H.DimUp * 8 + 128 * 8;
                 const int grid = (int)std::min<int64_t>(U.nrows, s->up_grid);
-                static bool attr2 = false;
-                if (!attr2) {
+                static OncePerDevice once2;
+                if (once2.first(s->device)) {
                     (void)hipFuncSetAttribute((const void *)k_uppass2<false, false, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
                     (void)hipFuncSetAttribute((const void *)k_uppass2<false, true, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-                    attr2 = true;
                 }
                 if (direct) {
-                    static bool attr3 = false;
-                    if (!attr3) {
+                    static OncePerDevice once3;
+                    if (once3.first(s->device)) {
                         (void)hipFuncSetAttribute((const void *)k_uppass2<true, false, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
                         (void)hipFuncSetAttribute((const void *)k_uppass2<true, true, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-                        attr3 = true;
                     }
                     if (epi) hipLaunchKernelGGL((k_uppass2<true, true, 1024>), dim3(grid), dim3(1024), lds, s->stream, U);
                     else hipLaunchKernelGGL((k_uppass2<true, false, 1024>), dim3(grid), dim3(1024), lds, s->stream, U);
@@ -321,8 +318,8 @@ static int hxv(S *s, const double *v, double *out, bool epi, const double *uprev
                 const int grid = (int)std::min<int64_t>(U.nrows, s->up_grid);
 #define UP_LAUNCH(D_, E_, T_)                                                                                                   \
     do {                                                                                                                            \
-        static bool attr_ = false;                                                                                                  \
-        if (!attr_) { (void)hipFuncSetAttribute((const void *)k_uppass<D_, E_, T_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_ = true; } \
+        static OncePerDevice once_;                                                                                                 \
+        if (once_.first(s->device)) (void)hipFuncSetAttribute((const void *)k_uppass<D_, E_, T_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
         hipLaunchKernelGGL((k_uppass<D_, E_, T_>), dim3(grid), dim3(T_), lds, s->stream, U);                                        \
     } while (0)
                 if (s->up_threads == 512) {
@@ -382,13 +379,12 @@ static int hxv(S *s, const double *v, double *out, bool epi, const double *uprev
                 } else {
                     const bool nt = dv != 2, rag = s->fac[1]->ragged;
                     // LDS also sets how many workgroups share a CU: fewer residents thrash the tile's L2 slab less (measured best: 48 KB)
-                    const size_t dlds = std::max<size_t>((size_t)D.R * D.dww * 12 + 16, (size_t)std::min(dbg_int("EDGPU_DW_LDS_KB", 48), 150) * 1024);
+                    const size_t dlds = std::max<size_t>((size_t)D.R * D.dww * 12 + 16, (size_t)s->dw_lds_kb * 1024);
 #define DW_LAUNCH(E_, N_, R_)                                                                                                   \
     do {                                                                                                                            \
-        static bool attr_ = false;                                                                                                  \
-        if (!attr_ && dlds > 60 * 1024) {      /* static LDS of the kernel comes on top: stay below the 160 KB of a CU */           \
+        static OncePerDevice once_;                                                                                                 \
+        if (dlds > 60 * 1024 && once_.first(s->device)) {      /* static LDS of the kernel comes on top: stay below the 160 KB of a CU */ \
             if (hipFuncSetAttribute((const void *)k_dwpass2<E_, N_, R_>, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024) != hipSuccess) (void)hipGetLastError(); \
-            attr_ = true;                                                                                                           \
         }                                                                                                                           \
         hipLaunchKernelGGL((k_dwpass2<E_, N_, R_>), dim3((unsigned)nblocks), dim3(256), dlds, s->stream, D);                        \
     } while (0)

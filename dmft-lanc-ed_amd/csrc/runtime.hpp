@@ -125,10 +125,13 @@ template <class T> struct DevBuf {
     ~DevBuf() { release(); }
 };
 
-struct KrylovPool { std::vector<double *> buf; std::vector<size_t> cap; int device = -1; double *slab = nullptr; size_t slab_cap = 0; };   // slab: all vectors of a small sector in one allocation
+// Single host thread per process (one rank per GPU, as the reference): the pool is not synchronised.  `in_use` is set for
+// the duration of a ground-state search: a failing allocation elsewhere must not free the vectors that search is using.
+struct KrylovPool { std::vector<double *> buf; std::vector<size_t> cap; int device = -1; double *slab = nullptr; size_t slab_cap = 0; bool in_use = false; };   // slab: all vectors of a small sector in one allocation
 static KrylovPool g_kpool;
 static void kpool_release()
 {
+    if (g_kpool.in_use) return;      // the out-of-memory retry then simply fails with EDGPU_ENOMEM
     for (double *q : g_kpool.buf) if (q) (void)hipFree(q);
     g_kpool.buf.clear(); g_kpool.cap.clear();
     if (g_kpool.slab) (void)hipFree(g_kpool.slab);
@@ -185,6 +188,8 @@ struct edgpu_sector_s {
     std::vector<hipEvent_t> comm_ev; int comm_slot = -1;     // timed bench steps: events around the exchange on the comm stream
     int64_t nnz_total = 0, bytes_stored = 0;
     int64_t npartial = 0;
+    // knobs read from the environment ONCE, at sector creation (never inside a product)
+    int dbg = 0; bool tables_wave = true; int dw_lds_kb = 48;
     int eig_ncv_used = 0;     // basis size the last edgpu_eigsh call actually ran with
     // Lanczos iteration fusion (single rank)
     int fuse_mode = -1; const double *fuse_zvec = nullptr;   // >= 0: the product's final reduction also performs this scalar step
@@ -222,6 +227,8 @@ namespace edgpu {
 using S = edgpu_sector_s;
 
 static int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+// launch attributes (dynamic LDS limit) are set once per function AND device
+struct OncePerDevice { bool done[64] = {}; bool first(int dev) { if (dev < 0 || dev >= 64) return true; const bool f = !done[dev]; done[dev] = true; return f; } };
 static int dbg_flags() { const char *e = getenv("EDGPU_DEBUG"); return e ? atoi(e) : 0; }
 static int dbg_int(const char *name, int dflt) { const char *e = getenv(name); return e ? atoi(e) : dflt; }
 

@@ -242,6 +242,14 @@ class HvSector:
             check(capi.lib().edgpu_imp_histogram(self._h, vec.ctypes.data, 0, hist.ctypes.data))
         return hist.reshape(int(self.DimPh), nI, nI).transpose(1, 2, 0)      # [mu, md, iph]
 
+    def local_energy(self, state, peso=1.0):
+        """ed_Epot, ed_Ehartree, ed_Eknot, ed_Dust, ed_Dund, ed_Dse, ed_Dph of lanc_local_energy (ED_OBSERVABLES.f90:372-616)
+        for one state (numpy array or DeviceVector) with weight `peso`."""
+        sp, _keep = _state_ptr(state)
+        out = np.zeros(7)
+        check(capi.lib().edgpu_local_energy(self._h, sp, out.ctypes.data))
+        return dict(zip(("Epot", "Ehartree", "Eknot", "Dust", "Dund", "Dse", "Dph"), out * peso))
+
     def observables(self, vec, peso=1.0):
         """dens, dens_up, dens_dw, docc, magz, sz2, n2, s2tot, Prob, prob_ph, dens_ph of
         lanc_observables (ED_OBSERVABLES.f90:150-215) from the impurity-configuration weights."""

@@ -40,6 +40,7 @@ module ED_HAMILTONIAN_GPU
   public :: lanc_phonon_leg_gpu      ! lanc_build_gf_phonon_main             (ED_GF_PHONON.f90:40-123)
   public :: imp_histogram_gpu        ! impurity-configuration weights -> every local observable (ED_OBSERVABLES.f90:150-215)
   public :: imp_density_offdiag_gpu  ! ED_OBSERVABLES.f90:283-313
+  public :: lanc_local_energy_gpu    ! per-state sums of lanc_local_energy (ED_OBSERVABLES.f90:372-616)
   public :: twin_reorder_gpu         ! es_return_cvector, itwin branch (ED_EIGENSPACE.f90:486-497)
 
   type sector_gpu
@@ -329,6 +330,17 @@ contains
     if (.not. Hstatus) stop "imp_density_offdiag_gpu ERROR: Hsector NOT set"
     call edgpu_check(edgpu_imp_density_offdiag(Hhandle, vec, dm), "imp_density_offdiag_gpu")
   end subroutine imp_density_offdiag_gpu
+
+  !> ed_Epot (incl. Hartree shift), ed_Ehartree, ed_Eknot, ed_Dust, ed_Dund, ed_Dse, ed_Dph of one state of the live sector,
+  !  weight 1: the host multiplies by peso and sums over its state list (ED_OBSERVABLES.f90:391-577)
+  subroutine lanc_local_energy_gpu(state, Epot, Ehartree, Eknot, Dust, Dund, Dse, Dph)
+    real(8), intent(in)  :: state(:)
+    real(8), intent(out) :: Epot, Ehartree, Eknot, Dust, Dund, Dse, Dph
+    real(c_double) :: o(7)
+    if (.not. Hstatus) stop "lanc_local_energy_gpu ERROR: Hsector NOT set"
+    call edgpu_check(edgpu_local_energy(Hhandle, state, o), "lanc_local_energy_gpu")
+    Epot = o(1); Ehartree = o(2); Eknot = o(3); Dust = o(4); Dund = o(5); Dse = o(6); Dph = o(7)
+  end subroutine lanc_local_energy_gpu
 
   !> state of the twin sector (ndw,nup) from a state of the live sector
   subroutine twin_reorder_gpu(vin, vout)

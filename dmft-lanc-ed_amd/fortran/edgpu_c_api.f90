@@ -170,6 +170,13 @@ module EDGPU_C_API
        real(c_double)             :: dm(*)
        integer(c_int)             :: rc
      end function edgpu_imp_density_offdiag
+     function edgpu_local_energy(handle, state, out7) bind(C, name="edgpu_local_energy") result(rc)
+       import :: c_int, c_double, c_ptr
+       type(c_ptr), value         :: handle
+       real(c_double), intent(in) :: state(*)
+       real(c_double)             :: out7(7)
+       integer(c_int)             :: rc
+     end function edgpu_local_energy
      function edgpu_twin_reorder(handle, vin, vout) bind(C, name="edgpu_twin_reorder") result(rc)
        import :: c_int, c_double, c_ptr
        type(c_ptr), value         :: handle

@@ -167,6 +167,14 @@ int edgpu_imp_histogram(edgpu_handle h, const double *vec, int32_t vec_on_device
  * dm[(s*Norb + a)*Norb + b], s = 0 (up) / 1 (dw), a != b; the diagonal follows from edgpu_imp_histogram. */
 int edgpu_imp_density_offdiag(edgpu_handle h, const double *vec_host, double *dm);
 
+/* local energy terms of one state (lanc_local_energy, ED_OBSERVABLES.f90:372-616), weight 1 -- the host applies
+ * peso = exp(-beta(Ei-Egs))/Z and sums over its state list: out7 = { ed_Epot (interaction energy including the Hartree shift,
+ * as line 589 leaves it), ed_Ehartree, ed_Eknot, ed_Dust, ed_Dund, ed_Dse, ed_Dph }.  Density terms from the
+ * impurity-configuration weights, the off-diagonal impHloc part of Eknot from the impurity density matrix, the spin-exchange
+ * and pair-hopping expectation values (Dse, Dph; only when Jx / Jp are non-zero, as in the reference) from one pass over the
+ * state in HBM.  state: host or device pointer, vecDim doubles; summed over ranks. */
+int edgpu_local_energy(edgpu_handle h, const double *state_host, double *out7);
+
 /* eigenvector hand-off for twin sectors (ed_twin): the state of sector B(ndw,nup) from the state of this
  * sector A(nup,ndw), vector_B(i) = cvec_A(Order(i)), Order = twin_sector_order (ED_SETUP.f90:852-880,
  * ED_EIGENSPACE.f90:486-497).  Host vectors of getDim doubles.  With more than one rank vin is the rank's shard of

@@ -382,6 +382,92 @@ def lanc_observables(S, state, peso=1.0):
     return o
 
 
+def local_energy(S, state, peso=1.0):
+    """Restatement of the per-state loop of lanc_local_energy (ED_OBSERVABLES.f90:372-616): loops over the basis states
+    of sector S, accumulates ed_Eknot (diagonal + off-diagonal impHloc), ed_Epot (density terms + Jx/Jp), ed_Dust,
+    ed_Dund, ed_Dse, ed_Dph and ed_Ehartree with the reference's conditions and c/cdg calls; ed_Epot includes the Hartree
+    shift as line 589 leaves it.  Small sectors only."""
+    m = S.model
+    Norb, Nspin = m["Norb"], m["Nspin"]
+    total_ud = m.get("ed_total_ud", True)
+    Ns_Ud = S.Ns_Ud
+    imp = np.asarray(m["impHloc"], float)
+    Uloc = [float(x) for x in m["Uloc"]]; Ust, Jh, Jx, Jp = m.get("Ust", 0.0), m.get("Jh", 0.0), m.get("Jx", 0.0), m.get("Jp", 0.0)
+    hfmode = m.get("hfmode", True)
+    Jhflag = Norb > 1 and (Jx != 0.0 or Jp != 0.0)
+    dims = [int(x) for x in list(S.DimUps) + list(S.DimDws)]
+    H = [S.map(k) for k in range(2 * Ns_Ud)]
+    iel = S.DimUp * S.DimDw
+    o = dict(Epot=0.0, Ehartree=0.0, Eknot=0.0, Dust=0.0, Dund=0.0, Dse=0.0, Dph=0.0)
+    for i in range(1, S.Dim + 1):
+        iph = (i - 1) // iel + 1
+        c = (i - 1) % iel; ind = []
+        for d in dims:
+            ind.append(c % d + 1); c //= d
+        if total_ud:
+            mup, mdw = int(H[0][ind[0] - 1]), int(H[1][ind[1] - 1])
+            nup = [(mup >> a) & 1 for a in range(Norb)]; ndw = [(mdw >> a) & 1 for a in range(Norb)]
+        else:
+            nup = [int(H[a][ind[a] - 1]) & 1 for a in range(Norb)]
+            ndw = [int(H[a + Ns_Ud][ind[a + Ns_Ud] - 1]) & 1 for a in range(Norb)]
+        gw = peso * abs(state[i - 1]) ** 2
+        for a in range(Norb):
+            o["Eknot"] += imp[0, 0, a, a] * nup[a] * gw
+            o["Eknot"] += imp[Nspin - 1, Nspin - 1, a, a] * ndw[a] * gw
+        if total_ud:
+            iup, idw = ind[0], ind[1]
+            for a in range(1, Norb + 1):
+                for b in range(1, Norb + 1):
+                    if imp[0, 0, a - 1, b - 1] != 0.0 and nup[b - 1] == 1 and nup[a - 1] == 0:
+                        k1, sg1 = c_op(b, mup); k2, sg2 = cdg_op(a, k1)
+                        j = binary_search(H[0], k2) + (idw - 1) * S.DimUp + (iph - 1) * iel
+                        o["Eknot"] += imp[0, 0, a - 1, b - 1] * sg1 * sg2 * state[i - 1] * state[j - 1] * peso
+                    if imp[Nspin - 1, Nspin - 1, a - 1, b - 1] != 0.0 and ndw[b - 1] == 1 and ndw[a - 1] == 0:
+                        k1, sg1 = c_op(b, mdw); k2, sg2 = cdg_op(a, k1)
+                        j = iup + (binary_search(H[1], k2) - 1) * S.DimUp + (iph - 1) * iel
+                        o["Eknot"] += imp[Nspin - 1, Nspin - 1, a - 1, b - 1] * sg1 * sg2 * state[i - 1] * state[j - 1] * peso
+            if Jhflag and Jx != 0.0:
+                for a in range(1, Norb + 1):
+                    for b in range(1, Norb + 1):
+                        if a != b and nup[b - 1] == 1 and ndw[a - 1] == 1 and ndw[b - 1] == 0 and nup[a - 1] == 0:
+                            k1, sg1 = c_op(a, mdw); k2, sg2 = cdg_op(b, k1)
+                            k3, sg3 = c_op(b, mup); k4, sg4 = cdg_op(a, k3)
+                            j = binary_search(H[0], k4) + (binary_search(H[1], k2) - 1) * S.DimUp + (iph - 1) * iel
+                            t = sg1 * sg2 * sg3 * sg4 * state[i - 1] * state[j - 1] * peso
+                            o["Epot"] += Jx * t; o["Dse"] += t
+            if Jhflag and Jp != 0.0:
+                for a in range(1, Norb + 1):
+                    for b in range(1, Norb + 1):
+                        if nup[b - 1] == 1 and ndw[b - 1] == 1 and ndw[a - 1] == 0 and nup[a - 1] == 0:
+                            k1, sg1 = c_op(b, mdw); k2, sg2 = cdg_op(a, k1)
+                            k3, sg3 = c_op(b, mup); k4, sg4 = cdg_op(a, k3)
+                            j = binary_search(H[0], k4) + (binary_search(H[1], k2) - 1) * S.DimUp + (iph - 1) * iel
+                            t = sg1 * sg2 * sg3 * sg4 * state[i - 1] * state[j - 1] * peso
+                            o["Epot"] += Jp * t; o["Dph"] += t
+        for a in range(Norb):
+            o["Epot"] += Uloc[a] * nup[a] * ndw[a] * gw
+        if Norb > 1:
+            for a in range(Norb):
+                for b in range(a + 1, Norb):
+                    o["Epot"] += Ust * (nup[a] * ndw[b] + nup[b] * ndw[a]) * gw
+                    o["Dust"] += (nup[a] * ndw[b] + nup[b] * ndw[a]) * gw
+            for a in range(Norb):
+                for b in range(a + 1, Norb):
+                    o["Epot"] += (Ust - Jh) * (nup[a] * nup[b] + ndw[a] * ndw[b]) * gw
+                    o["Dund"] += (nup[a] * nup[b] + ndw[a] * ndw[b]) * gw
+        if hfmode:
+            for a in range(Norb):
+                o["Ehartree"] += -0.5 * Uloc[a] * (nup[a] + ndw[a]) * gw + 0.25 * Uloc[a] * gw
+            if Norb > 1:
+                for a in range(Norb):
+                    for b in range(a + 1, Norb):
+                        n4 = nup[a] + ndw[a] + nup[b] + ndw[b]
+                        o["Ehartree"] += -0.5 * Ust * n4 * gw + 0.25 * Ust * gw
+                        o["Ehartree"] += -0.5 * (Ust - Jh) * n4 * gw + 0.25 * (Ust - Jh) * gw
+    o["Epot"] += o["Ehartree"]
+    return o
+
+
 def twin_sector_order(S):
     """Order(1:Dim) of twin_sector_order (ED_SETUP.f90:852-880): flip every state of sector S to
     |{dw}>|{up}>, take its global number (+ phonon offset) and return the sorting permutation (1-based),

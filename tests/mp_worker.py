@@ -184,6 +184,10 @@ def main():
             np.testing.assert_allclose(o[k], o1[k], rtol=0, atol=1e-12)
         if total_ud and m["Norb"] > 1:
             np.testing.assert_allclose(G.imp_density_offdiag(gloc), G1.imp_density_offdiag(gs), rtol=0, atol=1e-13)
+        le, le1 = G.local_energy(gloc), G1.local_energy(gs)      # Dse / Dph partner rows live on other ranks
+        lo = oracle.local_energy(S, gs)
+        for k in le1:
+            assert abs(le[k] - le1[k]) <= 1e-12 * max(1.0, abs(le1[k])) and abs(le1[k] - lo[k]) <= 1e-12 * max(1.0, abs(lo[k])), (k, le[k], le1[k], lo[k])
         nl = min(S.Dim, 30)
         cu = [0.5] + [0.0] * (m["Norb"] - 1); cd = [-0.5] + [0.25] * (m["Norb"] - 1)
         r, r1 = G.chi_lanczos(cu, cd, gloc, nl), G1.chi_lanczos(cu, cd, gs, nl)
