@@ -325,14 +325,17 @@ int edgpu_lanczos_time(edgpu_handle h, int32_t nwarm, int32_t niter, float *ms_p
     HIPCHK(hipSetDevice(h->device));
     CHK(lz_prepare(h, nwarm + niter + 1));
     LzVecs V{h->lz[0].p, h->lz[1].p, h->lz[2].p};
+    LzF F{h->lz[1].p, h->lz[0].p, h->lz[2].p};
+    const bool fused = fused_ok(h);
     const SectorHost &H = h->H;
     hipLaunchKernelGGL(k_random_start, dim3(2048), dim3(256), 0, h->stream, V.ucur, H.DimUp, H.Qdw, H.dw0, H.DimDw, H.DimPh, (uint64_t)1234567);
     HIPCHK(hipGetLastError());
-    CHK(lz_start(h, V));
+    if (fused) { HIPCHK(hipMemsetAsync(F.uprev, 0, (size_t)h->nloc * 8, h->stream)); CHK(lzf_begin(h, F, nullptr)); }
+    else CHK(lz_start(h, V));
     int k = 0;
-    for (; k < nwarm; k++) CHK(lz_iter(h, V, k, nullptr));
+    for (; k < nwarm; k++) { if (fused) CHK(lzf_iter(h, F, F.uprev, nullptr)); else CHK(lz_iter(h, V, k, nullptr)); }
     HIPCHK(hipEventRecord(h->ev_a, h->stream));
-    for (; k < nwarm + niter; k++) CHK(lz_iter(h, V, k, nullptr));
+    for (; k < nwarm + niter; k++) { if (fused) CHK(lzf_iter(h, F, F.uprev, nullptr)); else CHK(lz_iter(h, V, k, nullptr)); }
     HIPCHK(hipEventRecord(h->ev_b, h->stream));
     HIPCHK(hipEventSynchronize(h->ev_b));
     float ms = 0.f;
@@ -351,6 +354,7 @@ int edgpu_eigsh(edgpu_handle h, int32_t nev, int32_t ncv, int32_t maxiter, doubl
 
 int32_t edgpu_eigsh_ncv_cap(void) { return kMaxBasisBig; }
 int32_t edgpu_eigsh_ncv_used(edgpu_handle h) { return h ? h->eig_ncv_used : 0; }
+int32_t edgpu_lanczos_is_fused(edgpu_handle h) { return h && fused_ok(h) ? 1 : 0; }
 
 int edgpu_dvdson(edgpu_handle h, int32_t nev, int32_t maxiter, double tol, double *evals, double *evecs, int32_t *nconv, int32_t *nmatvec)
 {
@@ -717,7 +721,13 @@ int edgpu_lanczos_bench_begin(edgpu_handle h, int32_t max_steps)
     hipLaunchKernelGGL(k_random_start, dim3(2048), dim3(256), 0, h->stream, h->bv[1], H.DimUp, H.Qdw, H.dw0, H.DimDw, H.DimPh, (uint64_t)1234567);
     HIPCHK(hipGetLastError());
     LzVecs V{h->bv[0], h->bv[1], h->bv[2]};
-    CHK(lz_start(h, V));
+    h->bench_fused = fused_ok(h);
+    if (h->bench_fused) {      // roles: bv[0] = u_{k-1}, bv[1] = u_k, bv[2] = local part
+        LzF F{h->bv[1], h->bv[0], h->bv[2]};
+        HIPCHK(hipMemsetAsync(F.uprev, 0, (size_t)h->nloc * 8, h->stream));
+        CHK(lzf_begin(h, F, nullptr));
+    } else
+        CHK(lz_start(h, V));
     h->bench_k = 0;
     while ((int)h->bench_ev.size() < 2 * max_steps) { hipEvent_t e; HIPCHK(hipEventCreate(&e)); h->bench_ev.push_back(e); }
     if (h->multi) while ((int)h->comm_ev.size() < 2 * max_steps) { hipEvent_t e; HIPCHK(hipEventCreate(&e)); h->comm_ev.push_back(e); }
@@ -733,6 +743,17 @@ int edgpu_lanczos_bench_steps(edgpu_handle h, int32_t nsteps, int32_t timed)
     if (h->bench_k + nsteps > h->nmax - 1) return fail(EDGPU_EINVAL, "edgpu_lanczos_bench_steps: more steps than announced");
     HIPCHK(hipSetDevice(h->device));
     LzVecs V{h->bv[0], h->bv[1], h->bv[2]};
+    if (h->bench_fused) {      // a step = dw half of iteration k + local half of k+1 (which holds the axpy and the norm): all of it is "product"
+        LzF F{h->bv[1], h->bv[0], h->bv[2]};
+        for (int i = 0; i < nsteps; i++) {
+            if (timed) HIPCHK(hipEventRecord(h->bench_ev[2 * i], h->stream));
+            CHK(lzf_iter(h, F, F.uprev, nullptr));
+            if (timed) HIPCHK(hipEventRecord(h->bench_ev[2 * i + 1], h->stream));
+            h->bench_k++;
+        }
+        h->bv[0] = F.uprev; h->bv[1] = F.u; h->bv[2] = F.t;
+        return EDGPU_OK;
+    }
     for (int i = 0; i < nsteps; i++) {
         const int k = h->bench_k;
         if (timed) {   // lz_iter with the product bracketed by events

@@ -408,6 +408,113 @@ __global__ void __launch_bounds__(NT) k_uppass2(UpArgs2 A)
     }
 }
 
+// Local pass of the FUSED Lanczos iteration (lz_iter_fused in lanczos.hpp).  The plain loop runs three passes over the
+// vectors per iteration: local pass, dw pass, and the axpy+norm pass w -= alpha v, beta^2 = w.w (24 B per element), because
+// alpha needs the whole product.  That last pass has the same operands as the NEXT iteration's local pass -- the residual
+// r_{k-1} and u_{k-1} -- so it is folded into it: this kernel forms u_k = r_{k-1} - (alpha_{k-1} s_{k-1}) u_{k-1} row by
+// row on its way into LDS (writing it back in place of r_{k-1} and summing |u_k|^2 = beta_{k-1}^2), then computes the
+// UNSCALED local part T = d*u_k + up hops of u_k: the scale 1/beta_{k-1} is only known after this kernel's own
+// reduction and is applied by the dw pass (k_dwpass2 with uprev2), which also subtracts beta_{k-1} v_{k-1} and takes the
+// alpha dot.  72 B per element and iteration instead of 88, one launch fewer.  Same arithmetic as the three-pass loop up
+// to the association (s*(T_loc + T_dw) - c*u_prev  vs  (s*T_loc - c*u_prev) + s*T_dw).
+struct UpAxArgs {
+    int32_t DimUp, DimPh; int64_t Qdw, dw0, nrows;
+    const uint4 *packed; const double *tval; int32_t nterms;
+    const double *diag, *Eup, *Edw, *cross; const int32_t *mapup, *mapdw; int32_t impmask, nI; double econst;
+    double *r;               // in: r_{k-1}; out: u_k (in place)
+    const double *vprev;     // u_{k-1}
+    double *t_out;           // T = local part of H u_k, unscaled
+    const double *scal; double *partial;
+    double *acc; const double *zvec;   // optional eigenvector accumulation acc += zvec[K] * u_k (K = iteration counter in scal)
+};
+
+template <bool DIRECT, bool ACC, int NT>
+__global__ void __launch_bounds__(NT) k_uppass2_ax(UpAxArgs A)
+{
+    extern __shared__ double lds[];
+    constexpr int MAXQ = (13312 / 2 + NT - 1) / NT;      // pairs per lane
+    const int DimUp = A.DimUp, npair = DimUp >> 1, tid = threadIdx.x;
+    double *tv = lds + DimUp;
+    double *red = tv + 128;
+    double *crow = red + 32;                             // DIRECT: Edw + const + cross term of this row, per up impurity word
+    for (int t = tid; t < A.nterms; t += NT) tv[t] = A.tval[t];
+    const int nq = (npair + NT - 1) / NT;
+    const double c_ax = A.scal[SC_ALPHA] * A.scal[SC_SCUR];          // alpha_{k-1} * s_{k-1}  (0 at k = 0)
+    const double zk = ACC ? A.zvec[(int)A.scal[SC_K]] : 0.0;
+    double bsum = 0.0;
+    // u = r - c*vprev for one pair of row rw: written back over r, summed into the norm, kept by the caller for LDS
+    auto combine = [&](int64_t rw, int p, const dbl2v &r, const dbl2v &v) -> dbl2v {
+        const dbl2v u = r - c_ax * v;
+        *reinterpret_cast<dbl2v *>(A.r + rw * DimUp + 2 * p) = u;
+        bsum += u.x * u.x + u.y * u.y;
+        if (ACC) { dbl2v *pa = reinterpret_cast<dbl2v *>(A.acc + rw * DimUp + 2 * p); *pa = *pa + zk * u; }
+        return u;
+    };
+    dbl2v xu[MAXQ];                                      // u of the row that enters LDS next
+    int64_t row = blockIdx.x;
+    if (row < A.nrows) {
+#pragma unroll
+        for (int q = 0; q < MAXQ; q++) {
+            const int p = tid + q * NT;
+            if (q < nq && p < npair)
+                xu[q] = combine(row, p, *reinterpret_cast<const dbl2v *>(A.r + row * DimUp + 2 * p), *reinterpret_cast<const dbl2v *>(A.vprev + row * DimUp + 2 * p));
+        }
+    }
+    // The operands of step q+1 of the hop loop are loaded during step q: the H_up image and diagonal of pair q+1 of this row
+    // AND pair q+1 of the NEXT row's r and vprev, which step q+1 turns into u (registers, one pair per step) -- the next row
+    // is complete when this one is, with 8 staging registers instead of a second row-sized register array.
+    struct Ops { dbl2v d, nr, nv; uint4 w0, w1, w2; };      // d: stored diagonal (KRON) or Eup (DIRECT)
+    while (row < A.nrows) {
+        const int64_t idwl = row % A.Qdw, idw = A.dw0 + idwl;
+        const int64_t next = row + gridDim.x; const bool more = next < A.nrows;
+        auto load_ops = [&](int p, Ops &o) {
+            if (!DIRECT) o.d = *reinterpret_cast<const dbl2v *>(A.diag + idwl * DimUp + 2 * p);
+            else o.d = *reinterpret_cast<const dbl2v *>(A.Eup + 2 * p);
+            o.w0 = A.packed[3 * p]; o.w1 = A.packed[3 * p + 1]; o.w2 = A.packed[3 * p + 2];
+            if (more) { o.nr = *reinterpret_cast<const dbl2v *>(A.r + next * DimUp + 2 * p); o.nv = *reinterpret_cast<const dbl2v *>(A.vprev + next * DimUp + 2 * p); }
+        };
+        Ops cur, nxt;
+        if (tid < npair) load_ops(tid, cur);
+#pragma unroll
+        for (int q = 0; q < MAXQ; q++) { const int p = tid + q * NT; if (q < nq && p < npair) *reinterpret_cast<dbl2v *>(lds + 2 * p) = xu[q]; }
+        if (DIRECT && tid < A.nI) crow[tid] = A.Edw[idw] + A.econst + A.cross[tid * A.nI + ((uint32_t)A.mapdw[idw] & A.impmask)];
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < MAXQ; q++) {
+            const int p = tid + q * NT;
+            if (q < nq && p < npair) {
+                if (p + NT < npair) load_ops(p + NT, nxt);
+                if (more) xu[q] = combine(next, p, cur.nr, cur.nv);      // xu[q] of THIS row is in LDS already
+                const dbl2v x = *reinterpret_cast<const dbl2v *>(lds + 2 * p);
+                dbl2v dval;
+                if (DIRECT) {
+                    const int2 mm = *reinterpret_cast<const int2 *>(A.mapup + 2 * p);
+                    dval.x = cur.d.x + crow[(uint32_t)mm.x & A.impmask];
+                    dval.y = cur.d.y + crow[(uint32_t)mm.y & A.impmask];
+                } else dval = cur.d;
+                const uint32_t c0[4] = {cur.w0.x, cur.w0.y, cur.w0.z, cur.w0.w}, k0[2] = {cur.w1.x, cur.w1.y};
+                const uint32_t c1[4] = {cur.w1.z, cur.w1.w, cur.w2.x, cur.w2.y}, k1[2] = {cur.w2.z, cur.w2.w};
+                double a0 = dval.x * x.x, a1 = dval.y * x.y;
+#pragma unroll
+                for (int e = 0; e < 8; e++) {
+                    const uint32_t code0 = (k0[e >> 2] >> (8 * (e & 3))) & 0xffu, col0 = (c0[e >> 1] >> (16 * (e & 1))) & 0xffffu;
+                    const uint32_t code1 = (k1[e >> 2] >> (8 * (e & 3))) & 0xffu, col1 = (c1[e >> 1] >> (16 * (e & 1))) & 0xffffu;
+                    double t0 = tv[code0 & 0x7fu], t1 = tv[code1 & 0x7fu];
+                    t0 = (code0 & 0x80u) ? -t0 : t0; t1 = (code1 & 0x80u) ? -t1 : t1;
+                    a0 += t0 * lds[col0]; a1 += t1 * lds[col1];
+                }
+                dbl2v o; o.x = a0; o.y = a1;
+                *reinterpret_cast<dbl2v *>(A.t_out + row * DimUp + 2 * p) = o;
+                cur = nxt;
+            }
+        }
+        __syncthreads();
+        row = next;
+    }
+    const double rr = block_sum(bsum, red);
+    if (tid == 0) A.partial[blockIdx.x] = rr;
+}
+
 // Local pass for rows too long for LDS (Ns=18: DimUp=48620, 389 KB): the up-hop gathers go to the row in
 // global memory.  `rsplit` workgroups with equal blockIdx % 8 (one XCD under round-robin dispatch) share a row
 // so it is served from that XCD's L2; H_up comes from an element-major packed image of 8 dwords per up
@@ -474,6 +581,7 @@ struct DwArgs {
     const double *v, *vfull; double *out;
     const double *scal; double *partial;
     int32_t w, wshift, ntiles, R, chunks;
+    const double *uprev2;      // fused Lanczos iteration (EPI only): out holds the UNSCALED local part; out = s_cur*(out + dw part) - beta*s_prev*uprev2
 };
 
 template <bool EPI>
@@ -536,6 +644,7 @@ __global__ void __launch_bounds__(256) k_dwpass2(DwArgs A)
         const int j = threadIdx.x & (lpr - 1), r0 = threadIdx.x >> (A.wshift - 1), rstep = 256 >> (A.wshift - 1);
         const int iup = tile * A.w + 2 * j;
         const double s_cur = EPI ? A.scal[SC_SCUR] : 1.0;
+        const double c_prev2 = (EPI && A.uprev2) ? A.scal[SC_BETA] * A.scal[SC_SPREV] : 0.0;
         if (iup < A.DimUp)
             for (int r = r0; r < rb; r += rstep) {
                 const int64_t row = row0 + r;
@@ -552,7 +661,8 @@ __global__ void __launch_bounds__(256) k_dwpass2(DwArgs A)
                 dbl2v o = NT ? __builtin_nontemporal_load(po) : *po;
                 if (EPI) {
                     const dbl2v vl = *reinterpret_cast<const dbl2v *>(A.v + e);
-                    o += s_cur * acc;
+                    if (A.uprev2) { const dbl2v up = *reinterpret_cast<const dbl2v *>(A.uprev2 + e); o = s_cur * (o + acc) - c_prev2 * up; }
+                    else o += s_cur * acc;
                     asum += (s_cur * vl.x) * o.x + (s_cur * vl.y) * o.y;
                 } else o += acc;
                 if (NT) __builtin_nontemporal_store(o, po); else *po = o;
@@ -1590,6 +1700,12 @@ __device__ __forceinline__ void scalar_step(double *scal, double *alphas, double
         betas[k + 1] = b; scal[SC_BETA] = b; scal[SC_SPREV] = scal[SC_SCUR]; scal[SC_SCUR] = b > 0.0 ? 1.0 / b : 0.0; scal[SC_K] = (double)(k + 1);
     } else if (mode == 2) { scal[SC_SCUR] = 1.0 / sqrt(scal[SC_TMP]); scal[SC_SPREV] = 0.0; scal[SC_BETA] = 0.0; scal[SC_ALPHA] = 0.0; scal[SC_ZK] = 0.0; scal[SC_K] = 0.0; }
     else if (mode == 3) { scal[SC_ZK] = zvec ? zvec[k] : 0.0; }
+    // fused iteration (k_uppass2_ax + k_dwpass2 with uprev2): the norm comes first, the alpha dot second
+    else if (mode == 4) {      // after the local pass of iteration k: TMP = |u_k|^2
+        const double b = sqrt(scal[SC_TMP]);
+        if (k == 0) { scal[SC_SCUR] = b > 0.0 ? 1.0 / b : 0.0; scal[SC_SPREV] = 0.0; scal[SC_BETA] = 0.0; }
+        else { betas[k] = b; scal[SC_BETA] = b; scal[SC_SPREV] = scal[SC_SCUR]; scal[SC_SCUR] = b > 0.0 ? 1.0 / b : 0.0; }
+    } else if (mode == 5) { scal[SC_ALPHA] = scal[SC_TMP]; alphas[k] = scal[SC_TMP]; scal[SC_K] = (double)(k + 1); }   // after the dw pass: alpha_k
 }
 __global__ void k_scalar_step(double *scal, double *alphas, double *betas, const double *zvec, int k, int mode)
 {

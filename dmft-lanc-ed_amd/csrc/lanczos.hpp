@@ -156,6 +156,25 @@ static int lz_iters(S *s, LzVecs &V, int k, int count, double *acc)
     return EDGPU_OK;
 }
 
+// ---- fused iteration (k_uppass2_ax / k_dwpass2 with uprev2; product.hpp: fused_local, fused_dw) --------------------------
+// State after the local half of iteration k: u = u_k, uprev = u_{k-1}, t = local part of H u_k (unscaled), alphas[0..k-1] and
+// betas[1..k] on the device.  One iteration = dw half of k (r_k, alpha_k) + local half of k+1 (u_{k+1}, beta_k): two passes
+// over the vectors instead of three.
+struct LzF { double *u, *uprev, *t; };
+static int lzf_begin(S *s, LzF &F, double *acc)      // F.u holds the (unnormalised) start vector, F.uprev any finite buffer
+{
+    HIPCHK(hipMemsetAsync(s->scal.p, 0, SC_COUNT * sizeof(double), s->stream));       // alpha_{-1} = 0, iteration counter 0
+    return fused_local(s, F.u, F.uprev, F.t, acc);                                     // u_0 unchanged, s_0 = 1/|u_0|
+}
+static int lzf_iter(S *s, LzF &F, double *tnew, double *acc)
+{
+    CHK(fused_dw(s, F.u, F.t, F.uprev));              // t <- r_k, alpha_k
+    double *r = F.t;
+    CHK(fused_local(s, r, F.u, tnew, acc));           // r <- u_{k+1}, beta_k ; tnew <- local part of H u_{k+1}
+    F.uprev = F.u; F.u = r; F.t = tnew;
+    return EDGPU_OK;
+}
+
 static int fetch_coeffs(S *s, int k, std::vector<double> &al, std::vector<double> &be)
 {
     al.resize(k + 1); be.resize(k + 2);
@@ -237,14 +256,22 @@ static int lanczos_gs_impl(S *s, int nitermax, double threshold, int ncheck, dou
         const int guess = std::min(std::min(nitermax + 2, store_max), dbg_int("EDGPU_LZ_STORE_GUESS", 100));
         if (!slab_mode) for (int k = 0; k < guess; k++) if (!ring_get(k)) break;
     }
+    const bool fused = fused_ok(s);
     LzVecs V{s->lz[0].p, s->lz[1].p, s->lz[2].p};
+    LzF F{s->lz[0].p, s->lz[2].p, s->lz[1].p};
     if (store) {
-        double *b0 = ring_get(0), *b1 = ring_get(1);
-        if (b0 && b1) { V.ucur = b0; V.w = b1; } else store = false;
+        double *b0 = ring_get(0), *b1 = ring_get(1), *b2 = fused ? ring_get(2) : b1;
+        if (b0 && b1 && b2) { V.ucur = b0; V.w = b1; F.u = b0; F.t = b1; F.uprev = b0; } else store = false;
     }
-    HIPCHK(hipMemcpyAsync(V.ucur, start, (size_t)s->nloc * 8, hipMemcpyDeviceToDevice, s->stream));
-    CHK(lz_start(s, V));
     double s0 = 0.0;                                  // scale of the start vector: v_0 = s0 * u_0
+    if (fused) {
+        HIPCHK(hipMemcpyAsync(F.u, start, (size_t)s->nloc * 8, hipMemcpyDeviceToDevice, s->stream));
+        if (!store) HIPCHK(hipMemsetAsync(F.uprev, 0, (size_t)s->nloc * 8, s->stream));
+        CHK(lzf_begin(s, F, nullptr));
+    } else {
+        HIPCHK(hipMemcpyAsync(V.ucur, start, (size_t)s->nloc * 8, hipMemcpyDeviceToDevice, s->stream));
+        CHK(lz_start(s, V));
+    }
     HIPCHK(hipMemcpyAsync(&s0, s->scal.p + SC_SCUR, 8, hipMemcpyDeviceToHost, s->stream)); HIPCHK(hipStreamSynchronize(s->stream));
     std::vector<double> al, be;
     int nlanc = 0; double esave = 0.0, e0 = 0.0;
@@ -256,6 +283,13 @@ static int lanczos_gs_impl(S *s, int nitermax, double threshold, int ncheck, dou
     for (int k = 0; k < nitermax && !done;) {
         const int kend = std::min(nitermax, k + chunk);
         for (int j = k; j < kend; j++) {
+            if (fused) {                              // dw half of j + local half of j+1: alpha_j and beta_j
+                double *tnew = store ? ring_get(j + 2) : nullptr;
+                if (store && !tnew) store = false;    // out of memory: from here on the oldest of the three live vectors is recycled
+                if (!tnew) tnew = (j == 0 && F.uprev == F.u) ? s->lz[2].p : F.uprev;
+                CHK(lzf_iter(s, F, tnew, nullptr));
+                continue;
+            }
             CHK(lz_iter(s, V, j, nullptr));           // afterwards: uprev = u_j, ucur = u_{j+1}, w = recycled u_{j-1}
             if (store) {
                 double *nx = ring_get(j + 2);         // u_{j+2} gets a buffer of its own, u_{j-1} stays intact
@@ -297,12 +331,23 @@ static int lanczos_gs_impl(S *s, int nitermax, double threshold, int ncheck, dou
         }
     } else {
         // second pass: regenerate the Krylov vectors and accumulate vect = sum_k Z(k,1) v_k
+        if (fused) {
+            std::vector<double> zs(nlanc);            // the local half of iteration k adds zs[k] * u_k ; v_k = s_k u_k
+            for (int k = 0; k < nlanc; k++) zs[k] = z[k] * (k == 0 ? s0 : (be[k] > 0.0 ? 1.0 / be[k] : 0.0));
+            HIPCHK(hipMemcpyAsync(s->zvec.p, zs.data(), (size_t)nlanc * 8, hipMemcpyHostToDevice, s->stream));
+            HIPCHK(hipStreamSynchronize(s->stream));
+            F = LzF{s->lz[0].p, s->lz[2].p, s->lz[1].p};
+            HIPCHK(hipMemcpyAsync(F.u, start, (size_t)s->nloc * 8, hipMemcpyDeviceToDevice, s->stream));
+            HIPCHK(hipMemsetAsync(F.uprev, 0, (size_t)s->nloc * 8, s->stream));
+            CHK(lzf_begin(s, F, acc));
+            for (int k = 0; k + 1 < nlanc; k++) CHK(lzf_iter(s, F, F.uprev, acc));
+        } else {
         V = LzVecs{s->lz[0].p, s->lz[1].p, s->lz[2].p};
         HIPCHK(hipMemcpyAsync(s->zvec.p, z.data(), (size_t)nlanc * 8, hipMemcpyHostToDevice, s->stream));
-        V = LzVecs{s->lz[0].p, s->lz[1].p, s->lz[2].p};
         HIPCHK(hipMemcpyAsync(V.ucur, start, (size_t)s->nloc * 8, hipMemcpyDeviceToDevice, s->stream));
         CHK(lz_start(s, V));
         CHK(lz_iters(s, V, 0, nlanc, acc));
+        }
     }
     CHK(reduce_dot(s, acc, acc));
     hipLaunchKernelGGL(k_scalar_step, dim3(1), dim3(1), 0, s->stream, s->scal.p, s->alphas.p, s->betas.p, (const double *)nullptr, 0, 2);
@@ -317,16 +362,26 @@ static int lanczos_tridiag(S *s, const double *vin_dev, int nlanc, double thresh
 {
     if (nlanc < 1) return fail(EDGPU_EINVAL, "edgpu_lanczos_tridiag: nlanc < 1");
     CHK(lz_prepare(s, nlanc));
+    const bool fused = fused_ok(s);
     LzVecs V{s->lz[0].p, s->lz[1].p, s->lz[2].p};
-    HIPCHK(hipMemcpyAsync(V.ucur, vin_dev, (size_t)s->nloc * 8, hipMemcpyDeviceToDevice, s->stream));
-    CHK(lz_start(s, V));
+    LzF F{s->lz[0].p, s->lz[2].p, s->lz[1].p};
+    if (fused) {
+        HIPCHK(hipMemcpyAsync(F.u, vin_dev, (size_t)s->nloc * 8, hipMemcpyDeviceToDevice, s->stream));
+        HIPCHK(hipMemsetAsync(F.uprev, 0, (size_t)s->nloc * 8, s->stream));
+        CHK(lzf_begin(s, F, nullptr));
+    } else {
+        HIPCHK(hipMemcpyAsync(V.ucur, vin_dev, (size_t)s->nloc * 8, hipMemcpyDeviceToDevice, s->stream));
+        CHK(lz_start(s, V));
+    }
     for (int i = 0; i < nlanc; i++) { alanc[i] = 0.0; blanc[i] = 0.0; }
     std::vector<double> al, be;
     int used = 0;
     const int chunk = 8;  // look at beta on the host every `chunk` iterations
     for (int k = 0; k < nlanc;) {
         int kend = std::min(nlanc, k + chunk);
-        CHK(lz_iters(s, V, k, kend - k, nullptr)); k = kend;
+        if (fused) { for (int j = k; j < kend; j++) CHK(lzf_iter(s, F, F.uprev, nullptr)); }
+        else CHK(lz_iters(s, V, k, kend - k, nullptr));
+        k = kend;
         CHK(fetch_coeffs(s, k - 1, al, be));
         bool stop = false;
         for (int i = used; i < k; i++) {

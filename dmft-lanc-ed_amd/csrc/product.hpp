@@ -147,6 +147,80 @@ static int transposed_dw_pass(S *s, const double *v, hipStream_t st)
     return EDGPU_OK;
 }
 
+// ---------------------------------------------------------------------------------------
+// fused Lanczos iteration (single rank, two-factor operator of a large sector, stored or on the fly): see k_uppass2_ax
+// ---------------------------------------------------------------------------------------
+#ifndef LZAX_NT
+#define LZAX_NT 1024
+#endif
+static bool fused_ok(const S *s)
+{
+    const SectorHost &H = s->H;
+    return s->lz_fused_on && !s->multi && s->two_factor && !s->extra && s->kron_split && H.desc.storage != EDGPU_STORE_CSR && s->up_persistent && s->up_pairs &&
+           s->fac[0]->packed_elem && s->fac[0]->width <= 8 && s->use_lds && H.DimUp <= 13312 && (H.DimUp % 2 == 0) && s->dw_variant >= 2 && s->dw_w >= 4 && s->fac[1]->width <= 64;
+}
+// local half: r <- u_k = r - alpha s u_prev (in place), TMP = |u_k|^2 and the norm step, t <- local part of H u_k (unscaled)
+static int fused_local(S *s, double *r, const double *uprev, double *t, double *acc)
+{
+    const SectorHost &H = s->H; const edgpu_desc &d = H.desc;
+    const bool direct = d.storage == EDGPU_STORE_DIRECT;
+    if (direct) CHK(direct_tables(s));
+    UpAxArgs U{};
+    U.DimUp = (int32_t)H.DimUp; U.DimPh = H.DimPh; U.Qdw = H.Qdw; U.dw0 = H.dw0; U.nrows = H.Qdw * H.DimPh;
+    U.packed = reinterpret_cast<const uint4 *>(s->fac[0]->pelem.p); U.tval = s->fac[0]->ptval.p; U.nterms = s->fac[0]->pterms;
+    U.diag = s->diag.p; U.Eup = s->fac[0]->E.p; U.Edw = s->fac[1]->E.p; U.cross = s->cross.p; U.mapup = s->fac[0]->map.p; U.mapdw = s->fac[1]->map.p;
+    U.impmask = (1 << d.Norb) - 1; U.nI = 1 << d.Norb; U.econst = H.econst;
+    U.r = r; U.vprev = uprev; U.t_out = t; U.scal = s->scal.p; U.partial = s->partial.p; U.acc = acc; U.zvec = s->zvec.p;
+    const size_t lds = (size_t)H.DimUp * 8 + 128 * 8 + 32 * 8 + 32 * 8;
+    const int grid = (int)std::min<int64_t>(U.nrows, s->up_grid);
+    static OncePerDevice once;
+    if (once.first(s->device)) {
+        (void)hipFuncSetAttribute((const void *)k_uppass2_ax<false, false, LZAX_NT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void *)k_uppass2_ax<true, false, LZAX_NT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void *)k_uppass2_ax<false, true, LZAX_NT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void *)k_uppass2_ax<true, true, LZAX_NT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    }
+    const dim3 g(grid), b(LZAX_NT);
+    if (direct) { if (acc) hipLaunchKernelGGL((k_uppass2_ax<true, true, LZAX_NT>), g, b, lds, s->stream, U); else hipLaunchKernelGGL((k_uppass2_ax<true, false, LZAX_NT>), g, b, lds, s->stream, U); }
+    else { if (acc) hipLaunchKernelGGL((k_uppass2_ax<false, true, LZAX_NT>), g, b, lds, s->stream, U); else hipLaunchKernelGGL((k_uppass2_ax<false, false, LZAX_NT>), g, b, lds, s->stream, U); }
+    HIPCHK(hipGetLastError());
+    s->fuse_mode = 4; s->fuse_zvec = nullptr;
+    const int rc = reduce_partials(s, grid);
+    s->fuse_mode = -1;
+    return rc;
+}
+// dw half: t <- r_k = s_k (t + dw hops of u) - beta_{k-1} s_{k-1} u_prev ; TMP = (s_k u).r_k and the alpha step
+static int fused_dw(S *s, const double *u, double *t, const double *uprev)
+{
+    const SectorHost &H = s->H;
+    DwArgs D{};
+    D.DimUp = (int32_t)H.DimUp; D.DimDw = (int32_t)H.DimDw; D.DimPh = H.DimPh; D.Qdw = H.Qdw; D.dw0 = H.dw0;
+    D.dwc = s->fac[1]->ellc.p; D.dwv = s->fac[1]->ellv.p; D.dww = s->fac[1]->width; D.v = u; D.vfull = u; D.out = t; D.scal = s->scal.p; D.partial = s->partial.p;
+    D.uprev2 = uprev;
+    D.w = s->dw_w; D.wshift = 0; while ((1 << D.wshift) < D.w) D.wshift++;
+    D.ntiles = (int32_t)cdiv(H.DimUp, D.w);
+    D.R = std::min(64, s->dw_rows);
+    D.chunks = (int32_t)cdiv(H.Qdw * H.DimPh, D.R);
+    const int64_t nblocks = 8 * cdiv(D.ntiles, 8) * (int64_t)D.chunks;
+    const bool nt = s->dw_variant != 2, rag = s->fac[1]->ragged;
+    const size_t dlds = std::max<size_t>((size_t)D.R * D.dww * 12 + 16, (size_t)s->dw_lds_kb * 1024);
+#define DW2_LAUNCH(N_, R_)                                                                                                      \
+    do {                                                                                                                            \
+        static OncePerDevice once_;                                                                                                 \
+        if (dlds > 60 * 1024 && once_.first(s->device)) {                                                                           \
+            if (hipFuncSetAttribute((const void *)k_dwpass2<true, N_, R_>, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024) != hipSuccess) (void)hipGetLastError(); \
+        }                                                                                                                           \
+        hipLaunchKernelGGL((k_dwpass2<true, N_, R_>), dim3((unsigned)nblocks), dim3(256), dlds, s->stream, D);                      \
+    } while (0)
+    if (nt) { if (rag) DW2_LAUNCH(true, true); else DW2_LAUNCH(true, false); } else { if (rag) DW2_LAUNCH(false, true); else DW2_LAUNCH(false, false); }
+#undef DW2_LAUNCH
+    HIPCHK(hipGetLastError());
+    s->fuse_mode = 5; s->fuse_zvec = nullptr;
+    const int rc = reduce_partials(s, nblocks);
+    s->fuse_mode = -1;
+    return rc;
+}
+
 static int hxv(S *s, const double *v, double *out, bool epi, const double *uprev)
 {
     const SectorHost &H = s->H; const edgpu_desc &d = H.desc;

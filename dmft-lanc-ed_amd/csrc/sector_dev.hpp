@@ -326,6 +326,7 @@ static int create(const edgpu_desc *desc, S **out)
     s->extra = H.DimPh > 1 || H.Jhflag; s->has_ph = H.DimPh > 1; s->has_nd = H.Jhflag;
     s->nloc_el = H.DimUp * H.Qdw; s->nloc = s->nloc_el * H.DimPh; s->vecdim = s->nloc;
     s->multi = desc->mpi_size > 1 || (desc->reserved & 1);   // reserved bit 0: run the exchange path even on one rank (tests)
+    s->lz_fused_on = dbg_int("EDGPU_LZ_FUSED", 1) != 0;
     s->dbg = dbg_flags(); s->tables_wave = dbg_int("EDGPU_TABLES_WAVE", 1) != 0; s->dw_lds_kb = std::min(dbg_int("EDGPU_DW_LDS_KB", 48), 150);
     // distributed-transpose dw pass: opt-in (EDGPU_DW_TRANSPOSE=1) until an 8-GPU run has shown it correct and faster than the
     // needed-rows exchange; at most 64 ranks (larger jobs use the needed-rows exchange)

@@ -323,6 +323,11 @@ class HvSector:
         check(capi.lib().edgpu_sector_attach_comm(self._h, comm._c))
         self._comm = comm          # keep it alive as long as the sector
 
+    @property
+    def lanczos_fused(self):
+        """True when the Lanczos loops of this sector run the fused two-pass iteration (edgpu_lanczos_is_fused)."""
+        return bool(capi.lib().edgpu_lanczos_is_fused(self._h))
+
     def exchange_info(self):
         """(mode, send_bytes[size], recv_bytes[size]) of one product: mode 'none' | 'needed-rows' | 'all-gather' | 'transpose'."""
         P = int(self._desc.mpi_size)

@@ -150,6 +150,9 @@ int edgpu_eigsh(edgpu_handle h, int32_t nev, int32_t ncv, int32_t maxiter, doubl
  * thick-restart basis costs restarts, not accuracy -- and edgpu_eigsh_ncv_used() tells what the last call ran with. */
 int32_t edgpu_eigsh_ncv_cap(void);
 int32_t edgpu_eigsh_ncv_used(edgpu_handle h);
+/* 1 when this sector's Lanczos loops (edgpu_lanczos_gs / _tridiag and the searches built on them) run the fused two-pass
+ * iteration, 0 when they run product + axpy/norm as three passes (EDGPU_LZ_FUSED=0, multi-rank, CSR storage, non-local terms). */
+int32_t edgpu_lanczos_is_fused(edgpu_handle h);
 /* sp_dvdson_eigh(MatVec,eval,evec,nitermax,tol)   ED_DIAG.f90:189-203 (lanc_method="dvdson"): Davidson with the
  * diagonal of H as preconditioner; search space and its image under H in HBM.  `maxiter` products at most; a pair
  * counts as converged when |H x - theta x| <= max(tol,1e-11)*max(1,|theta|).  Same outputs as edgpu_eigsh. */

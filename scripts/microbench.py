@@ -1,4 +1,5 @@
-"""Ad-hoc kernel timing sweep (development aid): python tools_microbench.py <nbath> <storage> [nrep]"""
+"""Ad-hoc kernel timing sweep (development aid): python scripts/microbench.py <nbath> <storage> [nrep] [lanczos]
+(with a 4th argument `lanczos` the timed unit is one Lanczos iteration instead of one product)"""
 import sys, os
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "dmft-lanc-ed_amd"))
@@ -11,7 +12,7 @@ G = edgpu.HvSector(m, nu, nd, storage=st)
 N = G.Dim
 v = edgpu.DeviceVector(N); h = edgpu.DeviceVector(N)
 v.upload(np.random.RandomState(0).uniform(-0.5, 0.5, N))
-ms = G.hxv_time(v, h, 2, nrep)
+ms = G.lanczos_time(2, nrep) if len(sys.argv) > 4 and sys.argv[4] == "lanczos" else G.hxv_time(v, h, 2, nrep)
 nnz = N * (1 + m["Ns"])
 bcsr = 12 * nnz + 8 * (N + 1) + 16 * N
 fmt = {"csr": bcsr, "kron": 24 * N, "direct": 16 * N}[st]

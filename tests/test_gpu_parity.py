@@ -415,6 +415,40 @@ def test_ground_state_with_stored_krylov_vectors(edgpu_mod, monkeypatch):
             assert np.abs(x - x_ref).max() < 1e-10, tag
 
 
+def test_fused_iteration_equals_three_pass_iteration(edgpu_mod, monkeypatch):
+    """The fused Lanczos iteration (axpy+norm folded into the next local pass, scale and -beta*u_prev into the dw pass)
+    against the product + axpy/norm loop it replaces (EDGPU_LZ_FUSED=0) and against the oracle's restatement of
+    sp_lanc_tridiag: alpha/beta to 1e-9 relative over 40 steps, E0 to 1e-10, eigenvector to 1e-8."""
+    from edgpu import model
+    for nb, st in ((7, "kron"), (9, "direct"), (11, "kron"), (11, "direct")):
+        m, nu, nd = model.half_filled_c(nb)
+        S = oracle.Sector(m, nu, nd)
+        v0 = np.random.RandomState(11).uniform(0, 1, S.Dim)
+        n = 40
+        res = {}
+        monkeypatch.setenv("EDGPU_KRON_SPLIT", "1")      # the two-kernel product large sectors use (default above 48 MB per vector)
+        for tag, env in (("fused", {}), ("fused_twopass", {"EDGPU_LZ_STORE": "0"}), ("plain", {"EDGPU_LZ_FUSED": "0"})):
+            for k, v in env.items():
+                monkeypatch.setenv(k, v)
+            G = edgpu_mod.HvSector(m, nu, nd, storage=st)
+            assert G.lanczos_fused == (tag != "plain"), (nb, st, tag)
+            a, b, used = G.sp_lanc_tridiag(v0, n)
+            e0, x, nl = G.sp_lanc_eigh(v0, nitermax=300, threshold=1e-13)
+            res[tag] = (a, b, used, e0, x, nl, np.linalg.norm(G.spHtimesV(x) - e0 * x))
+            G.close()
+            for k in env:
+                monkeypatch.delenv(k)
+        a_ref, b_ref, used_ref = oracle.sp_lanc_tridiag(S.spmatvec, v0, n)
+        for tag in ("fused", "fused_twopass", "plain"):
+            a, b, used, e0, x, nl, r = res[tag]
+            assert used == used_ref and b[0] == 0.0
+            np.testing.assert_allclose(a[:used], a_ref[:used], rtol=1e-9, atol=1e-9)
+            np.testing.assert_allclose(b[1:used], b_ref[1:used], rtol=1e-9, atol=1e-9)
+            assert abs(e0 - res["plain"][3]) <= 1e-10 and abs(nl - res["plain"][5]) <= 1 and r < 1e-6, (tag, e0, nl, r)
+            assert abs(np.linalg.norm(x) - 1.0) < 1e-12
+            assert min(np.abs(x - res["plain"][4]).max(), np.abs(x + res["plain"][4]).max()) < 1e-8, tag
+
+
 def test_sweep_over_all_sectors_of_a_small_model(edgpu_mod):
     """What a DMFT iteration does: every (Nup,Ndw) sector of the Ns=6 model in turn (dimensions 1 ... 400), ground state of
     each against dense diagonalisation.  Exercises the work-vector cache across sectors of changing size."""
