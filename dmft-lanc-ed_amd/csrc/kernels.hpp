@@ -566,6 +566,240 @@ __global__ void __launch_bounds__(512) k_uppass_big(UpBigArgs A)
     }
 }
 
+// Local pass for rows too long for LDS, segment form (Ns=17/18).  The up configurations are sorted by value, so a
+// contiguous quarter of a row is (nearly) "the configurations with given top bath bits": 87 % of the up hops of an
+// element stay inside its own quarter (Ns=18, four segments of 95 KB), only the hops on the top levels leave it.  A
+// persistent 1024-thread workgroup therefore owns ONE segment of a row: it stages that segment in LDS (register prefetch
+// of the next row's segment while the current one computes, as k_uppass2), gathers in-segment sources from LDS and only
+// the out-of-segment ones -- 1.2 of 9 per element -- from global memory.  The nseg workgroups of a row sit on the same
+// XCD (blockIdx % 8) and run in step, so those loads find the row in that XCD's L2.  k_uppass_big does all 9 gathers
+// through the texture-address path, which is what bounded it.
+struct UpSegArgs {
+    int32_t DimUp, DimPh, nseg, seglen; int64_t Qdw, dw0, nrows;
+    const uint4 *packed8;     // [iup][2] uint4: 5 dwords of 16-bit columns, 3 dwords of 8-bit codes
+    const double *tval; int32_t nterms;
+    const double *diag, *Eup, *Edw, *cross; const int32_t *mapup, *mapdw; int32_t impmask, nI; double econst;
+    const double *v; double *out; const double *uprev; const double *scal;
+};
+template <bool DIRECT, bool EPI>
+__global__ void __launch_bounds__(1024) k_uppass_seg(UpSegArgs A)
+{
+    extern __shared__ double lds[];
+    constexpr int NT = 1024, MAXQ = 6;                   // segments of up to 12288 elements (96 KB)
+    const int DimUp = A.DimUp, tid = threadIdx.x;
+    const int x = blockIdx.x & 7, j = blockIdx.x >> 3, G = (int)(gridDim.x >> 3) / A.nseg;
+    const int g = j / A.nseg, sg = j - g * A.nseg;
+    const int lo = sg * A.seglen, hi = lo + A.seglen < DimUp ? lo + A.seglen : DimUp;
+    const int nel = hi - lo, npair = nel >> 1;
+    double *tv = lds + A.seglen;
+    double *crow = tv + 128;
+    for (int t = tid; t < A.nterms && t < 128; t += NT) tv[t] = A.tval[t];
+    if (g >= G) return;
+    const int nq = (npair + NT - 1) / NT;
+    dbl2v xr[MAXQ];
+    int64_t row = (int64_t)g * 8 + x; const int64_t rstep = (int64_t)G * 8;
+    auto fetch_row = [&](int64_t rw) {
+#pragma unroll
+        for (int q = 0; q < MAXQ; q++) { const int p = tid + q * NT; if (q < nq && p < npair) xr[q] = *reinterpret_cast<const dbl2v *>(A.v + rw * DimUp + lo + 2 * p); }
+    };
+    if (row < A.nrows) fetch_row(row);
+    double s_cur = 1.0, c_prev = 0.0;
+    if (EPI) { s_cur = A.scal[SC_SCUR]; c_prev = A.scal[SC_BETA] * A.scal[SC_SPREV]; }
+    struct Ops { dbl2v d, u; uint4 w0, w1, w2, w3; };    // d: stored diagonal (KRON) or Eup (DIRECT)
+    while (row < A.nrows) {
+        const int64_t idwl = row % A.Qdw, idw = A.dw0 + idwl;
+        const double *vrow = A.v + row * DimUp;
+        auto load_ops = [&](int p, Ops &o) {
+            const int i = lo + 2 * p;
+            if (!DIRECT) o.d = *reinterpret_cast<const dbl2v *>(A.diag + idwl * DimUp + i);
+            else o.d = *reinterpret_cast<const dbl2v *>(A.Eup + i);
+            if (EPI) o.u = *reinterpret_cast<const dbl2v *>(A.uprev + row * DimUp + i);
+            o.w0 = A.packed8[2 * i]; o.w1 = A.packed8[2 * i + 1]; o.w2 = A.packed8[2 * i + 2]; o.w3 = A.packed8[2 * i + 3];
+        };
+        Ops cur, nxt;
+        if (tid < npair) load_ops(tid, cur);
+#pragma unroll
+        for (int q = 0; q < MAXQ; q++) { const int p = tid + q * NT; if (q < nq && p < npair) *reinterpret_cast<dbl2v *>(lds + 2 * p) = xr[q]; }
+        if (DIRECT && tid < A.nI) crow[tid] = A.Edw[idw] + A.econst + A.cross[tid * A.nI + ((uint32_t)A.mapdw[idw] & A.impmask)];
+        __syncthreads();
+        const int64_t next = row + rstep;
+        if (next < A.nrows) fetch_row(next);
+        for (int p = tid; p < npair; p += NT) {
+            if (p + NT < npair) load_ops(p + NT, nxt);
+            const dbl2v xx = *reinterpret_cast<const dbl2v *>(lds + 2 * p);
+            dbl2v dval;
+            if (DIRECT) {
+                const int2 mm = *reinterpret_cast<const int2 *>(A.mapup + lo + 2 * p);
+                dval.x = cur.d.x + crow[(uint32_t)mm.x & A.impmask];
+                dval.y = cur.d.y + crow[(uint32_t)mm.y & A.impmask];
+            } else dval = cur.d;
+            const uint32_t c0[5] = {cur.w0.x, cur.w0.y, cur.w0.z, cur.w0.w, cur.w1.x}, k0[3] = {cur.w1.y, cur.w1.z, cur.w1.w};
+            const uint32_t c1[5] = {cur.w2.x, cur.w2.y, cur.w2.z, cur.w2.w, cur.w3.x}, k1[3] = {cur.w3.y, cur.w3.z, cur.w3.w};
+            double a0 = dval.x * xx.x, a1 = dval.y * xx.y;
+#pragma unroll
+            for (int e = 0; e < 10; e++) {
+                const uint32_t code0 = (k0[e >> 2] >> (8 * (e & 3))) & 0xffu, col0 = (c0[e >> 1] >> (16 * (e & 1))) & 0xffffu;
+                const uint32_t code1 = (k1[e >> 2] >> (8 * (e & 3))) & 0xffu, col1 = (c1[e >> 1] >> (16 * (e & 1))) & 0xffffu;
+                double t0 = tv[code0 & 0x7fu], t1 = tv[code1 & 0x7fu];
+                t0 = (code0 & 0x80u) ? -t0 : t0; t1 = (code1 & 0x80u) ? -t1 : t1;
+                const uint32_t r0 = col0 - (uint32_t)lo, r1 = col1 - (uint32_t)lo;
+                double x0, x1;
+                if (r0 < (uint32_t)nel) x0 = lds[r0]; else x0 = vrow[col0];
+                if (r1 < (uint32_t)nel) x1 = lds[r1]; else x1 = vrow[col1];
+                a0 += t0 * x0; a1 += t1 * x1;
+            }
+            dbl2v o;
+            if (EPI) { o.x = s_cur * a0 - c_prev * cur.u.x; o.y = s_cur * a1 - c_prev * cur.u.y; }
+            else { o.x = a0; o.y = a1; }
+            *reinterpret_cast<dbl2v *>(A.out + row * DimUp + lo + 2 * p) = o;
+            cur = nxt;
+        }
+        __syncthreads();
+        row = next;
+    }
+}
+
+// Segment + halo form of the long-row local pass.  k_uppass_seg still sends the out-of-segment gathers to global memory
+// in the middle of the hop loop, and every one of them is a dependent load the whole workgroup waits for (measured at
+// Ns=18: 66 % of the wave cycles waiting, HBM at 2 TB/s, VALU 39 %, LDS 21 % busy).  Here the workgroup's segment is
+// fixed for the whole launch, so the columns outside it that its hops reach are a fixed ascending list (seg_ext, built
+// once per sector): their values are fetched together with the segment -- one bulk prefetch per row, a full row ahead,
+// with the list itself held in registers -- into a halo area behind the segment in LDS, and the hop loop gathers from
+// LDS only (pseg8 holds LDS positions instead of columns).  Ns=18: 8 segments of 6 078 elements + <= 11 225 halo values
+// = 135 KB of LDS; 1.7 halo values per element, read from the XCD's L2 where the sibling workgroups of the same row are
+// loading them as their own segments at the same time.
+struct UpHaloArgs {
+    int32_t DimUp, DimPh, nseg, seglen, halocap; int64_t Qdw, dw0, nrows;
+    const uint4 *pseg8; const int32_t *ext, *ext_off;
+    const double *tval; int32_t nterms;
+    const double *diag, *Eup, *Edw, *cross; const int32_t *mapup, *mapdw; int32_t impmask, nI; double econst;
+    const double *v; double *out;
+};
+#ifndef HALO_SB
+#define HALO_SB 5
+#endif
+constexpr int kHaloSegMax = 6144, kHaloMax = 12288;     // up to 3 pairs and 12 halo values per lane of a 1024-thread workgroup
+template <bool DIRECT, int NQ, int MAXH>      // NQ: pairs per lane = steps per (row, segment) item; MAXH: halo values per lane
+__global__ void __launch_bounds__(1024) k_uppass_halo(UpHaloArgs A)
+{
+    extern __shared__ double lds[];
+    constexpr int NT = 1024;
+    const int DimUp = A.DimUp, tid = threadIdx.x;
+    const int x = blockIdx.x & 7, j = blockIdx.x >> 3, G = (int)(gridDim.x >> 3) / A.nseg;
+    const int g = j / A.nseg, sg = j - g * A.nseg;
+    const int lo = sg * A.seglen, hi = lo + A.seglen < DimUp ? lo + A.seglen : DimUp;
+    const int npair = (hi - lo) >> 1;
+    const int eoff = A.ext_off[sg], nh = A.ext_off[sg + 1] - eoff;
+    double *halo = lds + A.seglen;
+    double *tv = halo + A.halocap;
+    double *crow = tv + 128;
+    for (int t = tid; t < A.nterms && t < 128; t += NT) tv[t] = A.tval[t];
+    if (g >= G) return;
+    uint32_t hc[MAXH / 2];                               // this lane's halo columns, two 16-bit values per register: the same for every row
+#pragma unroll
+    for (int h = 0; h < MAXH; h += 2) {
+        const int t0 = tid + h * NT, t1 = t0 + NT;
+        hc[h >> 1] = (t0 < nh ? (uint32_t)A.ext[eoff + t0] : 0u) | ((t1 < nh ? (uint32_t)A.ext[eoff + t1] : 0u) << 16);
+    }
+    dbl2v xr[NQ]; double xh[MAXH];
+    const int64_t rstep = (int64_t)G * 8;
+    auto fetch_row = [&](int64_t rw) {
+        const double *vr = A.v + rw * DimUp;
+#pragma unroll
+        for (int q = 0; q < NQ; q++) { const int p = tid + q * NT; if (p < npair) xr[q] = *reinterpret_cast<const dbl2v *>(vr + lo + 2 * p); }
+#pragma unroll
+        for (int h = 0; h < MAXH; h++) if (tid + h * NT < nh) xh[h] = vr[(hc[h >> 1] >> (16 * (h & 1))) & 0xffffu];
+    };
+    // Operand ring of two slots, continuous across items: the image slice of a workgroup is the same for every row, so the
+    // operands of linear step L+2 (possibly of the next row) are requested as soon as step L has used its slot.  Loads return
+    // in order: requests a step waits for are issued BEFORE the next row's prefetch, never behind it.
+    struct Ops { dbl2v d; uint4 w0, w1, w2, w3; };       // d: stored diagonal (KRON) or Eup (DIRECT)
+    Ops o[2];
+    auto load_ops = [&](int64_t rw, int q, Ops &t) {
+        const int p = tid + q * NT;
+        if (rw < A.nrows && p < npair) {
+            const int i = lo + 2 * p;
+            if (!DIRECT) t.d = *reinterpret_cast<const dbl2v *>(A.diag + (rw % A.Qdw) * DimUp + i);
+            else t.d = *reinterpret_cast<const dbl2v *>(A.Eup + i);
+            t.w0 = A.pseg8[2 * i]; t.w1 = A.pseg8[2 * i + 1]; t.w2 = A.pseg8[2 * i + 2]; t.w3 = A.pseg8[2 * i + 3];
+        }
+    };
+    auto step = [&](int64_t rw, int q, const Ops &cur) {
+        const int p = tid + q * NT;
+        if (p < npair) {
+            const dbl2v xx = *reinterpret_cast<const dbl2v *>(lds + 2 * p);
+            dbl2v dval;
+            if (DIRECT) {           // byte 10 of the code dwords: the impurity word of the up configuration (k_seg_remap)
+                dval.x = cur.d.x + crow[(cur.w1.w >> 16) & 0xffu];
+                dval.y = cur.d.y + crow[(cur.w3.w >> 16) & 0xffu];
+            } else dval = cur.d;
+            const uint32_t c0[5] = {cur.w0.x, cur.w0.y, cur.w0.z, cur.w0.w, cur.w1.x}, k0[3] = {cur.w1.y, cur.w1.z, cur.w1.w};
+            const uint32_t c1[5] = {cur.w2.x, cur.w2.y, cur.w2.z, cur.w2.w, cur.w3.x}, k1[3] = {cur.w3.y, cur.w3.z, cur.w3.w};
+            double a0 = dval.x * xx.x, a1 = dval.y * xx.y;
+#pragma unroll
+            for (int e = 0; e < 10; e++) {
+                const uint32_t code0 = (k0[e >> 2] >> (8 * (e & 3))) & 0xffu, col0 = (c0[e >> 1] >> (16 * (e & 1))) & 0xffffu;
+                const uint32_t code1 = (k1[e >> 2] >> (8 * (e & 3))) & 0xffu, col1 = (c1[e >> 1] >> (16 * (e & 1))) & 0xffffu;
+                double t0 = tv[code0 & 0x7fu], t1 = tv[code1 & 0x7fu];
+                t0 = (code0 & 0x80u) ? -t0 : t0; t1 = (code1 & 0x80u) ? -t1 : t1;
+                a0 += t0 * lds[col0]; a1 += t1 * lds[col1];
+            }
+            dbl2v r; r.x = a0; r.y = a1;
+            *reinterpret_cast<dbl2v *>(A.out + rw * DimUp + lo + 2 * p) = r;
+        }
+    };
+    auto item = [&](auto par, int64_t rw) {              // par: slot of this item's step 0
+        constexpr int P = decltype(par)::value;
+        const int64_t idw = A.dw0 + rw % A.Qdw;
+#pragma unroll
+        for (int q = 0; q < NQ; q++) { const int p = tid + q * NT; if (p < npair) *reinterpret_cast<dbl2v *>(lds + 2 * p) = xr[q]; }
+#pragma unroll
+        for (int h = 0; h < MAXH; h++) if (tid + h * NT < nh) halo[tid + h * NT] = xh[h];
+        if (DIRECT && tid < A.nI) crow[tid] = A.Edw[idw] + A.econst + A.cross[tid * A.nI + ((uint32_t)A.mapdw[idw] & A.impmask)];
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < NQ; q++) {
+            Ops &slot = o[(P + q) & 1];
+            step(rw, q, slot);
+            load_ops(rw + (int64_t)((q + 2) / NQ) * rstep, (q + 2) % NQ, slot);
+            if (q == 0 && rw + rstep < A.nrows) fetch_row(rw + rstep);
+        }
+        __syncthreads();
+    };
+    int64_t row = (int64_t)g * 8 + x;
+    if (row < A.nrows) fetch_row(row);
+    load_ops(row, 0, o[0]);
+    load_ops(row + (int64_t)(1 / NQ) * rstep, 1 % NQ, o[1]);
+    while (row < A.nrows) {
+        item(std::integral_constant<int, 0>{}, row); row += rstep;
+        if (NQ & 1) { if (row >= A.nrows) break; item(std::integral_constant<int, 1>{}, row); row += rstep; }
+    }
+}
+
+// pelem8 (columns) -> pseg8 (positions in the [segment | halo] LDS image of the segment that owns the element)
+__global__ void k_seg_remap(const uint32_t *pelem8, uint32_t *pseg8, const int32_t *ext, const int32_t *ext_off, int32_t dim, int32_t seglen, int32_t halo_base, const int32_t *map, int32_t impmask)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= dim) return;
+    const int sg = i / seglen, lo = sg * seglen, hi = lo + seglen < dim ? lo + seglen : dim;
+    const int32_t *e = ext + ext_off[sg]; const int n = ext_off[sg + 1] - ext_off[sg];
+    uint32_t w[8];
+    for (int c = 0; c < 8; c++) w[c] = pelem8[(size_t)8 * i + c];
+    for (int q = 0; q < 10; q++) {
+        const uint32_t col = (w[q >> 1] >> (16 * (q & 1))) & 0xffffu;
+        uint32_t pos;
+        if ((int)col >= lo && (int)col < hi) pos = col - lo;
+        else {
+            int a = 0, b = n;                             // first entry >= col
+            while (a < b) { const int m = (a + b) >> 1; if (e[m] < (int)col) a = m + 1; else b = m; }
+            pos = (uint32_t)(halo_base + a);              // present by construction (the list is the set of such columns)
+        }
+        w[q >> 1] = (w[q >> 1] & ~(0xffffu << (16 * (q & 1)))) | (pos << (16 * (q & 1)));
+    }
+    w[7] = (w[7] & ~0x00ff0000u) | (((uint32_t)map[i] & (uint32_t)impmask & 0xffu) << 16);      // code byte 10: impurity word (on-the-fly diagonal)
+    for (int c = 0; c < 8; c++) pseg8[(size_t)8 * i + c] = w[c];
+}
+
 // ---------------------------------------------------------------------------------------------
 // dw-hop pass, column tiled: out(iup,idw) += sum_k Hdw[idw,k] * v(iup, jdw_k).
 // Every neighbour row jdw is needed by ~Ns/2 different idw rows that are spread over the whole

@@ -357,6 +357,10 @@ static int hxv(S *s, const double *v, double *out, bool epi, const double *uprev
         if (!split) CHK(dispatch_kron2(s, base | (s->use_lds ? KF_LDS : 0), A, nblocks));
         else {
             const bool plain = !s->extra || nd_pass;      // local pass = stored/on-the-fly diagonal + up hops only
+            // k_uppass_halo writes the unscaled local part; under the Lanczos epilogue the vectorised dw pass finishes it (uprev2)
+            const bool dw_vec2 = s->dw_variant >= 2 && (H.DimUp % 2 == 0) && s->dw_w >= 4 && s->fac[1]->width <= 64;
+            const bool halo_can = !s->use_lds && plain && s->fac[0]->seg_ok && s->up_halo && (!epi || (dw_vec2 && !s->extra && !s->tr_on));
+            bool halo_epi = false;
             const bool persistent = s->up_persistent && plain && s->fac[0]->packed && s->fac[0]->width <= 16 && s->use_lds && H.DimUp <= 13312;
             if (persistent && s->up_pairs && s->fac[0]->packed_elem) {
                 UpArgs2 U{};
@@ -405,6 +409,55 @@ static int hxv(S *s, const double *v, double *out, bool epi, const double *uprev
                 }
 #undef UP_LAUNCH
                 HIPCHK(hipGetLastError());
+            } else if (halo_can) {
+                // rows beyond LDS: a workgroup per row segment, out-of-segment sources prefetched into an LDS halo (k_uppass_halo)
+                DevFactor &f0 = *s->fac[0];
+                if (direct) {       // the on-the-fly tables were just rebuilt with columns: positions again
+                    hipLaunchKernelGGL(k_seg_remap, dim3((unsigned)cdiv(H.DimUp, 256)), dim3(256), 0, s->stream, f0.pelem8.p, f0.pseg8.p, f0.seg_ext.p, f0.seg_ext_off.p, (int32_t)H.DimUp, f0.seglen, f0.seglen, f0.map.p, (int32_t)A.impmask);
+                }
+                UpHaloArgs U{};
+                U.DimUp = A.DimUp; U.DimPh = A.DimPh; U.nseg = f0.nseg; U.seglen = f0.seglen; U.halocap = f0.seg_maxhalo;
+                U.Qdw = A.Qdw; U.dw0 = A.dw0; U.nrows = H.Qdw * H.DimPh;
+                U.pseg8 = reinterpret_cast<const uint4 *>(f0.pseg8.p); U.ext = f0.seg_ext.p; U.ext_off = f0.seg_ext_off.p; U.tval = f0.ptval.p; U.nterms = f0.pterms;
+                U.diag = A.diag; U.Eup = A.Eup; U.Edw = A.Edw; U.cross = A.cross; U.mapup = A.mapup; U.mapdw = A.mapdw; U.impmask = A.impmask; U.nI = A.nI; U.econst = A.econst;
+                U.v = v; U.out = out;
+                halo_epi = epi;     // the scale and the -beta*u_prev term move to the dw pass (DwArgs.uprev2): this pass writes the unscaled local part
+                const size_t lds = ((size_t)U.seglen + U.halocap + 128 + 32) * 8;
+                const unsigned grid = (unsigned)std::max(8 * U.nseg, s->up_grid & ~7);
+#define HALO_LAUNCH(D_, Q_, H_)                                                                                                 \
+    do {                                                                                                                            \
+        static OncePerDevice once_;                                                                                                 \
+        if (once_.first(s->device)) (void)hipFuncSetAttribute((const void *)k_uppass_halo<D_, Q_, H_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+        hipLaunchKernelGGL((k_uppass_halo<D_, Q_, H_>), dim3(grid), dim3(1024), lds, s->stream, U);                                 \
+    } while (0)
+#define HALO_Q(D_, H_) do { if (nq == 1) HALO_LAUNCH(D_, 1, H_); else if (nq == 2) HALO_LAUNCH(D_, 2, H_); else HALO_LAUNCH(D_, 3, H_); } while (0)
+                const int nq = (int)cdiv(U.seglen / 2, 1024);
+                if (U.halocap <= 8 * 1024) { if (direct) HALO_Q(true, 8); else HALO_Q(false, 8); }
+                else { if (direct) HALO_Q(true, 12); else HALO_Q(false, 12); }
+#undef HALO_Q
+#undef HALO_LAUNCH
+                HIPCHK(hipGetLastError());
+            } else if (!s->use_lds && plain && s->fac[0]->packed_elem8 && s->up_seg && (H.DimUp % 2 == 0) && H.DimUp <= 65536) {
+                // rows beyond LDS: a workgroup per row SEGMENT (k_uppass_seg)
+                UpSegArgs U{};
+                int nseg = 2; while (nseg < 8 && ((cdiv(H.DimUp, nseg) + 1) & ~(int64_t)1) > 12288) nseg *= 2;
+                U.DimUp = A.DimUp; U.DimPh = A.DimPh; U.nseg = nseg; U.seglen = (int32_t)((cdiv(H.DimUp, nseg) + 1) & ~(int64_t)1);
+                U.Qdw = A.Qdw; U.dw0 = A.dw0; U.nrows = H.Qdw * H.DimPh;
+                U.packed8 = reinterpret_cast<const uint4 *>(s->fac[0]->pelem8.p); U.tval = s->fac[0]->ptval.p; U.nterms = s->fac[0]->pterms;
+                U.diag = A.diag; U.Eup = A.Eup; U.Edw = A.Edw; U.cross = A.cross; U.mapup = A.mapup; U.mapdw = A.mapdw; U.impmask = A.impmask; U.nI = A.nI; U.econst = A.econst;
+                U.v = v; U.out = out; U.uprev = uprev; U.scal = s->scal.p;
+                const size_t lds = (size_t)U.seglen * 8 + 128 * 8 + 32 * 8;
+                const unsigned grid = (unsigned)std::max(8 * nseg, s->up_grid & ~7);
+#define SEG_LAUNCH(D_, E_)                                                                                                      \
+    do {                                                                                                                            \
+        static OncePerDevice once_;                                                                                                 \
+        if (once_.first(s->device)) (void)hipFuncSetAttribute((const void *)k_uppass_seg<D_, E_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+        hipLaunchKernelGGL((k_uppass_seg<D_, E_>), dim3(grid), dim3(1024), lds, s->stream, U);                                      \
+    } while (0)
+                if (direct) { if (epi) SEG_LAUNCH(true, true); else SEG_LAUNCH(true, false); }
+                else { if (epi) SEG_LAUNCH(false, true); else SEG_LAUNCH(false, false); }
+#undef SEG_LAUNCH
+                HIPCHK(hipGetLastError());
             } else if (!s->use_lds && plain && s->fac[0]->packed_elem8 && s->up_big) {
                 UpBigArgs U{};
                 U.DimUp = A.DimUp; U.DimPh = A.DimPh; U.rsplit = s->row_split; U.Qdw = A.Qdw; U.dw0 = A.dw0; U.nrows = H.Qdw * H.DimPh;
@@ -440,6 +493,7 @@ static int hxv(S *s, const double *v, double *out, bool epi, const double *uprev
                 DwArgs D{};
                 D.DimUp = A.DimUp; D.DimDw = A.DimDw; D.DimPh = A.DimPh; D.Qdw = A.Qdw; D.dw0 = A.dw0;
                 D.dwc = A.dwc; D.dwv = A.dwv; D.dww = A.dww; D.v = v; D.vfull = A.vfull; D.out = out; D.scal = s->scal.p; D.partial = s->partial.p;
+                D.uprev2 = halo_epi ? uprev : nullptr;
                 D.w = s->dw_w; D.wshift = 0; while ((1 << D.wshift) < D.w) D.wshift++;
                 const int dv = s->dw_variant;
                 const bool vec2 = dv >= 2 && (H.DimUp % 2 == 0) && D.w >= 4 && D.dww <= 64;

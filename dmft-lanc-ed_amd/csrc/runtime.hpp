@@ -141,6 +141,10 @@ static void kpool_release()
 struct DevFactor {
     DevBuf<int32_t> map, rank, rowptr, cols, ellc, talpha, tbeta;
     DevBuf<uint32_t> pcols, pcodes, pelem, pelem8; DevBuf<double> ptval; bool packed = false, packed_elem = false, packed_elem8 = false; int32_t pterms = 0;
+    // segment + halo form of the local pass for rows beyond LDS (k_uppass_halo): the row is cut into nseg segments; seg_ext
+    // lists, per segment and ascending, the columns outside it that its hops reach; pseg8 is pelem8 with every column
+    // replaced by its position in the workgroup's LDS image [segment | halo]
+    DevBuf<int32_t> seg_ext, seg_ext_off; DevBuf<uint32_t> pseg8; int32_t nseg = 0, seglen = 0, seg_maxhalo = 0; bool seg_ok = false;
     DevBuf<double> vals, ellv, E, tval, lin;
     int32_t width = 0;
     bool ragged = false;     // some row has fewer hops than `width` (ELL padding present)
@@ -181,7 +185,7 @@ struct edgpu_sector_s {
     int64_t nloc = 0, nloc_el = 0, vecdim = 0;
     int32_t nmax = 0;
     bool use_lds = false; int kron_threads = 256, kron_threads_override = 0; size_t kron_lds = 0;
-    bool two_factor = false, extra = false, has_ph = false, has_nd = false, multi = false, kron_split = false; int dw_w = 64, dw_variant = 2, dw_rows = 64; bool up_persistent = true, up_pairs = true; int up_grid = 256, up_threads = 1024, row_split = 4; bool up_big = true, nd_split = true;
+    bool two_factor = false, extra = false, has_ph = false, has_nd = false, multi = false, kron_split = false; int dw_w = 64, dw_variant = 2, dw_rows = 64; bool up_persistent = true, up_pairs = true; int up_grid = 256, up_threads = 1024, row_split = 4; bool up_big = true, up_seg = true, up_halo = true, nd_split = true;
     std::vector<hipEvent_t> bench_ev; int bench_k = 0; bool bench_fused = false; double *bv[3] = {nullptr, nullptr, nullptr};
     // distributed-transpose form of the dw hops (opt-in, EDGPU_DW_TRANSPOSE=1)
     bool tr_on = false; int64_t Qup = 0, up0 = 0; DevBuf<double> tA, tB, tVT, tHVT; bool tr_lds = false;

@@ -101,6 +101,41 @@ static int upload_factor(S *s, int k)
     return EDGPU_OK;
 }
 
+// Segments of the up factor for rows beyond LDS (k_uppass_halo): smallest power-of-two segment count whose segment and
+// halo list fit the kernel's register staging and 160 KB of LDS.  Structure only (which columns the hops reach), so the
+// lists serve the stored and the on-the-fly product alike.
+static int build_up_segments(S *s)
+{
+    const Factor &f = s->H.fac[0]; DevFactor &df = *s->fac[0];
+    if (!df.packed_elem8 || f.dim % 2 || f.dim > 65536) return EDGPU_OK;
+    // first choice: two pairs and eight halo values per lane (the kernel variant that fits 128 registers without spilling)
+    const int32_t lim[2][2] = {{std::min(dbg_int("EDGPU_UP_SEGMAX", 4096), kHaloSegMax), std::min(dbg_int("EDGPU_UP_HALOMAX", 8192), kHaloMax)}, {kHaloSegMax, kHaloMax}};
+    for (int pass = 0; pass < 2; pass++)
+        for (int nseg = 2; nseg <= 32; nseg *= 2) {
+            const int32_t seglen = (int32_t)((cdiv(f.dim, nseg) + 1) & ~(int64_t)1);
+            if (seglen > lim[pass][0]) continue;
+            std::vector<int32_t> ext, off(1, 0); int32_t maxh = 0; bool ok = true;
+            for (int sg = 0; sg < nseg && ok; sg++) {
+                const int32_t lo = std::min<int32_t>(sg * seglen, f.dim), hi = std::min<int32_t>(lo + seglen, f.dim);
+                std::vector<int32_t> e;
+                for (int32_t i = lo; i < hi; i++)
+                    for (int64_t p = f.rowptr[i]; p < f.rowptr[i + 1]; p++) if (f.cols[p] < lo || f.cols[p] >= hi) e.push_back(f.cols[p]);
+                std::sort(e.begin(), e.end()); e.erase(std::unique(e.begin(), e.end()), e.end());
+                if ((int64_t)e.size() > lim[pass][1]) ok = false;
+                maxh = std::max<int32_t>(maxh, (int32_t)e.size());
+                ext.insert(ext.end(), e.begin(), e.end()); off.push_back((int32_t)ext.size());
+            }
+            if (!ok || ((size_t)seglen + maxh + 160) * 8 > 156 * 1024) continue;
+            if (ext.empty()) ext.push_back(0);
+            CHK(df.seg_ext.upload(ext)); CHK(df.seg_ext_off.upload(off)); CHK(df.pseg8.alloc((size_t)8 * f.dim));
+            df.nseg = nseg; df.seglen = seglen; df.seg_maxhalo = maxh; df.seg_ok = true;
+            hipLaunchKernelGGL(k_seg_remap, dim3((unsigned)cdiv(f.dim, 256)), dim3(256), 0, s->stream, df.pelem8.p, df.pseg8.p, df.seg_ext.p, df.seg_ext_off.p, f.dim, seglen, seglen, df.map.p, s->H.desc.ed_total_ud ? (1 << s->H.desc.Norb) - 1 : 0);
+            HIPCHK(hipGetLastError());
+            return EDGPU_OK;
+        }
+    return EDGPU_OK;
+}
+
 // Which dw rows does each rank need from each other rank?  Row j of rank r is needed here iff some
 // local row i has H_dw[i,j] != 0 -- or, with Jx/Jp, j is the partner row of i (one impurity electron of the dw
 // word moved to another orbital, stored/H_non_local.f90:21-83).  H_dw is small and known to every rank, so the lists are
@@ -359,6 +394,9 @@ static int create(const edgpu_desc *desc, S **out)
         s->up_pairs = dbg_int("EDGPU_UP_PAIRS", 1) != 0;
         s->row_split = std::max(1, std::min(32, dbg_int("EDGPU_ROW_SPLIT", 4)));
         s->up_big = dbg_int("EDGPU_UP_BIG", 1) != 0;
+        s->up_seg = dbg_int("EDGPU_UP_SEG", 1) != 0;
+        s->up_halo = dbg_int("EDGPU_UP_HALO", 1) != 0;
+        if (!s->use_lds && s->up_halo && !s->tr_on) CHK(build_up_segments(s.get()));
         s->nd_split = dbg_int("EDGPU_ND_SPLIT", 1) != 0;
         s->up_threads = dbg_int("EDGPU_UP_THREADS", 1024) == 512 ? 512 : 1024;
         s->dw_rows = std::max(1, std::min(64, dbg_int("EDGPU_DW_ROWS", 64)));
