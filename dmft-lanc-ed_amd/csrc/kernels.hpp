@@ -566,108 +566,18 @@ __global__ void __launch_bounds__(512) k_uppass_big(UpBigArgs A)
     }
 }
 
-// Local pass for rows too long for LDS, segment form (Ns=17/18).  The up configurations are sorted by value, so a
-// contiguous quarter of a row is (nearly) "the configurations with given top bath bits": 87 % of the up hops of an
-// element stay inside its own quarter (Ns=18, four segments of 95 KB), only the hops on the top levels leave it.  A
-// persistent 1024-thread workgroup therefore owns ONE segment of a row: it stages that segment in LDS (register prefetch
-// of the next row's segment while the current one computes, as k_uppass2), gathers in-segment sources from LDS and only
-// the out-of-segment ones -- 1.2 of 9 per element -- from global memory.  The nseg workgroups of a row sit on the same
-// XCD (blockIdx % 8) and run in step, so those loads find the row in that XCD's L2.  k_uppass_big does all 9 gathers
-// through the texture-address path, which is what bounded it.
-struct UpSegArgs {
-    int32_t DimUp, DimPh, nseg, seglen; int64_t Qdw, dw0, nrows;
-    const uint4 *packed8;     // [iup][2] uint4: 5 dwords of 16-bit columns, 3 dwords of 8-bit codes
-    const double *tval; int32_t nterms;
-    const double *diag, *Eup, *Edw, *cross; const int32_t *mapup, *mapdw; int32_t impmask, nI; double econst;
-    const double *v; double *out; const double *uprev; const double *scal;
-};
-template <bool DIRECT, bool EPI>
-__global__ void __launch_bounds__(1024) k_uppass_seg(UpSegArgs A)
-{
-    extern __shared__ double lds[];
-    constexpr int NT = 1024, MAXQ = 6;                   // segments of up to 12288 elements (96 KB)
-    const int DimUp = A.DimUp, tid = threadIdx.x;
-    const int x = blockIdx.x & 7, j = blockIdx.x >> 3, G = (int)(gridDim.x >> 3) / A.nseg;
-    const int g = j / A.nseg, sg = j - g * A.nseg;
-    const int lo = sg * A.seglen, hi = lo + A.seglen < DimUp ? lo + A.seglen : DimUp;
-    const int nel = hi - lo, npair = nel >> 1;
-    double *tv = lds + A.seglen;
-    double *crow = tv + 128;
-    for (int t = tid; t < A.nterms && t < 128; t += NT) tv[t] = A.tval[t];
-    if (g >= G) return;
-    const int nq = (npair + NT - 1) / NT;
-    dbl2v xr[MAXQ];
-    int64_t row = (int64_t)g * 8 + x; const int64_t rstep = (int64_t)G * 8;
-    auto fetch_row = [&](int64_t rw) {
-#pragma unroll
-        for (int q = 0; q < MAXQ; q++) { const int p = tid + q * NT; if (q < nq && p < npair) xr[q] = *reinterpret_cast<const dbl2v *>(A.v + rw * DimUp + lo + 2 * p); }
-    };
-    if (row < A.nrows) fetch_row(row);
-    double s_cur = 1.0, c_prev = 0.0;
-    if (EPI) { s_cur = A.scal[SC_SCUR]; c_prev = A.scal[SC_BETA] * A.scal[SC_SPREV]; }
-    struct Ops { dbl2v d, u; uint4 w0, w1, w2, w3; };    // d: stored diagonal (KRON) or Eup (DIRECT)
-    while (row < A.nrows) {
-        const int64_t idwl = row % A.Qdw, idw = A.dw0 + idwl;
-        const double *vrow = A.v + row * DimUp;
-        auto load_ops = [&](int p, Ops &o) {
-            const int i = lo + 2 * p;
-            if (!DIRECT) o.d = *reinterpret_cast<const dbl2v *>(A.diag + idwl * DimUp + i);
-            else o.d = *reinterpret_cast<const dbl2v *>(A.Eup + i);
-            if (EPI) o.u = *reinterpret_cast<const dbl2v *>(A.uprev + row * DimUp + i);
-            o.w0 = A.packed8[2 * i]; o.w1 = A.packed8[2 * i + 1]; o.w2 = A.packed8[2 * i + 2]; o.w3 = A.packed8[2 * i + 3];
-        };
-        Ops cur, nxt;
-        if (tid < npair) load_ops(tid, cur);
-#pragma unroll
-        for (int q = 0; q < MAXQ; q++) { const int p = tid + q * NT; if (q < nq && p < npair) *reinterpret_cast<dbl2v *>(lds + 2 * p) = xr[q]; }
-        if (DIRECT && tid < A.nI) crow[tid] = A.Edw[idw] + A.econst + A.cross[tid * A.nI + ((uint32_t)A.mapdw[idw] & A.impmask)];
-        __syncthreads();
-        const int64_t next = row + rstep;
-        if (next < A.nrows) fetch_row(next);
-        for (int p = tid; p < npair; p += NT) {
-            if (p + NT < npair) load_ops(p + NT, nxt);
-            const dbl2v xx = *reinterpret_cast<const dbl2v *>(lds + 2 * p);
-            dbl2v dval;
-            if (DIRECT) {
-                const int2 mm = *reinterpret_cast<const int2 *>(A.mapup + lo + 2 * p);
-                dval.x = cur.d.x + crow[(uint32_t)mm.x & A.impmask];
-                dval.y = cur.d.y + crow[(uint32_t)mm.y & A.impmask];
-            } else dval = cur.d;
-            const uint32_t c0[5] = {cur.w0.x, cur.w0.y, cur.w0.z, cur.w0.w, cur.w1.x}, k0[3] = {cur.w1.y, cur.w1.z, cur.w1.w};
-            const uint32_t c1[5] = {cur.w2.x, cur.w2.y, cur.w2.z, cur.w2.w, cur.w3.x}, k1[3] = {cur.w3.y, cur.w3.z, cur.w3.w};
-            double a0 = dval.x * xx.x, a1 = dval.y * xx.y;
-#pragma unroll
-            for (int e = 0; e < 10; e++) {
-                const uint32_t code0 = (k0[e >> 2] >> (8 * (e & 3))) & 0xffu, col0 = (c0[e >> 1] >> (16 * (e & 1))) & 0xffffu;
-                const uint32_t code1 = (k1[e >> 2] >> (8 * (e & 3))) & 0xffu, col1 = (c1[e >> 1] >> (16 * (e & 1))) & 0xffffu;
-                double t0 = tv[code0 & 0x7fu], t1 = tv[code1 & 0x7fu];
-                t0 = (code0 & 0x80u) ? -t0 : t0; t1 = (code1 & 0x80u) ? -t1 : t1;
-                const uint32_t r0 = col0 - (uint32_t)lo, r1 = col1 - (uint32_t)lo;
-                double x0, x1;
-                if (r0 < (uint32_t)nel) x0 = lds[r0]; else x0 = vrow[col0];
-                if (r1 < (uint32_t)nel) x1 = lds[r1]; else x1 = vrow[col1];
-                a0 += t0 * x0; a1 += t1 * x1;
-            }
-            dbl2v o;
-            if (EPI) { o.x = s_cur * a0 - c_prev * cur.u.x; o.y = s_cur * a1 - c_prev * cur.u.y; }
-            else { o.x = a0; o.y = a1; }
-            *reinterpret_cast<dbl2v *>(A.out + row * DimUp + lo + 2 * p) = o;
-            cur = nxt;
-        }
-        __syncthreads();
-        row = next;
-    }
-}
-
-// Segment + halo form of the long-row local pass.  k_uppass_seg still sends the out-of-segment gathers to global memory
-// in the middle of the hop loop, and every one of them is a dependent load the whole workgroup waits for (measured at
-// Ns=18: 66 % of the wave cycles waiting, HBM at 2 TB/s, VALU 39 %, LDS 21 % busy).  Here the workgroup's segment is
-// fixed for the whole launch, so the columns outside it that its hops reach are a fixed ascending list (seg_ext, built
-// once per sector): their values are fetched together with the segment -- one bulk prefetch per row, a full row ahead,
-// with the list itself held in registers -- into a halo area behind the segment in LDS, and the hop loop gathers from
-// LDS only (pseg8 holds LDS positions instead of columns).  Ns=18: 8 segments of 6 078 elements + <= 11 225 halo values
-// = 135 KB of LDS; 1.7 halo values per element, read from the XCD's L2 where the sibling workgroups of the same row are
-// loading them as their own segments at the same time.
+// Local pass for rows too long for LDS, segment + halo form (Ns=17/18).  The up configurations are sorted by value, so a
+// contiguous 1/16 of a row is (nearly) "the configurations with given top bath bits": three quarters of the up hops of an
+// element stay inside its own segment, only the hops on the top levels leave it.  A persistent 1024-thread workgroup owns
+// ONE segment of the rows it walks.  That segment is fixed for the whole launch, so the columns outside it that its hops
+// reach are a fixed ascending list (seg_ext, built once per sector): their values are fetched together with the segment
+// -- one bulk prefetch per row, a full row ahead, with the list itself held in registers -- into a halo area behind the
+// segment in LDS, and the hop loop gathers from LDS only (pseg8 holds LDS positions instead of columns).  Ns=18: 16
+// segments of 3 040 elements + <= 7 962 halo values = 86 KB of LDS; 2.3 halo values per element, read from the XCD's L2
+// where the sibling workgroups of the same row (same blockIdx % 8) are loading them as their own segments at the same time.
+// Two earlier forms: k_uppass_big (all gathers through the texture-address path, 27 ms at Ns=18) and a segment form that
+// sent only the out-of-segment gathers to global memory from inside the hop loop (25 ms: every such gather is a dependent
+// load the whole workgroup waits for -- 66 % of the wave cycles waiting, HBM at 2 TB/s, VALU 39 %, LDS 21 % busy).
 struct UpHaloArgs {
     int32_t DimUp, DimPh, nseg, seglen, halocap; int64_t Qdw, dw0, nrows;
     const uint4 *pseg8; const int32_t *ext, *ext_off;

@@ -437,27 +437,6 @@ static int hxv(S *s, const double *v, double *out, bool epi, const double *uprev
 #undef HALO_Q
 #undef HALO_LAUNCH
                 HIPCHK(hipGetLastError());
-            } else if (!s->use_lds && plain && s->fac[0]->packed_elem8 && s->up_seg && (H.DimUp % 2 == 0) && H.DimUp <= 65536) {
-                // rows beyond LDS: a workgroup per row SEGMENT (k_uppass_seg)
-                UpSegArgs U{};
-                int nseg = 2; while (nseg < 8 && ((cdiv(H.DimUp, nseg) + 1) & ~(int64_t)1) > 12288) nseg *= 2;
-                U.DimUp = A.DimUp; U.DimPh = A.DimPh; U.nseg = nseg; U.seglen = (int32_t)((cdiv(H.DimUp, nseg) + 1) & ~(int64_t)1);
-                U.Qdw = A.Qdw; U.dw0 = A.dw0; U.nrows = H.Qdw * H.DimPh;
-                U.packed8 = reinterpret_cast<const uint4 *>(s->fac[0]->pelem8.p); U.tval = s->fac[0]->ptval.p; U.nterms = s->fac[0]->pterms;
-                U.diag = A.diag; U.Eup = A.Eup; U.Edw = A.Edw; U.cross = A.cross; U.mapup = A.mapup; U.mapdw = A.mapdw; U.impmask = A.impmask; U.nI = A.nI; U.econst = A.econst;
-                U.v = v; U.out = out; U.uprev = uprev; U.scal = s->scal.p;
-                const size_t lds = (size_t)U.seglen * 8 + 128 * 8 + 32 * 8;
-                const unsigned grid = (unsigned)std::max(8 * nseg, s->up_grid & ~7);
-#define SEG_LAUNCH(D_, E_)                                                                                                      \
-    do {                                                                                                                            \
-        static OncePerDevice once_;                                                                                                 \
-        if (once_.first(s->device)) (void)hipFuncSetAttribute((const void *)k_uppass_seg<D_, E_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
-        hipLaunchKernelGGL((k_uppass_seg<D_, E_>), dim3(grid), dim3(1024), lds, s->stream, U);                                      \
-    } while (0)
-                if (direct) { if (epi) SEG_LAUNCH(true, true); else SEG_LAUNCH(true, false); }
-                else { if (epi) SEG_LAUNCH(false, true); else SEG_LAUNCH(false, false); }
-#undef SEG_LAUNCH
-                HIPCHK(hipGetLastError());
             } else if (!s->use_lds && plain && s->fac[0]->packed_elem8 && s->up_big) {
                 UpBigArgs U{};
                 U.DimUp = A.DimUp; U.DimPh = A.DimPh; U.rsplit = s->row_split; U.Qdw = A.Qdw; U.dw0 = A.dw0; U.nrows = H.Qdw * H.DimPh;
@@ -506,7 +485,7 @@ static int hxv(S *s, const double *v, double *out, bool epi, const double *uprev
                     else hipLaunchKernelGGL(k_dwpass<false>, dim3((unsigned)nblocks), dim3(256), 0, s->stream, D);
                 } else {
                     const bool nt = dv != 2, rag = s->fac[1]->ragged;
-                    // LDS also sets how many workgroups share a CU: fewer residents thrash the tile's L2 slab less (measured best: 48 KB)
+                    // extra LDS (EDGPU_DW_LDS_KB) caps the workgroups per CU; with 16-row chunks full residency measured best (Ns=16 and Ns=18 sweeps, round 2)
                     const size_t dlds = std::max<size_t>((size_t)D.R * D.dww * 12 + 16, (size_t)s->dw_lds_kb * 1024);
 #define DW_LAUNCH(E_, N_, R_)                                                                                                   \
     do {                                                                                                                            \

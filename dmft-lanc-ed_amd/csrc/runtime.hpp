@@ -185,7 +185,7 @@ struct edgpu_sector_s {
     int64_t nloc = 0, nloc_el = 0, vecdim = 0;
     int32_t nmax = 0;
     bool use_lds = false; int kron_threads = 256, kron_threads_override = 0; size_t kron_lds = 0;
-    bool two_factor = false, extra = false, has_ph = false, has_nd = false, multi = false, kron_split = false; int dw_w = 64, dw_variant = 2, dw_rows = 64; bool up_persistent = true, up_pairs = true; int up_grid = 256, up_threads = 1024, row_split = 4; bool up_big = true, up_seg = true, up_halo = true, nd_split = true;
+    bool two_factor = false, extra = false, has_ph = false, has_nd = false, multi = false, kron_split = false; int dw_w = 64, dw_variant = 2, dw_rows = 16; bool up_persistent = true, up_pairs = true; int up_grid = 256, up_threads = 1024, row_split = 4; bool up_big = true, up_halo = true, nd_split = true;
     std::vector<hipEvent_t> bench_ev; int bench_k = 0; bool bench_fused = false; double *bv[3] = {nullptr, nullptr, nullptr};
     // distributed-transpose form of the dw hops (opt-in, EDGPU_DW_TRANSPOSE=1)
     bool tr_on = false; int64_t Qup = 0, up0 = 0; DevBuf<double> tA, tB, tVT, tHVT; bool tr_lds = false;
@@ -193,7 +193,7 @@ struct edgpu_sector_s {
     int64_t nnz_total = 0, bytes_stored = 0;
     int64_t npartial = 0;
     // knobs read from the environment ONCE, at sector creation (never inside a product)
-    int dbg = 0; bool tables_wave = true; int dw_lds_kb = 48; bool lz_fused_on = true;
+    int dbg = 0; bool tables_wave = true; int dw_lds_kb = 0; bool lz_fused_on = true;
     int eig_ncv_used = 0;     // basis size the last edgpu_eigsh call actually ran with
     // Lanczos iteration fusion (single rank)
     int fuse_mode = -1; const double *fuse_zvec = nullptr;   // >= 0: the product's final reduction also performs this scalar step

@@ -362,7 +362,7 @@ static int create(const edgpu_desc *desc, S **out)
     s->nloc_el = H.DimUp * H.Qdw; s->nloc = s->nloc_el * H.DimPh; s->vecdim = s->nloc;
     s->multi = desc->mpi_size > 1 || (desc->reserved & 1);   // reserved bit 0: run the exchange path even on one rank (tests)
     s->lz_fused_on = dbg_int("EDGPU_LZ_FUSED", 1) != 0;
-    s->dbg = dbg_flags(); s->tables_wave = dbg_int("EDGPU_TABLES_WAVE", 1) != 0; s->dw_lds_kb = std::min(dbg_int("EDGPU_DW_LDS_KB", 48), 150);
+    s->dbg = dbg_flags(); s->tables_wave = dbg_int("EDGPU_TABLES_WAVE", 1) != 0; s->dw_lds_kb = std::min(dbg_int("EDGPU_DW_LDS_KB", 0), 150);
     // distributed-transpose dw pass: opt-in (EDGPU_DW_TRANSPOSE=1) until an 8-GPU run has shown it correct and faster than the
     // needed-rows exchange; at most 64 ranks (larger jobs use the needed-rows exchange)
     s->tr_on = s->multi && s->two_factor && !s->extra && desc->storage != EDGPU_STORE_CSR && dbg_int("EDGPU_DW_TRANSPOSE", 0) != 0 && H.DimUp >= desc->mpi_size && desc->mpi_size <= 64;
@@ -394,12 +394,11 @@ static int create(const edgpu_desc *desc, S **out)
         s->up_pairs = dbg_int("EDGPU_UP_PAIRS", 1) != 0;
         s->row_split = std::max(1, std::min(32, dbg_int("EDGPU_ROW_SPLIT", 4)));
         s->up_big = dbg_int("EDGPU_UP_BIG", 1) != 0;
-        s->up_seg = dbg_int("EDGPU_UP_SEG", 1) != 0;
         s->up_halo = dbg_int("EDGPU_UP_HALO", 1) != 0;
         if (!s->use_lds && s->up_halo && !s->tr_on) CHK(build_up_segments(s.get()));
         s->nd_split = dbg_int("EDGPU_ND_SPLIT", 1) != 0;
         s->up_threads = dbg_int("EDGPU_UP_THREADS", 1024) == 512 ? 512 : 1024;
-        s->dw_rows = std::max(1, std::min(64, dbg_int("EDGPU_DW_ROWS", 64)));
+        s->dw_rows = std::max(1, std::min(64, dbg_int("EDGPU_DW_ROWS", 16)));
         if (s->dw_w != 8 && s->dw_w != 16 && s->dw_w != 32 && s->dw_w != 64 && s->dw_w != 128 && s->dw_w != 256) s->dw_w = 32;
     }
     // operator storage

@@ -234,8 +234,7 @@ def test_large_sector_code_paths_on_small_sectors(edgpu_mod, monkeypatch, name, 
                 {"EDGPU_CSR_SPLIT": "0", "EDGPU_KRON_SPLIT": "1", "EDGPU_UP_THREADS": "512", "EDGPU_UP_PAIRS": "0"},
                 {"EDGPU_KRON_SPLIT": "1", "EDGPU_DEBUG": "4"},                                  # long-row path: one workgroup per row segment, halo in LDS (k_uppass_halo)
                 {"EDGPU_KRON_SPLIT": "1", "EDGPU_DEBUG": "4", "EDGPU_UP_GRID": "24", "EDGPU_LZ_FUSED": "0"},     # ... with idle workgroups (3 per XCD, 2 segments)
-                {"EDGPU_KRON_SPLIT": "1", "EDGPU_DEBUG": "4", "EDGPU_UP_HALO": "0"},            # ... out-of-segment gathers from global memory (k_uppass_seg)
-                {"EDGPU_KRON_SPLIT": "1", "EDGPU_DEBUG": "4", "EDGPU_UP_SEG": "0", "EDGPU_ROW_SPLIT": "3"},       # long-row path: no LDS staging, packed 8-dword image
+                {"EDGPU_KRON_SPLIT": "1", "EDGPU_DEBUG": "4", "EDGPU_UP_HALO": "0", "EDGPU_ROW_SPLIT": "3"},       # long-row fallback: no LDS staging, packed 8-dword image (k_uppass_big)
                 {"EDGPU_KRON_SPLIT": "1", "EDGPU_DEBUG": "4", "EDGPU_UP_BIG": "0", "EDGPU_ROW_SPLIT": "1"}):
         for k, val in env.items():
             monkeypatch.setenv(k, val)
