@@ -51,6 +51,7 @@ static int dispatch_kron2(S *s, int flags, const Kron2Args &A, int64_t rows)
 static int direct_tables(S *s)
 {
     const SectorHost &H = s->H; const edgpu_desc &d = H.desc;
+    if (s->composite) return EDGPU_OK;      // composite blocks (ed_total_ud=F) keep their tables; only the diagonal is formed on the fly
     for (int k = 0; k < 2 * H.Ns_Ud; k++) {
         DevFactor &f = *s->fac[k];
         TabArgs T{};
@@ -113,9 +114,9 @@ static int transposed_dw_pass(S *s, const double *v, hipStream_t st)
     CHK(a2a(s->tA.p, sc, sd, s->tB.p, rc, rd));                                                       // tB: blocks by sender
     if (s->tr_lds) {
         // rows fit LDS: read the received blocks and write the blocks of the way back directly (tVT is the out buffer)
-        TdwFusedArgs F{}; F.DimDw = (int32_t)H.DimDw; F.dww = s->fac[1]->width; F.P = P; F.Qup = s->Qup;
+        TdwFusedArgs F{}; F.DimDw = (int32_t)H.DimDw; F.dww = s->dwf->width; F.P = P; F.Qup = s->Qup;
         for (int r = 0; r <= P; r++) F.dw0[r] = Bk.dw0[r];
-        F.ellc = s->fac[1]->ellc.p; F.ellv = s->fac[1]->ellv.p; F.blk_in = s->tB.p; F.blk_out = s->tVT.p;
+        F.ellc = s->dwf->ellc.p; F.ellv = s->dwf->ellv.p; F.blk_in = s->tB.p; F.blk_out = s->tVT.p;
         if (s->dbg & 2) F.dww = 0;
         if (s->Qup > 0) {
             static OncePerDevice once;
@@ -129,14 +130,14 @@ static int transposed_dw_pass(S *s, const double *v, hipStream_t st)
     const unsigned bgrid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(cdiv(s->Qup * H.DimDw, 256), 65536));
     Bk.blocks = s->tB.p; Bk.vt = s->tVT.p; Bk.dir = 0;
     hipLaunchKernelGGL(k_tblocks, dim3(bgrid), dim3(256), 0, st, Bk);
-    TdwArgs D{}; D.DimDw = (int32_t)H.DimDw; D.dww = s->fac[1]->width; D.use_lds = 0;
-    D.ellc = s->fac[1]->ellc.p; D.ellv = s->fac[1]->ellv.p; D.vt = s->tVT.p; D.hvt = s->tHVT.p;
+    TdwArgs D{}; D.DimDw = (int32_t)H.DimDw; D.dww = s->dwf->width; D.use_lds = 0;
+    D.ellc = s->dwf->ellc.p; D.ellv = s->dwf->ellv.p; D.vt = s->tVT.p; D.hvt = s->tHVT.p;
     if (s->dbg & 2) D.dww = 0;
-    if (s->Qup > 0 && s->fac[1]->packed_elem8 && s->up_big && D.dww > 0) {
+    if (s->Qup > 0 && s->dwf->packed_elem8 && s->up_big && D.dww > 0) {
         // long rows: the packed-image gather kernel of the local pass, applied to H_dw (no diagonal)
         UpBigArgs U{};
         U.DimUp = (int32_t)H.DimDw; U.DimPh = 1; U.rsplit = s->row_split; U.Qdw = s->Qup; U.dw0 = 0; U.nrows = s->Qup;
-        U.packed8 = reinterpret_cast<const uint4 *>(s->fac[1]->pelem8.p); U.tval = s->fac[1]->ptval.p; U.nterms = s->fac[1]->pterms;
+        U.packed8 = reinterpret_cast<const uint4 *>(s->dwf->pelem8.p); U.tval = s->dwf->ptval.p; U.nterms = s->dwf->pterms;
         U.v = s->tVT.p; U.out = s->tHVT.p; U.nodiag = 1;
         hipLaunchKernelGGL((k_uppass_big<false, false>), dim3((unsigned)(cdiv(U.nrows, 8) * 8 * s->row_split)), dim3(512), 0, st, U);
     } else if (s->Qup > 0) hipLaunchKernelGGL(k_tdw, dim3((unsigned)s->Qup), dim3(H.DimDw >= 4096 ? 1024 : 256), 0, st, D);
@@ -156,8 +157,8 @@ static int transposed_dw_pass(S *s, const double *v, hipStream_t st)
 static bool fused_ok(const S *s)
 {
     const SectorHost &H = s->H;
-    return s->lz_fused_on && !s->multi && s->two_factor && !s->extra && s->kron_split && H.desc.storage != EDGPU_STORE_CSR && s->up_persistent && s->up_pairs &&
-           s->fac[0]->packed_elem && s->fac[0]->width <= 8 && s->use_lds && H.DimUp <= 13312 && (H.DimUp % 2 == 0) && s->dw_variant >= 2 && s->dw_w >= 4 && s->fac[1]->width <= 64;
+    return s->lz_fused_on && !s->multi && s->kron2 && !s->extra && s->kron_split && H.desc.storage != EDGPU_STORE_CSR && s->up_persistent && s->up_pairs &&
+           s->upf->packed_elem && s->upf->width <= 8 && s->use_lds && H.DimUp <= 13312 && (H.DimUp % 2 == 0) && s->dw_variant >= 2 && s->dw_w >= 4 && s->dwf->width <= 64;
 }
 // local half: r <- u_k = r - alpha s u_prev (in place), TMP = |u_k|^2 and the norm step, t <- local part of H u_k (unscaled)
 static int fused_local(S *s, double *r, const double *uprev, double *t, double *acc)
@@ -167,8 +168,8 @@ static int fused_local(S *s, double *r, const double *uprev, double *t, double *
     if (direct) CHK(direct_tables(s));
     UpAxArgs U{};
     U.DimUp = (int32_t)H.DimUp; U.DimPh = H.DimPh; U.Qdw = H.Qdw; U.dw0 = H.dw0; U.nrows = H.Qdw * H.DimPh;
-    U.packed = reinterpret_cast<const uint4 *>(s->fac[0]->pelem.p); U.tval = s->fac[0]->ptval.p; U.nterms = s->fac[0]->pterms;
-    U.diag = s->diag.p; U.Eup = s->fac[0]->E.p; U.Edw = s->fac[1]->E.p; U.cross = s->cross.p; U.mapup = s->fac[0]->map.p; U.mapdw = s->fac[1]->map.p;
+    U.packed = reinterpret_cast<const uint4 *>(s->upf->pelem.p); U.tval = s->upf->ptval.p; U.nterms = s->upf->pterms;
+    U.diag = s->diag.p; U.Eup = s->upf->E.p; U.Edw = s->dwf->E.p; U.cross = s->cross.p; U.mapup = s->upf->map.p; U.mapdw = s->dwf->map.p;
     U.impmask = (1 << d.Norb) - 1; U.nI = 1 << d.Norb; U.econst = H.econst;
     U.r = r; U.vprev = uprev; U.t_out = t; U.scal = s->scal.p; U.partial = s->partial.p; U.acc = acc; U.zvec = s->zvec.p;
     const size_t lds = (size_t)H.DimUp * 8 + 128 * 8 + 32 * 8 + 32 * 8;
@@ -195,14 +196,14 @@ static int fused_dw(S *s, const double *u, double *t, const double *uprev)
     const SectorHost &H = s->H;
     DwArgs D{};
     D.DimUp = (int32_t)H.DimUp; D.DimDw = (int32_t)H.DimDw; D.DimPh = H.DimPh; D.Qdw = H.Qdw; D.dw0 = H.dw0;
-    D.dwc = s->fac[1]->ellc.p; D.dwv = s->fac[1]->ellv.p; D.dww = s->fac[1]->width; D.v = u; D.vfull = u; D.out = t; D.scal = s->scal.p; D.partial = s->partial.p;
+    D.dwc = s->dwf->ellc.p; D.dwv = s->dwf->ellv.p; D.dww = s->dwf->width; D.v = u; D.vfull = u; D.out = t; D.scal = s->scal.p; D.partial = s->partial.p;
     D.uprev2 = uprev;
     D.w = s->dw_w; D.wshift = 0; while ((1 << D.wshift) < D.w) D.wshift++;
     D.ntiles = (int32_t)cdiv(H.DimUp, D.w);
     D.R = std::min(64, s->dw_rows);
     D.chunks = (int32_t)cdiv(H.Qdw * H.DimPh, D.R);
     const int64_t nblocks = 8 * cdiv(D.ntiles, 8) * (int64_t)D.chunks;
-    const bool nt = s->dw_variant != 2, rag = s->fac[1]->ragged;
+    const bool nt = s->dw_variant != 2, rag = s->dwf->ragged;
     const size_t dlds = std::max<size_t>((size_t)D.R * D.dww * 12 + 16, (size_t)s->dw_lds_kb * 1024);
 #define DW2_LAUNCH(N_, R_)                                                                                                      \
     do {                                                                                                                            \
@@ -337,13 +338,13 @@ static int hxv(S *s, const double *v, double *out, bool epi, const double *uprev
                 HIPCHK(hipGetLastError());
             }
         }
-    } else if (s->two_factor) {
+    } else if (s->kron2) {
         Kron2Args A{};
         A.DimUp = (int32_t)H.DimUp; A.DimDw = (int32_t)(s->halo ? s->nhalo : H.DimDw); A.DimPh = H.DimPh; A.Norb = d.Norb; A.Qdw = H.Qdw; A.dw0 = H.dw0;
-        A.upc = s->fac[0]->ellc.p; A.upv = s->fac[0]->ellv.p; A.upw = s->fac[0]->width;
-        A.dwc = s->halo ? s->dw_ellc_x.p : s->fac[1]->ellc.p; A.dwv = s->fac[1]->ellv.p; A.dww = s->fac[1]->width;
-        A.diag = s->diag.p; A.Eup = s->fac[0]->E.p; A.Edw = s->fac[1]->E.p; A.cross = s->cross.p;
-        A.mapup = s->fac[0]->map.p; A.mapdw = s->fac[1]->map.p; A.rankup = s->fac[0]->rank.p; A.rankdw = s->fac[1]->rank.p;
+        A.upc = s->upf->ellc.p; A.upv = s->upf->ellv.p; A.upw = s->upf->width;
+        A.dwc = s->halo ? s->dw_ellc_x.p : s->dwf->ellc.p; A.dwv = s->dwf->ellv.p; A.dww = s->dwf->width;
+        A.diag = s->diag.p; A.Eup = s->upf->E.p; A.Edw = s->dwf->E.p; A.cross = s->cross.p;
+        A.mapup = s->upf->map.p; A.mapdw = s->dwf->map.p; A.rankup = s->upf->rank.p; A.rankdw = s->dwf->rank.p;
         A.impmask = (1 << d.Norb) - 1; A.nI = 1 << d.Norb; A.econst = H.econst; A.w0 = d.w0_ph; A.gsum = H.gph_sum; A.Jx = d.Jx; A.Jp = d.Jp;
         A.gup = s->gup.p; A.gdw = s->gdw.p;
         A.v = v; A.vfull = multi ? s->vfull.p : v; A.out = out; A.uprev = uprev; A.scal = s->scal.p; A.partial = s->partial.p;
@@ -358,14 +359,14 @@ static int hxv(S *s, const double *v, double *out, bool epi, const double *uprev
         else {
             const bool plain = !s->extra || nd_pass;      // local pass = stored/on-the-fly diagonal + up hops only
             // k_uppass_halo writes the unscaled local part; under the Lanczos epilogue the vectorised dw pass finishes it (uprev2)
-            const bool dw_vec2 = s->dw_variant >= 2 && (H.DimUp % 2 == 0) && s->dw_w >= 4 && s->fac[1]->width <= 64;
-            const bool halo_can = !s->use_lds && plain && s->fac[0]->seg_ok && s->up_halo && (!epi || (dw_vec2 && !s->extra && !s->tr_on));
+            const bool dw_vec2 = s->dw_variant >= 2 && (H.DimUp % 2 == 0) && s->dw_w >= 4 && s->dwf->width <= 64;
+            const bool halo_can = !s->use_lds && plain && s->upf->seg_ok && s->up_halo && (!epi || (dw_vec2 && !s->extra && !s->tr_on));
             bool halo_epi = false;
-            const bool persistent = s->up_persistent && plain && s->fac[0]->packed && s->fac[0]->width <= 16 && s->use_lds && H.DimUp <= 13312;
-            if (persistent && s->up_pairs && s->fac[0]->packed_elem) {
+            const bool persistent = s->up_persistent && plain && s->upf->packed && s->upf->width <= 16 && s->use_lds && H.DimUp <= 13312;
+            if (persistent && s->up_pairs && s->upf->packed_elem) {
                 UpArgs2 U{};
                 U.DimUp = A.DimUp; U.DimPh = A.DimPh; U.Qdw = A.Qdw; U.dw0 = A.dw0; U.nrows = H.Qdw * H.DimPh;
-                U.packed = reinterpret_cast<const uint4 *>(s->fac[0]->pelem.p); U.tval = s->fac[0]->ptval.p; U.nterms = s->fac[0]->pterms;
+                U.packed = reinterpret_cast<const uint4 *>(s->upf->pelem.p); U.tval = s->upf->ptval.p; U.nterms = s->upf->pterms;
                 U.diag = A.diag; U.Eup = A.Eup; U.Edw = A.Edw; U.cross = A.cross; U.mapup = A.mapup; U.mapdw = A.mapdw; U.impmask = A.impmask; U.nI = A.nI; U.econst = A.econst;
                 U.v = v; U.out = out; U.uprev = uprev; U.scal = s->scal.p;
                 const size_t lds = (size_t)H.DimUp * 8 + 128 * 8;
@@ -389,7 +390,7 @@ static int hxv(S *s, const double *v, double *out, bool epi, const double *uprev
             } else if (persistent) {
                 UpArgs U{};
                 U.DimUp = A.DimUp; U.DimPh = A.DimPh; U.Qdw = A.Qdw; U.dw0 = A.dw0; U.nrows = H.Qdw * H.DimPh;
-                U.pcols = s->fac[0]->pcols.p; U.pcodes = s->fac[0]->pcodes.p; U.upw = s->fac[0]->width; U.tval = s->fac[0]->ptval.p; U.nterms = s->fac[0]->pterms;
+                U.pcols = s->upf->pcols.p; U.pcodes = s->upf->pcodes.p; U.upw = s->upf->width; U.tval = s->upf->ptval.p; U.nterms = s->upf->pterms;
                 U.diag = A.diag; U.Eup = A.Eup; U.Edw = A.Edw; U.cross = A.cross; U.mapup = A.mapup; U.mapdw = A.mapdw; U.impmask = A.impmask; U.nI = A.nI; U.econst = A.econst;
                 U.v = v; U.out = out; U.uprev = uprev; U.scal = s->scal.p;
                 const size_t lds = (((size_t)H.DimUp + 1) & ~(size_t)1) * 8 + 128 * 8;
@@ -411,7 +412,7 @@ static int hxv(S *s, const double *v, double *out, bool epi, const double *uprev
                 HIPCHK(hipGetLastError());
             } else if (halo_can) {
                 // rows beyond LDS: a workgroup per row segment, out-of-segment sources prefetched into an LDS halo (k_uppass_halo)
-                DevFactor &f0 = *s->fac[0];
+                DevFactor &f0 = *s->upf;
                 if (direct) {       // the on-the-fly tables were just rebuilt with columns: positions again
                     hipLaunchKernelGGL(k_seg_remap, dim3((unsigned)cdiv(H.DimUp, 256)), dim3(256), 0, s->stream, f0.pelem8.p, f0.pseg8.p, f0.seg_ext.p, f0.seg_ext_off.p, (int32_t)H.DimUp, f0.seglen, f0.seglen, f0.map.p, (int32_t)A.impmask);
                 }
@@ -437,10 +438,10 @@ static int hxv(S *s, const double *v, double *out, bool epi, const double *uprev
 #undef HALO_Q
 #undef HALO_LAUNCH
                 HIPCHK(hipGetLastError());
-            } else if (!s->use_lds && plain && s->fac[0]->packed_elem8 && s->up_big) {
+            } else if (!s->use_lds && plain && s->upf->packed_elem8 && s->up_big) {
                 UpBigArgs U{};
                 U.DimUp = A.DimUp; U.DimPh = A.DimPh; U.rsplit = s->row_split; U.Qdw = A.Qdw; U.dw0 = A.dw0; U.nrows = H.Qdw * H.DimPh;
-                U.packed8 = reinterpret_cast<const uint4 *>(s->fac[0]->pelem8.p); U.tval = s->fac[0]->ptval.p; U.nterms = s->fac[0]->pterms;
+                U.packed8 = reinterpret_cast<const uint4 *>(s->upf->pelem8.p); U.tval = s->upf->ptval.p; U.nterms = s->upf->pterms;
                 U.diag = A.diag; U.Eup = A.Eup; U.Edw = A.Edw; U.cross = A.cross; U.mapup = A.mapup; U.mapdw = A.mapdw; U.impmask = A.impmask; U.nI = A.nI; U.econst = A.econst;
                 U.v = v; U.out = out; U.uprev = uprev; U.scal = s->scal.p;
                 const unsigned grid = (unsigned)(cdiv(U.nrows, 8) * 8 * s->row_split);
@@ -484,7 +485,7 @@ static int hxv(S *s, const double *v, double *out, bool epi, const double *uprev
                     if (epi) hipLaunchKernelGGL(k_dwpass<true>, dim3((unsigned)nblocks), dim3(256), 0, s->stream, D);
                     else hipLaunchKernelGGL(k_dwpass<false>, dim3((unsigned)nblocks), dim3(256), 0, s->stream, D);
                 } else {
-                    const bool nt = dv != 2, rag = s->fac[1]->ragged;
+                    const bool nt = dv != 2, rag = s->dwf->ragged;
                     // extra LDS (EDGPU_DW_LDS_KB) caps the workgroups per CU; with 16-row chunks full residency measured best (Ns=16 and Ns=18 sweeps, round 2)
                     const size_t dlds = std::max<size_t>((size_t)D.R * D.dww * 12 + 16, (size_t)s->dw_lds_kb * 1024);
 #define DW_LAUNCH(E_, N_, R_)                                                                                                   \

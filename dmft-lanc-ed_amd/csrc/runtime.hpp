@@ -161,6 +161,9 @@ struct edgpu_sector_s {
     hipStream_t stream = nullptr, cstream = nullptr;
     hipEvent_t ev_a = nullptr, ev_b = nullptr, ev_gather = nullptr, ev_ready = nullptr;
     std::vector<std::unique_ptr<DevFactor>> fac;
+    // the two factors the product kernels run on: fac[0], fac[1] (ed_total_ud=T) or the composite blocks (ed_total_ud=F, cdev)
+    std::unique_ptr<DevFactor> cdev[2]; DevFactor *upf = nullptr, *dwf = nullptr; const Factor *hup = nullptr, *hdw = nullptr;
+    bool kron2 = false, composite = false;
     DevBuf<double> diag, cross, gup, gdw, bd_up, bd_dw;
     DevBuf<int32_t> stride;
     // explicit CSR

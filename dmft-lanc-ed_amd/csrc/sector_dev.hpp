@@ -7,9 +7,12 @@ namespace edgpu {
 // ---------------------------------------------------------------------------------------
 // device-side construction
 // ---------------------------------------------------------------------------------------
+// k: index into H.fac (per-orbital / per-spin block), or -1 / -2 for the composite up / dw block of an ed_total_ud=F sector
 static int upload_factor(S *s, int k)
 {
-    const Factor &f = s->H.fac[k];
+    const bool comp = k < 0;
+    const Factor &f = comp ? s->H.cfac[-1 - k] : s->H.fac[k];
+    const bool is_up = comp ? k == -1 : k < s->H.Ns_Ud;
     auto df = std::make_unique<DevFactor>();
     CHK(df->map.upload(f.map)); CHK(df->rank.upload(f.rank));
     std::vector<int32_t> rp32(f.rowptr.begin(), f.rowptr.end());
@@ -20,7 +23,7 @@ static int upload_factor(S *s, int k)
     if (df->width > 64) return fail(EDGPU_EUNSUPPORTED, "edgpu: more than 64 hops per spin configuration");
     if ((int)f.terms.size() > kMaxTerms) return fail(EDGPU_EUNSUPPORTED, "edgpu: too many one-body hop terms");
     // ELL image: up factors transposed [width][dim] (lanes run over rows), dw factors [dim][width]
-    const bool transposed = k < s->H.Ns_Ud || s->tr_on;     // transpose mode: H_dw is applied along rows too
+    const bool transposed = is_up || s->tr_on;     // transpose mode: H_dw is applied along rows too
     std::vector<int32_t> ec((size_t)df->width * f.dim); std::vector<double> ev((size_t)df->width * f.dim);
     for (int32_t i = 0; i < f.dim; i++)
         for (int32_t q = 0; q < df->width; q++) {
@@ -31,7 +34,7 @@ static int upload_factor(S *s, int k)
     CHK(df->ellc.upload(ec)); CHK(df->ellv.upload(ev));
     // packed image for the persistent local pass: 16-bit column + (sign | term index) byte per hop;
     // padded slots use code 127 -> amplitude 0.  Only when every entry is a single hop term.
-    if ((k < s->H.Ns_Ud || s->tr_on) && f.dim <= 65536 && f.terms.size() < 127) {      // transpose mode: H_dw is applied along rows too
+    if ((is_up || s->tr_on) && f.dim <= 65536 && f.terms.size() < 127) {      // transpose mode: H_dw is applied along rows too
         const int W = df->width, ncw = (W + 1) / 2, ndw = (W + 3) / 4;
         std::vector<uint32_t> pc((size_t)ncw * f.dim, 0u), pd((size_t)ndw * f.dim, 0u);
         std::vector<double> tvl(128, 0.0);
@@ -82,7 +85,8 @@ static int upload_factor(S *s, int k)
     if (ta.empty()) { ta.push_back(1); tb.push_back(1); tv.push_back(0.0); }
     CHK(df->talpha.upload(ta)); CHK(df->tbeta.upload(tb)); CHK(df->tval.upload(tv));
     // per-level one-body coefficients for the on-the-fly energy table
-    {
+    if (comp) { std::vector<double> lin(std::max(f.nbits, 1), 0.0); CHK(df->lin.upload(lin)); }     // composite tables are not rebuilt on the fly
+    else {
         const edgpu_desc &d = s->H.desc; const SectorHost &H = s->H;
         int spin = k < H.Ns_Ud ? 1 : d.Nspin;
         std::vector<double> lin(f.nbits, 0.0);
@@ -97,7 +101,7 @@ static int upload_factor(S *s, int k)
         }
         CHK(df->lin.upload(lin));
     }
-    s->fac.push_back(std::move(df));
+    if (comp) s->cdev[-1 - k] = std::move(df); else s->fac.push_back(std::move(df));
     return EDGPU_OK;
 }
 
@@ -106,7 +110,7 @@ static int upload_factor(S *s, int k)
 // lists serve the stored and the on-the-fly product alike.
 static int build_up_segments(S *s)
 {
-    const Factor &f = s->H.fac[0]; DevFactor &df = *s->fac[0];
+    const Factor &f = *s->hup; DevFactor &df = *s->upf;
     if (!df.packed_elem8 || f.dim % 2 || f.dim > 65536) return EDGPU_OK;
     // first choice: two pairs and eight halo values per lane (the kernel variant that fits 128 registers without spilling)
     const int32_t lim[2][2] = {{std::min(dbg_int("EDGPU_UP_SEGMAX", 4096), kHaloSegMax), std::min(dbg_int("EDGPU_UP_HALOMAX", 8192), kHaloMax)}, {kHaloSegMax, kHaloMax}};
@@ -143,7 +147,7 @@ static int build_up_segments(S *s)
 // of the all-gather volume at 2 / 4 / 8 ranks.
 static int setup_halo(S *s)
 {
-    const SectorHost &H = s->H; const Factor &dw = H.fac[1];
+    const SectorHost &H = s->H; const Factor &dw = *s->hdw;
     const int P = s->comm.size, me = s->comm.rank;
     auto range_of = [&](int r, int64_t &d0, int64_t &qd) { int64_t q = H.DimDw / P, rem = H.DimDw % P; qd = r < rem ? q + 1 : q; d0 = r < rem ? r * (q + 1) : r * q + rem; };
     std::vector<int> owner(H.DimDw);
@@ -190,7 +194,7 @@ static int setup_halo(S *s)
     CHK(s->send_list.upload(send_list));
     CHK(s->sendbuf.alloc((size_t)std::max<int64_t>(so, 1) * H.DimUp * H.DimPh));
     // H_dw column indices translated to x-space for the local rows (ELL image and CSR image)
-    const int W = s->fac[1]->width;
+    const int W = s->dwf->width;
     std::vector<int32_t> ec((size_t)W * dw.dim, 0), cc(dw.cols.size(), 0);
     for (int64_t i = H.dw0; i < H.dw0 + H.Qdw; i++) {
         for (int q = 0; q < W; q++) { int64_t p = dw.rowptr[i] + q; bool has = p < dw.rowptr[i + 1]; ec[(size_t)i * W + q] = has ? xmap[dw.cols[p]] : xmap[i]; }
@@ -223,9 +227,9 @@ static int build_diag(S *s)
 static int build_csr(S *s)
 {
     const SectorHost &H = s->H;
-    if (!s->two_factor || H.DimPh > 1 || H.Jhflag) return fail(EDGPU_EUNSUPPORTED, "edgpu: storage=CSR supports ed_total_ud=T without phonons and Jx/Jp");
+    if (!s->kron2 || H.DimPh > 1 || H.Jhflag) return fail(EDGPU_EUNSUPPORTED, "edgpu: storage=CSR supports sectors without phonons and Jx/Jp");
     if (H.DimUp * s->nhalo >= ((int64_t)1 << 31)) return fail(EDGPU_EUNSUPPORTED, "edgpu: storage=CSR needs DimUp*(rows of x) < 2^31 (int32 columns)");
-    const Factor &up = H.fac[0], &dw = H.fac[1];
+    const Factor &up = *s->hup, &dw = *s->hdw;
     std::vector<int64_t> uppre(up.dim + 1, 0), dwpre(H.Qdw + 1, 0);
     for (int i = 0; i < up.dim; i++) uppre[i + 1] = uppre[i] + 1 + (up.rowptr[i + 1] - up.rowptr[i]);
     int64_t maxrow = 0; int upmax = 0;
@@ -244,8 +248,8 @@ static int build_csr(S *s)
     s->csrL_nnz = H.Qdw * uppre[up.dim]; s->csrD_nnz = s->csr_nnz - s->csrL_nnz;
     CsrBuildArgs A{};
     A.DimUp = (int32_t)H.DimUp; A.DimDw = (int32_t)H.DimDw; A.Qdw = H.Qdw; A.dw0 = H.dw0;
-    A.uprp = s->fac[0]->rowptr.p; A.upc = s->fac[0]->cols.p; A.upv = s->fac[0]->vals.p;
-    A.dwrp = s->fac[1]->rowptr.p; A.dwc = s->halo ? s->dw_cols_x.p : s->fac[1]->cols.p; A.dwv = s->fac[1]->vals.p;
+    A.uprp = s->upf->rowptr.p; A.upc = s->upf->cols.p; A.upv = s->upf->vals.p;
+    A.dwrp = s->dwf->rowptr.p; A.dwc = s->halo ? s->dw_cols_x.p : s->dwf->cols.p; A.dwv = s->dwf->vals.p;
     A.rowshift = s->halo ? H.dw0 : 0;     // x-space index of local row idw is idw - rowshift
     A.uppre = s->uppre.p; A.dwpre = s->dwpre.p; A.diag = s->diag.p;
     const unsigned gb = (unsigned)cdiv(s->nloc_el + 1, 256);
@@ -331,7 +335,7 @@ static int build_csr(S *s)
 static int64_t max_partials(const S *s)
 {
     int64_t n = std::max<int64_t>(s->H.Qdw * s->H.DimPh, 4096);
-    if (s->two_factor) {   // column-tiled dw pass: one partial per workgroup
+    if (s->kron2) {   // column-tiled dw pass: one partial per workgroup
         const int w = s->dw_w, R = std::min(256 / w, s->dw_rows);
         n = std::max<int64_t>(n, 8 * cdiv(cdiv(s->H.DimUp, w), 8) * cdiv(s->H.Qdw * s->H.DimPh, std::max(R, 1)));
     }
@@ -367,6 +371,10 @@ static int create(const edgpu_desc *desc, S **out)
     // needed-rows exchange; at most 64 ranks (larger jobs use the needed-rows exchange)
     s->tr_on = s->multi && s->two_factor && !s->extra && desc->storage != EDGPU_STORE_CSR && dbg_int("EDGPU_DW_TRANSPOSE", 0) != 0 && H.DimUp >= desc->mpi_size && desc->mpi_size <= 64;
     for (int k = 0; k < 2 * H.Ns_Ud; k++) CHK(upload_factor(s.get(), k));
+    s->composite = !s->two_factor && H.cfac.size() == 2 && dbg_int("EDGPU_COMPOSITE", 1) != 0;
+    s->kron2 = s->two_factor || s->composite;
+    if (s->composite) { CHK(upload_factor(s.get(), -1)); CHK(upload_factor(s.get(), -2)); s->upf = s->cdev[0].get(); s->dwf = s->cdev[1].get(); s->hup = &H.cfac[0]; s->hdw = &H.cfac[1]; }
+    else if (s->two_factor) { s->upf = s->fac[0].get(); s->dwf = s->fac[1].get(); s->hup = &H.fac[0]; s->hdw = &H.fac[1]; }
     CHK(s->cross.upload(H.cross)); CHK(s->gup.upload(H.gph_up)); CHK(s->gdw.upload(H.gph_dw));
     {
         std::vector<double> bu((size_t)desc->Nfoo * desc->Nbath), bd((size_t)desc->Nfoo * desc->Nbath);
@@ -376,7 +384,7 @@ static int create(const edgpu_desc *desc, S **out)
         CHK(s->bd_up.upload(bu)); CHK(s->bd_dw.upload(bd)); CHK(s->stride.upload(st));
     }
     // launch geometry of the fused two-factor kernel
-    if (s->two_factor) {
+    if (s->kron2) {
         size_t rowbytes = (size_t)H.DimUp * sizeof(double);
         s->use_lds = rowbytes + 128 <= 150 * 1024 && !(dbg_flags() & 4);
         if (dbg_int("EDGPU_KRON_THREADS", 0)) s->kron_threads_override = dbg_int("EDGPU_KRON_THREADS", 0);
@@ -403,8 +411,8 @@ static int create(const edgpu_desc *desc, S **out)
     }
     // operator storage
     int64_t nnz_fac = 0;
-    if (s->two_factor) {
-        const Factor &up = H.fac[0], &dw = H.fac[1];
+    if (s->kron2) {
+        const Factor &up = *s->hup, &dw = *s->hdw;
         int64_t nd = dw.rowptr[H.dw0 + H.Qdw] - dw.rowptr[H.dw0];
         nnz_fac = (int64_t)up.cols.size() * H.Qdw + nd * H.DimUp;
     } else {
@@ -413,7 +421,7 @@ static int create(const edgpu_desc *desc, S **out)
     s->nnz_total = (s->nloc_el + nnz_fac) * H.DimPh;
     s->multi = desc->mpi_size > 1 || (desc->reserved & 1);   // reserved bit 0: run the exchange path even on one rank (tests)
     s->nhalo = H.DimDw;
-    if (s->multi && !s->tr_on && s->two_factor && (!s->extra || (s->has_nd && !s->has_ph && s->nd_split)) && dbg_int("EDGPU_HALO", 1)) CHK(setup_halo(s.get()));
+    if (s->multi && !s->tr_on && s->kron2 && (!s->extra || (s->has_nd && !s->has_ph && s->nd_split)) && dbg_int("EDGPU_HALO", 1)) CHK(setup_halo(s.get()));
     if (s->tr_on) {     // up-block of this rank in the transposed space (same rule as the dw split)
         const int64_t P = s->comm.size, r = s->comm.rank, q = H.DimUp / P, rem = H.DimUp % P;
         s->Qup = r < rem ? q + 1 : q; s->up0 = r < rem ? r * (q + 1) : r * q + rem;

@@ -58,6 +58,9 @@ struct SectorHost {
     int Ns = 0, Ns_Orb = 0, Ns_Ud = 0, DimPh = 1, Jhflag = 0, isector = 0;
     int stride[EDGPU_MAX_ORB][64];      // getBathStride(iorb,kp), 1-based level index
     std::vector<Factor> fac;            // [ups(0..Ns_Ud-1), dws(0..Ns_Ud-1)]
+    // ed_total_ud=F: the composite up / dw blocks H_up = sum_a 1 x .. x H_a x .. x 1 over the mixed-radix up (dw) index,
+    // as two explicit factors, so that the sector runs through the two-factor product kernels (empty when ed_total_ud=T)
+    std::vector<Factor> cfac;
     int64_t DimUp = 1, DimDw = 1, Dim = 0;
     int64_t Qdw = 0, dw0 = 0;           // local dw columns [dw0, dw0+Qdw)
     double econst = 0.0;                // state-independent part of the diagonal
@@ -147,7 +150,46 @@ struct SectorHost {
         build_terms();
         for (auto &f : fac) build_rows(f);
         build_energy_tables();
+        if (!d.ed_total_ud) build_composite();
         return "";
+    }
+
+    // Composite factor of the Ns_Ud per-orbital blocks fac[first .. first+Ns_Ud): index = sum_a dig_a * prod_{b<a} dim_b (the
+    // reference's state order, ED_SETUP.f90 state2indices), rows = Kronecker sum with ascending columns, every entry with
+    // the sign its own orbital block gave it (stored/Orbs/H_up.f90:7-30 acts on one orbital's word at a time), E = sum of
+    // the blocks' tables, map = impurity word (bit a = impurity level of orbital a+1 occupied).
+    void build_composite()
+    {
+        cfac.assign(2, Factor());
+        for (int side = 0; side < 2; side++) {
+            Factor &c = cfac[side];
+            const int first = side * Ns_Ud;
+            int64_t dim = 1; std::vector<int64_t> st(Ns_Ud);
+            for (int a = 0; a < Ns_Ud; a++) { st[a] = dim; dim *= fac[first + a].dim; }
+            int64_t wsum = 0; for (int a = 0; a < Ns_Ud; a++) wsum += fac[first + a].width;
+            if (dim > ((int64_t)1 << 26) || dim * std::max<int64_t>(wsum, 1) > ((int64_t)1 << 30)) { cfac.clear(); return; }   // too large to tabulate: generic kernel
+            c.nbits = Ns; c.npart = 0; c.dim = (int32_t)dim;
+            c.rank.assign(1, 0);
+            for (int a = 0; a < Ns_Ud; a++) for (auto &t : fac[first + a].terms) c.terms.push_back(t);
+            c.map.resize(dim); c.E.resize(dim); c.rowptr.assign((size_t)dim + 1, 0);
+            std::vector<int32_t> dig(Ns_Ud, 0);
+            struct Ent { int32_t j; double v; };
+            std::vector<Ent> row;
+            for (int64_t i = 0; i < dim; i++) {
+                uint32_t m = 0; double e = 0.0; row.clear();
+                for (int a = 0; a < Ns_Ud; a++) {
+                    const Factor &f = fac[first + a];
+                    m |= ((uint32_t)f.map[dig[a]] & 1u) << a; e += f.E[dig[a]];
+                    for (int64_t q = f.rowptr[dig[a]]; q < f.rowptr[dig[a] + 1]; q++) row.push_back({(int32_t)(i + (int64_t)(f.cols[q] - dig[a]) * st[a]), f.vals[q]});
+                }
+                std::sort(row.begin(), row.end(), [](const Ent &x, const Ent &y) { return x.j < y.j; });
+                for (auto &r : row) { c.cols.push_back(r.j); c.vals.push_back(r.v); }
+                c.rowptr[i + 1] = (int64_t)c.cols.size();
+                c.width = std::max<int32_t>(c.width, (int32_t)row.size());
+                c.map[i] = (int32_t)m; c.E[i] = e;
+                for (int a = 0; a < Ns_Ud; a++) { if (++dig[a] < fac[first + a].dim) break; dig[a] = 0; }
+            }
+        }
     }
 
     // Flatten the one-body couplings into hop terms in the statement order of

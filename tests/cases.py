@@ -75,6 +75,9 @@ def zoo():
     m = model.make_model(Norb=2, Nbath=3, ed_total_ud=False, Uloc=(2.0, 2.0), Ust=1.5, Jh=0.25, impHloc=np.diag([0.3, -0.3]).reshape(1, 1, 2, 2))
     Z.append(("orbs_norb2_nb3", m, [2, 2], [2, 2]))
     Z.append(("orbs_norb2_nb3_uneven", m, [1, 3], [2, 0]))
+    m = model.make_model(Norb=2, Nbath=4, ed_total_ud=False, Uloc=(2.0, 1.0), Ust=0.8, Jh=0.1, impHloc=np.diag([0.1, -0.2]).reshape(1, 1, 2, 2),
+                         bath_v=np.random.RandomState(8).uniform(0.2, 0.6, (1, 2, 4)), bath_e=np.random.RandomState(9).uniform(-1, 1, (1, 2, 4)))
+    Z.append(("orbs_norb2_nb4", m, [2, 3], [3, 2]))
     m = model.make_model(Norb=1, Nbath=3, Nph=3, w0_ph=0.7, g_ph=(0.4,), Uloc=(2.0,))
     Z.append(("phonons_nb3_nph3", m, [2], [2]))
     m = model.make_model(Norb=2, Nbath=2, Nph=2, w0_ph=0.5, g_ph=(0.3, 0.2), Uloc=(2.0, 2.0), Ust=1.0, Jh=0.2, Jx=0.2, Jp=0.2)

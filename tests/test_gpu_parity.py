@@ -43,7 +43,7 @@ def _sample_rows(DimUp, DimDw, rng, nrandom, parts=8, tile=64, above=None):
 
 def _storages(m):
     st = ["kron", "direct"]
-    if m.get("ed_total_ud", True) and m.get("Nph", 0) == 0 and not (m["Norb"] > 1 and (m.get("Jx", 0) or m.get("Jp", 0))):
+    if m.get("Nph", 0) == 0 and not (m["Norb"] > 1 and (m.get("Jx", 0) or m.get("Jp", 0))):      # ed_total_ud=F: explicit CSR of the composite blocks
         st.append("csr")
     return st
 
@@ -209,7 +209,7 @@ def test_device_pointer_path_and_errors(edgpu_mod):
     G.close()
 
 
-FORCED = [z for z in ZOO if z[0] in ("c_nb7_half", "nb5_offhalf_2_4", "nb6_even", "nspin2_random_bath", "norb2_normal_offdiag_hloc", "c_nb5_half",
+FORCED = [z for z in ZOO if z[0] in ("orbs_norb2_nb3", "orbs_norb2_nb4", "phonons_orbs", "c_nb7_half", "nb5_offhalf_2_4", "nb6_even", "nspin2_random_bath", "norb2_normal_offdiag_hloc", "c_nb5_half",
                                     "norb2_normal_JxJp", "norb2_hybrid_JxJp", "replica_sz_sx_JxJp", "norb3_nb1_JxJp")]   # Jx/Jp: the non-local pass
 
 
@@ -224,6 +224,7 @@ def test_large_sector_code_paths_on_small_sectors(edgpu_mod, monkeypatch, name, 
     tol = HXV_RTOL * np.abs(ref).max()
     w = np.linalg.eigvalsh(S.hmat())
     for env in ({"EDGPU_KRON_SPLIT": "1", "EDGPU_CSR_SPLIT": "1"},
+                {"EDGPU_COMPOSITE": "0"},      # ed_total_ud=F through the generic mixed-radix kernel instead of the composite two-factor path (no CSR there)
                 # persistent pipelined CSR kernels (x window in LDS / XCD-owned tiles), which small sectors do not pick by themselves
                 {"EDGPU_CSR_SPLIT": "1", "EDGPU_CSR_LDS": "1", "EDGPU_CSRD_PIPE": "1"},
                 {"EDGPU_CSR_SPLIT": "1", "EDGPU_CSR_LDS": "1", "EDGPU_CSRD_PIPE": "1", "EDGPU_CSR_LDS_NT": "512", "EDGPU_CSR_LDS_GRID": "3", "EDGPU_CSRD_PIPE_GRID": "16", "EDGPU_CSRD_PIPE_ROWS": "16"},
@@ -239,6 +240,8 @@ def test_large_sector_code_paths_on_small_sectors(edgpu_mod, monkeypatch, name, 
         for k, val in env.items():
             monkeypatch.setenv(k, val)
         for st in _storages(m):
+            if st == "csr" and env.get("EDGPU_COMPOSITE") == "0" and not m.get("ed_total_ud", True):
+                continue
             G = edgpu_mod.HvSector(m, nu, nd, storage=st)
             hv = G.spHtimesV(v)
             assert np.abs(hv - ref).max() <= tol, (env, st, np.abs(hv - ref).max())
