@@ -223,15 +223,34 @@ int edgpu_csr_rows(edgpu_handle h, int64_t row0, int64_t nrows, int64_t *row_ptr
         return EDGPU_OK;
     };
     // merged view (ascending columns) of the one, two or three stored blocks
-    std::vector<int64_t> rp[3]; std::vector<int32_t> cc[3]; std::vector<double> vv[3];
+    std::vector<int64_t> rp[4]; std::vector<int32_t> cc[4]; std::vector<double> vv[4];
     int nblk = 1;
     CHK(fetch(h->csr_rowptr, h->csr_cols, h->csr_vals, rp[0], cc[0], vv[0]));
     if (h->csr_split) { CHK(fetch(h->csrD_rowptr, h->csrD_cols, h->csrD_vals, rp[1], cc[1], vv[1])); nblk = 2; }
     if (h->csr_three) { CHK(fetch(h->csrO_rowptr, h->csrO_cols, h->csrO_vals, rp[2], cc[2], vv[2])); nblk = 3; }
+    if (h->nd_nr > 0) {     // non-local block (compressed rows): expand the window's part into a row-pointer form
+        auto at = [&](const int64_t *p, int64_t i, int64_t &o) -> int { HIPCHK(hipMemcpy(&o, p + i, 8, hipMemcpyDeviceToHost)); return EDGPU_OK; };
+        auto lower = [&](int64_t key, int64_t &pos) -> int {       // first non-empty row >= key
+            int64_t a = 0, b = h->nd_nr;
+            while (a < b) { const int64_t m = (a + b) / 2; int64_t r; CHK(at(h->nd_rows.p, m, r)); if (r < key) a = m + 1; else b = m; }
+            pos = a; return EDGPU_OK;
+        };
+        int64_t i0, i1; CHK(lower(row0, i0)); CHK(lower(row0 + nrows, i1));
+        std::vector<int64_t> rr((size_t)(i1 - i0)), pp((size_t)(i1 - i0) + 1);
+        if (i1 > i0) HIPCHK(hipMemcpy(rr.data(), h->nd_rows.p + i0, (size_t)(i1 - i0) * 8, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(pp.data(), h->nd_ptr.p + i0, (size_t)(i1 - i0 + 1) * 8, hipMemcpyDeviceToHost));
+        const int64_t ne = pp.back() - pp[0];
+        cc[nblk].resize(ne); vv[nblk].resize(ne);
+        if (ne) { HIPCHK(hipMemcpy(cc[nblk].data(), h->nd_cols.p + pp[0], (size_t)ne * 4, hipMemcpyDeviceToHost)); HIPCHK(hipMemcpy(vv[nblk].data(), h->nd_vals.p + pp[0], (size_t)ne * 8, hipMemcpyDeviceToHost)); }
+        rp[nblk].assign((size_t)nrows + 1, 0);
+        for (size_t k = 0; k < rr.size(); k++) rp[nblk][rr[k] - row0 + 1] = pp[k + 1] - pp[k];
+        for (int64_t r = 0; r < nrows; r++) rp[nblk][r + 1] += rp[nblk][r];
+        nblk++;
+    }
     int64_t n = 0;
     row_ptr[0] = 0;
     for (int64_t r = 0; r < nrows; r++) {
-        int64_t a[3], ae[3];
+        int64_t a[4], ae[4];
         for (int b = 0; b < nblk; b++) { a[b] = rp[b][r] - rp[b][0]; ae[b] = rp[b][r + 1] - rp[b][0]; }
         for (;;) {
             int pick = -1;

@@ -892,6 +892,124 @@ __global__ void __launch_bounds__(256) k_ndpass(NdArgs A)
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Stored form of the non-local block (the reference's spH0nd, ED_HAMILTONIAN_SPARSE_HxV.f90:473-483, filled by
+// stored/H_non_local.f90:21-83) for storage=CSR.  Most rows of it are empty (a spin-exchange / pair-hopping term needs
+// matching impurity bits in both spin words), so it is kept as a compressed-row matrix: the ascending list of non-empty
+// rows, their entry offsets, and the entries (column in the x-space of the dw block, value, and the row's position in
+// its group of 64 non-empty rows).  Built on the device in two sweeps of the k_ndpass term loop (count, fill) with a host
+// scan over the per-dw-row totals in between; entries of a row in ascending column order.
+// ---------------------------------------------------------------------------------------------
+struct NdBuildArgs {
+    int32_t DimUp, DimDw, Norb; int64_t Qdw, dw0;
+    const int32_t *mapup, *mapdw, *rankup, *rankdw, *xmap; double Jx, Jp;
+    int64_t *row_nr, *row_ne;                 // per dw row: non-empty elements / entries (count sweep: totals; fill sweep: exclusive offsets)
+    int64_t *rows, *ptr; int32_t *cols; double *vals; uint8_t *slot;
+};
+constexpr int kNdMaxEnt = 2 * EDGPU_MAX_ORB * (EDGPU_MAX_ORB - 1);
+__device__ __forceinline__ int nd_row_entries(const NdBuildArgs &A, const int32_t *s_jdw, const double *s_t, int iup, int32_t *cj, double *cv)
+{
+    const uint32_t mup = (uint32_t)A.mapup[iup];
+    int n = 0;
+    for (int a = 0; a < A.Norb; a++)
+        for (int b = 0; b < A.Norb; b++) {
+            const uint32_t ba = 1u << a, bb = 1u << b;
+            if (a == b || !(mup & bb) || (mup & ba)) continue;
+            const uint32_t k3 = mup & ~bb, k4 = k3 | ba;
+            const int sgu = __popc(mup & (bb - 1)) + __popc(k3 & (ba - 1));
+            const int sl = 2 * (a * A.Norb + b);
+            for (int kind = 0; kind < 2; kind++) {
+                const int32_t jd = s_jdw[sl + kind];
+                if (jd < 0) continue;
+                const int32_t col = (int32_t)((int64_t)jd * A.DimUp + A.rankup[k4]);
+                const double t = (sgu & 1) ? -s_t[sl + kind] : s_t[sl + kind];
+                int q = n++;                              // insertion by ascending column
+                while (q > 0 && cj[q - 1] > col) { cj[q] = cj[q - 1]; cv[q] = cv[q - 1]; q--; }
+                cj[q] = col; cv[q] = t;
+            }
+        }
+    return n;
+}
+template <int FILL>
+__global__ void __launch_bounds__(256) k_nd_build(NdBuildArgs A)
+{
+    __shared__ int32_t s_jdw[2 * EDGPU_MAX_ORB * EDGPU_MAX_ORB];
+    __shared__ double s_t[2 * EDGPU_MAX_ORB * EDGPU_MAX_ORB];
+    __shared__ int32_t sc_r[256], sc_e[256];
+    __shared__ int64_t s_br, s_be;
+    const int64_t idwl = blockIdx.x, idw = A.dw0 + idwl;
+    const uint32_t mdw = (uint32_t)A.mapdw[idw];
+    if ((int)threadIdx.x < 2 * A.Norb * A.Norb) {         // partner dw row and amplitude of every (a,b,kind): as k_ndpass
+        const int kind = threadIdx.x & 1, ab = threadIdx.x >> 1, a = ab / A.Norb, b = ab - a * A.Norb;
+        const uint32_t ba = 1u << a, bb = 1u << b;
+        int32_t jd = -1; double t = 0.0;
+        if (a != b) {
+            if (kind == 0 && A.Jx != 0.0 && (mdw & ba) && !(mdw & bb)) {
+                const uint32_t k1 = mdw & ~ba, k2 = k1 | bb;
+                const int sg = __popc(mdw & (ba - 1)) + __popc(k1 & (bb - 1));
+                jd = A.rankdw[k2]; t = (sg & 1) ? -A.Jx : A.Jx;
+            }
+            if (kind == 1 && A.Jp != 0.0 && (mdw & bb) && !(mdw & ba)) {
+                const uint32_t k1 = mdw & ~bb, k2 = k1 | ba;
+                const int sg = __popc(mdw & (bb - 1)) + __popc(k1 & (ba - 1));
+                jd = A.rankdw[k2]; t = (sg & 1) ? -A.Jp : A.Jp;
+            }
+        }
+        if (jd >= 0 && A.xmap) jd = A.xmap[jd];
+        s_jdw[threadIdx.x] = jd; s_t[threadIdx.x] = t;
+    }
+    if (threadIdx.x == 0) { s_br = FILL ? A.row_nr[idwl] : 0; s_be = FILL ? A.row_ne[idwl] : 0; }
+    __syncthreads();
+    int32_t cj[kNdMaxEnt]; double cv[kNdMaxEnt];
+    for (int base = 0; base < A.DimUp; base += 256) {
+        const int iup = base + threadIdx.x;
+        const int n = iup < A.DimUp ? nd_row_entries(A, s_jdw, s_t, iup, cj, cv) : 0;
+        sc_r[threadIdx.x] = n > 0; sc_e[threadIdx.x] = n;
+        __syncthreads();
+        for (int d = 1; d < 256; d <<= 1) {               // inclusive scans of both counters over the chunk
+            const int r = threadIdx.x >= d ? sc_r[threadIdx.x - d] : 0, e = threadIdx.x >= d ? sc_e[threadIdx.x - d] : 0;
+            __syncthreads();
+            sc_r[threadIdx.x] += r; sc_e[threadIdx.x] += e;
+            __syncthreads();
+        }
+        if (FILL && n > 0) {
+            const int64_t ir = s_br + sc_r[threadIdx.x] - 1, ie = s_be + sc_e[threadIdx.x] - n;
+            A.rows[ir] = idwl * A.DimUp + iup; A.ptr[ir] = ie;
+            for (int q = 0; q < n; q++) { A.cols[ie + q] = cj[q]; A.vals[ie + q] = cv[q]; A.slot[ie + q] = (uint8_t)(ir & 63); }
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) { s_br += sc_r[255]; s_be += sc_e[255]; }
+        __syncthreads();
+    }
+    if (!FILL && threadIdx.x == 0) { A.row_nr[idwl] = s_br; A.row_ne[idwl] = s_be; }
+}
+
+// y += [s_cur *] ND x for the compressed-row block: a wave takes 64 consecutive non-empty rows, whose entries are one
+// contiguous range; lanes sweep that range (coalesced), products are summed per row by a segmented scan across the wave
+// (entries of a row sit in consecutive lanes) and the tail lane of each segment adds into the row's LDS slot.
+struct NdCsrArgs { int64_t nr; const int64_t *rows, *ptr; const int32_t *cols; const double *vals; const uint8_t *slot; const double *x; double *y; const double *scal; };
+template <bool EPI>
+__global__ void __launch_bounds__(256) k_csr_nd(NdCsrArgs A)
+{
+    __shared__ double acc[4][64];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t i0 = ((int64_t)blockIdx.x * 4 + wave) * 64;
+    const int n = i0 < A.nr ? (int)(A.nr - i0 < 64 ? A.nr - i0 : 64) : 0;
+    acc[wave][lane] = 0.0;
+    if (n > 0) {
+        const int64_t e0 = A.ptr[i0], e1 = A.ptr[i0 + n];
+        for (int64_t eb = e0; eb < e1; eb += 64) {
+            const int64_t e = eb + lane;
+            double p = 0.0; int sg = -1;
+            if (e < e1) { p = A.vals[e] * A.x[A.cols[e]]; sg = A.slot[e]; }
+            for (int d = 1; d < 64; d <<= 1) { const double q = __shfl_up(p, d); const int sq = __shfl_up(sg, d); if (lane >= d && sq == sg) p += q; }
+            const int snext = __shfl_down(sg, 1);
+            if (sg >= 0 && (lane == 63 || snext != sg)) acc[wave][sg] += p;      // a row that continues in the next 64 entries adds again there
+        }
+        if (lane < n) { const int64_t r = A.rows[i0 + lane]; const double sc = EPI ? A.scal[SC_SCUR] : 1.0; A.y[r] += sc * acc[wave][lane]; }
+    }
+}
+
 // Expectation values of the spin-exchange and pair-hopping operators in a state (lanc_local_energy, ED_OBSERVABLES.f90:
 // 470-527: ed_Dse, ed_Dph): sum_i sgn * v_i * v_j over the same (a,b) terms as k_ndpass, with unit amplitude and the two
 // kinds kept apart.  out[row*2 + kind]: partial sums per (idw,iph) row in a fixed order.

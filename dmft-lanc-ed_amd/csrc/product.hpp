@@ -322,6 +322,15 @@ static int hxv(S *s, const double *v, double *out, bool epi, const double *uprev
                 }
             }
             if (overlap) { HIPCHK(hipStreamWaitEvent(s->stream, s->ev_gather, 0)); A.x = s->vfull.p; }
+            if (s->nd_nr > 0) {     // stored non-local block (Jx/Jp): compressed rows, wave-level segmented sums
+                NdCsrArgs Nd{};
+                Nd.nr = s->nd_nr; Nd.rows = s->nd_rows.p; Nd.ptr = s->nd_ptr.p; Nd.cols = s->nd_cols.p; Nd.vals = s->nd_vals.p; Nd.slot = s->nd_slot.p;
+                Nd.x = multi ? s->vfull.p : v; Nd.y = out; Nd.scal = s->scal.p;
+                const unsigned g = (unsigned)cdiv(s->nd_nr, 256);
+                if (epi) hipLaunchKernelGGL(k_csr_nd<true>, dim3(g), dim3(256), 0, s->stream, Nd);
+                else hipLaunchKernelGGL(k_csr_nd<false>, dim3(g), dim3(256), 0, s->stream, Nd);
+                HIPCHK(hipGetLastError());
+            }
             A.rowptr = s->csrD_rowptr.p; A.cols = s->csrD_cols.p; A.vals = s->csrD_vals.p;
             A.pass = 2;
             if (s->csrD_pipe) CHK(launch_lds(false, A.rowptr, A.cols, A.vals, 2, s->csrD_pipe_rb, A.x));

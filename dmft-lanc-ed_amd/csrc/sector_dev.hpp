@@ -224,10 +224,41 @@ static int build_diag(S *s)
     return EDGPU_OK;
 }
 
+// Non-local (Jx/Jp) block of the explicit storage: count sweep, host scan over the dw rows, fill sweep (k_nd_build)
+static int build_csr_nd(S *s)
+{
+    const SectorHost &H = s->H; const edgpu_desc &d = H.desc;
+    NdBuildArgs A{};
+    A.DimUp = (int32_t)H.DimUp; A.DimDw = (int32_t)(s->halo ? s->nhalo : H.DimDw); A.Norb = d.Norb; A.Qdw = H.Qdw; A.dw0 = H.dw0;
+    A.mapup = s->upf->map.p; A.mapdw = s->dwf->map.p; A.rankup = s->upf->rank.p; A.rankdw = s->dwf->rank.p; A.xmap = s->halo ? s->xmap_dev.p : nullptr;
+    A.Jx = d.Jx; A.Jp = d.Jp;
+    DevBuf<int64_t> rnr, rne;
+    CHK(rnr.alloc((size_t)H.Qdw)); CHK(rne.alloc((size_t)H.Qdw));
+    A.row_nr = rnr.p; A.row_ne = rne.p;
+    hipLaunchKernelGGL(k_nd_build<0>, dim3((unsigned)H.Qdw), dim3(256), 0, s->stream, A);
+    HIPCHK(hipGetLastError());
+    std::vector<int64_t> nr((size_t)H.Qdw), ne((size_t)H.Qdw);
+    HIPCHK(hipMemcpyAsync(nr.data(), rnr.p, (size_t)H.Qdw * 8, hipMemcpyDeviceToHost, s->stream));
+    HIPCHK(hipMemcpyAsync(ne.data(), rne.p, (size_t)H.Qdw * 8, hipMemcpyDeviceToHost, s->stream));
+    HIPCHK(hipStreamSynchronize(s->stream));
+    int64_t tr = 0, te = 0;
+    for (int64_t q = 0; q < H.Qdw; q++) { const int64_t a = nr[q], b = ne[q]; nr[q] = tr; ne[q] = te; tr += a; te += b; }
+    s->nd_nr = tr; s->nd_nnz = te;
+    CHK(s->nd_rows.alloc((size_t)tr + 1)); CHK(s->nd_ptr.alloc((size_t)tr + 1)); CHK(s->nd_cols.alloc((size_t)te + 1)); CHK(s->nd_vals.alloc((size_t)te + 1)); CHK(s->nd_slot.alloc((size_t)te + 1));
+    HIPCHK(hipMemcpyAsync(rnr.p, nr.data(), (size_t)H.Qdw * 8, hipMemcpyHostToDevice, s->stream));
+    HIPCHK(hipMemcpyAsync(rne.p, ne.data(), (size_t)H.Qdw * 8, hipMemcpyHostToDevice, s->stream));
+    HIPCHK(hipMemcpyAsync(s->nd_ptr.p + tr, &te, 8, hipMemcpyHostToDevice, s->stream));
+    A.rows = s->nd_rows.p; A.ptr = s->nd_ptr.p; A.cols = s->nd_cols.p; A.vals = s->nd_vals.p; A.slot = s->nd_slot.p;
+    hipLaunchKernelGGL(k_nd_build<1>, dim3((unsigned)H.Qdw), dim3(256), 0, s->stream, A);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(s->stream));      // rnr / rne and the host copy of `te` go out of scope
+    return EDGPU_OK;
+}
+
 static int build_csr(S *s)
 {
     const SectorHost &H = s->H;
-    if (!s->kron2 || H.DimPh > 1 || H.Jhflag) return fail(EDGPU_EUNSUPPORTED, "edgpu: storage=CSR supports sectors without phonons and Jx/Jp");
+    if (!s->kron2 || H.DimPh > 1) return fail(EDGPU_EUNSUPPORTED, "edgpu: storage=CSR does not cover the phonon terms (Nph>0)");
     if (H.DimUp * s->nhalo >= ((int64_t)1 << 31)) return fail(EDGPU_EUNSUPPORTED, "edgpu: storage=CSR needs DimUp*(rows of x) < 2^31 (int32 columns)");
     const Factor &up = *s->hup, &dw = *s->hdw;
     std::vector<int64_t> uppre(up.dim + 1, 0), dwpre(H.Qdw + 1, 0);
@@ -244,7 +275,7 @@ static int build_csr(S *s)
     // Two storage forms of the same explicit matrix: one CSR, or (default for large sectors) two CSR
     // blocks H = H_loc + H_dw so that each block can be streamed in the order that keeps ITS gathers
     // cache resident (rows for the up hops, XCD-owned column tiles for the dw hops).
-    s->csr_split = dbg_int("EDGPU_CSR_SPLIT", (H.DimUp * H.DimDw * 8 > ((int64_t)48 << 20)) ? 1 : 0) != 0;
+    s->csr_split = dbg_int("EDGPU_CSR_SPLIT", (H.DimUp * H.DimDw * 8 > ((int64_t)48 << 20)) ? 1 : 0) != 0 || H.Jhflag;      // the non-local block goes between the local and the dw block
     s->csrL_nnz = H.Qdw * uppre[up.dim]; s->csrD_nnz = s->csr_nnz - s->csrL_nnz;
     CsrBuildArgs A{};
     A.DimUp = (int32_t)H.DimUp; A.DimDw = (int32_t)H.DimDw; A.Qdw = H.Qdw; A.dw0 = H.dw0;
@@ -329,6 +360,7 @@ static int build_csr(S *s)
     if (s->csr_rpb < 1) return fail(EDGPU_EUNSUPPORTED, "edgpu: a CSR row exceeds the LDS tile");
     s->csr_bpr = (int32_t)cdiv(H.DimUp, s->csr_rpb);
     s->csr_tile = std::max(1, std::min(dbg_int("EDGPU_CSR_TILE", 1 << 20), s->csr_bpr));
+    if (H.Jhflag) CHK(build_csr_nd(s));
     return EDGPU_OK;
 }
 
@@ -432,7 +464,8 @@ static int create(const edgpu_desc *desc, S **out)
     if (desc->storage != EDGPU_STORE_DIRECT) { CHK(build_diag(s.get())); s->bytes_stored = s->nloc_el * 8; }
     if (desc->storage == EDGPU_STORE_CSR) {
         CHK(build_csr(s.get()));
-        s->bytes_stored = s->csr_nnz * 12 + (s->nloc_el + 1) * 8 * (s->csr_three ? 3 : (s->csr_split ? 2 : 1));
+        s->bytes_stored = s->csr_nnz * 12 + (s->nloc_el + 1) * 8 * (s->csr_three ? 3 : (s->csr_split ? 2 : 1)) + s->nd_nnz * 13 + (s->nd_nr + 1) * 16;
+        s->nnz_total += s->nd_nnz;
     }
     if (s->multi && !s->tr_on) CHK(s->vfull.alloc((size_t)(H.DimUp * s->nhalo * H.DimPh)));
     s->npartial = max_partials(s.get());

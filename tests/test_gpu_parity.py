@@ -43,7 +43,7 @@ def _sample_rows(DimUp, DimDw, rng, nrandom, parts=8, tile=64, above=None):
 
 def _storages(m):
     st = ["kron", "direct"]
-    if m.get("Nph", 0) == 0 and not (m["Norb"] > 1 and (m.get("Jx", 0) or m.get("Jp", 0))):      # ed_total_ud=F: explicit CSR of the composite blocks
+    if m.get("Nph", 0) == 0:      # explicit CSR: composite blocks for ed_total_ud=F, compressed-row non-local block for Jx/Jp; no phonon terms
         st.append("csr")
     return st
 
@@ -502,7 +502,7 @@ def test_c5_full_size_properties(edgpu_mod):
         assert np.abs(hv[idx] - orc0).max() <= HXV_RTOL * np.abs(orc0).max(), (st, "Jx=Jp=0")
         G.close(); del hv
     ref = None
-    for st, env in (("kron", {}), ("direct", {}), ("kron", {"EDGPU_ND_SPLIT": "0"})):
+    for st, env in (("kron", {}), ("direct", {}), ("kron", {"EDGPU_ND_SPLIT": "0"}), ("csr", {})):      # csr: stored non-local block (k_csr_nd)
         os.environ.update(env)
         try:
             G = edgpu_mod.HvSector(m, [8], [8], storage=st)
