@@ -1534,301 +1534,6 @@ __global__ void __launch_bounds__(ROWS) k_csr_spmv2(CsrArgs A)
     if (A.epi && (A.pass == 0 || A.pass == 2)) { double r = block_sum(asum, red); if (tid == 0) A.partial[blockIdx.x] = r; }
 }
 
-// The same row-block product with NB chunks per (one-wave) workgroup.  The product is bound by how many bytes of the
-// (value, column) stream a CU has in flight -- about 60 KB with one chunk per resident workgroup, against the
-// >= 100 KB that ~3 us of loaded HBM latency need at a CU's share of the bandwidth.  LDS cannot hold more (it sets the
-// 20 resident workgroups), the register file can: a workgroup requests the streams of its NB chunks at once, keeps
-// them in registers, and stages and computes them one after the other through the one LDS image.
-// Local mode: chunks jb*NB .. jb*NB+NB-1 of one dw row.  Column-tile mode (dw block): the chunk of tile jb in the
-// NB consecutive dw rows idwl*NB .. (XCD-owned tiles as in k_csr_spmv2).
-template <int CAPN, int NB, bool NT>
-__global__ void __launch_bounds__(64) k_csr_spmv3(CsrArgs A)
-{
-    constexpr int ROWS = 64;
-    constexpr int NC = (CAPN / 4 + 1 + 63) / 64;        // 4-entry groups per lane
-    __shared__ __attribute__((aligned(32))) double sval[CAPN + 8];
-    __shared__ __attribute__((aligned(16))) int32_t scol[CAPN + 8];
-    const int tid = threadIdx.x;
-    int64_t idwl0; int jb0, didw, djb, nb = NB;
-    if (A.coltiles) {
-        const int xcd = blockIdx.x & 7; const int64_t sidx = blockIdx.x >> 3;
-        const int64_t nrowg = (A.Qdw + NB - 1) / NB;
-        const int64_t tl = sidx / nrowg; const int64_t rg = sidx - tl * nrowg;
-        idwl0 = rg * NB; jb0 = (int)(tl * 8 + xcd); didw = 1; djb = 0;
-        if (jb0 >= A.blocks_per_row) { if (A.epi && (A.pass == 0 || A.pass == 2) && tid == 0) A.partial[blockIdx.x] = 0.0; return; }
-        if (idwl0 + nb > A.Qdw) nb = (int)(A.Qdw - idwl0);
-    } else {
-        const int64_t gpr = (A.blocks_per_row + NB - 1) / NB;        // chunk groups per dw row
-        const int64_t b = blockIdx.x;
-        idwl0 = b / gpr; jb0 = (int)(b - idwl0 * gpr) * NB; didw = 0; djb = 1;
-        if (jb0 + nb > A.blocks_per_row) nb = A.blocks_per_row - jb0;
-    }
-    int64_t row0[NB], p0[NB]; int nr[NB], ng[NB], ra[NB], re[NB]; double up[NB], xl[NB];
-    dbl2_t rv[NB][2 * NC]; int4_t rc[NB][NC];
-    // row pointers of all chunks, then all streams: 2 memory latencies per workgroup whatever NB
-    int64_t ra64[NB], re64[NB];
-#pragma unroll
-    for (int i = 0; i < NB; i++) {
-        const int64_t idwl = idwl0 + (int64_t)i * didw; const int jb = jb0 + i * djb;
-        const int iup0 = jb * ROWS;
-        int n_ = A.DimUp - iup0; if (n_ > ROWS) n_ = ROWS; if (i >= nb) n_ = 0;
-        nr[i] = n_; row0[i] = idwl * A.DimUp + iup0;
-        const int rcl = n_ > 0 ? (tid < n_ ? tid : n_ - 1) : 0;
-        ra64[i] = 0; re64[i] = 0;
-        if (n_ > 0) { ra64[i] = A.rowptr[row0[i] + rcl]; re64[i] = A.rowptr[row0[i] + rcl + 1]; }
-    }
-#pragma unroll
-    for (int i = 0; i < NB; i++) {
-        up[i] = 0.0; xl[i] = 0.0; p0[i] = 0; ng[i] = 0; ra[i] = 0; re[i] = 0;
-        if (nr[i] > 0) {
-            const int64_t q0 = __shfl(ra64[i], 0, 64), q1 = __shfl(re64[i], nr[i] - 1, 64);
-            const int sh = (int)(q0 & 3);
-            p0[i] = q0 - sh; ng[i] = (sh + (int)(q1 - q0) + 3) >> 2;
-            if (tid < nr[i]) { ra[i] = (int)(ra64[i] - p0[i]); re[i] = (int)(re64[i] - p0[i]); }
-            const dbl2_t *pv = reinterpret_cast<const dbl2_t *>(A.vals + p0[i]); const int4_t *pc = reinterpret_cast<const int4_t *>(A.cols + p0[i]);
-            const int glast = ng[i] > 0 ? ng[i] - 1 : 0;
-#pragma unroll
-            for (int j = 0; j < NC; j++) {
-                int g = tid + 64 * j; g = g < glast ? g : glast;            // lanes past the end re-read the last group: no divergent loads
-                if (NT) { rc[i][j] = __builtin_nontemporal_load(pc + g); rv[i][2 * j] = __builtin_nontemporal_load(pv + 2 * g); rv[i][2 * j + 1] = __builtin_nontemporal_load(pv + 2 * g + 1); }
-                else { rc[i][j] = pc[g]; rv[i][2 * j] = pv[2 * g]; rv[i][2 * j + 1] = pv[2 * g + 1]; }
-            }
-            const int rcl = tid < nr[i] ? tid : nr[i] - 1;
-            if (A.epi && A.pass < 2) up[i] = A.uprev[row0[i] + rcl];
-            if (A.epi && (A.pass == 0 || A.pass == 2)) xl[i] = A.v_local[row0[i] + rcl];
-            if (A.pass >= 2) up[i] = A.y[row0[i] + rcl];
-        }
-    }
-    double s_cur = 1.0, c_prev = 0.0, asum = 0.0;
-    if (A.epi) { s_cur = A.scal[SC_SCUR]; c_prev = A.scal[SC_BETA] * A.scal[SC_SPREV]; }
-    dbl2_t *sv2 = reinterpret_cast<dbl2_t *>(sval); int4_t *sc4 = reinterpret_cast<int4_t *>(scol);
-#pragma unroll
-    for (int i = 0; i < NB; i++) {
-        if (nr[i] > 0) {
-#pragma unroll
-            for (int j = 0; j < NC; j++) { const int g = tid + 64 * j; if (g < ng[i]) { sc4[g] = rc[i][j]; sv2[2 * g] = rv[i][2 * j]; sv2[2 * g + 1] = rv[i][2 * j + 1]; } }
-        }
-        __syncthreads();
-        if (tid < nr[i]) {
-            const int64_t row = row0[i] + tid;
-            double acc0 = 0.0, acc1 = 0.0;
-            int k = ra[i];
-            const int e = re[i];
-            for (; k + 4 <= e; k += 4) {
-                const double x0 = A.x[scol[k]], x1 = A.x[scol[k + 1]], x2 = A.x[scol[k + 2]], x3 = A.x[scol[k + 3]];
-                acc0 += sval[k] * x0; acc1 += sval[k + 1] * x1; acc0 += sval[k + 2] * x2; acc1 += sval[k + 3] * x3;
-            }
-            for (; k < e; k++) acc0 += sval[k] * A.x[scol[k]];
-            const double acc = acc0 + acc1;
-            if (A.epi) {
-                const double w = A.pass >= 2 ? up[i] + s_cur * acc : s_cur * acc - c_prev * up[i];
-                A.y[row] = w; asum += (s_cur * xl[i]) * w;
-            } else A.y[row] = A.pass >= 2 ? up[i] + acc : acc;
-        }
-        __syncthreads();
-    }
-    if (A.epi && (A.pass == 0 || A.pass == 2)) { const double r = wave_sum(asum); if (tid == 0) A.partial[blockIdx.x] = r; }
-}
-
-// ---------------------------------------------------------------------------------------------
-// Persistent, software-pipelined form of the row-block CSR product with an LDS-staged vector tile.
-//
-// k_csr_spmv2 above is one wave per launch-time block: rowptr -> stream -> gathers -> store is a serial chain per
-// block, and the up-hop gathers (8 of the 9 entries of a local-block row) are 64 uncoalesced 8-byte loads each:
-// counters showed the address/data path of the vector memory unit busy 90-100 % with the HBM stream waiting behind
-// it.  Here
-//   * WIN: a workgroup owns one dw row (DimUp matrix rows) at a time and keeps that row of x -- the column window
-//     [xrow*DimUp, (xrow+1)*DimUp) that every up hop and the diagonal read -- in LDS (103 KB at Ns=16); in-window
-//     columns are LDS reads, anything else (dw hops of an unsplit CSR) a global gather.  The next window is already on
-//     its way into registers while the current one is in use.
-//   * every wave walks its own chunks of `rb` consecutive rows with the next D chunks already requested: their
-//     (value, column) streams sit in REGISTERS (the 512 KB register file of a CU is the prefetch buffer; LDS holds the
-//     window and one chunk per wave), the entry range of chunk t+D+1 comes by scalar loads a task earlier still.  A CU
-//     keeps D x waves x chunk bytes of the HBM stream in flight however long the gathers take;
-//   * rows shorter than the wave is wide share their lanes: 64/rb lanes split the entries of one row and are summed
-//     by a segmented wave reduction (xor shuffles over the lane bits above log2 rb).
-// !WIN: no window, chunks are dealt in XCD-owned column-tile order (the dw block of the split form; see k_dwpass).
-// ---------------------------------------------------------------------------------------------
-struct CsrLdsArgs {
-    int64_t Qdw; int32_t DimUp; int32_t rb, rbshift; int32_t cpr;      // rows per chunk (power of two <= 64), chunks per dw row
-    const int64_t *rowptr; const int32_t *cols; const double *vals;
-    const double *x; int64_t xrow0;        // WIN: window of local dw row idwl starts at x[(xrow0 + idwl) * DimUp]
-    double *y; const double *v_local, *uprev, *scal; double *partial; int32_t epi, pass;
-    int32_t dbg;       // timing ablations only (wrong results): 1 no entry/row phases, 2 no staging either
-};
-
-template <int NT, int CAP, bool WIN, int D, bool ALLWIN>
-__global__ void __launch_bounds__(NT) k_csr_lds(CsrLdsArgs A)
-{
-    extern __shared__ __attribute__((aligned(32))) unsigned char csr_smem[];
-    constexpr int NW = NT / 64;
-    constexpr int NG = (CAP + 4 + 3) / 4;                  // 4-entry groups of a staged chunk (shift of up to 3 included)
-    constexpr int NC = (NG + 63) / 64;                     // groups per lane
-    constexpr int STAGE = (CAP + 8) * 12;                  // bytes of one wave's staging area
-    constexpr int MAXQ = WIN ? (13312 / 2 + NT - 1) / NT : 1;
-    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int DimUp = A.DimUp, npair = DimUp >> 1;
-    const int xwbytes = WIN ? ((DimUp * 8 + 31) & ~31) : 0;
-    double *xw = reinterpret_cast<double *>(csr_smem);
-    double *sval = reinterpret_cast<double *>(csr_smem + xwbytes + wv * STAGE);
-    int32_t *scol = reinterpret_cast<int32_t *>(sval + CAP + 8);
-    double *red = reinterpret_cast<double *>(csr_smem + xwbytes + NW * STAGE);
-    dbl2_t *sv2 = reinterpret_cast<dbl2_t *>(sval); int4_t *sc4 = reinterpret_cast<int4_t *>(scol);
-    const int rb = A.rb, r = lane;                         // chunk = rb (<= 64) consecutive rows; lane r owns row r in the row phase
-    const int cpw = (A.cpr + NW - 1) / NW;                 // chunk slots per wave and dw row (WIN)
-    const int nblk = (int)gridDim.x, blk = (int)blockIdx.x;
-    // tasks of this wave: t -> (idwl, first row of the chunk, rows in it); nr = 0: empty slot / past the end
-    int64_t ntask;
-    if (WIN) { const int64_t rows_here = A.Qdw > blk ? (A.Qdw - blk + nblk - 1) / nblk : 0; ntask = rows_here * cpw; }
-    else {
-        // XCD x = blockIdx % 8 owns the column tiles x, x+8, ...; its wave slots walk (tile, idwl) with idwl fastest
-        const int xcd = blk & 7; const int64_t slots = (int64_t)(nblk >> 3) * NW;
-        const int64_t ntile = A.cpr > xcd ? (A.cpr - xcd + 7) / 8 : 0, tot = ntile * A.Qdw, me = (int64_t)(blk >> 3) * NW + wv;
-        ntask = tot > me ? (tot - me + slots - 1) / slots : 0;
-    }
-    // wave-uniform description of a task: where its chunk is and the range [p0, p1) of its entries (scalar loads)
-    struct TK { int64_t idwl, p0; int iup0, nr, ng, sh, end; };
-    struct PK { int64_t idwl, p0, p1; int iup0, nr; };
-    auto load_p = [&](int64_t t, PK &o) {
-        o.idwl = 0; o.iup0 = 0; o.nr = 0; o.p0 = 0; o.p1 = 0;
-        if (t >= ntask) return;
-        int c;
-        if (WIN) { o.idwl = blk + (t / cpw) * nblk; c = wv + (int)(t % cpw) * NW; }
-        else {
-            const int xcd = blk & 7; const int64_t slots = (int64_t)(nblk >> 3) * NW;
-            const int64_t u = (int64_t)(blk >> 3) * NW + wv + t * slots;
-            const int64_t tl = u / A.Qdw; o.idwl = u - tl * A.Qdw; c = (int)(tl * 8 + xcd);
-        }
-        o.iup0 = c * rb; int nr = DimUp - o.iup0; if (nr > rb) nr = rb; if (c >= A.cpr || nr < 0) nr = 0;
-        o.nr = nr;
-        if (nr > 0) { const int64_t row0 = o.idwl * DimUp + o.iup0; o.p0 = A.rowptr[row0]; o.p1 = A.rowptr[row0 + nr]; }
-    };
-    // per-lane part of a task in flight: the (value, column) stream groups of this lane, its row's range and epilogue operands
-    struct ST { dbl2_t v[2 * NC]; int4_t c[NC]; int64_t ra, re; double up, xl; };
-    auto issue = [&](const PK &p, ST &o, TK &k) {
-        k.idwl = p.idwl; k.iup0 = p.iup0; k.nr = p.nr; k.p0 = p.p0; k.sh = (int)(p.p0 & 3); k.end = k.sh + (int)(p.p1 - p.p0); k.ng = (k.end + 3) >> 2;
-        if (p.nr == 0) return;
-        const dbl2_t *pv = reinterpret_cast<const dbl2_t *>(A.vals + (p.p0 - k.sh)); const int4_t *pc = reinterpret_cast<const int4_t *>(A.cols + (p.p0 - k.sh));
-        const int glast = k.ng > 0 ? k.ng - 1 : 0;          // lanes past the end re-read the last group (no divergent loads)
-#pragma unroll
-        for (int j = 0; j < NC; j++) {
-            int g = lane + 64 * j; g = g < glast ? g : glast;
-            o.c[j] = __builtin_nontemporal_load(pc + g); o.v[2 * j] = __builtin_nontemporal_load(pv + 2 * g); o.v[2 * j + 1] = __builtin_nontemporal_load(pv + 2 * g + 1);
-        }
-        const int rc = r < p.nr ? r : p.nr - 1;
-        const int64_t row = p.idwl * DimUp + p.iup0 + rc;
-        o.ra = A.rowptr[row]; o.re = A.rowptr[row + 1];
-        o.up = 0.0; o.xl = 0.0;
-        if (A.epi && A.pass < 2) o.up = A.uprev[row];
-        if (A.epi && (A.pass == 0 || A.pass == 2)) o.xl = A.v_local[row];
-        if (A.pass >= 2) o.up = A.y[row];                     // running value of the earlier blocks
-    };
-    double s_cur = 1.0, c_prev = 0.0, asum = 0.0;
-    if (A.epi) { s_cur = A.scal[SC_SCUR]; c_prev = A.scal[SC_BETA] * A.scal[SC_SPREV]; }
-    // window prefetch registers (WIN)
-    dbl2_t xr[MAXQ];
-    const int nq = WIN ? (npair + NT - 1) / NT : 0;
-    auto load_win = [&](int64_t idwl) {
-        const dbl2_t *src = reinterpret_cast<const dbl2_t *>(A.x + (A.xrow0 + idwl) * DimUp);
-#pragma unroll
-        for (int q = 0; q < MAXQ; q++) { const int p = tid + q * NT; if (q < nq && p < npair) xr[q] = src[p]; }
-    };
-    if (WIN && blk < A.Qdw) load_win(blk);
-    // Batches of D tasks.  The compiler drains the vector-memory counter (vmcnt(0)) before the first use of a loaded
-    // register, so loads that are issued one by one would each cost a full memory latency per task; instead all D
-    // streams of the NEXT batch are issued together, right after the last chunk of the current batch has left its
-    // registers for LDS, and fly while that chunk is computed: one latency per D chunks and wave.
-    ST st[D]; TK tk[D]; PK pn[D];
-#pragma unroll
-    for (int d = 0; d < D; d++) load_p(d, pn[d]);
-#pragma unroll
-    for (int d = 0; d < D; d++) { issue(pn[d], st[d], tk[d]); load_p(D + d, pn[d]); }
-    int64_t cur_idwl = -1;
-    for (int64_t t0 = 0; t0 < ntask; t0 += D) {
-#pragma unroll
-        for (int d = 0; d < D; d++) {
-            const TK k = tk[d];                 // tasks past the end have nr = 0 (load_p): nothing staged, nothing computed
-            if (WIN && k.nr >= 0 && t0 + d < ntask && k.idwl != cur_idwl) {
-                // every wave of the workgroup changes dw row at the same task index (cpw slots per row each)
-                __syncthreads();
-#pragma unroll
-                for (int q = 0; q < MAXQ; q++) { const int p = tid + q * NT; if (q < nq && p < npair) reinterpret_cast<dbl2_t *>(xw)[p] = xr[q]; }
-                if ((DimUp & 1) && tid == 0) xw[DimUp - 1] = A.x[(A.xrow0 + k.idwl) * DimUp + DimUp - 1];
-                cur_idwl = k.idwl;
-                const int64_t nxt = cur_idwl + nblk;
-                if (nxt < A.Qdw) load_win(nxt);
-                __syncthreads();
-            }
-            // registers -> this wave's staging area
-            int ra = 0, re = 0; double up_i = 0.0, xl_i = 0.0;
-            if (k.nr > 0) {
-                if (!(A.dbg & 2)) {
-#pragma unroll
-                    for (int j = 0; j < NC; j++) { const int g = lane + 64 * j; if (g < k.ng) { sc4[g] = st[d].c[j]; sv2[2 * g] = st[d].v[2 * j]; sv2[2 * g + 1] = st[d].v[2 * j + 1]; } }
-                } else {
-#pragma unroll
-                    for (int j = 0; j < NC; j++) asum += st[d].v[2 * j].x + st[d].v[2 * j + 1].y + (double)st[d].c[j].x;
-                }
-                if (r < k.nr) { ra = (int)(st[d].ra - k.p0) + k.sh; re = (int)(st[d].re - k.p0) + k.sh; }
-                up_i = st[d].up; xl_i = st[d].xl;
-            }
-            if (d == D - 1) {                   // all D slots are free: request the whole next batch, and the entry ranges of the one after
-#pragma unroll
-                for (int e = 0; e < D; e++) { issue(pn[e], st[e], tk[e]); load_p(t0 + 2 * D + e, pn[e]); }
-            }
-            __builtin_amdgcn_wave_barrier();
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            if (k.nr > 0 && (A.dbg & 3)) {
-                if (r < k.nr) A.y[k.idwl * DimUp + k.iup0 + r] = up_i + xl_i + (double)(re - ra) + asum;
-            } else if (k.nr > 0) {
-                // entry phase: lane l takes entries l, l+64, ... of the staged chunk -- no row structure involved, so all
-                // (column, value) reads and then all x reads are independent and go out back to back; the product
-                // replaces the value in place
-                const int32_t base = WIN ? (int32_t)((A.xrow0 + k.idwl) * DimUp) : 0;
-                const int end = k.end;                      // entries [sh, end) of the staged image are the chunk's
-                constexpr int NJ = (CAP + 8 + 63) / 64, NH = (NJ + 1) / 2;      // in two halves: bounds the registers live at once
-#pragma unroll
-                for (int h = 0; h < 2; h++) {
-                    int32_t cc[NH]; double vv[NH], xx[NH];
-#pragma unroll
-                    for (int j = 0; j < NH; j++) { const int idx = lane + 64 * (h * NH + j); cc[j] = base; vv[j] = 0.0; if (h * NH + j < NJ && idx < end) { cc[j] = scol[idx]; vv[j] = sval[idx]; } }
-#pragma unroll
-                    for (int j = 0; j < NH; j++) {
-                        const int idx = lane + 64 * (h * NH + j);
-                        xx[j] = 0.0;
-                        if (h * NH + j < NJ && idx >= k.sh && idx < end) {
-                            if (WIN) {
-                                const uint32_t o = (uint32_t)(cc[j] - base);
-                                if (ALLWIN) xx[j] = xw[o < (uint32_t)DimUp ? o : 0];
-                                else xx[j] = o < (uint32_t)DimUp ? xw[o] : A.x[cc[j]];
-                            } else xx[j] = A.x[cc[j]];
-                        }
-                    }
-#pragma unroll
-                    for (int j = 0; j < NH; j++) { const int idx = lane + 64 * (h * NH + j); if (h * NH + j < NJ && idx < end) sval[idx] = vv[j] * xx[j]; }
-                }
-                __builtin_amdgcn_wave_barrier();
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                // row phase: the segments [ra, re) of the product array, one row per lane, summed in storage order
-                double acc = 0.0;
-                if (r < k.nr) {
-                    int e = ra;
-                    for (; e + 4 <= re; e += 4) { const double q0 = sval[e], q1 = sval[e + 1], q2 = sval[e + 2], q3 = sval[e + 3]; acc += q0; acc += q1; acc += q2; acc += q3; }
-                    for (; e < re; e++) acc += sval[e];
-                    const int64_t row = k.idwl * DimUp + k.iup0 + r;
-                    if (A.epi) {
-                        const double w = A.pass >= 2 ? up_i + s_cur * acc : s_cur * acc - c_prev * up_i;
-                        A.y[row] = w; asum += (s_cur * xl_i) * w;
-                    } else A.y[row] = A.pass >= 2 ? up_i + acc : acc;
-                }
-            }
-            __builtin_amdgcn_wave_barrier();
-            asm volatile("" ::: "memory");
-        }
-    }
-    if (A.epi && (A.pass == 0 || A.pass == 2)) { double rr = block_sum(asum, red); if (tid == 0) A.partial[blockIdx.x] = rr; }
-}
-
 // ---------------------------------------------------------------------------------------------
 // |out> = c^+_{orb,spin} |in>  or  c_{orb,spin} |in>  between two sectors, gather form over the
 // target index (ED_GF_NORMAL.f90:190-213 and 264-283 loop over the source and scatter).

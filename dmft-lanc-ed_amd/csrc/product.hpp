@@ -249,63 +249,11 @@ static int hxv(S *s, const double *v, double *out, bool epi, const double *uprev
         A.rowptr = s->csr_rowptr.p; A.cols = s->csr_cols.p; A.vals = s->csr_vals.p;
         A.x = overlap ? (s->halo ? v : v - H.dw0 * H.DimUp) : (multi ? s->vfull.p : v); A.y = out; A.v_local = v; A.uprev = uprev; A.scal = s->scal.p; A.partial = s->partial.p; A.epi = epi; A.xcd_rows = s->csr_xcd_rows;
         // the column index is global; on one GPU local == global
-        // persistent pipelined kernels (k_csr_lds): x window of the dw row in LDS for the local block (or the whole unsplit
-        // matrix), XCD-owned column tiles without a window for the dw block(s)
-        auto launch_lds = [&](bool win, const int64_t *rp, const int32_t *cc, const double *vv, int pass, int rb, const double *xptr) -> int {
-            CsrLdsArgs L{};
-            L.Qdw = H.Qdw; L.DimUp = (int32_t)H.DimUp; L.rb = rb; L.rbshift = 0; while ((1 << L.rbshift) < rb) L.rbshift++;
-            L.cpr = (int32_t)cdiv(H.DimUp, rb);
-            L.rowptr = rp; L.cols = cc; L.vals = vv; L.x = xptr; L.xrow0 = s->halo ? 0 : H.dw0;     // x-space row of local dw row 0 (columns are x-space: build_csr's rowshift)
-            L.y = out; L.v_local = v; L.uprev = uprev; L.scal = s->scal.p; L.partial = s->partial.p; L.epi = epi; L.pass = pass; L.dbg = (s->dbg >> 3) & 3;
-            if (win) {
-                const int grid = (int)std::min<int64_t>(H.Qdw, s->csr_lds_grid);
-                const size_t xw = (((size_t)H.DimUp * 8 + 31) & ~(size_t)31);
-#define CSRW_LAUNCH(NT_, CAP_, D_)                                                                                           \
-    do {                                                                                                                         \
-        const size_t lds = xw + (NT_ / 64) * (size_t)((CAP_ + 8) * 12) + 128;                                                    \
-        static OncePerDevice once_;                                                                                              \
-        if (once_.first(s->device)) {                                                                                            \
-            HIPCHK(hipFuncSetAttribute((const void *)k_csr_lds<NT_, CAP_, true, D_, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));  \
-            HIPCHK(hipFuncSetAttribute((const void *)k_csr_lds<NT_, CAP_, true, D_, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
-        }                                                                                                                        \
-        if (pass != 0) hipLaunchKernelGGL((k_csr_lds<NT_, CAP_, true, D_, true>), dim3(grid), dim3(NT_), lds, s->stream, L);     /* local block of the split form: every column lies in the window */ \
-        else hipLaunchKernelGGL((k_csr_lds<NT_, CAP_, true, D_, false>), dim3(grid), dim3(NT_), lds, s->stream, L);              \
-    } while (0)
-                if (s->csr_lds_nt == 512) { if (s->csr_lds_depth >= 3) CSRW_LAUNCH(512, 576, 3); else if (s->csr_lds_depth == 2) CSRW_LAUNCH(512, 576, 2); else CSRW_LAUNCH(512, 576, 1); }
-                else { if (s->csr_lds_depth >= 2) CSRW_LAUNCH(1024, 288, 2); else CSRW_LAUNCH(1024, 288, 1); }
-#undef CSRW_LAUNCH
-                nblocks = grid;
-            } else {
-                const int grid = s->csrD_pipe_grid;                                 // multiple of 8: XCD-owned column tiles
-                const size_t lds = 4 * (size_t)((576 + 8) * 12) + 128;
-                if (s->csrD_pipe_depth >= 2) hipLaunchKernelGGL((k_csr_lds<256, 576, false, 2, false>), dim3(grid), dim3(256), lds, s->stream, L);
-                else hipLaunchKernelGGL((k_csr_lds<256, 576, false, 1, false>), dim3(grid), dim3(256), lds, s->stream, L);
-                nblocks = grid;
-            }
-            HIPCHK(hipGetLastError());
-            return EDGPU_OK;
-        };
-        // one-wave workgroups with NB chunks each (k_csr_spmv3): needs 64-row chunks that fit the 640-entry image
-        auto launch_nb = [&](bool nt) -> int {
-            const int nb = s->csr_nb;
-            if (A.coltiles) nblocks = 8 * cdiv(A.blocks_per_row, 8) * cdiv(H.Qdw, nb);
-            else nblocks = cdiv(A.blocks_per_row, nb) * H.Qdw;
-#define NB_LAUNCH(NB_) do { if (nt) hipLaunchKernelGGL((k_csr_spmv3<640, NB_, true>), dim3((unsigned)nblocks), dim3(64), 0, s->stream, A); \
-                            else hipLaunchKernelGGL((k_csr_spmv3<640, NB_, false>), dim3((unsigned)nblocks), dim3(64), 0, s->stream, A); } while (0)
-            if (nb == 2) NB_LAUNCH(2); else if (nb == 3) NB_LAUNCH(3); else NB_LAUNCH(4);
-#undef NB_LAUNCH
-            HIPCHK(hipGetLastError());
-            return EDGPU_OK;
-        };
         nblocks = (int64_t)s->csr_bpr * H.Qdw;
         A.pass = s->csr_split ? 1 : 0; A.coltiles = 0;
-        if (s->csr_lds) CHK(launch_lds(true, s->csr_rowptr.p, s->csr_cols.p, s->csr_vals.p, A.pass, s->csr_lds_rb, A.x));
-        else if (s->csr_split && s->csrL_small && s->csr_rpb == 64 && s->csr_nb > 1) CHK(launch_nb(false));
-        else {
-            if (s->csr_split && s->csrL_small) hipLaunchKernelGGL((k_csr_spmv2<64, 640, false>), dim3((unsigned)nblocks), dim3(64), 0, s->stream, A);
-            else hipLaunchKernelGGL((k_csr_spmv2<64, 1152, false>), dim3((unsigned)nblocks), dim3(64), 0, s->stream, A);
-            HIPCHK(hipGetLastError());
-        }
+        if (s->csr_split && s->csrL_small) hipLaunchKernelGGL((k_csr_spmv2<64, 640, false>), dim3((unsigned)nblocks), dim3(64), 0, s->stream, A);
+        else hipLaunchKernelGGL((k_csr_spmv2<64, 1152, false>), dim3((unsigned)nblocks), dim3(64), 0, s->stream, A);
+        HIPCHK(hipGetLastError());
         if (s->csr_split) {
             A.rows_per_block = s->csrD_rpb; A.blocks_per_row = s->csrD_bpr; A.coltiles = 1; A.xcd_rows = 0;
             nblocks = 8 * cdiv(s->csrD_bpr, 8) * H.Qdw;
@@ -313,13 +261,9 @@ static int hxv(S *s, const double *v, double *out, bool epi, const double *uprev
                 // dw hops into the rank's own rows: their columns are the first Qdw rows of the x-space, i.e. the local
                 // shard itself -- this block too runs while the exchange is in flight
                 A.rowptr = s->csrO_rowptr.p; A.cols = s->csrO_cols.p; A.vals = s->csrO_vals.p; A.pass = 3;
-                if (s->csrD_pipe) CHK(launch_lds(false, A.rowptr, A.cols, A.vals, 3, s->csrD_pipe_rb, A.x));
-                else if (s->csrD_small && s->csrD_rpb == 64 && s->csr_nb > 1) CHK(launch_nb(false));
-                else {
-                    if (s->csrD_small) hipLaunchKernelGGL((k_csr_spmv2<64, 640, false>), dim3((unsigned)nblocks), dim3(64), 0, s->stream, A);
-                    else hipLaunchKernelGGL((k_csr_spmv2<64, 1152, false>), dim3((unsigned)nblocks), dim3(64), 0, s->stream, A);
-                    HIPCHK(hipGetLastError());
-                }
+                if (s->csrD_small) hipLaunchKernelGGL((k_csr_spmv2<64, 640, false>), dim3((unsigned)nblocks), dim3(64), 0, s->stream, A);
+                else hipLaunchKernelGGL((k_csr_spmv2<64, 1152, false>), dim3((unsigned)nblocks), dim3(64), 0, s->stream, A);
+                HIPCHK(hipGetLastError());
             }
             if (overlap) { HIPCHK(hipStreamWaitEvent(s->stream, s->ev_gather, 0)); A.x = s->vfull.p; }
             if (s->nd_nr > 0) {     // stored non-local block (Jx/Jp): compressed rows, wave-level segmented sums
@@ -333,9 +277,7 @@ static int hxv(S *s, const double *v, double *out, bool epi, const double *uprev
             }
             A.rowptr = s->csrD_rowptr.p; A.cols = s->csrD_cols.p; A.vals = s->csrD_vals.p;
             A.pass = 2;
-            if (s->csrD_pipe) CHK(launch_lds(false, A.rowptr, A.cols, A.vals, 2, s->csrD_pipe_rb, A.x));
-            else if (s->csrD_small && s->csrD_rpb == 64 && s->csr_nb > 1) CHK(launch_nb(s->csrD_nt != 0));
-            else {
+            {
                 nblocks = 8 * cdiv(s->csrD_bpr, 8) * H.Qdw;
                 if (s->csrD_small) {
                     if (s->csrD_nt) hipLaunchKernelGGL((k_csr_spmv2<64, 640, true>), dim3((unsigned)nblocks), dim3(64), 0, s->stream, A);

@@ -176,8 +176,7 @@ struct edgpu_sector_s {
     DevBuf<int64_t> nd_rows, nd_ptr; DevBuf<int32_t> nd_cols; DevBuf<double> nd_vals; DevBuf<uint8_t> nd_slot; int64_t nd_nr = 0, nd_nnz = 0;
     bool csr_split = false; int64_t csrL_nnz = 0, csrD_nnz = 0; int32_t csrD_rpb = 64, csrD_bpr = 0; int csrD_nt = 1; bool csrL_small = false, csrD_small = false;
     int64_t csr_nnz = 0; int32_t csr_rpb = 0, csr_bpr = 0, csr_tile = 1;
-    // persistent pipelined CSR kernels (k_csr_lds): window form for the local block / unsplit matrix, tile form for the dw block(s)
-    bool csr_lds = false, csrD_pipe = false; int csr_lds_nt = 512, csr_lds_rb = 64, csr_lds_grid = 256, csr_lds_depth = 3, csrD_pipe_rb = 64, csrD_pipe_grid = 1024, csrD_pipe_depth = 1; int csr_xcd_rows = 0; int csr_nb = 1;      // chunks per one-wave workgroup (k_csr_spmv3)
+    int csr_xcd_rows = 0;
     // work vectors
     // halo exchange (multi-rank, ed_total_ud=T without Jx/Jp/phonon extras): x-space of the dw hops is
     // [own rows | rows needed from rank 0 | rank 1 | ...] instead of the whole gathered vector

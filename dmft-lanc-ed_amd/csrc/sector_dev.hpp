@@ -327,35 +327,7 @@ static int build_csr(S *s)
         s->csrD_small = ndmax * s->csrD_rpb <= 640 && dbg_int("EDGPU_CSR_SMALL", 1);
     }
     HIPCHK(hipGetLastError());
-    // persistent pipelined kernels: chunk = largest power-of-two row count whose entries fit a wave's staging area
-    {
-        auto pow2_rows = [](int64_t cap, int64_t rowmax) { int rb = 64; while (rb > 1 && (int64_t)rb * rowmax > cap) rb >>= 1; return rb; };
-        s->csr_xcd_rows = dbg_int("EDGPU_CSR_XCD", 0);
-        s->csr_nb = std::max(1, std::min(4, dbg_int("EDGPU_CSR_NB", 1)));
-        s->csr_lds_nt = dbg_int("EDGPU_CSR_LDS_NT", 512) == 1024 ? 1024 : 512;
-        s->csr_lds_depth = std::max(1, dbg_int("EDGPU_CSR_LDS_DEPTH", 3));
-        s->csrD_pipe_depth = std::max(1, dbg_int("EDGPU_CSRD_PIPE_DEPTH", 1));
-        const int64_t cap = s->csr_lds_nt == 512 ? 576 : 288;
-        const int64_t rowmax = s->csr_split ? 1 + upmax : maxrow;
-        const bool fits = (((size_t)H.DimUp * 8 + 31) & ~(size_t)31) + (s->csr_lds_nt / 64) * (size_t)((cap + 8) * 12) + 128 <= 160 * 1024;
-        // worth it once a dw row is long enough to keep a 16-wave workgroup busy; small sectors stay with one wave per block
-        s->csr_lds = fits && rowmax <= cap && dbg_int("EDGPU_CSR_LDS", 0) != 0;
-        s->csr_lds_rb = pow2_rows(cap, rowmax);
-        int ncu = 256; { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, s->device) == hipSuccess) ncu = pr.multiProcessorCount; else (void)hipGetLastError(); }
-        s->csr_lds_grid = std::max(1, dbg_int("EDGPU_CSR_LDS_GRID", ncu));
-        int64_t ndmax2 = 1;
-        for (int64_t q = 0; q < H.Qdw; q++) ndmax2 = std::max<int64_t>(ndmax2, dw.rowptr[H.dw0 + q + 1] - dw.rowptr[H.dw0 + q]);
-        s->csrD_pipe = s->csr_split && ndmax2 <= 576 && dbg_int("EDGPU_CSRD_PIPE", 0) != 0;
-        s->csrD_pipe_rb = std::min(pow2_rows(576, ndmax2), std::max(1, dbg_int("EDGPU_CSRD_PIPE_ROWS", 64)));
-        {   // 4-wave workgroups, as many as are resident at once (a second round of workgroups would start from an empty pipeline)
-            int per_cu = 4;
-            const size_t ldsD = 4 * (size_t)((576 + 8) * 12) + 128;
-            hipError_t oe = s->csrD_pipe_depth >= 2 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_csr_lds<256, 576, false, 2, false>, 256, ldsD)
-                                                    : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_csr_lds<256, 576, false, 1, false>, 256, ldsD);
-            if (oe != hipSuccess) { (void)hipGetLastError(); per_cu = 4; }
-            s->csrD_pipe_grid = 8 * std::max(1, dbg_int("EDGPU_CSRD_PIPE_GRID", ncu * std::max(per_cu, 1)) / 8);
-        }
-    }
+    s->csr_xcd_rows = dbg_int("EDGPU_CSR_XCD", 0);
     s->csr_rpb = (int32_t)std::min<int64_t>(64, 1152 / std::max<int64_t>(maxrow, 1));      // one wave per row block
     if (s->csr_rpb < 1) return fail(EDGPU_EUNSUPPORTED, "edgpu: a CSR row exceeds the LDS tile");
     s->csr_bpr = (int32_t)cdiv(H.DimUp, s->csr_rpb);
@@ -374,7 +346,6 @@ static int64_t max_partials(const S *s)
     if (s->tr_on) n = std::max<int64_t>(n, cdiv(s->H.DimUp, 32) * cdiv(s->H.Qdw, 32));      // k_tadd: one partial per 32x32 tile
     if (s->csr_bpr) n = std::max<int64_t>(n, (int64_t)s->csr_bpr * s->H.Qdw);
     if (s->csrD_bpr) n = std::max<int64_t>(n, 8 * cdiv(s->csrD_bpr, 8) * s->H.Qdw);
-    n = std::max<int64_t>(n, std::max(s->csr_lds_grid, s->csrD_pipe_grid));
     return n;
 }
 

@@ -3,8 +3,21 @@
 (scripts/profile_round.sh): mean counter value per dispatch of every product kernel, corrected as
 MI355X_MICROARCH.md prescribes (units of 1 KiB; FETCH_SIZE tallies 64 B per 128-B request on gfx950 -> x2),
 summed over the kernels that make one product.  Prints a summary and writes pmc_traffic.json next to it."""
-import collections, csv, glob, json, os, sys
+import collections, csv, glob, hashlib, json, os, sys
 root = sys.argv[1]
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def source_stamp():      # same digest as bench.py: the summary is only quoted while the kernel sources are the ones it was measured on
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "dmft-lanc-ed_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".hpp")):
+            h.update(f.encode()); h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+STAMP = source_stamp()
 PRODUCT = {"csr": ("k_csr_spmv2",), "kron": ("k_uppass", "k_dwpass"), "direct": ("k_uppass", "k_dwpass", "k_direct_tables")}
 out = []
 for st, prefixes in PRODUCT.items():
@@ -32,6 +45,7 @@ for st, prefixes in PRODUCT.items():
         print("  %-50s FETCH_SIZE %.4g KiB  WRITE_SIZE %.4g KiB  -> %.3f GB per product (n=%d)" % (kn, fs, ws, b / 1e9, n))
         tot += b
     print("  total %.2f GB per product" % (tot / 1e9))
-    out.append({"storage": st, "nbath": 15, "n_gpus": 1, "hbm_bytes_per_launch": tot,
+    out.append({"storage": st, "nbath": 15, "n_gpus": 1, "hbm_bytes_per_launch": tot, "source_stamp": STAMP, "kernels": sorted(per["FETCH_SIZE"]),
+                "file": "profiles/r02/pmc_traffic_summary.txt",
                 "source": "profiles: (2*FETCH_SIZE + WRITE_SIZE)*1024 per dispatch, summed over the kernels of one product (%s); FETCH_SIZE doubled per MI355X_MICROARCH.md (64 B tallied per 128-B request); fabric-side count, Infinity-Cache hits included" % ", ".join(sorted(per["FETCH_SIZE"]))})
 json.dump(out, open(os.path.join(root, "pmc_traffic.json"), "w"), indent=1)

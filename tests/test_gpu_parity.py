@@ -225,11 +225,6 @@ def test_large_sector_code_paths_on_small_sectors(edgpu_mod, monkeypatch, name, 
     w = np.linalg.eigvalsh(S.hmat())
     for env in ({"EDGPU_KRON_SPLIT": "1", "EDGPU_CSR_SPLIT": "1"},
                 {"EDGPU_COMPOSITE": "0"},      # ed_total_ud=F through the generic mixed-radix kernel instead of the composite two-factor path (no CSR there)
-                # persistent pipelined CSR kernels (x window in LDS / XCD-owned tiles), which small sectors do not pick by themselves
-                {"EDGPU_CSR_SPLIT": "1", "EDGPU_CSR_LDS": "1", "EDGPU_CSRD_PIPE": "1"},
-                {"EDGPU_CSR_SPLIT": "1", "EDGPU_CSR_LDS": "1", "EDGPU_CSRD_PIPE": "1", "EDGPU_CSR_LDS_NT": "512", "EDGPU_CSR_LDS_GRID": "3", "EDGPU_CSRD_PIPE_GRID": "16", "EDGPU_CSRD_PIPE_ROWS": "16"},
-                {"EDGPU_CSR_SPLIT": "0", "EDGPU_CSR_LDS": "1", "EDGPU_CSR_LDS_GRID": "2"},      # unsplit matrix: dw hops gather outside the window
-                {"EDGPU_CSR_SPLIT": "1", "EDGPU_CSR_NB": "3"}, {"EDGPU_CSR_SPLIT": "1", "EDGPU_CSR_NB": "4", "EDGPU_CSRD_NT": "0"}, {"EDGPU_CSR_SPLIT": "1", "EDGPU_CSR_NB": "1"},
                 {"EDGPU_KRON_SPLIT": "1", "EDGPU_CSR_SPLIT": "1", "EDGPU_DW_W": "8", "EDGPU_DW_ROWS": "16", "EDGPU_CSRD_ROWS": "16", "EDGPU_UP_GRID": "3"},
                 {"EDGPU_KRON_SPLIT": "1", "EDGPU_DW_VARIANT": "1", "EDGPU_UP_PERSISTENT": "0", "EDGPU_CSR_SPLIT": "1", "EDGPU_CSRD_NT": "0"},
                 {"EDGPU_CSR_SPLIT": "0", "EDGPU_KRON_SPLIT": "1", "EDGPU_UP_THREADS": "512", "EDGPU_UP_PAIRS": "0"},

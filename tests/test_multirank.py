@@ -101,7 +101,7 @@ def test_multirank_on_one_gpu_callback_exchange(edgpu_mod, case, size):
 def test_multirank_large_sector_forms(edgpu_mod, case, size):
     """The storage forms that switch on for large sectors, forced on small ones with several ranks: two-pass stored
     product, and the explicit CSR as three blocks (local | dw hops into own rows | dw hops into received rows)."""
-    res = _launch("gpu", case, size, extra_env={"EDGPU_KRON_SPLIT": "1", "EDGPU_CSR_SPLIT": "1", "EDGPU_CSR_LDS": "1", "EDGPU_CSRD_PIPE": "1"})
+    res = _launch("gpu", case, size, extra_env={"EDGPU_KRON_SPLIT": "1", "EDGPU_CSR_SPLIT": "1"})
     name, m, nu, nd = [z for z in __import__("cases").zoo() if z[0] == case][0]
     from oracle import oracle
     e_dense = np.linalg.eigvalsh(oracle.Sector(m, nu, nd).hmat())[0]
