@@ -290,10 +290,10 @@ static int build_csr(S *s)
         hipLaunchKernelGGL(k_csr_build, dim3(gb), dim3(256), 0, s->stream, A, 0);
     } else {
         CHK(s->csr_rowptr.alloc((size_t)s->nloc_el + 1)); CHK(s->csr_cols.alloc((size_t)s->csrL_nnz + 8)); CHK(s->csr_vals.alloc((size_t)s->csrL_nnz + 8));
-        if (!(s->halo && dbg_int("EDGPU_CSR_THREE", 1) != 0)) { CHK(s->csrD_rowptr.alloc((size_t)s->nloc_el + 1)); CHK(s->csrD_cols.alloc((size_t)s->csrD_nnz + 8)); CHK(s->csrD_vals.alloc((size_t)s->csrD_nnz + 8)); }
+        s->csr_three = s->halo && !H.Jhflag && dbg_int("EDGPU_CSR_THREE", 1) != 0;      // the stored non-local block reads own and received rows from one x buffer: keep the own-row copy
+        if (!s->csr_three) { CHK(s->csrD_rowptr.alloc((size_t)s->nloc_el + 1)); CHK(s->csrD_cols.alloc((size_t)s->csrD_nnz + 8)); CHK(s->csrD_vals.alloc((size_t)s->csrD_nnz + 8)); }
         A.rowptr = s->csr_rowptr.p; A.cols = s->csr_cols.p; A.vals = s->csr_vals.p;
         hipLaunchKernelGGL(k_csr_build, dim3(gb), dim3(256), 0, s->stream, A, 1);
-        s->csr_three = s->halo && dbg_int("EDGPU_CSR_THREE", 1) != 0;
         if (!s->csr_three) {
             A.rowptr = s->csrD_rowptr.p; A.cols = s->csrD_cols.p; A.vals = s->csrD_vals.p;
             hipLaunchKernelGGL(k_csr_build, dim3(gb), dim3(256), 0, s->stream, A, 2);

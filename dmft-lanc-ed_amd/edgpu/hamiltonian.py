@@ -7,11 +7,18 @@ SciFortran entry points the reference calls with that operator, ``sp_lanc_eigh``
 libedgpu.so on the GPU; numpy arrays only carry inputs and results.
 """
 import ctypes as C
+import sys
 
 import numpy as np
 
 from . import capi
 from .capi import check
+
+
+def _finalizing():
+    """True while the interpreter shuts down: device objects still alive then are left to the process exit (the HIP / RCCL
+    runtimes of an embedding PyTorch may already be gone, and freeing through them then corrupts their heaps)."""
+    return sys is None or sys.is_finalizing()
 
 
 class DeviceVector:
@@ -40,6 +47,8 @@ class DeviceVector:
             self.ptr = None
 
     def __del__(self):
+        if _finalizing():
+            return
         try:
             self.free()
         except Exception:
@@ -110,6 +119,8 @@ class HvSector:
     close = delete_Hv_sector
 
     def __del__(self):
+        if _finalizing():
+            return
         try:
             self.delete_Hv_sector()
         except Exception:
@@ -418,6 +429,8 @@ class Communicator:
         self._c = None
 
     def __del__(self):
+        if _finalizing():
+            return
         try:
             self.close()
         except Exception:

@@ -64,8 +64,10 @@ def test_bench_starts_its_own_ranks(storage):
 
 @pytest.mark.gpu
 def test_bench_refuses_to_report_fewer_gpus_than_asked():
-    import torch
-    if torch.cuda.device_count() >= 2:
+    # counted in a child: importing torch HERE, after other tests have loaded libedgpu.so against the system HIP / RCCL, would
+    # put a second copy of both runtimes into this process (PyTorch bundles its own) and their exit handlers collide
+    ndev = int(subprocess.run([sys.executable, "-c", "import torch; print(torch.cuda.device_count())"], stdout=subprocess.PIPE, timeout=300).stdout.split()[-1])
+    if ndev >= 2:
         pytest.skip("needs a box with fewer devices than ranks")
     err = _run(["--gpus", "2", "--no-extra"], expect_fail=True)
     assert "only 1 device" in err
