@@ -869,31 +869,49 @@ int edgpu_sp_dump_matrix(edgpu_spmat m, double *dense)
         for (size_t k = 0; k < m->cols[(size_t)i].size(); k++) dense[(i + m->ishift) + m->nglob * (m->cols[(size_t)i][k] - 1)] += m->vals[(size_t)i][k];   // ED_SPARSE_MATRIX.f90:399-405, 425-430
     return EDGPU_OK;
 }
+// stored entries -> device CSR (once after the last insert); the product kernels then read only device memory
+static int sp_sync_device(edgpu_spmat m)
+{
+    if (!m->dirty) return EDGPU_OK;
+    std::vector<int64_t> rp((size_t)m->nrow + 1, 0); std::vector<int32_t> cc; std::vector<double> vv;
+    for (int64_t i = 0; i < m->nrow; i++) {
+        for (size_t k = 0; k < m->cols[(size_t)i].size(); k++) { cc.push_back((int32_t)(m->cols[(size_t)i][k] - 1)); vv.push_back(m->vals[(size_t)i][k]); }
+        rp[(size_t)i + 1] = (int64_t)cc.size();
+    }
+    m->nnz = (int64_t)cc.size();
+    if (cc.empty()) { cc.push_back(0); vv.push_back(0.0); }
+    CHK(m->d_rp.upload(rp)); CHK(m->d_cols.upload(cc)); CHK(m->d_vals.upload(vv));
+    CHK(m->d_x.alloc((size_t)std::max<int64_t>(m->ncol, 1))); CHK(m->d_y.alloc((size_t)std::max<int64_t>(m->nrow, 1)));
+    m->dirty = false;
+    return EDGPU_OK;
+}
+static int sp_launch(edgpu_spmat m, const double *x_dev, double *y_dev, int accumulate, hipStream_t st)
+{
+    const bool longrows = m->nnz > 32 * m->nrow;
+    if (longrows) hipLaunchKernelGGL(k_spgen_wave, dim3((unsigned)std::min<int64_t>(cdiv(m->nrow, 4), 65536)), dim3(256), 0, st, m->nrow, (const int64_t *)m->d_rp.p, (const int32_t *)m->d_cols.p, (const double *)m->d_vals.p, x_dev, y_dev, accumulate);
+    else hipLaunchKernelGGL(k_spgen_lane, dim3((unsigned)std::min<int64_t>(cdiv(m->nrow, 256), 65536)), dim3(256), 0, st, m->nrow, (const int64_t *)m->d_rp.p, (const int32_t *)m->d_cols.p, (const double *)m->d_vals.p, x_dev, y_dev, accumulate);
+    HIPCHK(hipGetLastError());
+    return EDGPU_OK;
+}
 int edgpu_sp_matvec(edgpu_spmat m, const double *v_host, double *hv_host, int32_t accumulate)
 {
     if (!m || !v_host || !hv_host) return fail(EDGPU_EINVAL, "edgpu_sp_matvec: null argument");
     CHK(require_device());
-    if (m->dirty) {
-        std::vector<int64_t> rp((size_t)m->nrow + 1, 0); std::vector<int32_t> cc; std::vector<double> vv;
-        for (int64_t i = 0; i < m->nrow; i++) {
-            for (size_t k = 0; k < m->cols[(size_t)i].size(); k++) { cc.push_back((int32_t)(m->cols[(size_t)i][k] - 1)); vv.push_back(m->vals[(size_t)i][k]); }
-            rp[(size_t)i + 1] = (int64_t)cc.size();
-        }
-        m->nnz = (int64_t)cc.size();
-        if (cc.empty()) { cc.push_back(0); vv.push_back(0.0); }
-        CHK(m->d_rp.upload(rp)); CHK(m->d_cols.upload(cc)); CHK(m->d_vals.upload(vv));
-        CHK(m->d_x.alloc((size_t)std::max<int64_t>(m->ncol, 1))); CHK(m->d_y.alloc((size_t)std::max<int64_t>(m->nrow, 1)));
-        m->dirty = false;
-    }
+    CHK(sp_sync_device(m));
     if (m->nrow == 0) return EDGPU_OK;
     HIPCHK(hipMemcpy(m->d_x.p, v_host, (size_t)m->ncol * 8, hipMemcpyHostToDevice));
     if (accumulate) HIPCHK(hipMemcpy(m->d_y.p, hv_host, (size_t)m->nrow * 8, hipMemcpyHostToDevice));
-    const bool longrows = m->nnz > 32 * m->nrow;
-    if (longrows) hipLaunchKernelGGL(k_spgen_wave, dim3((unsigned)std::min<int64_t>(cdiv(m->nrow, 4), 65536)), dim3(256), 0, 0, m->nrow, (const int64_t *)m->d_rp.p, (const int32_t *)m->d_cols.p, (const double *)m->d_vals.p, (const double *)m->d_x.p, m->d_y.p, (int)accumulate);
-    else hipLaunchKernelGGL(k_spgen_lane, dim3((unsigned)std::min<int64_t>(cdiv(m->nrow, 256), 65536)), dim3(256), 0, 0, m->nrow, (const int64_t *)m->d_rp.p, (const int32_t *)m->d_cols.p, (const double *)m->d_vals.p, (const double *)m->d_x.p, m->d_y.p, (int)accumulate);
-    HIPCHK(hipGetLastError());
+    CHK(sp_launch(m, m->d_x.p, m->d_y.p, (int)accumulate, nullptr));
     HIPCHK(hipMemcpy(hv_host, m->d_y.p, (size_t)m->nrow * 8, hipMemcpyDeviceToHost));
     return EDGPU_OK;
+}
+int edgpu_sp_matvec_device(edgpu_spmat m, const double *v_dev, double *hv_dev, int32_t accumulate, void *hip_stream)
+{
+    if (!m || !v_dev || !hv_dev) return fail(EDGPU_EINVAL, "edgpu_sp_matvec_device: null argument");
+    CHK(require_device());
+    CHK(sp_sync_device(m));
+    if (m->nrow == 0) return EDGPU_OK;
+    return sp_launch(m, v_dev, hv_dev, (int)accumulate, (hipStream_t)hip_stream);
 }
 
 int edgpu_comm_unique_id(void *id128)

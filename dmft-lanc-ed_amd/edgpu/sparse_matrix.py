@@ -70,6 +70,13 @@ def sp_row(sparse, i):
     return cols, vals
 
 
+def sp_matvec_device(sparse, v_dev, hv_dev, accumulate=False, stream=None):
+    """Hv (+)= A v on device vectors (edgpu.DeviceVector or raw device pointers): nothing crosses PCIe; asynchronous on
+    `stream` (a hipStream_t value, None = default stream) -- synchronise before reading the result."""
+    pv = getattr(v_dev, "ptr", v_dev); ph = getattr(hv_dev, "ptr", hv_dev)
+    check(capi.lib().edgpu_sp_matvec_device(sparse._h, pv, ph, 1 if accumulate else 0, stream))
+
+
 def sp_matvec(sparse, v, hv=None):
     v = np.ascontiguousarray(v, np.float64)
     acc = hv is not None

@@ -305,6 +305,12 @@ module EDGPU_C_API
        integer(c_int32_t), value  :: accumulate
        integer(c_int)             :: rc
      end function edgpu_sp_matvec
+     function edgpu_sp_matvec_device(m, v_dev, hv_dev, accumulate, hip_stream) bind(C, name="edgpu_sp_matvec_device") result(rc)
+       import :: c_int, c_int32_t, c_ptr
+       type(c_ptr), value         :: m, v_dev, hv_dev, hip_stream     ! device pointers; hip_stream: c_null_ptr = default stream
+       integer(c_int32_t), value  :: accumulate
+       integer(c_int)             :: rc
+     end function edgpu_sp_matvec_device
      function edgpu_cache_release() bind(C, name="edgpu_cache_release") result(rc)
        import :: c_int
        integer(c_int) :: rc

@@ -285,6 +285,9 @@ int edgpu_sp_dump_matrix(edgpu_spmat m, double *dense);
 int edgpu_sp_row(edgpu_spmat m, int64_t i, int32_t *size, int64_t *cols, double *vals, int32_t cap);
 /* Hv = A v (accumulate=0) or Hv += A v (accumulate=1); host vectors, product on the device */
 int edgpu_sp_matvec(edgpu_spmat m, const double *v_host, double *hv_host, int32_t accumulate);
+/* the same on device vectors (edgpu_malloc / any HIP allocation of ncol and nrow doubles): nothing crosses PCIe per call.
+ * Asynchronous on `hip_stream` (a hipStream_t, NULL = the default stream); the caller synchronises. */
+int edgpu_sp_matvec_device(edgpu_spmat m, const double *v_dev, double *hv_dev, int32_t accumulate, void *hip_stream);
 
 /* The library keeps large work vectors (the stored Krylov basis of edgpu_lanczos_gs) in a process-wide cache between
  * calls and sectors; it gives them back by itself when one of its allocations fails.  Call this to return the memory

@@ -80,6 +80,12 @@ def test_container_matvec_on_gpu_and_reference_insertion_sequence():
         np.testing.assert_allclose(hv, D @ v, rtol=0, atol=1e-13 * max(1.0, np.abs(D).sum()))
         hv2 = spm.sp_matvec(A, v, hv)                              # Hv += A v, as the reference's sweeps do
         np.testing.assert_allclose(hv2, 2 * (D @ v), rtol=0, atol=1e-12 * max(1.0, np.abs(D).sum()))
+        # device-resident vectors: no PCIe per product
+        import edgpu
+        dv, dh = edgpu.DeviceVector(m).upload(v), edgpu.DeviceVector(n).upload(np.zeros(n))
+        spm.sp_matvec_device(A, dv, dh); spm.sp_matvec_device(A, dv, dh, accumulate=True)
+        np.testing.assert_array_equal(dh.download(), hv2)          # same kernels, same order: same bits (download synchronises)
+        dv.free(); dh.free()
         spm.sp_delete_matrix(A)
     # row window: the local product returns the window's rows
     W = spm.sparse_matrix_csr(); spm.sp_set_mpi_matrix(W, 11, 30, 10); spm.sp_init_matrix(W, 50)
