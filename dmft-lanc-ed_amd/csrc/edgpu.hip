@@ -347,10 +347,17 @@ int edgpu_lanczos_time(edgpu_handle h, int32_t nwarm, int32_t niter, float *ms_p
     LzF F{h->lz[1].p, h->lz[0].p, h->lz[2].p};
     const bool fused = fused_ok(h);
     const SectorHost &H = h->H;
-    hipLaunchKernelGGL(k_random_start, dim3(2048), dim3(256), 0, h->stream, V.ucur, H.DimUp, H.Qdw, H.dw0, H.DimDw, H.DimPh, (uint64_t)1234567);
-    HIPCHK(hipGetLastError());
-    if (fused) { HIPCHK(hipMemsetAsync(F.uprev, 0, (size_t)h->nloc * 8, h->stream)); CHK(lzf_begin(h, F, nullptr)); }
-    else CHK(lz_start(h, V));
+    if (fused) {      // the start vector is generated in the dense layout and copied into the (possibly pitched) work vector
+        if (h->lz[3].n != (size_t)h->nloc) CHK(h->lz[3].alloc((size_t)h->nloc));
+        hipLaunchKernelGGL(k_random_start, dim3(2048), dim3(256), 0, h->stream, h->lz[3].p, H.DimUp, H.Qdw, H.dw0, H.DimDw, H.DimPh, (uint64_t)1234567);
+        HIPCHK(hipGetLastError());
+        CHK(lzf_copy_in(h, F.u, h->lz[3].p));
+        HIPCHK(hipMemsetAsync(F.uprev, 0, (size_t)h->vlen * 8, h->stream)); CHK(lzf_begin(h, F, nullptr));
+    } else {
+        hipLaunchKernelGGL(k_random_start, dim3(2048), dim3(256), 0, h->stream, V.ucur, H.DimUp, H.Qdw, H.dw0, H.DimDw, H.DimPh, (uint64_t)1234567);
+        HIPCHK(hipGetLastError());
+        CHK(lz_start(h, V));
+    }
     int k = 0;
     for (; k < nwarm; k++) { if (fused) CHK(lzf_iter(h, F, F.uprev, nullptr)); else CHK(lz_iter(h, V, k, nullptr)); }
     HIPCHK(hipEventRecord(h->ev_a, h->stream));
@@ -737,16 +744,21 @@ int edgpu_lanczos_bench_begin(edgpu_handle h, int32_t max_steps)
     CHK(lz_prepare(h, max_steps + 1));
     h->bv[0] = h->lz[0].p; h->bv[1] = h->lz[1].p; h->bv[2] = h->lz[2].p;
     const SectorHost &H = h->H;
-    hipLaunchKernelGGL(k_random_start, dim3(2048), dim3(256), 0, h->stream, h->bv[1], H.DimUp, H.Qdw, H.dw0, H.DimDw, H.DimPh, (uint64_t)1234567);
-    HIPCHK(hipGetLastError());
     LzVecs V{h->bv[0], h->bv[1], h->bv[2]};
     h->bench_fused = fused_ok(h);
     if (h->bench_fused) {      // roles: bv[0] = u_{k-1}, bv[1] = u_k, bv[2] = local part
         LzF F{h->bv[1], h->bv[0], h->bv[2]};
-        HIPCHK(hipMemsetAsync(F.uprev, 0, (size_t)h->nloc * 8, h->stream));
+        if (h->lz[3].n != (size_t)h->nloc) CHK(h->lz[3].alloc((size_t)h->nloc));
+        hipLaunchKernelGGL(k_random_start, dim3(2048), dim3(256), 0, h->stream, h->lz[3].p, H.DimUp, H.Qdw, H.dw0, H.DimDw, H.DimPh, (uint64_t)1234567);
+        HIPCHK(hipGetLastError());
+        CHK(lzf_copy_in(h, F.u, h->lz[3].p));
+        HIPCHK(hipMemsetAsync(F.uprev, 0, (size_t)h->vlen * 8, h->stream));
         CHK(lzf_begin(h, F, nullptr));
-    } else
+    } else {
+        hipLaunchKernelGGL(k_random_start, dim3(2048), dim3(256), 0, h->stream, h->bv[1], H.DimUp, H.Qdw, H.dw0, H.DimDw, H.DimPh, (uint64_t)1234567);
+        HIPCHK(hipGetLastError());
         CHK(lz_start(h, V));
+    }
     h->bench_k = 0;
     while ((int)h->bench_ev.size() < 2 * max_steps) { hipEvent_t e; HIPCHK(hipEventCreate(&e)); h->bench_ev.push_back(e); }
     if (h->multi) while ((int)h->comm_ev.size() < 2 * max_steps) { hipEvent_t e; HIPCHK(hipEventCreate(&e)); h->comm_ev.push_back(e); }

@@ -426,6 +426,7 @@ struct UpAxArgs {
     double *t_out;           // T = local part of H u_k, unscaled
     const double *scal; double *partial;
     double *acc; const double *zvec;   // optional eigenvector accumulation acc += zvec[K] * u_k (K = iteration counter in scal)
+    int32_t ld;              // row pitch of r / vprev / t_out / acc in doubles (0: DimUp); the stored diagonal keeps pitch DimUp
 };
 
 template <bool DIRECT, bool ACC, int NT>
@@ -434,6 +435,7 @@ __global__ void __launch_bounds__(NT) k_uppass2_ax(UpAxArgs A)
     extern __shared__ double lds[];
     constexpr int MAXQ = (13312 / 2 + NT - 1) / NT;      // pairs per lane
     const int DimUp = A.DimUp, npair = DimUp >> 1, tid = threadIdx.x;
+    const int64_t ld = A.ld ? A.ld : DimUp;
     double *tv = lds + DimUp;
     double *red = tv + 128;
     double *crow = red + 32;                             // DIRECT: Edw + const + cross term of this row, per up impurity word
@@ -445,9 +447,9 @@ __global__ void __launch_bounds__(NT) k_uppass2_ax(UpAxArgs A)
     // u = r - c*vprev for one pair of row rw: written back over r, summed into the norm, kept by the caller for LDS
     auto combine = [&](int64_t rw, int p, const dbl2v &r, const dbl2v &v) -> dbl2v {
         const dbl2v u = r - c_ax * v;
-        *reinterpret_cast<dbl2v *>(A.r + rw * DimUp + 2 * p) = u;
+        *reinterpret_cast<dbl2v *>(A.r + rw * ld + 2 * p) = u;
         bsum += u.x * u.x + u.y * u.y;
-        if (ACC) { dbl2v *pa = reinterpret_cast<dbl2v *>(A.acc + rw * DimUp + 2 * p); *pa = *pa + zk * u; }
+        if (ACC) { dbl2v *pa = reinterpret_cast<dbl2v *>(A.acc + rw * ld + 2 * p); *pa = *pa + zk * u; }
         return u;
     };
     dbl2v xu[MAXQ];                                      // u of the row that enters LDS next
@@ -457,7 +459,7 @@ __global__ void __launch_bounds__(NT) k_uppass2_ax(UpAxArgs A)
         for (int q = 0; q < MAXQ; q++) {
             const int p = tid + q * NT;
             if (q < nq && p < npair)
-                xu[q] = combine(row, p, *reinterpret_cast<const dbl2v *>(A.r + row * DimUp + 2 * p), *reinterpret_cast<const dbl2v *>(A.vprev + row * DimUp + 2 * p));
+                xu[q] = combine(row, p, *reinterpret_cast<const dbl2v *>(A.r + row * ld + 2 * p), *reinterpret_cast<const dbl2v *>(A.vprev + row * ld + 2 * p));
         }
     }
     // The operands of step q+1 of the hop loop are loaded during step q: the H_up image and diagonal of pair q+1 of this row
@@ -471,7 +473,7 @@ __global__ void __launch_bounds__(NT) k_uppass2_ax(UpAxArgs A)
             if (!DIRECT) o.d = *reinterpret_cast<const dbl2v *>(A.diag + idwl * DimUp + 2 * p);
             else o.d = *reinterpret_cast<const dbl2v *>(A.Eup + 2 * p);
             o.w0 = A.packed[3 * p]; o.w1 = A.packed[3 * p + 1]; o.w2 = A.packed[3 * p + 2];
-            if (more) { o.nr = *reinterpret_cast<const dbl2v *>(A.r + next * DimUp + 2 * p); o.nv = *reinterpret_cast<const dbl2v *>(A.vprev + next * DimUp + 2 * p); }
+            if (more) { o.nr = *reinterpret_cast<const dbl2v *>(A.r + next * ld + 2 * p); o.nv = *reinterpret_cast<const dbl2v *>(A.vprev + next * ld + 2 * p); }
         };
         Ops cur, nxt;
         if (tid < npair) load_ops(tid, cur);
@@ -504,7 +506,7 @@ __global__ void __launch_bounds__(NT) k_uppass2_ax(UpAxArgs A)
                     a0 += t0 * lds[col0]; a1 += t1 * lds[col1];
                 }
                 dbl2v o; o.x = a0; o.y = a1;
-                *reinterpret_cast<dbl2v *>(A.t_out + row * DimUp + 2 * p) = o;
+                *reinterpret_cast<dbl2v *>(A.t_out + row * ld + 2 * p) = o;
                 cur = nxt;
             }
         }
@@ -725,6 +727,7 @@ struct DwArgs {
     const double *v, *vfull; double *out;
     const double *scal; double *partial;
     int32_t w, wshift, ntiles, R, chunks;
+    int32_t ld;                // row pitch of v / vfull / out / uprev2 in doubles (0: DimUp)
     const double *uprev2;      // fused Lanczos iteration (EPI only): out holds the UNSCALED local part; out = s_cur*(out + dw part) - beta*s_prev*uprev2
 };
 
@@ -789,16 +792,17 @@ __global__ void __launch_bounds__(256) k_dwpass2(DwArgs A)
         const int iup = tile * A.w + 2 * j;
         const double s_cur = EPI ? A.scal[SC_SCUR] : 1.0;
         const double c_prev2 = (EPI && A.uprev2) ? A.scal[SC_BETA] * A.scal[SC_SPREV] : 0.0;
+        const int64_t ld = A.ld ? A.ld : A.DimUp;
         if (iup < A.DimUp)
             for (int r = r0; r < rb; r += rstep) {
                 const int64_t row = row0 + r;
                 const int iph = (int)(row / A.Qdw);
-                const int64_t e = row * A.DimUp + iup, fbase = (int64_t)iph * A.DimDw * A.DimUp + iup;
+                const int64_t e = row * ld + iup, fbase = (int64_t)iph * A.DimDw * ld + iup;
                 dbl2v acc = {0.0, 0.0};
                 const double *tvr = tv + r * A.dww; const int32_t *tcr = tc + r * A.dww;
                 const int nk = RAGGED ? tn[r] : A.dww;   // hops of this row (ELL padding sits at the end: not gathered)
                 for (int k = 0; k < nk; k++) {
-                    const dbl2v x = *reinterpret_cast<const dbl2v *>(A.vfull + fbase + (int64_t)tcr[k] * A.DimUp);
+                    const dbl2v x = *reinterpret_cast<const dbl2v *>(A.vfull + fbase + (int64_t)tcr[k] * ld);
                     acc += tvr[k] * x;
                 }
                 dbl2v *po = reinterpret_cast<dbl2v *>(A.out + e);
@@ -1693,6 +1697,14 @@ __global__ void __launch_bounds__(1024) k_reduce_final_step(const double *__rest
 }
 
 // x[i] *= scal[idx]
+// zero the padding columns [DimUp, ld) of every row of a pitched vector (elementwise passes then run over the padded length)
+__global__ void __launch_bounds__(256) k_zero_pads(double *__restrict__ x, int64_t nrows, int32_t DimUp, int32_t ld)
+{
+    const int np = ld - DimUp;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nrows * np; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / np; x[r * ld + DimUp + (i - r * np)] = 0.0;
+    }
+}
 __global__ void __launch_bounds__(256) k_scale(double *__restrict__ x, const double *__restrict__ scal, int idx, int64_t n)
 {
     const double s = scal[idx];

@@ -75,7 +75,7 @@ static bool tridiag_lowest(const double *al, const double *be, int k, double *e0
 // ---------------------------------------------------------------------------------------
 static int lz_prepare(S *s, int nmax)
 {
-    for (int i = 0; i < 3; i++) if (s->lz[i].n != (size_t)s->nloc) CHK(s->lz[i].alloc((size_t)s->nloc));
+    for (int i = 0; i < 3; i++) if (s->lz[i].n != (size_t)s->vlen) CHK(s->lz[i].alloc((size_t)s->vlen));      // vlen: padded length when the fused loops pad the row pitch
     if (s->nmax < nmax) {
         CHK(s->alphas.alloc((size_t)nmax + 2)); CHK(s->betas.alloc((size_t)nmax + 2)); CHK(s->zvec.alloc((size_t)nmax + 2));
         s->nmax = nmax;
@@ -85,11 +85,12 @@ static int lz_prepare(S *s, int nmax)
     return EDGPU_OK;
 }
 
-static int reduce_dot(S *s, const double *a, const double *b)
+static int reduce_dot(S *s, const double *a, const double *b, int64_t n = -1)
 {
-    int nb = (int)std::min<int64_t>(cdiv(s->nloc, 256 * 8), 2048);
+    if (n < 0) n = s->nloc;
+    int nb = (int)std::min<int64_t>(cdiv(n, 256 * 8), 2048);
     nb = std::max(nb, 1);
-    hipLaunchKernelGGL(k_dot_partial, dim3(nb), dim3(256), 0, s->stream, a, b, s->nloc, s->partial.p);
+    hipLaunchKernelGGL(k_dot_partial, dim3(nb), dim3(256), 0, s->stream, a, b, n, s->partial.p);
     hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(1024), 0, s->stream, s->partial.p, (int64_t)nb, s->scal.p + SC_TMP);
     HIPCHK(hipGetLastError());
     return allreduce_tmp(s);
@@ -161,6 +162,27 @@ static int lz_iters(S *s, LzVecs &V, int k, int count, double *acc)
 // betas[1..k] on the device.  One iteration = dw half of k (r_k, alpha_k) + local half of k+1 (u_{k+1}, beta_k): two passes
 // over the vectors instead of three.
 struct LzF { double *u, *uprev, *t; };
+// dense vector (the caller's layout) <-> pitched vector of the fused loops; the padding columns of `dst` end up zero
+static int lzf_copy_in(S *s, double *dst, const double *src)
+{
+    if (!s->pad_on) { HIPCHK(hipMemcpyAsync(dst, src, (size_t)s->nloc * 8, hipMemcpyDeviceToDevice, s->stream)); return EDGPU_OK; }
+    HIPCHK(hipMemsetAsync(dst, 0, (size_t)s->vlen * 8, s->stream));
+    HIPCHK(hipMemcpy2DAsync(dst, (size_t)s->vld * 8, src, (size_t)s->H.DimUp * 8, (size_t)s->H.DimUp * 8, (size_t)(s->nloc / s->H.DimUp), hipMemcpyDeviceToDevice, s->stream));
+    return EDGPU_OK;
+}
+static int lzf_copy_out(S *s, double *dst, const double *src)
+{
+    if (!s->pad_on) { HIPCHK(hipMemcpyAsync(dst, src, (size_t)s->nloc * 8, hipMemcpyDeviceToDevice, s->stream)); return EDGPU_OK; }
+    HIPCHK(hipMemcpy2DAsync(dst, (size_t)s->H.DimUp * 8, src, (size_t)s->vld * 8, (size_t)s->H.DimUp * 8, (size_t)(s->nloc / s->H.DimUp), hipMemcpyDeviceToDevice, s->stream));
+    return EDGPU_OK;
+}
+static int lzf_zero_pads(S *s, double *x)      // a buffer that joins the elementwise passes (stored Krylov vectors) must carry zeros there
+{
+    if (!s->pad_on) return EDGPU_OK;
+    hipLaunchKernelGGL(k_zero_pads, dim3(256), dim3(256), 0, s->stream, x, s->nloc / s->H.DimUp, (int32_t)s->H.DimUp, (int32_t)s->vld);
+    HIPCHK(hipGetLastError());
+    return EDGPU_OK;
+}
 static int lzf_begin(S *s, LzF &F, double *acc)      // F.u holds the (unnormalised) start vector, F.uprev any finite buffer
 {
     HIPCHK(hipMemsetAsync(s->scal.p, 0, SC_COUNT * sizeof(double), s->stream));       // alpha_{-1} = 0, iteration counter 0
@@ -200,8 +222,11 @@ static int lanczos_gs_impl(S *s, int nitermax, double threshold, int ncheck, dou
     if (ncheck < 1) ncheck = 10;
     if ((int64_t)nitermax > s->H.Dim) nitermax = (int)s->H.Dim;   // ED_DIAG.f90:100 Nitermax=min(dim,lanc_niter)
     CHK(lz_prepare(s, nitermax));
-    for (int i = 3; i < 5; i++) if (s->lz[i].n != (size_t)s->nloc) CHK(s->lz[i].alloc((size_t)s->nloc));
-    double *start = s->lz[3].p, *acc = s->lz[4].p;
+    const bool fused = fused_ok(s);
+    const int64_t vlen = fused ? s->vlen : s->nloc;      // length of a work vector (padded row pitch in the fused loops)
+    if (s->lz[3].n != (size_t)s->nloc) CHK(s->lz[3].alloc((size_t)s->nloc));
+    if (s->lz[4].n != (size_t)vlen) CHK(s->lz[4].alloc((size_t)vlen));
+    double *start = s->lz[3].p, *acc = s->lz[4].p;      // start keeps the caller's dense layout
     // zero input => library-generated start vector (ED_DIAG.f90:147 passes eig_basis=0)
     HIPCHK(hipMemcpyAsync(start, vect_dev, (size_t)s->nloc * 8, hipMemcpyDeviceToDevice, s->stream));
     CHK(reduce_dot(s, start, start));
@@ -223,14 +248,14 @@ static int lanczos_gs_impl(S *s, int nitermax, double threshold, int ncheck, dou
         if (g_kpool.device != s->device) { g_kpool.in_use = false; kpool_release(); g_kpool.in_use = true; g_kpool.device = s->device; }
         size_t fr = 0, tot = 0; HIPCHK(hipMemGetInfo(&fr, &tot));
         budget = (int64_t)fr - (int64_t)((double)tot * 0.04) - ((int64_t)2 << 30);     // head-room left to everything else
-        for (size_t k = 0; k < g_kpool.cap.size(); k++) if (g_kpool.cap[k] >= (size_t)s->nloc) budget += (int64_t)s->nloc * 8;   // already ours
+        for (size_t k = 0; k < g_kpool.cap.size(); k++) if (g_kpool.cap[k] >= (size_t)vlen) budget += (int64_t)vlen * 8;   // already ours
         // a search rarely ends before ~50 iterations: when not even that many vectors fit (Ns=18: 19 GB each) do not
         // tie the memory up for nothing, go straight to the two-pass form
-        if (budget < (int64_t)std::min(nitermax, 48) * s->nloc * 8) store = false;
+        if (budget < (int64_t)std::min(nitermax, 48) * vlen * 8) store = false;
     }
     // small sectors: every vector of the search in ONE cached allocation (grown geometrically), so that a run over many
     // small sectors of growing size does not pay a hundred allocations each time
-    const int64_t want_all = (int64_t)std::min(nitermax + 2, store_max) * s->nloc;
+    const int64_t want_all = (int64_t)std::min(nitermax + 2, store_max) * vlen;
     const bool slab_mode = store && want_all * 8 <= ((int64_t)512 << 20);
     if (slab_mode && g_kpool.slab_cap < (size_t)want_all) {
         if (g_kpool.slab) { (void)hipFree(g_kpool.slab); g_kpool.slab = nullptr; }
@@ -240,15 +265,15 @@ static int lanczos_gs_impl(S *s, int nitermax, double threshold, int ncheck, dou
     // buffer of u_k: cached from an earlier search when large enough, else (re)allocated within the budget
     auto ring_get = [&](int k) -> double * {
         if (k >= store_max) return nullptr;
-        if (slab_mode) return (g_kpool.slab && (size_t)(k + 1) * (size_t)s->nloc <= g_kpool.slab_cap) ? g_kpool.slab + (int64_t)k * s->nloc : nullptr;
+        if (slab_mode) return (g_kpool.slab && (size_t)(k + 1) * (size_t)vlen <= g_kpool.slab_cap) ? g_kpool.slab + (int64_t)k * vlen : nullptr;
         while ((int)g_kpool.buf.size() <= k) { g_kpool.buf.push_back(nullptr); g_kpool.cap.push_back(0); }
-        if (g_kpool.cap[k] >= (size_t)s->nloc) return g_kpool.buf[k];
-        const int64_t need = (int64_t)s->nloc * 8;
+        if (g_kpool.cap[k] >= (size_t)vlen) return g_kpool.buf[k];
+        const int64_t need = (int64_t)vlen * 8;
         if (g_kpool.buf[k]) { (void)hipFree(g_kpool.buf[k]); budget += (int64_t)g_kpool.cap[k] * 8; g_kpool.buf[k] = nullptr; g_kpool.cap[k] = 0; }
         if (budget < need) return nullptr;
         double *q = nullptr;
         if (hipMalloc((void **)&q, (size_t)need) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
-        budget -= need; g_kpool.buf[k] = q; g_kpool.cap[k] = (size_t)s->nloc;
+        budget -= need; g_kpool.buf[k] = q; g_kpool.cap[k] = (size_t)vlen;
         return q;
     };
     if (store) {
@@ -256,7 +281,6 @@ static int lanczos_gs_impl(S *s, int nitermax, double threshold, int ncheck, dou
         const int guess = std::min(std::min(nitermax + 2, store_max), dbg_int("EDGPU_LZ_STORE_GUESS", 100));
         if (!slab_mode) for (int k = 0; k < guess; k++) if (!ring_get(k)) break;
     }
-    const bool fused = fused_ok(s);
     LzVecs V{s->lz[0].p, s->lz[1].p, s->lz[2].p};
     LzF F{s->lz[0].p, s->lz[2].p, s->lz[1].p};
     if (store) {
@@ -265,8 +289,9 @@ static int lanczos_gs_impl(S *s, int nitermax, double threshold, int ncheck, dou
     }
     double s0 = 0.0;                                  // scale of the start vector: v_0 = s0 * u_0
     if (fused) {
-        HIPCHK(hipMemcpyAsync(F.u, start, (size_t)s->nloc * 8, hipMemcpyDeviceToDevice, s->stream));
-        if (!store) HIPCHK(hipMemsetAsync(F.uprev, 0, (size_t)s->nloc * 8, s->stream));
+        CHK(lzf_copy_in(s, F.u, start));
+        if (!store) HIPCHK(hipMemsetAsync(F.uprev, 0, (size_t)vlen * 8, s->stream));
+        if (store) CHK(lzf_zero_pads(s, F.t));
         CHK(lzf_begin(s, F, nullptr));
     } else {
         HIPCHK(hipMemcpyAsync(V.ucur, start, (size_t)s->nloc * 8, hipMemcpyDeviceToDevice, s->stream));
@@ -286,7 +311,8 @@ static int lanczos_gs_impl(S *s, int nitermax, double threshold, int ncheck, dou
             if (fused) {                              // dw half of j + local half of j+1: alpha_j and beta_j
                 double *tnew = store ? ring_get(j + 2) : nullptr;
                 if (store && !tnew) store = false;    // out of memory: from here on the oldest of the three live vectors is recycled
-                if (!tnew) tnew = (j == 0 && F.uprev == F.u) ? s->lz[2].p : F.uprev;
+                if (tnew) CHK(lzf_zero_pads(s, tnew));
+                else tnew = (j == 0 && F.uprev == F.u) ? s->lz[2].p : F.uprev;
                 CHK(lzf_iter(s, F, tnew, nullptr));
                 continue;
             }
@@ -314,8 +340,8 @@ static int lanczos_gs_impl(S *s, int nitermax, double threshold, int ncheck, dou
         HIPCHK(hipMemcpyAsync(one.data(), f.p, 8, hipMemcpyDeviceToHost, s->stream)); HIPCHK(hipStreamSynchronize(s->stream));
         if (one[0] < (double)s->comm.size - 0.5) store = false;
     }
-    HIPCHK(hipMemsetAsync(acc, 0, (size_t)s->nloc * 8, s->stream));
-    const int nbk = (int)std::max<int64_t>(1, std::min<int64_t>(cdiv(s->nloc, 256 * 4), 4096));
+    HIPCHK(hipMemsetAsync(acc, 0, (size_t)vlen * 8, s->stream));
+    const int nbk = (int)std::max<int64_t>(1, std::min<int64_t>(cdiv(vlen, 256 * 4), 4096));
     if (store) {
         // vect = sum_k z_k v_k = sum_k (z_k s_k) u_k over the stored vectors, kMaxBasis of them per pass over acc
         std::vector<double> coef(nlanc);
@@ -326,7 +352,7 @@ static int lanczos_gs_impl(S *s, int nitermax, double threshold, int ncheck, dou
             for (int i = 0; i < B.nv; i++) B.V[i] = ring_get(k0 + i);
             HIPCHK(hipMemcpyAsync(s->eig_h.p, coef.data() + k0, (size_t)B.nv * 8, hipMemcpyHostToDevice, s->stream));
             HIPCHK(hipStreamSynchronize(s->stream));      // coef lives on the host stack of this call
-            hipLaunchKernelGGL(k_multiaxpy, dim3(nbk), dim3(256), 0, s->stream, B, (const double *)s->eig_h.p, acc, s->nloc);
+            hipLaunchKernelGGL(k_multiaxpy, dim3(nbk), dim3(256), 0, s->stream, B, (const double *)s->eig_h.p, acc, vlen);
             HIPCHK(hipGetLastError());
         }
     } else {
@@ -337,8 +363,8 @@ static int lanczos_gs_impl(S *s, int nitermax, double threshold, int ncheck, dou
             HIPCHK(hipMemcpyAsync(s->zvec.p, zs.data(), (size_t)nlanc * 8, hipMemcpyHostToDevice, s->stream));
             HIPCHK(hipStreamSynchronize(s->stream));
             F = LzF{s->lz[0].p, s->lz[2].p, s->lz[1].p};
-            HIPCHK(hipMemcpyAsync(F.u, start, (size_t)s->nloc * 8, hipMemcpyDeviceToDevice, s->stream));
-            HIPCHK(hipMemsetAsync(F.uprev, 0, (size_t)s->nloc * 8, s->stream));
+            CHK(lzf_copy_in(s, F.u, start));
+            HIPCHK(hipMemsetAsync(F.uprev, 0, (size_t)vlen * 8, s->stream));
             CHK(lzf_begin(s, F, acc));
             for (int k = 0; k + 1 < nlanc; k++) CHK(lzf_iter(s, F, F.uprev, acc));
         } else {
@@ -349,11 +375,12 @@ static int lanczos_gs_impl(S *s, int nitermax, double threshold, int ncheck, dou
         CHK(lz_iters(s, V, 0, nlanc, acc));
         }
     }
-    CHK(reduce_dot(s, acc, acc));
+    CHK(reduce_dot(s, acc, acc, vlen));
     hipLaunchKernelGGL(k_scalar_step, dim3(1), dim3(1), 0, s->stream, s->scal.p, s->alphas.p, s->betas.p, (const double *)nullptr, 0, 2);
-    hipLaunchKernelGGL(k_scale, dim3(nbk), dim3(256), 0, s->stream, acc, s->scal.p, (int)SC_SCUR, s->nloc);
+    hipLaunchKernelGGL(k_scale, dim3(nbk), dim3(256), 0, s->stream, acc, s->scal.p, (int)SC_SCUR, vlen);
     HIPCHK(hipGetLastError());
-    HIPCHK(hipMemcpyAsync(vect_dev, acc, (size_t)s->nloc * 8, hipMemcpyDeviceToDevice, s->stream));
+    if (fused) CHK(lzf_copy_out(s, vect_dev, acc));
+    else HIPCHK(hipMemcpyAsync(vect_dev, acc, (size_t)s->nloc * 8, hipMemcpyDeviceToDevice, s->stream));
     HIPCHK(hipStreamSynchronize(s->stream));
     return EDGPU_OK;
 }
@@ -366,8 +393,8 @@ static int lanczos_tridiag(S *s, const double *vin_dev, int nlanc, double thresh
     LzVecs V{s->lz[0].p, s->lz[1].p, s->lz[2].p};
     LzF F{s->lz[0].p, s->lz[2].p, s->lz[1].p};
     if (fused) {
-        HIPCHK(hipMemcpyAsync(F.u, vin_dev, (size_t)s->nloc * 8, hipMemcpyDeviceToDevice, s->stream));
-        HIPCHK(hipMemsetAsync(F.uprev, 0, (size_t)s->nloc * 8, s->stream));
+        CHK(lzf_copy_in(s, F.u, vin_dev));
+        HIPCHK(hipMemsetAsync(F.uprev, 0, (size_t)s->vlen * 8, s->stream));
         CHK(lzf_begin(s, F, nullptr));
     } else {
         HIPCHK(hipMemcpyAsync(V.ucur, vin_dev, (size_t)s->nloc * 8, hipMemcpyDeviceToDevice, s->stream));

@@ -171,7 +171,7 @@ static int fused_local(S *s, double *r, const double *uprev, double *t, double *
     U.packed = reinterpret_cast<const uint4 *>(s->upf->pelem.p); U.tval = s->upf->ptval.p; U.nterms = s->upf->pterms;
     U.diag = s->diag.p; U.Eup = s->upf->E.p; U.Edw = s->dwf->E.p; U.cross = s->cross.p; U.mapup = s->upf->map.p; U.mapdw = s->dwf->map.p;
     U.impmask = (1 << d.Norb) - 1; U.nI = 1 << d.Norb; U.econst = H.econst;
-    U.r = r; U.vprev = uprev; U.t_out = t; U.scal = s->scal.p; U.partial = s->partial.p; U.acc = acc; U.zvec = s->zvec.p;
+    U.r = r; U.vprev = uprev; U.t_out = t; U.scal = s->scal.p; U.partial = s->partial.p; U.acc = acc; U.zvec = s->zvec.p; U.ld = (int32_t)s->vld;
     const size_t lds = (size_t)H.DimUp * 8 + 128 * 8 + 32 * 8 + 32 * 8;
     const int grid = (int)std::min<int64_t>(U.nrows, s->up_grid);
     static OncePerDevice once;
@@ -198,6 +198,7 @@ static int fused_dw(S *s, const double *u, double *t, const double *uprev)
     D.DimUp = (int32_t)H.DimUp; D.DimDw = (int32_t)H.DimDw; D.DimPh = H.DimPh; D.Qdw = H.Qdw; D.dw0 = H.dw0;
     D.dwc = s->dwf->ellc.p; D.dwv = s->dwf->ellv.p; D.dww = s->dwf->width; D.v = u; D.vfull = u; D.out = t; D.scal = s->scal.p; D.partial = s->partial.p;
     D.uprev2 = uprev;
+    D.ld = (int32_t)s->vld;
     D.w = s->dw_w; D.wshift = 0; while ((1 << D.wshift) < D.w) D.wshift++;
     D.ntiles = (int32_t)cdiv(H.DimUp, D.w);
     D.R = std::min(64, s->dw_rows);

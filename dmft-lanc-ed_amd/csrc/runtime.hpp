@@ -164,6 +164,9 @@ struct edgpu_sector_s {
     // the two factors the product kernels run on: fac[0], fac[1] (ed_total_ud=T) or the composite blocks (ed_total_ud=F, cdev)
     std::unique_ptr<DevFactor> cdev[2]; DevFactor *upf = nullptr, *dwf = nullptr; const Factor *hup = nullptr, *hdw = nullptr;
     bool kron2 = false, composite = false;
+    // Lanczos vectors of the fused iteration live with a row pitch padded to the 128-B line (vld doubles, vlen = rows * vld);
+    // vld == DimUp when padding is off.  Vectors the caller passes in and out keep the reference's dense layout.
+    int64_t vld = 0, vlen = 0; bool pad_on = false;
     DevBuf<double> diag, cross, gup, gdw, bd_up, bd_dw;
     DevBuf<int32_t> stride;
     // explicit CSR

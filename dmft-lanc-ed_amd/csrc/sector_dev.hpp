@@ -224,6 +224,8 @@ static int build_diag(S *s)
     return EDGPU_OK;
 }
 
+static bool fused_ok(const S *s);      // product.hpp
+
 // Non-local (Jx/Jp) block of the explicit storage: count sweep, host scan over the dw rows, fill sweep (k_nd_build)
 static int build_csr_nd(S *s)
 {
@@ -406,6 +408,7 @@ static int create(const edgpu_desc *desc, S **out)
         s->row_split = std::max(1, std::min(32, dbg_int("EDGPU_ROW_SPLIT", 4)));
         s->up_big = dbg_int("EDGPU_UP_BIG", 1) != 0;
         s->up_halo = dbg_int("EDGPU_UP_HALO", 1) != 0;
+
         if (!s->use_lds && s->up_halo && !s->tr_on) CHK(build_up_segments(s.get()));
         s->nd_split = dbg_int("EDGPU_ND_SPLIT", 1) != 0;
         s->up_threads = dbg_int("EDGPU_UP_THREADS", 1024) == 512 ? 512 : 1024;
@@ -439,6 +442,9 @@ static int create(const edgpu_desc *desc, S **out)
         s->nnz_total += s->nd_nnz;
     }
     if (s->multi && !s->tr_on) CHK(s->vfull.alloc((size_t)(H.DimUp * s->nhalo * H.DimPh)));
+    s->vld = H.DimUp; s->vlen = s->nloc;
+    s->pad_on = fused_ok(s.get()) && (H.DimUp % 16) != 0 && dbg_int("EDGPU_PAD", 1) != 0;
+    if (s->pad_on) { s->vld = (H.DimUp + 15) & ~(int64_t)15; s->vlen = (s->nloc / H.DimUp) * s->vld; }
     s->npartial = max_partials(s.get());
     CHK(s->partial.alloc((size_t)s->npartial));
     CHK(s->partial2.alloc(1024));
