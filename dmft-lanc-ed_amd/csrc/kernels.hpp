@@ -834,6 +834,7 @@ struct NdArgs {
     const int32_t *xmap;     // needed-rows exchange: global dw row -> row of the compact x-space (else null)
     double Jx, Jp;
     const double *vfull; double *out; const double *scal;
+    int32_t ld;              // row pitch of vfull / out in doubles (0: DimUp)
 };
 template <bool EPI>
 __global__ void __launch_bounds__(256) k_ndpass(NdArgs A)
@@ -871,7 +872,8 @@ __global__ void __launch_bounds__(256) k_ndpass(NdArgs A)
     __syncthreads();
     if (!s_any) return;
     const int DimUp = A.DimUp;
-    const int64_t rbase = row * DimUp, fbase = (int64_t)iph * A.DimDw * DimUp;
+    const int64_t ld = A.ld ? A.ld : DimUp;
+    const int64_t rbase = row * ld, fbase = (int64_t)iph * A.DimDw * ld;
     const double s_cur = EPI ? A.scal[SC_SCUR] : 1.0;
     for (int iup = threadIdx.x; iup < DimUp; iup += blockDim.x) {
         const uint32_t mup = (uint32_t)A.mapup[iup];
@@ -888,7 +890,7 @@ __global__ void __launch_bounds__(256) k_ndpass(NdArgs A)
                     const int32_t jd = s_jdw[slot + kind];
                     if (jd < 0) continue;
                     const double t = (sgu & 1) ? -s_t[slot + kind] : s_t[slot + kind];
-                    acc += t * A.vfull[fbase + (int64_t)jd * DimUp + A.rankup[k4]];
+                    acc += t * A.vfull[fbase + (int64_t)jd * ld + A.rankup[k4]];
                     hit = true;
                 }
             }

@@ -154,11 +154,21 @@ static int transposed_dw_pass(S *s, const double *v, hipStream_t st)
 #ifndef LZAX_NT
 #define LZAX_NT 1024
 #endif
+// the local half of the fused iteration exists in the pair form only (<= 8 hops per up configuration, rows that fit LDS); a
+// one-configuration-per-lane form for 9-16 hops (multi-orbital replica baths) needs the 13 staging steps of a row unrolled
+// and spills ~300 registers -- those sectors keep the three-pass iteration
+static int fused_form(const S *s)
+{
+    if (!s->upf || !s->up_persistent || !s->use_lds || s->H.DimUp > 13312) return 0;
+    return (s->up_pairs && s->upf->packed_elem && s->upf->width <= 8) ? 2 : 0;
+}
 static bool fused_ok(const S *s)
 {
     const SectorHost &H = s->H;
-    return s->lz_fused_on && !s->multi && s->kron2 && !s->extra && s->kron_split && H.desc.storage != EDGPU_STORE_CSR && s->up_persistent && s->up_pairs &&
-           s->upf->packed_elem && s->upf->width <= 8 && s->use_lds && H.DimUp <= 13312 && (H.DimUp % 2 == 0) && s->dw_variant >= 2 && s->dw_w >= 4 && s->dwf->width <= 64;
+    // Jx/Jp sectors run their non-local pass between the two halves; phonon terms live in the row-wise kernel only
+    const bool terms_ok = !s->extra || (s->has_nd && !s->has_ph && s->nd_split);
+    return s->lz_fused_on && !s->multi && s->kron2 && terms_ok && s->kron_split && H.desc.storage != EDGPU_STORE_CSR && fused_form(s) != 0 &&
+           (H.DimUp % 2 == 0) && s->dw_variant >= 2 && s->dw_w >= 4 && s->dwf->width <= 64;
 }
 // local half: r <- u_k = r - alpha s u_prev (in place), TMP = |u_k|^2 and the norm step, t <- local part of H u_k (unscaled)
 static int fused_local(S *s, double *r, const double *uprev, double *t, double *acc)
@@ -172,23 +182,32 @@ static int fused_local(S *s, double *r, const double *uprev, double *t, double *
     U.diag = s->diag.p; U.Eup = s->upf->E.p; U.Edw = s->dwf->E.p; U.cross = s->cross.p; U.mapup = s->upf->map.p; U.mapdw = s->dwf->map.p;
     U.impmask = (1 << d.Norb) - 1; U.nI = 1 << d.Norb; U.econst = H.econst;
     U.r = r; U.vprev = uprev; U.t_out = t; U.scal = s->scal.p; U.partial = s->partial.p; U.acc = acc; U.zvec = s->zvec.p; U.ld = (int32_t)s->vld;
-    const size_t lds = (size_t)H.DimUp * 8 + 128 * 8 + 32 * 8 + 32 * 8;
+    const size_t lds = (((size_t)H.DimUp + 1) & ~(size_t)1) * 8 + 128 * 8 + 32 * 8 + 32 * 8;
     const int grid = (int)std::min<int64_t>(U.nrows, s->up_grid);
-    static OncePerDevice once;
-    if (once.first(s->device)) {
-        (void)hipFuncSetAttribute((const void *)k_uppass2_ax<false, false, LZAX_NT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void *)k_uppass2_ax<true, false, LZAX_NT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void *)k_uppass2_ax<false, true, LZAX_NT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void *)k_uppass2_ax<true, true, LZAX_NT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    }
     const dim3 g(grid), b(LZAX_NT);
-    if (direct) { if (acc) hipLaunchKernelGGL((k_uppass2_ax<true, true, LZAX_NT>), g, b, lds, s->stream, U); else hipLaunchKernelGGL((k_uppass2_ax<true, false, LZAX_NT>), g, b, lds, s->stream, U); }
-    else { if (acc) hipLaunchKernelGGL((k_uppass2_ax<false, true, LZAX_NT>), g, b, lds, s->stream, U); else hipLaunchKernelGGL((k_uppass2_ax<false, false, LZAX_NT>), g, b, lds, s->stream, U); }
+#define AX_LAUNCH(D_, A_)                                                                                                       \
+    do {                                                                                                                            \
+        static OncePerDevice once_;                                                                                                 \
+        if (once_.first(s->device)) (void)hipFuncSetAttribute((const void *)k_uppass2_ax<D_, A_, LZAX_NT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+        hipLaunchKernelGGL((k_uppass2_ax<D_, A_, LZAX_NT>), g, b, lds, s->stream, U);                                               \
+    } while (0)
+    if (direct) { if (acc) AX_LAUNCH(true, true); else AX_LAUNCH(true, false); }
+    else { if (acc) AX_LAUNCH(false, true); else AX_LAUNCH(false, false); }
+#undef AX_LAUNCH
     HIPCHK(hipGetLastError());
     s->fuse_mode = 4; s->fuse_zvec = nullptr;
     const int rc = reduce_partials(s, grid);
     s->fuse_mode = -1;
-    return rc;
+    if (rc != EDGPU_OK) return rc;
+    if (s->has_nd) {       // spin-exchange / pair-hopping terms of u_k (complete now), unscaled, into the local part
+        NdArgs Nd{};
+        Nd.DimUp = (int32_t)H.DimUp; Nd.DimDw = (int32_t)H.DimDw; Nd.DimPh = H.DimPh; Nd.Norb = d.Norb; Nd.Qdw = H.Qdw; Nd.dw0 = H.dw0;
+        Nd.mapup = s->upf->map.p; Nd.mapdw = s->dwf->map.p; Nd.rankup = s->upf->rank.p; Nd.rankdw = s->dwf->rank.p; Nd.Jx = d.Jx; Nd.Jp = d.Jp;
+        Nd.vfull = r; Nd.out = t; Nd.scal = s->scal.p; Nd.xmap = nullptr; Nd.ld = (int32_t)s->vld;
+        hipLaunchKernelGGL(k_ndpass<false>, dim3((unsigned)(H.Qdw * H.DimPh)), dim3(256), 0, s->stream, Nd);
+        HIPCHK(hipGetLastError());
+    }
+    return EDGPU_OK;
 }
 // dw half: t <- r_k = s_k (t + dw hops of u) - beta_{k-1} s_{k-1} u_prev ; TMP = (s_k u).r_k and the alpha step
 static int fused_dw(S *s, const double *u, double *t, const double *uprev)
