@@ -354,8 +354,11 @@ int edgpu_lanczos_time(edgpu_handle h, int32_t nwarm, int32_t niter, float *ms_p
         CHK(lzf_copy_in(h, F.u, h->lz[3].p));
         HIPCHK(hipMemsetAsync(F.uprev, 0, (size_t)h->vlen * 8, h->stream)); CHK(lzf_begin(h, F, nullptr));
     } else {
-        hipLaunchKernelGGL(k_random_start, dim3(2048), dim3(256), 0, h->stream, V.ucur, H.DimUp, H.Qdw, H.dw0, H.DimDw, H.DimPh, (uint64_t)1234567);
+        if (h->lz[3].n != (size_t)h->nloc) CHK(h->lz[3].alloc((size_t)h->nloc));
+        hipLaunchKernelGGL(k_random_start, dim3(2048), dim3(256), 0, h->stream, h->lz[3].p, H.DimUp, H.Qdw, H.dw0, H.DimDw, H.DimPh, (uint64_t)1234567);
         HIPCHK(hipGetLastError());
+        CHK(lzf_copy_in(h, V.ucur, h->lz[3].p));
+        if (h->pad_on) HIPCHK(hipMemsetAsync(V.w, 0, (size_t)h->vlen * 8, h->stream));
         CHK(lz_start(h, V));
     }
     int k = 0;
@@ -755,8 +758,11 @@ int edgpu_lanczos_bench_begin(edgpu_handle h, int32_t max_steps)
         HIPCHK(hipMemsetAsync(F.uprev, 0, (size_t)h->vlen * 8, h->stream));
         CHK(lzf_begin(h, F, nullptr));
     } else {
-        hipLaunchKernelGGL(k_random_start, dim3(2048), dim3(256), 0, h->stream, h->bv[1], H.DimUp, H.Qdw, H.dw0, H.DimDw, H.DimPh, (uint64_t)1234567);
+        if (h->lz[3].n != (size_t)h->nloc) CHK(h->lz[3].alloc((size_t)h->nloc));
+        hipLaunchKernelGGL(k_random_start, dim3(2048), dim3(256), 0, h->stream, h->lz[3].p, H.DimUp, H.Qdw, H.dw0, H.DimDw, H.DimPh, (uint64_t)1234567);
         HIPCHK(hipGetLastError());
+        CHK(lzf_copy_in(h, h->bv[1], h->lz[3].p));
+        if (h->pad_on) HIPCHK(hipMemsetAsync(h->bv[2], 0, (size_t)h->vlen * 8, h->stream));
         CHK(lz_start(h, V));
     }
     h->bench_k = 0;
@@ -791,7 +797,7 @@ int edgpu_lanczos_bench_steps(edgpu_handle h, int32_t nsteps, int32_t timed)
             HIPCHK(hipEventRecord(h->bench_ev[2 * i], h->stream));
             if (!h->multi) h->fuse_mode = 0;          // as lz_iter: the alpha step rides on the product's final reduction
             h->comm_slot = i;
-            const int rc = hxv(h, V.ucur, V.w, true, V.uprev);
+            const int rc = hxv(h, V.ucur, V.w, true, V.uprev, h->vld);
             h->fuse_mode = -1; h->comm_slot = -1;
             if (rc) return rc;
             HIPCHK(hipEventRecord(h->bench_ev[2 * i + 1], h->stream));

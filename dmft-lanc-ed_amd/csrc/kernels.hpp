@@ -251,6 +251,7 @@ struct UpArgs {
     const double *tval; int32_t nterms;
     const double *diag, *Eup, *Edw, *cross; const int32_t *mapup, *mapdw; int32_t impmask, nI; double econst;
     const double *v; double *out; const double *uprev; const double *scal;
+    int32_t ld;              // row pitch of v / out / uprev in doubles (0: DimUp); the stored diagonal keeps pitch DimUp
 };
 
 template <bool DIRECT, bool EPI, int NT>
@@ -260,6 +261,7 @@ __global__ void __launch_bounds__(NT) k_uppass(UpArgs A)
     constexpr int MAXQ = 13312 / NT;               // DimUp <= 13312 (Ns <= 16 at half filling)
     constexpr int MAXC = 4;                        // <= 16 hops per up configuration
     const int DimUp = A.DimUp, tid = threadIdx.x;
+    const int64_t ld = A.ld ? A.ld : DimUp;
     double *tv = lds + ((DimUp + 1) & ~1);
     for (int t = tid; t < A.nterms; t += NT) tv[t] = A.tval[t];
     const int nq = (DimUp + NT - 1) / NT;
@@ -271,7 +273,7 @@ __global__ void __launch_bounds__(NT) k_uppass(UpArgs A)
     int64_t row = blockIdx.x;
     if (row < A.nrows) {
 #pragma unroll
-        for (int q = 0; q < MAXQ; q++) { const int i = tid + q * NT; xr[q] = (q < nq && i < DimUp) ? A.v[row * DimUp + i] : 0.0; }
+        for (int q = 0; q < MAXQ; q++) { const int i = tid + q * NT; xr[q] = (q < nq && i < DimUp) ? A.v[row * ld + i] : 0.0; }
     }
     double s_cur = 1.0, c_prev = 0.0;
     if (EPI) { s_cur = A.scal[SC_SCUR]; c_prev = A.scal[SC_BETA] * A.scal[SC_SPREV]; }
@@ -280,7 +282,7 @@ __global__ void __launch_bounds__(NT) k_uppass(UpArgs A)
         const int64_t idwl = row % A.Qdw, idw = A.dw0 + idwl;
         auto load_ops = [&](int i, Ops &o) {
             if (!DIRECT) o.d = A.diag[idwl * DimUp + i];
-            if (EPI) o.u = A.uprev[row * DimUp + i];
+            if (EPI) o.u = A.uprev[row * ld + i];
 #pragma unroll
             for (int c = 0; c < MAXC; c++) if (c < ndw) o.codes[c] = A.pcodes[(int64_t)c * DimUp + i];
 #pragma unroll
@@ -294,7 +296,7 @@ __global__ void __launch_bounds__(NT) k_uppass(UpArgs A)
         const int64_t next = row + gridDim.x;
         if (next < A.nrows) {
 #pragma unroll
-            for (int q = 0; q < MAXQ; q++) { const int i = tid + q * NT; if (q < nq && i < DimUp) xr[q] = A.v[next * DimUp + i]; }
+            for (int q = 0; q < MAXQ; q++) { const int i = tid + q * NT; if (q < nq && i < DimUp) xr[q] = A.v[next * ld + i]; }
         }
         uint32_t mdw = 0; double edw = 0.0;
         if (DIRECT) { mdw = (uint32_t)A.mapdw[idw] & A.impmask; edw = A.Edw[idw] + A.econst; }
@@ -317,8 +319,8 @@ __global__ void __launch_bounds__(NT) k_uppass(UpArgs A)
                         acc += t * lds[col];
                     }
                 }
-            if (EPI) A.out[row * DimUp + i] = s_cur * acc - c_prev * cur.u;
-            else A.out[row * DimUp + i] = acc;
+            if (EPI) A.out[row * ld + i] = s_cur * acc - c_prev * cur.u;
+            else A.out[row * ld + i] = acc;
             cur = nxt;
         }
         __syncthreads();
@@ -336,6 +338,7 @@ struct UpArgs2 {
     const double *tval; int32_t nterms;
     const double *diag, *Eup, *Edw, *cross; const int32_t *mapup, *mapdw; int32_t impmask, nI; double econst;
     const double *v; double *out; const double *uprev; const double *scal;
+    int32_t ld;              // row pitch of v / out / uprev in doubles (0: DimUp)
 };
 
 template <bool DIRECT, bool EPI, int NT>
@@ -344,6 +347,7 @@ __global__ void __launch_bounds__(NT) k_uppass2(UpArgs2 A)
     extern __shared__ double lds[];
     constexpr int MAXQ = (13312 / 2 + NT - 1) / NT;      // pairs per lane
     const int DimUp = A.DimUp, npair = DimUp >> 1, tid = threadIdx.x;
+    const int64_t ld = A.ld ? A.ld : DimUp;
     double *tv = lds + DimUp;
     for (int t = tid; t < A.nterms; t += NT) tv[t] = A.tval[t];
     const int nq = (npair + NT - 1) / NT;
@@ -351,7 +355,7 @@ __global__ void __launch_bounds__(NT) k_uppass2(UpArgs2 A)
     int64_t row = blockIdx.x;
     if (row < A.nrows) {
 #pragma unroll
-        for (int q = 0; q < MAXQ; q++) { const int p = tid + q * NT; if (q < nq && p < npair) xr[q] = *reinterpret_cast<const dbl2v *>(A.v + row * DimUp + 2 * p); }
+        for (int q = 0; q < MAXQ; q++) { const int p = tid + q * NT; if (q < nq && p < npair) xr[q] = *reinterpret_cast<const dbl2v *>(A.v + row * ld + 2 * p); }
     }
     double s_cur = 1.0, c_prev = 0.0;
     if (EPI) { s_cur = A.scal[SC_SCUR]; c_prev = A.scal[SC_BETA] * A.scal[SC_SPREV]; }
@@ -360,7 +364,7 @@ __global__ void __launch_bounds__(NT) k_uppass2(UpArgs2 A)
         const int64_t idwl = row % A.Qdw, idw = A.dw0 + idwl;
         auto load_ops = [&](int p, Ops &o) {
             if (!DIRECT) o.d = *reinterpret_cast<const dbl2v *>(A.diag + idwl * DimUp + 2 * p);
-            if (EPI) o.u = *reinterpret_cast<const dbl2v *>(A.uprev + row * DimUp + 2 * p);
+            if (EPI) o.u = *reinterpret_cast<const dbl2v *>(A.uprev + row * ld + 2 * p);
             o.w0 = A.packed[3 * p]; o.w1 = A.packed[3 * p + 1]; o.w2 = A.packed[3 * p + 2];
         };
         Ops cur, nxt;
@@ -371,7 +375,7 @@ __global__ void __launch_bounds__(NT) k_uppass2(UpArgs2 A)
         const int64_t next = row + gridDim.x;
         if (next < A.nrows) {
 #pragma unroll
-            for (int q = 0; q < MAXQ; q++) { const int p = tid + q * NT; if (q < nq && p < npair) xr[q] = *reinterpret_cast<const dbl2v *>(A.v + next * DimUp + 2 * p); }
+            for (int q = 0; q < MAXQ; q++) { const int p = tid + q * NT; if (q < nq && p < npair) xr[q] = *reinterpret_cast<const dbl2v *>(A.v + next * ld + 2 * p); }
         }
         uint32_t mdw = 0; double edw = 0.0;
         if (DIRECT) { mdw = (uint32_t)A.mapdw[idw] & A.impmask; edw = A.Edw[idw] + A.econst; }
@@ -400,7 +404,7 @@ __global__ void __launch_bounds__(NT) k_uppass2(UpArgs2 A)
             dbl2v o;
             if (EPI) { o.x = s_cur * a0 - c_prev * cur.u.x; o.y = s_cur * a1 - c_prev * cur.u.y; }
             else { o.x = a0; o.y = a1; }
-            *reinterpret_cast<dbl2v *>(A.out + row * DimUp + 2 * p) = o;
+            *reinterpret_cast<dbl2v *>(A.out + row * ld + 2 * p) = o;
             cur = nxt;
         }
         __syncthreads();
@@ -586,6 +590,7 @@ struct UpHaloArgs {
     const double *tval; int32_t nterms;
     const double *diag, *Eup, *Edw, *cross; const int32_t *mapup, *mapdw; int32_t impmask, nI; double econst;
     const double *v; double *out;
+    int32_t ld;              // row pitch of v / out in doubles (0: DimUp)
 };
 #ifndef HALO_SB
 #define HALO_SB 5
@@ -597,6 +602,7 @@ __global__ void __launch_bounds__(1024) k_uppass_halo(UpHaloArgs A)
     extern __shared__ double lds[];
     constexpr int NT = 1024;
     const int DimUp = A.DimUp, tid = threadIdx.x;
+    const int64_t ld = A.ld ? A.ld : DimUp;
     const int x = blockIdx.x & 7, j = blockIdx.x >> 3, G = (int)(gridDim.x >> 3) / A.nseg;
     const int g = j / A.nseg, sg = j - g * A.nseg;
     const int lo = sg * A.seglen, hi = lo + A.seglen < DimUp ? lo + A.seglen : DimUp;
@@ -616,7 +622,7 @@ __global__ void __launch_bounds__(1024) k_uppass_halo(UpHaloArgs A)
     dbl2v xr[NQ]; double xh[MAXH];
     const int64_t rstep = (int64_t)G * 8;
     auto fetch_row = [&](int64_t rw) {
-        const double *vr = A.v + rw * DimUp;
+        const double *vr = A.v + rw * ld;
 #pragma unroll
         for (int q = 0; q < NQ; q++) { const int p = tid + q * NT; if (p < npair) xr[q] = *reinterpret_cast<const dbl2v *>(vr + lo + 2 * p); }
 #pragma unroll
@@ -657,7 +663,7 @@ __global__ void __launch_bounds__(1024) k_uppass_halo(UpHaloArgs A)
                 a0 += t0 * lds[col0]; a1 += t1 * lds[col1];
             }
             dbl2v r; r.x = a0; r.y = a1;
-            *reinterpret_cast<dbl2v *>(A.out + rw * DimUp + lo + 2 * p) = r;
+            *reinterpret_cast<dbl2v *>(A.out + rw * ld + lo + 2 * p) = r;
         }
     };
     auto item = [&](auto par, int64_t rw) {              // par: slot of this item's step 0

@@ -101,8 +101,8 @@ struct LzVecs { double *uprev, *ucur, *w; };
 // start: ucur holds the (unnormalised) start vector
 static int lz_start(S *s, LzVecs &V)
 {
-    HIPCHK(hipMemsetAsync(V.uprev, 0, (size_t)s->nloc * 8, s->stream));
-    CHK(reduce_dot(s, V.ucur, V.ucur));
+    HIPCHK(hipMemsetAsync(V.uprev, 0, (size_t)s->vlen * 8, s->stream));
+    CHK(reduce_dot(s, V.ucur, V.ucur, s->vlen));
     hipLaunchKernelGGL(k_scalar_step, dim3(1), dim3(1), 0, s->stream, s->scal.p, s->alphas.p, s->betas.p, (const double *)nullptr, 0, 2);
     HIPCHK(hipGetLastError());
     return EDGPU_OK;
@@ -115,8 +115,8 @@ static int lz_iter_tail(S *s, LzVecs &V, int k, double *acc, bool alpha_done = f
         hipLaunchKernelGGL(k_scalar_step, dim3(1), dim3(1), 0, s->stream, s->scal.p, s->alphas.p, s->betas.p, (const double *)nullptr, k, 0);
         if (acc) hipLaunchKernelGGL(k_scalar_step, dim3(1), dim3(1), 0, s->stream, s->scal.p, s->alphas.p, s->betas.p, (const double *)s->zvec.p, k, 3);
     }
-    int nb = (int)std::max<int64_t>(1, std::min<int64_t>(cdiv(s->nloc, 256 * 4), 4096));
-    hipLaunchKernelGGL(k_axpy_norm, dim3(nb), dim3(256), 0, s->stream, V.w, V.ucur, acc, s->scal.p, s->nloc, s->partial.p);
+    int nb = (int)std::max<int64_t>(1, std::min<int64_t>(cdiv(s->vlen, 256 * 4), 4096));
+    hipLaunchKernelGGL(k_axpy_norm, dim3(nb), dim3(256), 0, s->stream, V.w, V.ucur, acc, s->scal.p, s->vlen, s->partial.p);      // padding columns are zero and stay zero
     if (!s->multi) {   // no all-reduce between the sum and the step that uses it: one launch
         hipLaunchKernelGGL(k_reduce_final_step, dim3(1), dim3(1024), 0, s->stream, s->partial.p, (int64_t)nb, s->scal.p, s->alphas.p, s->betas.p, (const double *)nullptr, 1);
         HIPCHK(hipGetLastError());
@@ -134,12 +134,12 @@ static int lz_iter(S *s, LzVecs &V, int k, double *acc)
 {
     if (!s->multi) {   // alpha step rides on the product's final reduction (device counter == k by construction)
         s->fuse_mode = 0; s->fuse_zvec = acc ? s->zvec.p : nullptr;
-        int rc = hxv(s, V.ucur, V.w, true, V.uprev);
+        int rc = hxv(s, V.ucur, V.w, true, V.uprev, s->vld);
         s->fuse_mode = -1; s->fuse_zvec = nullptr;
         if (rc) return rc;
         return lz_iter_tail(s, V, k, acc, true);
     }
-    CHK(hxv(s, V.ucur, V.w, true, V.uprev));
+    CHK(hxv(s, V.ucur, V.w, true, V.uprev, s->vld));
     return lz_iter_tail(s, V, k, acc);
 }
 
@@ -223,7 +223,7 @@ static int lanczos_gs_impl(S *s, int nitermax, double threshold, int ncheck, dou
     if ((int64_t)nitermax > s->H.Dim) nitermax = (int)s->H.Dim;   // ED_DIAG.f90:100 Nitermax=min(dim,lanc_niter)
     CHK(lz_prepare(s, nitermax));
     const bool fused = fused_ok(s);
-    const int64_t vlen = fused ? s->vlen : s->nloc;      // length of a work vector (padded row pitch in the fused loops)
+    const int64_t vlen = s->vlen;      // length of a work vector (row pitch padded to the 128-B line where the product kernels take one)
     if (s->lz[3].n != (size_t)s->nloc) CHK(s->lz[3].alloc((size_t)s->nloc));
     if (s->lz[4].n != (size_t)vlen) CHK(s->lz[4].alloc((size_t)vlen));
     double *start = s->lz[3].p, *acc = s->lz[4].p;      // start keeps the caller's dense layout
@@ -294,7 +294,8 @@ static int lanczos_gs_impl(S *s, int nitermax, double threshold, int ncheck, dou
         if (store) CHK(lzf_zero_pads(s, F.t));
         CHK(lzf_begin(s, F, nullptr));
     } else {
-        HIPCHK(hipMemcpyAsync(V.ucur, start, (size_t)s->nloc * 8, hipMemcpyDeviceToDevice, s->stream));
+        CHK(lzf_copy_in(s, V.ucur, start));
+        CHK(lzf_zero_pads(s, V.w));
         CHK(lz_start(s, V));
     }
     HIPCHK(hipMemcpyAsync(&s0, s->scal.p + SC_SCUR, 8, hipMemcpyDeviceToHost, s->stream)); HIPCHK(hipStreamSynchronize(s->stream));
@@ -319,7 +320,7 @@ static int lanczos_gs_impl(S *s, int nitermax, double threshold, int ncheck, dou
             CHK(lz_iter(s, V, j, nullptr));           // afterwards: uprev = u_j, ucur = u_{j+1}, w = recycled u_{j-1}
             if (store) {
                 double *nx = ring_get(j + 2);         // u_{j+2} gets a buffer of its own, u_{j-1} stays intact
-                if (nx) V.w = nx; else store = false; // out of memory: keep rotating through the last three
+                if (nx) { V.w = nx; CHK(lzf_zero_pads(s, nx)); } else store = false; // out of memory: keep rotating through the last three
             }
         }
         CHK(fetch_coeffs(s, kend - 1, al, be));
@@ -370,7 +371,8 @@ static int lanczos_gs_impl(S *s, int nitermax, double threshold, int ncheck, dou
         } else {
         V = LzVecs{s->lz[0].p, s->lz[1].p, s->lz[2].p};
         HIPCHK(hipMemcpyAsync(s->zvec.p, z.data(), (size_t)nlanc * 8, hipMemcpyHostToDevice, s->stream));
-        HIPCHK(hipMemcpyAsync(V.ucur, start, (size_t)s->nloc * 8, hipMemcpyDeviceToDevice, s->stream));
+        CHK(lzf_copy_in(s, V.ucur, start));
+        HIPCHK(hipMemsetAsync(V.w, 0, (size_t)vlen * 8, s->stream));      // padding columns of the third rotating vector
         CHK(lz_start(s, V));
         CHK(lz_iters(s, V, 0, nlanc, acc));
         }
@@ -379,8 +381,7 @@ static int lanczos_gs_impl(S *s, int nitermax, double threshold, int ncheck, dou
     hipLaunchKernelGGL(k_scalar_step, dim3(1), dim3(1), 0, s->stream, s->scal.p, s->alphas.p, s->betas.p, (const double *)nullptr, 0, 2);
     hipLaunchKernelGGL(k_scale, dim3(nbk), dim3(256), 0, s->stream, acc, s->scal.p, (int)SC_SCUR, vlen);
     HIPCHK(hipGetLastError());
-    if (fused) CHK(lzf_copy_out(s, vect_dev, acc));
-    else HIPCHK(hipMemcpyAsync(vect_dev, acc, (size_t)s->nloc * 8, hipMemcpyDeviceToDevice, s->stream));
+    CHK(lzf_copy_out(s, vect_dev, acc));
     HIPCHK(hipStreamSynchronize(s->stream));
     return EDGPU_OK;
 }
@@ -397,7 +398,8 @@ static int lanczos_tridiag(S *s, const double *vin_dev, int nlanc, double thresh
         HIPCHK(hipMemsetAsync(F.uprev, 0, (size_t)s->vlen * 8, s->stream));
         CHK(lzf_begin(s, F, nullptr));
     } else {
-        HIPCHK(hipMemcpyAsync(V.ucur, vin_dev, (size_t)s->nloc * 8, hipMemcpyDeviceToDevice, s->stream));
+        CHK(lzf_copy_in(s, V.ucur, vin_dev));
+        if (s->pad_on) HIPCHK(hipMemsetAsync(V.w, 0, (size_t)s->vlen * 8, s->stream));
         CHK(lz_start(s, V));
     }
     for (int i = 0; i < nlanc; i++) { alanc[i] = 0.0; blanc[i] = 0.0; }

@@ -154,6 +154,18 @@ static int transposed_dw_pass(S *s, const double *v, hipStream_t st)
 #ifndef LZAX_NT
 #define LZAX_NT 1024
 #endif
+// Can hxv() of this sector take vectors with a padded row pitch?  Only the two-pass product of a single rank whose local
+// pass is one of the LDS-staged kernels and whose dw pass is the vectorised column-tiled one (Jx/Jp through k_ndpass).
+static bool pitch_ok(const S *s)
+{
+    const SectorHost &H = s->H;
+    if (s->multi || !s->kron2 || !s->kron_split || H.desc.storage == EDGPU_STORE_CSR || H.DimPh != 1 || s->tr_on) return false;
+    if (s->extra && !(s->has_nd && !s->has_ph && s->nd_split)) return false;
+    if (!(s->dw_variant >= 2 && (H.DimUp % 2 == 0) && s->dw_w >= 4 && s->dwf->width <= 64)) return false;
+    const bool persistent = s->up_persistent && s->upf->packed && s->upf->width <= 16 && s->use_lds && H.DimUp <= 13312;
+    const bool halo = !s->use_lds && s->upf->seg_ok && s->up_halo && !s->extra;
+    return persistent || halo;
+}
 // the local half of the fused iteration exists in the pair form only (<= 8 hops per up configuration, rows that fit LDS); a
 // one-configuration-per-lane form for 9-16 hops (multi-orbital replica baths) needs the 13 staging steps of a row unrolled
 // and spills ~300 registers -- those sectors keep the three-pass iteration
@@ -242,8 +254,11 @@ static int fused_dw(S *s, const double *u, double *t, const double *uprev)
     return rc;
 }
 
-static int hxv(S *s, const double *v, double *out, bool epi, const double *uprev)
+// `ld`: row pitch of v / out / uprev in doubles when the Lanczos loops run on pitched vectors (pitch_ok sectors only), 0 = dense
+static int hxv(S *s, const double *v, double *out, bool epi, const double *uprev, int64_t ld = 0)
 {
+    if (ld == s->H.DimUp) ld = 0;
+    if (ld && !pitch_ok(s)) return fail(EDGPU_EINVAL, "edgpu: internal: pitched vectors on a product form without pitch support");
     const SectorHost &H = s->H; const edgpu_desc &d = H.desc;
     const bool multi = s->multi;
     const bool direct = d.storage == EDGPU_STORE_DIRECT;
@@ -339,7 +354,7 @@ static int hxv(S *s, const double *v, double *out, bool epi, const double *uprev
                 U.DimUp = A.DimUp; U.DimPh = A.DimPh; U.Qdw = A.Qdw; U.dw0 = A.dw0; U.nrows = H.Qdw * H.DimPh;
                 U.packed = reinterpret_cast<const uint4 *>(s->upf->pelem.p); U.tval = s->upf->ptval.p; U.nterms = s->upf->pterms;
                 U.diag = A.diag; U.Eup = A.Eup; U.Edw = A.Edw; U.cross = A.cross; U.mapup = A.mapup; U.mapdw = A.mapdw; U.impmask = A.impmask; U.nI = A.nI; U.econst = A.econst;
-                U.v = v; U.out = out; U.uprev = uprev; U.scal = s->scal.p;
+                U.v = v; U.out = out; U.uprev = uprev; U.scal = s->scal.p; U.ld = (int32_t)ld;
                 const size_t lds = (size_t)H.DimUp * 8 + 128 * 8;
                 const int grid = (int)std::min<int64_t>(U.nrows, s->up_grid);
                 static OncePerDevice once2;
@@ -363,7 +378,7 @@ static int hxv(S *s, const double *v, double *out, bool epi, const double *uprev
                 U.DimUp = A.DimUp; U.DimPh = A.DimPh; U.Qdw = A.Qdw; U.dw0 = A.dw0; U.nrows = H.Qdw * H.DimPh;
                 U.pcols = s->upf->pcols.p; U.pcodes = s->upf->pcodes.p; U.upw = s->upf->width; U.tval = s->upf->ptval.p; U.nterms = s->upf->pterms;
                 U.diag = A.diag; U.Eup = A.Eup; U.Edw = A.Edw; U.cross = A.cross; U.mapup = A.mapup; U.mapdw = A.mapdw; U.impmask = A.impmask; U.nI = A.nI; U.econst = A.econst;
-                U.v = v; U.out = out; U.uprev = uprev; U.scal = s->scal.p;
+                U.v = v; U.out = out; U.uprev = uprev; U.scal = s->scal.p; U.ld = (int32_t)ld;
                 const size_t lds = (((size_t)H.DimUp + 1) & ~(size_t)1) * 8 + 128 * 8;
                 const int grid = (int)std::min<int64_t>(U.nrows, s->up_grid);
 #define UP_LAUNCH(D_, E_, T_)                                                                                                   \
@@ -392,7 +407,7 @@ static int hxv(S *s, const double *v, double *out, bool epi, const double *uprev
                 U.Qdw = A.Qdw; U.dw0 = A.dw0; U.nrows = H.Qdw * H.DimPh;
                 U.pseg8 = reinterpret_cast<const uint4 *>(f0.pseg8.p); U.ext = f0.seg_ext.p; U.ext_off = f0.seg_ext_off.p; U.tval = f0.ptval.p; U.nterms = f0.pterms;
                 U.diag = A.diag; U.Eup = A.Eup; U.Edw = A.Edw; U.cross = A.cross; U.mapup = A.mapup; U.mapdw = A.mapdw; U.impmask = A.impmask; U.nI = A.nI; U.econst = A.econst;
-                U.v = v; U.out = out;
+                U.v = v; U.out = out; U.ld = (int32_t)ld;
                 halo_epi = epi;     // the scale and the -beta*u_prev term move to the dw pass (DwArgs.uprev2): this pass writes the unscaled local part
                 const size_t lds = ((size_t)U.seglen + U.halocap + 128 + 32) * 8;
                 const unsigned grid = (unsigned)std::max(8 * U.nseg, s->up_grid & ~7);
@@ -409,6 +424,8 @@ static int hxv(S *s, const double *v, double *out, bool epi, const double *uprev
 #undef HALO_Q
 #undef HALO_LAUNCH
                 HIPCHK(hipGetLastError());
+            } else if (ld) {
+                return fail(EDGPU_EINVAL, "edgpu: internal: pitched vectors on a product form without pitch support");
             } else if (!s->use_lds && plain && s->upf->packed_elem8 && s->up_big) {
                 UpBigArgs U{};
                 U.DimUp = A.DimUp; U.DimPh = A.DimPh; U.rsplit = s->row_split; U.Qdw = A.Qdw; U.dw0 = A.dw0; U.nrows = H.Qdw * H.DimPh;
@@ -436,7 +453,7 @@ static int hxv(S *s, const double *v, double *out, bool epi, const double *uprev
                     NdArgs Nd{};
                     Nd.DimUp = A.DimUp; Nd.DimDw = A.DimDw; Nd.DimPh = A.DimPh; Nd.Norb = A.Norb; Nd.Qdw = A.Qdw; Nd.dw0 = A.dw0;
                     Nd.mapup = A.mapup; Nd.mapdw = A.mapdw; Nd.rankup = A.rankup; Nd.rankdw = A.rankdw; Nd.Jx = A.Jx; Nd.Jp = A.Jp;
-                    Nd.vfull = A.vfull; Nd.out = out; Nd.scal = s->scal.p; Nd.xmap = s->halo ? s->xmap_dev.p : nullptr;
+                    Nd.vfull = A.vfull; Nd.out = out; Nd.scal = s->scal.p; Nd.xmap = s->halo ? s->xmap_dev.p : nullptr; Nd.ld = (int32_t)ld;
                     if (epi) hipLaunchKernelGGL(k_ndpass<true>, dim3((unsigned)(H.Qdw * H.DimPh)), dim3(256), 0, s->stream, Nd);
                     else hipLaunchKernelGGL(k_ndpass<false>, dim3((unsigned)(H.Qdw * H.DimPh)), dim3(256), 0, s->stream, Nd);
                     HIPCHK(hipGetLastError());
@@ -444,7 +461,7 @@ static int hxv(S *s, const double *v, double *out, bool epi, const double *uprev
                 DwArgs D{};
                 D.DimUp = A.DimUp; D.DimDw = A.DimDw; D.DimPh = A.DimPh; D.Qdw = A.Qdw; D.dw0 = A.dw0;
                 D.dwc = A.dwc; D.dwv = A.dwv; D.dww = A.dww; D.v = v; D.vfull = A.vfull; D.out = out; D.scal = s->scal.p; D.partial = s->partial.p;
-                D.uprev2 = halo_epi ? uprev : nullptr;
+                D.uprev2 = halo_epi ? uprev : nullptr; D.ld = (int32_t)ld;
                 D.w = s->dw_w; D.wshift = 0; while ((1 << D.wshift) < D.w) D.wshift++;
                 const int dv = s->dw_variant;
                 const bool vec2 = dv >= 2 && (H.DimUp % 2 == 0) && D.w >= 4 && D.dww <= 64;

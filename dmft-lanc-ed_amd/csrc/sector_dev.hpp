@@ -225,6 +225,7 @@ static int build_diag(S *s)
 }
 
 static bool fused_ok(const S *s);      // product.hpp
+static bool pitch_ok(const S *s);
 
 // Non-local (Jx/Jp) block of the explicit storage: count sweep, host scan over the dw rows, fill sweep (k_nd_build)
 static int build_csr_nd(S *s)
@@ -443,7 +444,7 @@ static int create(const edgpu_desc *desc, S **out)
     }
     if (s->multi && !s->tr_on) CHK(s->vfull.alloc((size_t)(H.DimUp * s->nhalo * H.DimPh)));
     s->vld = H.DimUp; s->vlen = s->nloc;
-    s->pad_on = fused_ok(s.get()) && (H.DimUp % 16) != 0 && dbg_int("EDGPU_PAD", 1) != 0;
+    s->pad_on = (fused_ok(s.get()) || pitch_ok(s.get())) && (H.DimUp % 16) != 0 && dbg_int("EDGPU_PAD", 1) != 0;
     if (s->pad_on) { s->vld = (H.DimUp + 15) & ~(int64_t)15; s->vlen = (s->nloc / H.DimUp) * s->vld; }
     s->npartial = max_partials(s.get());
     CHK(s->partial.alloc((size_t)s->npartial));
