@@ -208,7 +208,8 @@ int edgpu_sector_hmat(edgpu_handle h, double *hmat)
     return EDGPU_OK;
 }
 
-int edgpu_csr_rows(edgpu_handle h, int64_t row0, int64_t nrows, int64_t *row_ptr, int32_t *cols, double *vals, int64_t cap)
+// rows [row0, row0+nrows) of the ELECTRONIC operator (one phonon block): merged view of the stored blocks, ascending columns
+static int csr_rows_el(edgpu_handle h, int64_t row0, int64_t nrows, int64_t *row_ptr, int32_t *cols, double *vals, int64_t cap)
 {
     if (!h || !row_ptr) return fail(EDGPU_EINVAL, "edgpu_csr_rows: null argument");
     if (!h->csr_rowptr.p) return fail(EDGPU_EINVAL, "edgpu_csr_rows: sector was not created with storage=CSR");
@@ -259,6 +260,40 @@ int edgpu_csr_rows(edgpu_handle h, int64_t row0, int64_t nrows, int64_t *row_ptr
             if (n >= cap) return fail(EDGPU_EINVAL, "edgpu_csr_rows: capacity too small");
             if (cols && vals) { cols[n] = cc[pick][a[pick]]; vals[n] = vv[pick][a[pick]]; }
             a[pick]++; n++;
+        }
+        row_ptr[r + 1] = n;
+    }
+    return EDGPU_OK;
+}
+
+int edgpu_csr_rows(edgpu_handle h, int64_t row0, int64_t nrows, int64_t *row_ptr, int32_t *cols, double *vals, int64_t cap)
+{
+    if (!h || !row_ptr) return fail(EDGPU_EINVAL, "edgpu_csr_rows: null argument");
+    if (!h->csr_rowptr.p) return fail(EDGPU_EINVAL, "edgpu_csr_rows: sector was not created with storage=CSR");
+    if (h->H.DimPh == 1) return csr_rows_el(h, row0, nrows, row_ptr, cols, vals, cap);
+    // phonon sectors: row r = iel + iph*nloc_el is the electronic row iel shifted into block iph (+ w0*iph on its diagonal)
+    // plus the stored e-ph entries g(iel) sqrt(.) in the neighbouring phonon blocks
+    if (row0 < 0 || nrows < 0 || row0 + nrows > h->nloc) return fail(EDGPU_EINVAL, "edgpu_csr_rows: row window out of range");
+    if (h->multi) return fail(EDGPU_EUNSUPPORTED, "edgpu_csr_rows: phonon sectors are exported on one rank only");
+    const int64_t nel = h->nloc_el; const double w0 = h->H.desc.w0_ph;
+    int64_t n = 0; row_ptr[0] = 0;
+    std::vector<int32_t> ec(4096); std::vector<double> ev(4096);
+    for (int64_t r = 0; r < nrows; r++) {
+        const int64_t row = row0 + r, iph = row / nel, iel = row - iph * nel;
+        int64_t rp2[2];
+        CHK(csr_rows_el(h, iel, 1, rp2, ec.data(), ev.data(), (int64_t)ec.size()));
+        double g = 0.0; HIPCHK(hipMemcpy(&g, h->csr_gel.p + iel, 8, hipMemcpyDeviceToHost));
+        struct E { int64_t c; double v; }; std::vector<E> ent;
+        bool has_diag = false;
+        for (int64_t k = 0; k < rp2[1]; k++) { double val = ev[k]; if (ec[k] == iel) { val += w0 * iph; has_diag = true; } ent.push_back({ec[k] + iph * nel, val}); }
+        if (!has_diag && w0 * iph != 0.0) ent.push_back({row, w0 * iph});
+        if (iph + 1 < h->H.DimPh && g != 0.0) ent.push_back({iel + (iph + 1) * nel, g * std::sqrt((double)(iph + 1))});
+        if (iph > 0 && g != 0.0) ent.push_back({iel + (iph - 1) * nel, g * std::sqrt((double)iph)});
+        std::sort(ent.begin(), ent.end(), [](const E &x, const E &y) { return x.c < y.c; });
+        for (auto &e : ent) {
+            if (n >= cap) return fail(EDGPU_EINVAL, "edgpu_csr_rows: capacity too small");
+            if (cols && vals) { cols[n] = (int32_t)e.c; vals[n] = e.v; }
+            n++;
         }
         row_ptr[r + 1] = n;
     }

@@ -996,6 +996,33 @@ __global__ void __launch_bounds__(256) k_nd_build(NdBuildArgs A)
     if (!FILL && threadIdx.x == 0) { A.row_nr[idwl] = s_br; A.row_ne[idwl] = s_be; }
 }
 
+// Phonon part of the explicit storage (Nph > 0): the reference keeps H_eph = spH0e_eph (x) spH0ph_eph, an electronic
+// diagonal g(iel) times the (b + b^+) matrix of the phonon index, and H_ph = w0 n_ph (stored/H_ph.f90:2-5,
+// H_e_ph.f90:2-39).  Stored here the same way: g_el[iel] once per sector; this pass adds, for every phonon block,
+//   y(iel,iph) += [s_cur *] ( w0*iph*x(iel,iph) + g(iel) * ( sqrt(iph+1) x(iel,iph+1) + sqrt(iph) x(iel,iph-1) ) )
+// (phonon neighbours of a row are on the same rank).
+__global__ void __launch_bounds__(256) k_build_gel(int64_t nel, int32_t DimUp, int64_t dw0, const int32_t *mapup, const int32_t *mapdw, int32_t impmask,
+                                                   const double *gup, const double *gdw, double gsum, double *gel)
+{
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nel; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t idwl = i / DimUp; const int iup = (int)(i - idwl * DimUp);
+        gel[i] = gup[(uint32_t)mapup[iup] & impmask] + gdw[(uint32_t)mapdw[dw0 + idwl] & impmask] - gsum;
+    }
+}
+template <bool EPI>
+__global__ void __launch_bounds__(256) k_csr_ph(int64_t nel, int32_t DimPh, double w0, const double *__restrict__ gel, const double *__restrict__ x, double *__restrict__ y, const double *scal)
+{
+    const double sc = EPI ? scal[SC_SCUR] : 1.0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nel * DimPh; i += (int64_t)gridDim.x * blockDim.x) {
+        const int iph = (int)(i / nel); const int64_t iel = i - (int64_t)iph * nel;
+        const double g = gel[iel];
+        double acc = w0 * iph * x[i];
+        if (iph + 1 < DimPh) acc += g * sqrt((double)(iph + 1)) * x[i + nel];
+        if (iph > 0) acc += g * sqrt((double)iph) * x[i - nel];
+        y[i] += sc * acc;
+    }
+}
+
 // y += [s_cur *] ND x for the compressed-row block: a wave takes 64 consecutive non-empty rows, whose entries are one
 // contiguous range; lanes sweep that range (coalesced), products are summed per row by a segmented scan across the wave
 // (entries of a row sit in consecutive lanes) and the tail lane of each segment adds into the row's LDS slot.

@@ -284,10 +284,23 @@ static int hxv(S *s, const double *v, double *out, bool epi, const double *uprev
         A.rowptr = s->csr_rowptr.p; A.cols = s->csr_cols.p; A.vals = s->csr_vals.p;
         A.x = overlap ? (s->halo ? v : v - H.dw0 * H.DimUp) : (multi ? s->vfull.p : v); A.y = out; A.v_local = v; A.uprev = uprev; A.scal = s->scal.p; A.partial = s->partial.p; A.epi = epi; A.xcd_rows = s->csr_xcd_rows;
         // the column index is global; on one GPU local == global
+        // Phonon sectors: the electronic blocks are the same for every phonon block iph; they run once per iph on the
+        // slices x(:,iph), y(:,iph) (x-space of one block: Xel elements; phonon sectors of several ranks use the full gather)
+        const int nph = H.DimPh;
+        const int64_t Xel = H.DimUp * (multi ? s->nhalo : H.DimDw);
+        auto launch = [&](const CsrArgs &B0, bool small, bool nt, int64_t nb) {
+            for (int iph = 0; iph < nph; iph++) {
+                CsrArgs B = B0;
+                B.x += (int64_t)iph * Xel; B.y += (int64_t)iph * s->nloc_el; B.v_local += (int64_t)iph * s->nloc_el;
+                if (B.uprev) B.uprev += (int64_t)iph * s->nloc_el;
+                B.partial += (int64_t)iph * nb;
+                if (small) { if (nt) hipLaunchKernelGGL((k_csr_spmv2<64, 640, true>), dim3((unsigned)nb), dim3(64), 0, s->stream, B); else hipLaunchKernelGGL((k_csr_spmv2<64, 640, false>), dim3((unsigned)nb), dim3(64), 0, s->stream, B); }
+                else { if (nt) hipLaunchKernelGGL((k_csr_spmv2<64, 1152, true>), dim3((unsigned)nb), dim3(64), 0, s->stream, B); else hipLaunchKernelGGL((k_csr_spmv2<64, 1152, false>), dim3((unsigned)nb), dim3(64), 0, s->stream, B); }
+            }
+        };
         nblocks = (int64_t)s->csr_bpr * H.Qdw;
         A.pass = s->csr_split ? 1 : 0; A.coltiles = 0;
-        if (s->csr_split && s->csrL_small) hipLaunchKernelGGL((k_csr_spmv2<64, 640, false>), dim3((unsigned)nblocks), dim3(64), 0, s->stream, A);
-        else hipLaunchKernelGGL((k_csr_spmv2<64, 1152, false>), dim3((unsigned)nblocks), dim3(64), 0, s->stream, A);
+        launch(A, s->csr_split && s->csrL_small, false, nblocks);
         HIPCHK(hipGetLastError());
         if (s->csr_split) {
             A.rows_per_block = s->csrD_rpb; A.blocks_per_row = s->csrD_bpr; A.coltiles = 1; A.xcd_rows = 0;
@@ -296,34 +309,34 @@ static int hxv(S *s, const double *v, double *out, bool epi, const double *uprev
                 // dw hops into the rank's own rows: their columns are the first Qdw rows of the x-space, i.e. the local
                 // shard itself -- this block too runs while the exchange is in flight
                 A.rowptr = s->csrO_rowptr.p; A.cols = s->csrO_cols.p; A.vals = s->csrO_vals.p; A.pass = 3;
-                if (s->csrD_small) hipLaunchKernelGGL((k_csr_spmv2<64, 640, false>), dim3((unsigned)nblocks), dim3(64), 0, s->stream, A);
-                else hipLaunchKernelGGL((k_csr_spmv2<64, 1152, false>), dim3((unsigned)nblocks), dim3(64), 0, s->stream, A);
+                launch(A, s->csrD_small, false, nblocks);
                 HIPCHK(hipGetLastError());
             }
             if (overlap) { HIPCHK(hipStreamWaitEvent(s->stream, s->ev_gather, 0)); A.x = s->vfull.p; }
             if (s->nd_nr > 0) {     // stored non-local block (Jx/Jp): compressed rows, wave-level segmented sums
-                NdCsrArgs Nd{};
-                Nd.nr = s->nd_nr; Nd.rows = s->nd_rows.p; Nd.ptr = s->nd_ptr.p; Nd.cols = s->nd_cols.p; Nd.vals = s->nd_vals.p; Nd.slot = s->nd_slot.p;
-                Nd.x = multi ? s->vfull.p : v; Nd.y = out; Nd.scal = s->scal.p;
-                const unsigned g = (unsigned)cdiv(s->nd_nr, 256);
-                if (epi) hipLaunchKernelGGL(k_csr_nd<true>, dim3(g), dim3(256), 0, s->stream, Nd);
-                else hipLaunchKernelGGL(k_csr_nd<false>, dim3(g), dim3(256), 0, s->stream, Nd);
+                for (int iph = 0; iph < nph; iph++) {
+                    NdCsrArgs Nd{};
+                    Nd.nr = s->nd_nr; Nd.rows = s->nd_rows.p; Nd.ptr = s->nd_ptr.p; Nd.cols = s->nd_cols.p; Nd.vals = s->nd_vals.p; Nd.slot = s->nd_slot.p;
+                    Nd.x = (multi ? s->vfull.p : v) + (int64_t)iph * Xel; Nd.y = out + (int64_t)iph * s->nloc_el; Nd.scal = s->scal.p;
+                    const unsigned g = (unsigned)cdiv(s->nd_nr, 256);
+                    if (epi) hipLaunchKernelGGL(k_csr_nd<true>, dim3(g), dim3(256), 0, s->stream, Nd);
+                    else hipLaunchKernelGGL(k_csr_nd<false>, dim3(g), dim3(256), 0, s->stream, Nd);
+                }
+                HIPCHK(hipGetLastError());
+            }
+            if (nph > 1) {      // stored phonon part: w0 n_ph and g(iel) (b + b^+); phonon neighbours are rows of this rank
+                const unsigned g = (unsigned)std::min<int64_t>(cdiv(s->nloc, 256), 65536);
+                if (epi) hipLaunchKernelGGL(k_csr_ph<true>, dim3(g), dim3(256), 0, s->stream, s->nloc_el, (int32_t)nph, d.w0_ph, (const double *)s->csr_gel.p, v, out, (const double *)s->scal.p);
+                else hipLaunchKernelGGL(k_csr_ph<false>, dim3(g), dim3(256), 0, s->stream, s->nloc_el, (int32_t)nph, d.w0_ph, (const double *)s->csr_gel.p, v, out, (const double *)s->scal.p);
                 HIPCHK(hipGetLastError());
             }
             A.rowptr = s->csrD_rowptr.p; A.cols = s->csrD_cols.p; A.vals = s->csrD_vals.p;
             A.pass = 2;
-            {
-                nblocks = 8 * cdiv(s->csrD_bpr, 8) * H.Qdw;
-                if (s->csrD_small) {
-                    if (s->csrD_nt) hipLaunchKernelGGL((k_csr_spmv2<64, 640, true>), dim3((unsigned)nblocks), dim3(64), 0, s->stream, A);
-                    else hipLaunchKernelGGL((k_csr_spmv2<64, 640, false>), dim3((unsigned)nblocks), dim3(64), 0, s->stream, A);
-                } else {
-                    if (s->csrD_nt) hipLaunchKernelGGL((k_csr_spmv2<64, 1152, true>), dim3((unsigned)nblocks), dim3(64), 0, s->stream, A);
-                    else hipLaunchKernelGGL((k_csr_spmv2<64, 1152, false>), dim3((unsigned)nblocks), dim3(64), 0, s->stream, A);
-                }
-                HIPCHK(hipGetLastError());
-            }
+            nblocks = 8 * cdiv(s->csrD_bpr, 8) * H.Qdw;
+            launch(A, s->csrD_small, s->csrD_nt != 0, nblocks);
+            HIPCHK(hipGetLastError());
         }
+        nblocks *= nph;      // one partial per workgroup and phonon block
     } else if (s->kron2) {
         Kron2Args A{};
         A.DimUp = (int32_t)H.DimUp; A.DimDw = (int32_t)(s->halo ? s->nhalo : H.DimDw); A.DimPh = H.DimPh; A.Norb = d.Norb; A.Qdw = H.Qdw; A.dw0 = H.dw0;

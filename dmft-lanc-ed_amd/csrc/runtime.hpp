@@ -176,6 +176,7 @@ struct edgpu_sector_s {
     // is in flight) and hops into received rows (csrD_*: runs after it)
     DevBuf<int64_t> csrO_rowptr, selpre_own, selpre_halo; DevBuf<int32_t> csrO_cols; DevBuf<double> csrO_vals; bool csr_three = false; int64_t csrO_nnz = 0;
     // non-local (Jx/Jp) block of the explicit storage, compressed rows: k_nd_build / k_csr_nd
+    DevBuf<double> csr_gel;      // phonon sectors: electronic factor of the e-ph coupling (the reference's diagonal spH0e_eph)
     DevBuf<int64_t> nd_rows, nd_ptr; DevBuf<int32_t> nd_cols; DevBuf<double> nd_vals; DevBuf<uint8_t> nd_slot; int64_t nd_nr = 0, nd_nnz = 0;
     bool csr_split = false; int64_t csrL_nnz = 0, csrD_nnz = 0; int32_t csrD_rpb = 64, csrD_bpr = 0; int csrD_nt = 1; bool csrL_small = false, csrD_small = false;
     int64_t csr_nnz = 0; int32_t csr_rpb = 0, csr_bpr = 0, csr_tile = 1;

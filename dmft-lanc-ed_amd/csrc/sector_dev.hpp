@@ -261,7 +261,7 @@ static int build_csr_nd(S *s)
 static int build_csr(S *s)
 {
     const SectorHost &H = s->H;
-    if (!s->kron2 || H.DimPh > 1) return fail(EDGPU_EUNSUPPORTED, "edgpu: storage=CSR does not cover the phonon terms (Nph>0)");
+    if (!s->kron2) return fail(EDGPU_EUNSUPPORTED, "edgpu: storage=CSR needs the two-factor form of the sector (composite blocks too large)");
     if (H.DimUp * s->nhalo >= ((int64_t)1 << 31)) return fail(EDGPU_EUNSUPPORTED, "edgpu: storage=CSR needs DimUp*(rows of x) < 2^31 (int32 columns)");
     const Factor &up = *s->hup, &dw = *s->hdw;
     std::vector<int64_t> uppre(up.dim + 1, 0), dwpre(H.Qdw + 1, 0);
@@ -278,7 +278,7 @@ static int build_csr(S *s)
     // Two storage forms of the same explicit matrix: one CSR, or (default for large sectors) two CSR
     // blocks H = H_loc + H_dw so that each block can be streamed in the order that keeps ITS gathers
     // cache resident (rows for the up hops, XCD-owned column tiles for the dw hops).
-    s->csr_split = dbg_int("EDGPU_CSR_SPLIT", (H.DimUp * H.DimDw * 8 > ((int64_t)48 << 20)) ? 1 : 0) != 0 || H.Jhflag;      // the non-local block goes between the local and the dw block
+    s->csr_split = dbg_int("EDGPU_CSR_SPLIT", (H.DimUp * H.DimDw * 8 > ((int64_t)48 << 20)) ? 1 : 0) != 0 || H.Jhflag || H.DimPh > 1;      // the non-local / phonon passes go between the local and the dw block
     s->csrL_nnz = H.Qdw * uppre[up.dim]; s->csrD_nnz = s->csr_nnz - s->csrL_nnz;
     CsrBuildArgs A{};
     A.DimUp = (int32_t)H.DimUp; A.DimDw = (int32_t)H.DimDw; A.Qdw = H.Qdw; A.dw0 = H.dw0;
@@ -336,6 +336,12 @@ static int build_csr(S *s)
     s->csr_bpr = (int32_t)cdiv(H.DimUp, s->csr_rpb);
     s->csr_tile = std::max(1, std::min(dbg_int("EDGPU_CSR_TILE", 1 << 20), s->csr_bpr));
     if (H.Jhflag) CHK(build_csr_nd(s));
+    if (H.DimPh > 1) {
+        CHK(s->csr_gel.alloc((size_t)s->nloc_el));
+        hipLaunchKernelGGL(k_build_gel, dim3((unsigned)std::min<int64_t>(cdiv(s->nloc_el, 256), 65536)), dim3(256), 0, s->stream, s->nloc_el, (int32_t)H.DimUp, H.dw0,
+                           s->upf->map.p, s->dwf->map.p, (int32_t)((1 << H.desc.Norb) - 1), s->gup.p, s->gdw.p, H.gph_sum, s->csr_gel.p);
+        HIPCHK(hipGetLastError());
+    }
     return EDGPU_OK;
 }
 
@@ -347,8 +353,8 @@ static int64_t max_partials(const S *s)
         n = std::max<int64_t>(n, 8 * cdiv(cdiv(s->H.DimUp, w), 8) * cdiv(s->H.Qdw * s->H.DimPh, std::max(R, 1)));
     }
     if (s->tr_on) n = std::max<int64_t>(n, cdiv(s->H.DimUp, 32) * cdiv(s->H.Qdw, 32));      // k_tadd: one partial per 32x32 tile
-    if (s->csr_bpr) n = std::max<int64_t>(n, (int64_t)s->csr_bpr * s->H.Qdw);
-    if (s->csrD_bpr) n = std::max<int64_t>(n, 8 * cdiv(s->csrD_bpr, 8) * s->H.Qdw);
+    if (s->csr_bpr) n = std::max<int64_t>(n, (int64_t)s->csr_bpr * s->H.Qdw * s->H.DimPh);
+    if (s->csrD_bpr) n = std::max<int64_t>(n, 8 * cdiv(s->csrD_bpr, 8) * s->H.Qdw * s->H.DimPh);
     return n;
 }
 

@@ -38,7 +38,9 @@ enum { EDGPU_BATH_NORMAL = 0, EDGPU_BATH_HYBRID = 1, EDGPU_BATH_REPLICA = 2 };
 /* How the sector operator is held in HBM.
  *  KRON   : the reference's stored format (ed_sparse_H=T): diagonal spH0d + per-spin
  *           factors spH0ups/spH0dws (+ spH0nd, phonon blocks); ED_VARS_GLOBAL.f90:142-146.
- *  CSR    : the same operator expanded to one explicit CSR (int64 row_ptr, int32 col, fp64 val).
+ *  CSR    : the same operator expanded to explicit CSR (int64 row_ptr, int32 col, fp64 val): for large sectors as a local
+ *           block + a dw block; Jx/Jp sectors add the stored non-local block (spH0nd) as compressed rows, phonon sectors
+ *           the stored electronic factor of the e-ph coupling (spH0e_eph); ed_total_ud=F through composite up/dw blocks.
  *  DIRECT : nothing stored (ed_sparse_H=F): diagonal and hop tables are recomputed from the
  *           bit patterns at every product; ED_HAMILTONIAN_DIRECT_HxV.f90:21-95. */
 enum { EDGPU_STORE_KRON = 0, EDGPU_STORE_CSR = 1, EDGPU_STORE_DIRECT = 2 };

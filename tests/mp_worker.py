@@ -238,7 +238,7 @@ def main():
         res["ok"] = True; res["nlegs"] = nlegs
     else:
         import edgpu
-        csr_ok = m.get("Nph", 0) == 0
+        csr_ok = True
         for st in (["kron", "direct", "csr"] if csr_ok else ["kron", "direct"]):
             G = edgpu.HvSector(m, nu, nd, storage=st, rank=rank, size=size)
             ex = exchange.device_staged(dist)

@@ -42,10 +42,9 @@ def _sample_rows(DimUp, DimDw, rng, nrandom, parts=8, tile=64, above=None):
 
 
 def _storages(m):
-    st = ["kron", "direct"]
-    if m.get("Nph", 0) == 0:      # explicit CSR: composite blocks for ed_total_ud=F, compressed-row non-local block for Jx/Jp; no phonon terms
-        st.append("csr")
-    return st
+    # explicit CSR for every sector: composite blocks for ed_total_ud=F, compressed-row non-local block for Jx/Jp, stored
+    # electronic factor of the e-ph coupling for phonons
+    return ["kron", "direct", "csr"]
 
 
 @pytest.mark.parametrize("name,m,nu,nd", ZOO, ids=IDS)
@@ -249,7 +248,10 @@ def test_large_sector_code_paths_on_small_sectors(edgpu_mod, monkeypatch, name, 
                     c = cols[rp[i]:rp[i + 1]]
                     assert np.all(np.diff(c) > 0)
                     row = np.zeros(S.Dim); row[c] = vals[rp[i]:rp[i + 1]]
-                    np.testing.assert_array_equal(row, H[i])
+                    if m.get("Nph", 0) == 0:
+                        np.testing.assert_array_equal(row, H[i])
+                    else:      # w0*iph and g*sqrt(iph) are formed in a different order than the oracle's dense build
+                        np.testing.assert_allclose(row, H[i], rtol=0, atol=1e-14)
             G.close()
         for k in env:
             monkeypatch.delenv(k)
