@@ -297,7 +297,7 @@ def main():
         "iters_per_sec": K / dt,
         "config": {"workload": "1-orbital Anderson impurity, Nbath=%d (Ns=%d), sector Nup=Ndw=%d, N=%d, default initial bath, operator storage=%s, one Lanczos iteration per step"
                                % (a.nbath, Ns, nu[0], N, a.storage),
-                   "storage": a.storage, "N": N, "nnz": nnz, "parallelism": par},
+                   "storage": a.storage, "N": N, "nnz": nnz, "parallelism": par, "forms": G.describe()},
         "roofline": {"bound": "hbm", "kernel": KERNELS[a.storage],
                      "achieved": bytes_fmt / (hxv_ms * 1e-3) / 1e9 if hxv_ms > 0 else None, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": (bytes_fmt / (hxv_ms * 1e-3) / 1e9) / HBM_PEAK_GBPS if hxv_ms > 0 else None,

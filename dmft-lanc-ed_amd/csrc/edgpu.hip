@@ -419,6 +419,32 @@ int edgpu_eigsh(edgpu_handle h, int32_t nev, int32_t ncv, int32_t maxiter, doubl
 int32_t edgpu_eigsh_ncv_cap(void) { return kMaxBasisBig; }
 int32_t edgpu_eigsh_ncv_used(edgpu_handle h) { return h ? h->eig_ncv_used : 0; }
 int32_t edgpu_lanczos_is_fused(edgpu_handle h) { return h && fused_ok(h) ? 1 : 0; }
+int edgpu_sector_describe(edgpu_handle h, char *buf, int32_t cap)
+{
+    if (!h || !buf || cap < 1) return fail(EDGPU_EINVAL, "edgpu_sector_describe: bad argument");
+    const SectorHost &H = h->H; const edgpu_desc &d = H.desc;
+    std::string t = d.storage == EDGPU_STORE_CSR ? "storage=csr" : (d.storage == EDGPU_STORE_DIRECT ? "storage=direct" : "storage=kron");
+    if (d.storage == EDGPU_STORE_CSR) {
+        t += h->csr_three ? " blocks=local+own-dw+received-dw" : (h->csr_split ? " blocks=local+dw" : " blocks=one");
+        if (h->nd_nr > 0) t += "+nonlocal(compressed rows)";
+        if (H.DimPh > 1) t += "+phonon(stored g)";
+    } else if (h->kron2) {
+        const bool nd_pass = h->has_nd && !h->has_ph && h->nd_split;
+        const bool split = h->multi || (h->kron_split && (!h->extra || nd_pass));
+        t += split ? " product=two-pass" : " product=one-pass(k_kron2)";
+        if (split) {
+            if (h->use_lds) t += fused_form(h) == 2 ? " local=pairs" : (h->upf->packed && h->upf->width <= 16 && h->up_persistent ? " local=persistent" : " local=row-kernel");
+            else t += h->upf->seg_ok && h->up_halo ? " local=segment+halo(nseg=" + std::to_string(h->upf->nseg) + ")" : " local=long-row-gather";
+            if (nd_pass) t += "+nonlocal-pass";
+        }
+    } else t += " product=generic";
+    if (h->composite) t += " composite(ed_total_ud=F)";
+    t += fused_ok(h) ? " lanczos=fused" : " lanczos=three-pass";
+    t += h->pad_on ? " pitch=" + std::to_string(h->vld) : " pitch=dense";
+    if (h->multi) t += h->tr_on ? " exchange=transpose" : (h->halo ? " exchange=needed-rows" : " exchange=all-gather");
+    snprintf(buf, (size_t)cap, "%s", t.c_str());
+    return EDGPU_OK;
+}
 
 int edgpu_dvdson(edgpu_handle h, int32_t nev, int32_t maxiter, double tol, double *evals, double *evecs, int32_t *nconv, int32_t *nmatvec)
 {

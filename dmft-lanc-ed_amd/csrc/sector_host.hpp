@@ -167,7 +167,7 @@ struct SectorHost {
             int64_t dim = 1; std::vector<int64_t> st(Ns_Ud);
             for (int a = 0; a < Ns_Ud; a++) { st[a] = dim; dim *= fac[first + a].dim; }
             int64_t wsum = 0; for (int a = 0; a < Ns_Ud; a++) wsum += fac[first + a].width;
-            if (dim > ((int64_t)1 << 26) || dim * std::max<int64_t>(wsum, 1) > ((int64_t)1 << 30)) { cfac.clear(); return; }   // too large to tabulate: generic kernel
+            if (dim > ((int64_t)1 << 24) || dim * std::max<int64_t>(wsum, 1) > ((int64_t)1 << 27)) { cfac.clear(); return; }   // too large to tabulate (1.6 GB of table): generic kernel
             c.nbits = Ns; c.npart = 0; c.dim = (int32_t)dim;
             c.rank.assign(1, 0);
             for (int a = 0; a < Ns_Ud; a++) for (auto &t : fac[first + a].terms) c.terms.push_back(t);

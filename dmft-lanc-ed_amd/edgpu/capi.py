@@ -21,7 +21,7 @@ SYMBOLS = [
     "edgpu_hxv", "edgpu_hxv64", "edgpu_hxv_device", "edgpu_hxv_time",
     "edgpu_lanczos_gs", "edgpu_lanczos_gs_device", "edgpu_lanczos_tridiag", "edgpu_lanczos_tridiag_device",
     "edgpu_lanczos_time", "edgpu_lanczos_bench_begin", "edgpu_lanczos_bench_steps", "edgpu_lanczos_bench_result", "edgpu_lanczos_bench_comm_ms",
-    "edgpu_eigsh", "edgpu_eigsh_ncv_cap", "edgpu_eigsh_ncv_used", "edgpu_lanczos_is_fused", "edgpu_dvdson", "edgpu_cache_release", "edgpu_twin_reorder", "edgpu_imp_density_offdiag", "edgpu_imp_histogram", "edgpu_local_energy", "edgpu_apply_op", "edgpu_gf_lanczos", "edgpu_chi_lanczos", "edgpu_phonon_lanczos",
+    "edgpu_eigsh", "edgpu_eigsh_ncv_cap", "edgpu_eigsh_ncv_used", "edgpu_lanczos_is_fused", "edgpu_sector_describe", "edgpu_dvdson", "edgpu_cache_release", "edgpu_twin_reorder", "edgpu_imp_density_offdiag", "edgpu_imp_histogram", "edgpu_local_energy", "edgpu_apply_op", "edgpu_gf_lanczos", "edgpu_chi_lanczos", "edgpu_phonon_lanczos",
     "edgpu_sp_init_matrix", "edgpu_sp_init_matrix_mpi", "edgpu_sp_load_matrix", "edgpu_sp_insert_element", "edgpu_sp_delete_matrix", "edgpu_sp_dump_matrix", "edgpu_sp_row", "edgpu_sp_matvec", "edgpu_sp_matvec_device",
     "edgpu_comm_unique_id", "edgpu_comm_init_rccl", "edgpu_comm_init_callbacks",
     "edgpu_comm_create_rccl", "edgpu_comm_create_callbacks", "edgpu_comm_sub", "edgpu_comm_destroy", "edgpu_sector_attach_comm",
@@ -104,6 +104,7 @@ def lib():
         "edgpu_eigsh_ncv_cap": (i32, []),
         "edgpu_eigsh_ncv_used": (i32, [vp]),
         "edgpu_lanczos_is_fused": (i32, [vp]),
+        "edgpu_sector_describe": (C.c_int, [vp, vp, i32]),
         "edgpu_cache_release": (C.c_int, []),
         "edgpu_imp_histogram": (C.c_int, [vp, vp, i32, vp]),
         "edgpu_local_energy": (C.c_int, [vp, vp, vp]),

@@ -339,6 +339,12 @@ class HvSector:
         """True when the Lanczos loops of this sector run the fused two-pass iteration (edgpu_lanczos_is_fused)."""
         return bool(capi.lib().edgpu_lanczos_is_fused(self._h))
 
+    def describe(self):
+        """one line: which forms the product and the Lanczos loops of this sector take (edgpu_sector_describe)"""
+        buf = C.create_string_buffer(512)
+        check(capi.lib().edgpu_sector_describe(self._h, buf, 512))
+        return buf.value.decode()
+
     def exchange_info(self):
         """(mode, send_bytes[size], recv_bytes[size]) of one product: mode 'none' | 'needed-rows' | 'all-gather' | 'transpose'."""
         P = int(self._desc.mpi_size)

@@ -155,6 +155,10 @@ int32_t edgpu_eigsh_ncv_used(edgpu_handle h);
 /* 1 when this sector's Lanczos loops (edgpu_lanczos_gs / _tridiag and the searches built on them) run the fused two-pass
  * iteration, 0 when they run product + axpy/norm as three passes (EDGPU_LZ_FUSED=0, multi-rank, CSR storage, non-local terms). */
 int32_t edgpu_lanczos_is_fused(edgpu_handle h);
+/* One-line description of the forms this sector's product and Lanczos loops take (storage, one- or two-pass product,
+ * local-pass kernel, composite blocks, fused iteration, row pitch of the work vectors, exchange mode): written to buf
+ * (NUL-terminated, truncated to cap).  For logs and bench records; no reference counterpart. */
+int edgpu_sector_describe(edgpu_handle h, char *buf, int32_t cap);
 /* sp_dvdson_eigh(MatVec,eval,evec,nitermax,tol)   ED_DIAG.f90:189-203 (lanc_method="dvdson"): Davidson with the
  * diagonal of H as preconditioner; search space and its image under H in HBM.  `maxiter` products at most; a pair
  * counts as converged when |H x - theta x| <= max(tol,1e-11)*max(1,|theta|).  Same outputs as edgpu_eigsh. */

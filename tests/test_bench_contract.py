@@ -37,7 +37,7 @@ def test_bench_line(extra):
     assert d["value"] > 0 and d["ms_per_step"] > 0
     r = d["roofline"]
     assert r["bound"] == "hbm" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
-    assert "workload" in d["config"] and "model" not in d["config"]
+    assert "workload" in d["config"] and "model" not in d["config"] and "storage=" in d["config"]["forms"]
     assert d["time_split_ms"]["hxv_product"] > 0
     if "--force-dist" in extra:      # the exchange step is timed on the comm stream
         assert d["time_split_ms"]["exchange_on_comm_stream_overlapped_with_local_blocks"] >= 0.0

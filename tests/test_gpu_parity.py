@@ -437,6 +437,7 @@ def test_fused_iteration_equals_three_pass_iteration(edgpu_mod, monkeypatch):
                 monkeypatch.setenv(k, v)
             G = edgpu_mod.HvSector(m, nu, nd, storage=st)
             assert G.lanczos_fused == (tag != "plain"), (nb, st, tag)
+            assert ("lanczos=fused" in G.describe()) == (tag != "plain") and "product=two-pass" in G.describe() and "storage=" + st in G.describe()
             a, b, used = G.sp_lanc_tridiag(v0, n)
             e0, x, nl = G.sp_lanc_eigh(v0, nitermax=300, threshold=1e-13)
             res[tag] = (a, b, used, e0, x, nl, np.linalg.norm(G.spHtimesV(x) - e0 * x))
