@@ -432,12 +432,14 @@ def test_fused_iteration_equals_three_pass_iteration(edgpu_mod, monkeypatch):
         n = 40 if S.Dim > 2000 else 16      # small sectors: compare before rounding differences get amplified by the loss of orthogonality
         res = {}
         monkeypatch.setenv("EDGPU_KRON_SPLIT", "1")      # the two-kernel product large sectors use (default above 48 MB per vector)
-        for tag, env in (("fused", {}), ("fused_twopass", {"EDGPU_LZ_STORE": "0"}), ("plain", {"EDGPU_LZ_FUSED": "0"})):
+        for tag, env in (("fused", {}), ("fused_twopass", {"EDGPU_LZ_STORE": "0"}), ("fused_dense", {"EDGPU_PAD": "0"}), ("plain_dense", {"EDGPU_LZ_FUSED": "0", "EDGPU_PAD": "0"}),
+                         ("plain", {"EDGPU_LZ_FUSED": "0"})):      # dense: work vectors without the padded row pitch (what several ranks use)
             for k, v in env.items():
                 monkeypatch.setenv(k, v)
             G = edgpu_mod.HvSector(m, nu, nd, storage=st)
-            assert G.lanczos_fused == (tag != "plain"), (nb, st, tag)
-            assert ("lanczos=fused" in G.describe()) == (tag != "plain") and "product=two-pass" in G.describe() and "storage=" + st in G.describe()
+            assert G.lanczos_fused == (not tag.startswith("plain")), (nb, st, tag)
+            assert ("lanczos=fused" in G.describe()) == (not tag.startswith("plain")) and "product=two-pass" in G.describe() and "storage=" + st in G.describe()
+            assert ("pitch=dense" in G.describe()) == (tag.endswith("dense") or G.DimUp % 16 == 0), (tag, G.describe())
             a, b, used = G.sp_lanc_tridiag(v0, n)
             e0, x, nl = G.sp_lanc_eigh(v0, nitermax=300, threshold=1e-13)
             res[tag] = (a, b, used, e0, x, nl, np.linalg.norm(G.spHtimesV(x) - e0 * x))
@@ -445,7 +447,7 @@ def test_fused_iteration_equals_three_pass_iteration(edgpu_mod, monkeypatch):
             for k in env:
                 monkeypatch.delenv(k)
         a_ref, b_ref, used_ref = oracle.sp_lanc_tridiag(S.spmatvec, v0, n)
-        for tag in ("fused", "fused_twopass", "plain"):
+        for tag in ("fused", "fused_twopass", "fused_dense", "plain_dense", "plain"):
             a, b, used, e0, x, nl, r = res[tag]
             assert used == used_ref and b[0] == 0.0
             np.testing.assert_allclose(a[:used], a_ref[:used], rtol=1e-9, atol=1e-9)
