@@ -592,9 +592,6 @@ struct UpHaloArgs {
     const double *v; double *out;
     int32_t ld;              // row pitch of v / out in doubles (0: DimUp)
 };
-#ifndef HALO_SB
-#define HALO_SB 5
-#endif
 constexpr int kHaloSegMax = 6144, kHaloMax = 12288;     // up to 3 pairs and 12 halo values per lane of a 1024-thread workgroup
 template <bool DIRECT, int NQ, int MAXH>      // NQ: pairs per lane = steps per (row, segment) item; MAXH: halo values per lane
 __global__ void __launch_bounds__(1024) k_uppass_halo(UpHaloArgs A)
