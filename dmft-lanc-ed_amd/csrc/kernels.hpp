@@ -431,6 +431,7 @@ struct UpAxArgs {
     const double *scal; double *partial;
     double *acc; const double *zvec;   // optional eigenvector accumulation acc += zvec[K] * u_k (K = iteration counter in scal)
     int32_t ld;              // row pitch of r / vprev / t_out / acc in doubles (0: DimUp); the stored diagonal keeps pitch DimUp
+    const uint32_t *pcols, *pcodes; int32_t upw;      // k_uppass_ax (one configuration per lane, up to 16 hops): packed ELL image as k_uppass
 };
 
 template <bool DIRECT, bool ACC, int NT>
@@ -570,6 +571,89 @@ __global__ void __launch_bounds__(512) k_uppass_big(UpBigArgs A)
         }
         A.out[rbase + i] = EPI ? s_cur * acc - c_prev * up : acc;
     }
+}
+
+// The same local half for up factors with 9-16 hops per configuration (multi-orbital replica baths, BASELINE config 5):
+// one configuration per lane and step, packed ELL image of k_uppass.  Staging the next row pair by pair inside the hop loop
+// (as the pair form does) would need the 13 steps of a row unrolled around a 16-hop body -- ~300 spilled registers -- so
+// here only r of the next row is prefetched into registers during the hop loop; u_prev of the row is loaded at the row
+// switch, where it is combined into u (one exposed memory round trip per row, ~10 % of a row's time).
+template <bool DIRECT, bool ACC, int NT>
+__global__ void __launch_bounds__(NT) k_uppass_ax(UpAxArgs A)
+{
+    extern __shared__ double lds[];
+    constexpr int MAXQ = 13312 / NT, MAXC = 4;
+    const int DimUp = A.DimUp, tid = threadIdx.x;
+    const int64_t ld = A.ld ? A.ld : DimUp;
+    double *tv = lds + ((DimUp + 1) & ~1);
+    double *red = tv + 128;
+    double *crow = red + 32;
+    for (int t = tid; t < A.nterms; t += NT) tv[t] = A.tval[t];
+    const int nq = (DimUp + NT - 1) / NT;
+    const int ncw = (A.upw + 1) >> 1, ndw = (A.upw + 3) >> 2;
+    const double c_ax = A.scal[SC_ALPHA] * A.scal[SC_SCUR];
+    const double zk = ACC ? A.zvec[(int)A.scal[SC_K]] : 0.0;
+    double bsum = 0.0;
+    double xr[MAXQ];
+    int64_t row = blockIdx.x;
+    if (row < A.nrows) {
+#pragma unroll
+        for (int q = 0; q < MAXQ; q++) { const int i = tid + q * NT; xr[q] = (q < nq && i < DimUp) ? A.r[row * ld + i] : 0.0; }
+    }
+    struct Ops { double d; uint32_t codes[MAXC], cols[2 * MAXC]; };
+    while (row < A.nrows) {
+        const int64_t idwl = row % A.Qdw, idw = A.dw0 + idwl;
+        auto load_ops = [&](int i, Ops &o) {
+            o.d = DIRECT ? A.Eup[i] : A.diag[idwl * DimUp + i];
+#pragma unroll
+            for (int c = 0; c < MAXC; c++) if (c < ndw) o.codes[c] = A.pcodes[(int64_t)c * DimUp + i];
+#pragma unroll
+            for (int c = 0; c < 2 * MAXC; c++) if (c < ncw) o.cols[c] = A.pcols[(int64_t)c * DimUp + i];
+        };
+        Ops cur, nxt;
+        if (tid < DimUp) load_ops(tid, cur);
+        // u = r - c * u_prev for this row: into LDS, back over r, into the norm (and the eigenvector accumulation)
+#pragma unroll
+        for (int q = 0; q < MAXQ; q++) {
+            const int i = tid + q * NT;
+            if (q < nq && i < DimUp) {
+                const double u = xr[q] - c_ax * A.vprev[row * ld + i];
+                lds[i] = u; A.r[row * ld + i] = u; bsum += u * u;
+                if (ACC) A.acc[row * ld + i] += zk * u;
+            }
+        }
+        if (DIRECT && tid < A.nI) crow[tid] = A.Edw[idw] + A.econst + A.cross[tid * A.nI + ((uint32_t)A.mapdw[idw] & A.impmask)];
+        __syncthreads();
+        const int64_t next = row + gridDim.x;
+        if (next < A.nrows) {
+#pragma unroll
+            for (int q = 0; q < MAXQ; q++) { const int i = tid + q * NT; if (q < nq && i < DimUp) xr[q] = A.r[next * ld + i]; }
+        }
+        for (int i = tid; i < DimUp; i += NT) {
+            if (i + NT < DimUp) load_ops(i + NT, nxt);
+            const double x = lds[i];
+            const double dval = DIRECT ? cur.d + crow[(uint32_t)A.mapup[i] & A.impmask] : cur.d;
+            double acc = dval * x;
+#pragma unroll
+            for (int c = 0; c < MAXC; c++)
+                if (c < ndw && __any(cur.codes[c] != 0x7f7f7f7fu)) {
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        const uint32_t code = (cur.codes[c] >> (8 * e)) & 0xffu;
+                        const uint32_t col = (cur.cols[2 * c + (e >> 1)] >> (16 * (e & 1))) & 0xffffu;
+                        double t = tv[code & 0x7fu];
+                        t = (code & 0x80u) ? -t : t;
+                        acc += t * lds[col];
+                    }
+                }
+            A.t_out[row * ld + i] = acc;
+            cur = nxt;
+        }
+        __syncthreads();
+        row = next;
+    }
+    const double rr = block_sum(bsum, red);
+    if (tid == 0) A.partial[blockIdx.x] = rr;
 }
 
 // Local pass for rows too long for LDS, segment + halo form (Ns=17/18).  The up configurations are sorted by value, so a

@@ -166,13 +166,13 @@ static bool pitch_ok(const S *s)
     const bool halo = !s->use_lds && s->upf->seg_ok && s->up_halo && !s->extra;
     return persistent || halo;
 }
-// the local half of the fused iteration exists in the pair form only (<= 8 hops per up configuration, rows that fit LDS); a
-// one-configuration-per-lane form for 9-16 hops (multi-orbital replica baths) needs the 13 staging steps of a row unrolled
-// and spills ~300 registers -- those sectors keep the three-pass iteration
+// which local-half kernel the fused iteration uses: 2 = pair form (<= 8 hops per up configuration), 1 = one configuration per
+// lane (<= 16 hops), 0 = none (rows beyond LDS, wider factors)
 static int fused_form(const S *s)
 {
     if (!s->upf || !s->up_persistent || !s->use_lds || s->H.DimUp > 13312) return 0;
-    return (s->up_pairs && s->upf->packed_elem && s->upf->width <= 8) ? 2 : 0;
+    if (s->up_pairs && s->upf->packed_elem && s->upf->width <= 8) return 2;
+    return (s->upf->packed && s->upf->width <= 16) ? 1 : 0;
 }
 static bool fused_ok(const S *s)
 {
@@ -196,15 +196,21 @@ static int fused_local(S *s, double *r, const double *uprev, double *t, double *
     U.r = r; U.vprev = uprev; U.t_out = t; U.scal = s->scal.p; U.partial = s->partial.p; U.acc = acc; U.zvec = s->zvec.p; U.ld = (int32_t)s->vld;
     const size_t lds = (((size_t)H.DimUp + 1) & ~(size_t)1) * 8 + 128 * 8 + 32 * 8 + 32 * 8;
     const int grid = (int)std::min<int64_t>(U.nrows, s->up_grid);
+    U.pcols = s->upf->pcols.p; U.pcodes = s->upf->pcodes.p; U.upw = s->upf->width;
     const dim3 g(grid), b(LZAX_NT);
-#define AX_LAUNCH(D_, A_)                                                                                                       \
+#define AX_LAUNCH(K_, D_, A_)                                                                                                   \
     do {                                                                                                                            \
         static OncePerDevice once_;                                                                                                 \
-        if (once_.first(s->device)) (void)hipFuncSetAttribute((const void *)k_uppass2_ax<D_, A_, LZAX_NT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
-        hipLaunchKernelGGL((k_uppass2_ax<D_, A_, LZAX_NT>), g, b, lds, s->stream, U);                                               \
+        if (once_.first(s->device)) (void)hipFuncSetAttribute((const void *)K_<D_, A_, LZAX_NT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+        hipLaunchKernelGGL((K_<D_, A_, LZAX_NT>), g, b, lds, s->stream, U);                                                         \
     } while (0)
-    if (direct) { if (acc) AX_LAUNCH(true, true); else AX_LAUNCH(true, false); }
-    else { if (acc) AX_LAUNCH(false, true); else AX_LAUNCH(false, false); }
+    if (fused_form(s) == 2) {
+        if (direct) { if (acc) AX_LAUNCH(k_uppass2_ax, true, true); else AX_LAUNCH(k_uppass2_ax, true, false); }
+        else { if (acc) AX_LAUNCH(k_uppass2_ax, false, true); else AX_LAUNCH(k_uppass2_ax, false, false); }
+    } else {
+        if (direct) { if (acc) AX_LAUNCH(k_uppass_ax, true, true); else AX_LAUNCH(k_uppass_ax, true, false); }
+        else { if (acc) AX_LAUNCH(k_uppass_ax, false, true); else AX_LAUNCH(k_uppass_ax, false, false); }
+    }
 #undef AX_LAUNCH
     HIPCHK(hipGetLastError());
     s->fuse_mode = 4; s->fuse_zvec = nullptr;

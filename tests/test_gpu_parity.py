@@ -424,7 +424,7 @@ def test_fused_iteration_equals_three_pass_iteration(edgpu_mod, monkeypatch):
     from edgpu import model
     zoo = {z[0]: z[1:] for z in ZOO}
     todo = [model.half_filled_c(nb) + (st,) for nb, st in ((7, "kron"), (9, "direct"), (11, "kron"), (11, "direct"))]
-    todo += [zoo[name] + (st,) for name in ("norb2_normal_JxJp", "norb3_nb1_JxJp") for st in ("kron", "direct")]      # non-local pass between the two halves
+    todo += [zoo[name] + (st,) for name in ("norb2_normal_JxJp", "norb3_nb1_JxJp", "replica_sz_sx_JxJp", "norb2_normal_offdiag_hloc") for st in ("kron", "direct")]      # non-local pass between the two halves; factors with more than 8 hops (k_uppass_ax)
     for m, nu, nd, st in todo:
         nb = m["Nbath"]
         S = oracle.Sector(m, nu, nd)
