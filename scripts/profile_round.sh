@@ -38,4 +38,7 @@ for st in kron direct csr; do python3 scripts/microbench_orbs.py 7 $st 10; done 
 EDGPU_COMPOSITE=0 python3 scripts/microbench_orbs.py 7 kron 10 >> $OUT/orbs_times.txt 2>&1
 python3 scripts/gs_time.py 15 kron > $OUT/gs_time_kron.txt 2>&1
 python3 scripts/bw_probe.py > $OUT/bw_probe.txt 2>&1
-cat $OUT/c5_times.txt $OUT/orbs_times.txt $OUT/ns18_direct_product.txt $OUT/ns18_kron_iteration.txt $OUT/c3_isolated_products.txt $OUT/gs_time_kron.txt $OUT/bw_probe.txt | grep -v "^W2026\|^E2026"
+python3 scripts/small_sector_bench.py > $OUT/small_sectors.txt 2>&1
+python3 scripts/eig_time.py 15 kron 2 > $OUT/eig_time_c3.txt 2>&1
+python3 scripts/create_time.py > $OUT/create_time.txt 2>&1
+cat $OUT/small_sectors.txt $OUT/eig_time_c3.txt $OUT/create_time.txt $OUT/c5_times.txt $OUT/orbs_times.txt $OUT/ns18_direct_product.txt $OUT/ns18_kron_iteration.txt $OUT/c3_isolated_products.txt $OUT/gs_time_kron.txt $OUT/bw_probe.txt | grep -v "^W2026\|^E2026"
