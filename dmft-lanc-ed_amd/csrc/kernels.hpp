@@ -286,7 +286,7 @@ __global__ void __launch_bounds__(NT) k_uppass(UpArgs A)
 #pragma unroll
             for (int c = 0; c < MAXC; c++) if (c < ndw) o.codes[c] = A.pcodes[(int64_t)c * DimUp + i];
 #pragma unroll
-            for (int c = 0; c < 2 * MAXC; c++) if (c < ncw) o.cols[c] = A.pcols[(int64_t)c * DimUp + i];
+            for (int c = 0; c < 2 * MAXC; c++) o.cols[c] = c < ncw ? A.pcols[(int64_t)c * DimUp + i] : ((uint32_t)i | ((uint32_t)i << 16));      // slots beyond the image (odd widths): the row's own position, like any padding slot -- never an uninitialised LDS index
         };
         Ops cur, nxt;
         if (tid < DimUp) load_ops(tid, cur);
@@ -608,7 +608,7 @@ __global__ void __launch_bounds__(NT) k_uppass_ax(UpAxArgs A)
 #pragma unroll
             for (int c = 0; c < MAXC; c++) if (c < ndw) o.codes[c] = A.pcodes[(int64_t)c * DimUp + i];
 #pragma unroll
-            for (int c = 0; c < 2 * MAXC; c++) if (c < ncw) o.cols[c] = A.pcols[(int64_t)c * DimUp + i];
+            for (int c = 0; c < 2 * MAXC; c++) o.cols[c] = c < ncw ? A.pcols[(int64_t)c * DimUp + i] : ((uint32_t)i | ((uint32_t)i << 16));      // slots beyond the image (odd widths): the row's own position, like any padding slot -- never an uninitialised LDS index
         };
         Ops cur, nxt;
         if (tid < DimUp) load_ops(tid, cur);
