@@ -10,10 +10,13 @@
  * accumulation order and 1-based indexing follow the reference so that the
  * floating point results are those of the reference's CPU path.
  *
- * Parity pin status: see oracle/README.md -- pinned against the known-answer
- * values recorded from the reference build in SURVEY.md section 8c
- * (tests/golden/survey_known_answers.json) and against dense
- * diagonalisation; the reference itself has no tests or golden vectors.
+ * Parity pin status: PARITY UNPINNED.  The reference holds no tests, fixtures or golden
+ * vectors for this path and cannot be built in this repository (its modules need SciFortran,
+ * DMFT_Tools and MPI; no stand-ins are written), so nothing of the reference itself pins this
+ * restatement.  Its external anchors are the known-answer values the survey recorded
+ * (tests/golden/survey_known_answers.json -- one of the six records is
+ * marked unpinned there), dense diagonalisation, and the internal redundancy
+ * stored == direct == dense*v == sampled rows (orc_rows).  See oracle/README.md.
  */
 #include <stdint.h>
 #include <stdio.h>
