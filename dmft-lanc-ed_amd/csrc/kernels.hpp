@@ -1560,6 +1560,9 @@ struct CsrArgs {
     int32_t pass;      // 0: whole product; 1: first block of a split CSR (no alpha); 2: last block (y +=, alpha);
                        // 3: a block in between (y +=, no alpha)
     int32_t coltiles;  // 1: blocks sweep XCD-affine column tiles (idw fastest) -- the dw block of a split CSR
+    // dw-type blocks: every row of one idw row has the same length, rowptr(iup, idw) = rowbase[idw] + iup * rowcnt[idw];
+    // when set the row pointer array is not read at all
+    const int64_t *rowbase; const int32_t *rowcnt;
 };
 
 // Row-block CSR product.  A workgroup owns `rows_per_block` consecutive rows of one idw row.  Their
@@ -1603,13 +1606,15 @@ __global__ void __launch_bounds__(ROWS) k_csr_spmv2(CsrArgs A)
     const int iup0 = jb * A.rows_per_block;
     int nr = A.DimUp - iup0; if (nr > A.rows_per_block) nr = A.rows_per_block;
     const int64_t row0 = idwl * A.DimUp + iup0;
-    const int64_t p0 = A.rowptr[row0], p1 = A.rowptr[row0 + nr];
-    const int n = (int)(p1 - p0);
+    int64_t p0; int n, ucnt = 0;
+    if (A.rowbase) { ucnt = A.rowcnt[idwl]; p0 = A.rowbase[idwl] + (int64_t)iup0 * ucnt; n = nr * ucnt; }
+    else { p0 = A.rowptr[row0]; n = (int)(A.rowptr[row0 + nr] - p0); }
     const int sh = (int)(p0 & 3);
     int ra = 0, re = 0;
     double up_i = 0.0, xl_i = 0.0;   // epilogue operands, requested before the stream so their latency hides under it
     if (tid < nr) {
-        ra = (int)(A.rowptr[row0 + tid] - p0) + sh; re = (int)(A.rowptr[row0 + tid + 1] - p0) + sh;
+        if (A.rowbase) { ra = tid * ucnt + sh; re = ra + ucnt; }
+        else { ra = (int)(A.rowptr[row0 + tid] - p0) + sh; re = (int)(A.rowptr[row0 + tid + 1] - p0) + sh; }
         if (A.epi && A.pass < 2) up_i = A.uprev[row0 + tid];
         if (A.epi && (A.pass == 0 || A.pass == 2)) xl_i = A.v_local[row0 + tid];
         if (A.pass >= 2) up_i = A.y[row0 + tid];        // running value of the earlier blocks

@@ -315,6 +315,7 @@ static int hxv(S *s, const double *v, double *out, bool epi, const double *uprev
                 // dw hops into the rank's own rows: their columns are the first Qdw rows of the x-space, i.e. the local
                 // shard itself -- this block too runs while the exchange is in flight
                 A.rowptr = s->csrO_rowptr.p; A.cols = s->csrO_cols.p; A.vals = s->csrO_vals.p; A.pass = 3;
+                if (s->csr_uni) { A.rowbase = s->csrO_base.p; A.rowcnt = s->csrO_cnt.p; }
                 launch(A, s->csrD_small, false, nblocks);
                 HIPCHK(hipGetLastError());
             }
@@ -337,6 +338,7 @@ static int hxv(S *s, const double *v, double *out, bool epi, const double *uprev
                 HIPCHK(hipGetLastError());
             }
             A.rowptr = s->csrD_rowptr.p; A.cols = s->csrD_cols.p; A.vals = s->csrD_vals.p;
+            if (s->csr_uni) { A.rowbase = s->csrD_base.p; A.rowcnt = s->csrD_cnt.p; }
             A.pass = 2;
             nblocks = 8 * cdiv(s->csrD_bpr, 8) * H.Qdw;
             launch(A, s->csrD_small, s->csrD_nt != 0, nblocks);

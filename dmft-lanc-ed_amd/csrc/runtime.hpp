@@ -172,6 +172,10 @@ struct edgpu_sector_s {
     // explicit CSR
     DevBuf<int64_t> csr_rowptr, uppre, dwpre; DevBuf<int32_t> csr_cols; DevBuf<double> csr_vals;
     DevBuf<int64_t> csrD_rowptr; DevBuf<int32_t> csrD_cols; DevBuf<double> csrD_vals;   // dw block of the split form
+    // every row of one idw row holds the same number of dw hops: the dw-type blocks keep their row pointer in the factored
+    // form rowptr(iup, idw) = base[idw] + iup * cnt[idw] (the full arrays above stay for the row export only) and the
+    // product streams no row pointer for them
+    DevBuf<int64_t> csrD_base, csrO_base; DevBuf<int32_t> csrD_cnt, csrO_cnt; bool csr_uni = false;
     // needed-rows exchange: the dw block is stored as two blocks, hops into the rank's own rows (runs while the exchange
     // is in flight) and hops into received rows (csrD_*: runs after it)
     DevBuf<int64_t> csrO_rowptr, selpre_own, selpre_halo; DevBuf<int32_t> csrO_cols; DevBuf<double> csrO_vals; bool csr_three = false; int64_t csrO_nnz = 0;

@@ -319,6 +319,19 @@ static int build_csr(S *s)
             hipLaunchKernelGGL(k_csr_build, dim3(gb), dim3(256), 0, s->stream, A, 2);
             A.sel = 0; A.selpre = nullptr;
         }
+        {   // factored row pointers of the dw-type blocks
+            std::vector<int64_t> bD(H.Qdw + 1, 0), bO(H.Qdw + 1, 0); std::vector<int32_t> cD(H.Qdw, 0), cO(H.Qdw, 0);
+            std::vector<int32_t> xc;
+            if (s->csr_three) { xc.resize(dw.cols.size()); HIPCHK(hipMemcpy(xc.data(), s->dw_cols_x.p, xc.size() * 4, hipMemcpyDeviceToHost)); }
+            for (int64_t q = 0; q < H.Qdw; q++) {
+                int32_t no = 0, nh = 0;
+                for (int64_t pp = dw.rowptr[H.dw0 + q]; pp < dw.rowptr[H.dw0 + q + 1]; pp++) (s->csr_three && xc[pp] < H.Qdw ? no : nh)++;
+                cD[q] = nh; cO[q] = no; bD[q + 1] = bD[q] + (int64_t)nh * up.dim; bO[q + 1] = bO[q] + (int64_t)no * up.dim;
+            }
+            CHK(s->csrD_base.upload(bD)); CHK(s->csrD_cnt.upload(cD));
+            if (s->csr_three) { CHK(s->csrO_base.upload(bO)); CHK(s->csrO_cnt.upload(cO)); }
+            s->csr_uni = dbg_int("EDGPU_CSR_UNI", 1) != 0;
+        }
         int64_t ndmax = 0;
         for (int64_t q = 0; q < H.Qdw; q++) ndmax = std::max<int64_t>(ndmax, dw.rowptr[H.dw0 + q + 1] - dw.rowptr[H.dw0 + q]);
         s->csrD_rpb = (int32_t)std::min<int64_t>(dbg_int("EDGPU_CSRD_ROWS", 64), 1152 / std::max<int64_t>(ndmax, 1));
