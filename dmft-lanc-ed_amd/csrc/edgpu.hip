@@ -426,6 +426,7 @@ int edgpu_sector_describe(edgpu_handle h, char *buf, int32_t cap)
     std::string t = d.storage == EDGPU_STORE_CSR ? "storage=csr" : (d.storage == EDGPU_STORE_DIRECT ? "storage=direct" : "storage=kron");
     if (d.storage == EDGPU_STORE_CSR) {
         t += h->csr_three ? " blocks=local+own-dw+received-dw" : (h->csr_split ? " blocks=local+dw" : " blocks=one");
+        if (h->csr_split && h->csr_uni) t += " dw-rowptr=factored";
         if (h->nd_nr > 0) t += "+nonlocal(compressed rows)";
         if (H.DimPh > 1) t += "+phonon(stored g)";
     } else if (h->kron2) {

@@ -225,7 +225,7 @@ def test_large_sector_code_paths_on_small_sectors(edgpu_mod, monkeypatch, name, 
     for env in ({"EDGPU_KRON_SPLIT": "1", "EDGPU_CSR_SPLIT": "1"},
                 {"EDGPU_COMPOSITE": "0"},      # ed_total_ud=F through the generic mixed-radix kernel instead of the composite two-factor path (no CSR there)
                 {"EDGPU_KRON_SPLIT": "1", "EDGPU_CSR_SPLIT": "1", "EDGPU_DW_W": "8", "EDGPU_DW_ROWS": "16", "EDGPU_CSRD_ROWS": "16", "EDGPU_UP_GRID": "3"},
-                {"EDGPU_KRON_SPLIT": "1", "EDGPU_DW_VARIANT": "1", "EDGPU_UP_PERSISTENT": "0", "EDGPU_CSR_SPLIT": "1", "EDGPU_CSRD_NT": "0"},
+                {"EDGPU_KRON_SPLIT": "1", "EDGPU_DW_VARIANT": "1", "EDGPU_UP_PERSISTENT": "0", "EDGPU_CSR_SPLIT": "1", "EDGPU_CSRD_NT": "0", "EDGPU_CSR_UNI": "0"},
                 {"EDGPU_CSR_SPLIT": "0", "EDGPU_KRON_SPLIT": "1", "EDGPU_UP_THREADS": "512", "EDGPU_UP_PAIRS": "0"},
                 {"EDGPU_KRON_SPLIT": "1", "EDGPU_DEBUG": "4"},                                  # long-row path: one workgroup per row segment, halo in LDS (k_uppass_halo)
                 {"EDGPU_KRON_SPLIT": "1", "EDGPU_DEBUG": "4", "EDGPU_UP_GRID": "24", "EDGPU_LZ_FUSED": "0"},     # ... with idle workgroups (3 per XCD, 2 segments)
