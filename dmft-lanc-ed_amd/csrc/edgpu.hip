@@ -223,12 +223,61 @@ static int csr_rows_el(edgpu_handle h, int64_t row0, int64_t nrows, int64_t *row
         if (n) { HIPCHK(hipMemcpy(hc.data(), cc.p + hrp[0], (size_t)n * 4, hipMemcpyDeviceToHost)); HIPCHK(hipMemcpy(hv.data(), vv.p + hrp[0], (size_t)n * 8, hipMemcpyDeviceToHost)); }
         return EDGPU_OK;
     };
+    // blocks stored lane-major per 64-row block (k_csr_il): fetch the row blocks that cover the window and undo the interleave
+    auto fetch_il = [&](DevBuf<int64_t> &rp, DevBuf<int32_t> &cc, DevBuf<double> &vv, std::vector<int64_t> &hrp, std::vector<int32_t> &hc, std::vector<double> &hv) -> int {
+        const int64_t DU = h->H.DimUp;
+        auto blk0 = [&](int64_t r) { const int64_t q = r / DU, i = r - q * DU; return q * DU + (i / 64) * 64; };
+        auto blkn = [&](int64_t r) { const int64_t q = r / DU, i = r - q * DU; return std::min<int64_t>(64, DU - (i / 64) * 64); };
+        hrp.assign((size_t)nrows + 1, 0);
+        if (nrows == 0) { HIPCHK(hipMemcpy(hrp.data(), rp.p + row0, 8, hipMemcpyDeviceToHost)); return EDGPU_OK; }
+        const int64_t rA = blk0(row0), rl = row0 + nrows - 1, rB = blk0(rl) + blkn(rl);
+        std::vector<int64_t> w((size_t)(rB - rA) + 1);
+        HIPCHK(hipMemcpy(w.data(), rp.p + rA, w.size() * 8, hipMemcpyDeviceToHost));
+        const int64_t m = w.back() - w[0];
+        std::vector<int32_t> tc((size_t)m); std::vector<double> tv((size_t)m);
+        if (m) { HIPCHK(hipMemcpy(tc.data(), cc.p + w[0], (size_t)m * 4, hipMemcpyDeviceToHost)); HIPCHK(hipMemcpy(tv.data(), vv.p + w[0], (size_t)m * 8, hipMemcpyDeviceToHost)); }
+        for (int64_t r = 0; r <= nrows; r++) hrp[r] = w[row0 + r - rA];
+        hc.resize((size_t)(hrp[nrows] - hrp[0])); hv.resize(hc.size());
+        for (int64_t r = 0; r < nrows; r++) {
+            const int64_t g = row0 + r, b0 = blk0(g), nr = blkn(g), len = hrp[r + 1] - hrp[r], base = w[b0 - rA] - w[0];
+            for (int64_t e = 0; e < len; e++) { hc[hrp[r] - hrp[0] + e] = tc[base + e * nr + (g - b0)]; hv[hrp[r] - hrp[0] + e] = tv[base + e * nr + (g - b0)]; }
+        }
+        return EDGPU_OK;
+    };
+    // ... and stored tile-major (dw-type blocks): block (jb, idw) at jb*64*ctot + rows(jb)*cpre[idw]; one copy per block touched
+    auto fetch_tm = [&](DevBuf<int64_t> &rp, DevBuf<int32_t> &cc, DevBuf<double> &vv, const std::vector<int32_t> &cnt, std::vector<int64_t> &hrp, std::vector<int32_t> &hc, std::vector<double> &hv) -> int {
+        const int64_t DU = h->H.DimUp;
+        std::vector<int64_t> cpre(cnt.size() + 1, 0);
+        for (size_t q = 0; q < cnt.size(); q++) cpre[q + 1] = cpre[q] + cnt[q];
+        const int64_t ctot = cpre.back();
+        hrp.resize((size_t)nrows + 1);
+        HIPCHK(hipMemcpy(hrp.data(), rp.p + row0, (size_t)(nrows + 1) * 8, hipMemcpyDeviceToHost));
+        hc.resize((size_t)(hrp[nrows] - hrp[0])); hv.resize(hc.size());
+        std::vector<int32_t> tc; std::vector<double> tv; int64_t have = -1;
+        for (int64_t r = 0; r < nrows; r++) {
+            const int64_t g = row0 + r, q = g / DU, i = g - q * DU, i0 = (i / 64) * 64, nr = std::min<int64_t>(64, DU - i0), len = cnt[q];
+            const int64_t base = i0 * ctot + nr * cpre[q];
+            if (base != have && len > 0) {
+                tc.resize((size_t)(nr * len)); tv.resize(tc.size()); have = base;
+                HIPCHK(hipMemcpy(tc.data(), cc.p + base, tc.size() * 4, hipMemcpyDeviceToHost)); HIPCHK(hipMemcpy(tv.data(), vv.p + base, tv.size() * 8, hipMemcpyDeviceToHost));
+            }
+            if (hrp[r + 1] - hrp[r] != len) return fail(EDGPU_EINVAL, "edgpu_csr_rows: internal: row length mismatch in a tile-major block");
+            for (int64_t e = 0; e < len; e++) { hc[hrp[r] - hrp[0] + e] = tc[e * nr + (i - i0)]; hv[hrp[r] - hrp[0] + e] = tv[e * nr + (i - i0)]; }
+        }
+        return EDGPU_OK;
+    };
+    auto fetch_dw = [&](DevBuf<int64_t> &rp, DevBuf<int32_t> &cc, DevBuf<double> &vv, const std::vector<int32_t> &cnt, std::vector<int64_t> &hrp, std::vector<int32_t> &hc, std::vector<double> &hv) -> int {
+        if (h->csr_tm) return fetch_tm(rp, cc, vv, cnt, hrp, hc, hv);
+        if (h->csr_il_dw) return fetch_il(rp, cc, vv, hrp, hc, hv);
+        return fetch(rp, cc, vv, hrp, hc, hv);
+    };
     // merged view (ascending columns) of the one, two or three stored blocks
     std::vector<int64_t> rp[4]; std::vector<int32_t> cc[4]; std::vector<double> vv[4];
     int nblk = 1;
-    CHK(fetch(h->csr_rowptr, h->csr_cols, h->csr_vals, rp[0], cc[0], vv[0]));
-    if (h->csr_split) { CHK(fetch(h->csrD_rowptr, h->csrD_cols, h->csrD_vals, rp[1], cc[1], vv[1])); nblk = 2; }
-    if (h->csr_three) { CHK(fetch(h->csrO_rowptr, h->csrO_cols, h->csrO_vals, rp[2], cc[2], vv[2])); nblk = 3; }
+    if (h->csr_split && h->csr_il_loc) CHK(fetch_il(h->csr_rowptr, h->csr_cols, h->csr_vals, rp[0], cc[0], vv[0]));
+    else CHK(fetch(h->csr_rowptr, h->csr_cols, h->csr_vals, rp[0], cc[0], vv[0]));
+    if (h->csr_split) { CHK(fetch_dw(h->csrD_rowptr, h->csrD_cols, h->csrD_vals, h->h_cntD, rp[1], cc[1], vv[1])); nblk = 2; }
+    if (h->csr_three) { CHK(fetch_dw(h->csrO_rowptr, h->csrO_cols, h->csrO_vals, h->h_cntO, rp[2], cc[2], vv[2])); nblk = 3; }
     if (h->nd_nr > 0) {     // non-local block (compressed rows): expand the window's part into a row-pointer form
         auto at = [&](const int64_t *p, int64_t i, int64_t &o) -> int { HIPCHK(hipMemcpy(&o, p + i, 8, hipMemcpyDeviceToHost)); return EDGPU_OK; };
         auto lower = [&](int64_t key, int64_t &pos) -> int {       // first non-empty row >= key
@@ -427,6 +476,7 @@ int edgpu_sector_describe(edgpu_handle h, char *buf, int32_t cap)
     if (d.storage == EDGPU_STORE_CSR) {
         t += h->csr_three ? " blocks=local+own-dw+received-dw" : (h->csr_split ? " blocks=local+dw" : " blocks=one");
         if (h->csr_split && h->csr_uni) t += " dw-rowptr=factored";
+        if (h->csr_split && (h->csr_il_loc || h->csr_il_dw)) t += std::string(" lane-major-blocks=") + (h->csr_il_loc ? "local" : "") + (h->csr_il_loc && h->csr_il_dw ? "+" : "") + (h->csr_il_dw ? (h->csr_tm ? "dw(tile-major)" : "dw") : "");
         if (h->nd_nr > 0) t += "+nonlocal(compressed rows)";
         if (H.DimPh > 1) t += "+phonon(stored g)";
     } else if (h->kron2) {

@@ -1515,6 +1515,10 @@ struct CsrBuildArgs {
     int64_t *rowptr; int32_t *cols; double *vals;
     int32_t sel; const int64_t *selpre;   // part 2 only: 0 all dw hops; 1 those into the rank's own rows; 2 those into received (halo)
                                           // rows.  selpre[idwl] = entries of the selected kind in the rows before idwl (times DimUp)
+    int32_t tm; const int64_t *cpre;      // tm (dw-type blocks, with il): blocks stored tile-major, block (jb, idw) at jb*rpb*cpre[Qdw] + rows(jb)*cpre[idw]
+    int32_t il, rpb;                      // il: entries of each block of `rpb` consecutive rows of one idw row are stored lane-major
+                                          // (entry e of the block's row lr at block_start + e*rows_in_block + lr); all rows of a block
+                                          // have the same length.  rowptr keeps the row-major numbers (block start, row lengths).
 };
 
 // row (iup, idw) holds, in ascending column order: dw hops to jdw<idw, up hops jup<iup, the
@@ -1534,21 +1538,33 @@ __global__ void __launch_bounds__(256) k_csr_build(CsrBuildArgs A, int part)
     const int32_t d0 = A.dwrp[idw], d1 = A.dwrp[idw + 1], u0 = A.uprp[iup], u1 = A.uprp[iup + 1];
     const int ndw = d1 - d0;
     auto keep = [&](int32_t xr) { return A.sel == 0 || (A.sel == 1) == (xr < A.Qdw); };   // x-space rows [0,Qdw) are the rank's own
-    int64_t p;
-    if (part == 0) p = A.dwpre[idwl] + (int64_t)iup * ndw + A.uppre[iup];
-    else if (part == 1) p = idwl * upall + A.uppre[iup];
-    else if (A.sel == 0) p = A.dwpre[idwl] - idwl * upall + (int64_t)iup * ndw;
-    else { int nsel = 0; for (int32_t q = d0; q < d1; q++) nsel += keep(A.dwc[q]) ? 1 : 0; p = A.selpre[idwl] + (int64_t)iup * nsel; }
+    int nsel = 0;
+    if (part == 2 && A.sel) for (int32_t q = d0; q < d1; q++) nsel += keep(A.dwc[q]) ? 1 : 0;
+    auto rowstart = [&](int ix) -> int64_t {
+        if (part == 0) return A.dwpre[idwl] + (int64_t)ix * ndw + A.uppre[ix];
+        if (part == 1) return idwl * upall + A.uppre[ix];
+        if (A.sel == 0) return A.dwpre[idwl] - idwl * upall + (int64_t)ix * ndw;
+        return A.selpre[idwl] + (int64_t)ix * nsel;
+    };
+    const int64_t p = rowstart(iup);
     A.rowptr[il] = p;
+    // position of the row's e-th entry: row-major p + e, or lane-major inside the row block
+    int64_t q0 = p, qs = 1;
+    if (A.il) {
+        const int iup0 = (iup / A.rpb) * A.rpb; int nr = A.DimUp - iup0; if (nr > A.rpb) nr = A.rpb;
+        q0 = (A.tm && part == 2 ? (int64_t)iup0 * A.cpre[A.Qdw] + (int64_t)nr * A.cpre[idwl] : rowstart(iup0)) + (iup - iup0); qs = nr;
+    }
+    int e = 0;
+    auto emit = [&](int32_t c, double v) { const int64_t q = q0 + (int64_t)e * qs; A.cols[q] = c; A.vals[q] = v; e++; };
     const int64_t xrow = idw - A.rowshift;     // index of this dw row in the column (x) space
-    if (part != 1) for (int32_t q = d0; q < d1; q++) if (A.dwc[q] < xrow && keep(A.dwc[q])) { A.cols[p] = (int32_t)((int64_t)A.dwc[q] * A.DimUp + iup); A.vals[p] = A.dwv[q]; p++; }
+    if (part != 1) for (int32_t q = d0; q < d1; q++) if (A.dwc[q] < xrow && keep(A.dwc[q])) emit((int32_t)((int64_t)A.dwc[q] * A.DimUp + iup), A.dwv[q]);
     if (part != 2) {
         int32_t r = u0;
-        for (; r < u1 && A.upc[r] < iup; r++) { A.cols[p] = (int32_t)(xrow * A.DimUp + A.upc[r]); A.vals[p] = A.upv[r]; p++; }
-        A.cols[p] = (int32_t)(xrow * A.DimUp + iup); A.vals[p] = A.diag[il]; p++;
-        for (; r < u1; r++) { A.cols[p] = (int32_t)(xrow * A.DimUp + A.upc[r]); A.vals[p] = A.upv[r]; p++; }
+        for (; r < u1 && A.upc[r] < iup; r++) emit((int32_t)(xrow * A.DimUp + A.upc[r]), A.upv[r]);
+        emit((int32_t)(xrow * A.DimUp + iup), A.diag[il]);
+        for (; r < u1; r++) emit((int32_t)(xrow * A.DimUp + A.upc[r]), A.upv[r]);
     }
-    if (part != 1) for (int32_t q = d0; q < d1; q++) if (A.dwc[q] >= xrow && keep(A.dwc[q])) { A.cols[p] = (int32_t)((int64_t)A.dwc[q] * A.DimUp + iup); A.vals[p] = A.dwv[q]; p++; }
+    if (part != 1) for (int32_t q = d0; q < d1; q++) if (A.dwc[q] >= xrow && keep(A.dwc[q])) emit((int32_t)((int64_t)A.dwc[q] * A.DimUp + iup), A.dwv[q]);
 }
 
 struct CsrArgs {
@@ -1563,6 +1579,7 @@ struct CsrArgs {
     // dw-type blocks: every row of one idw row has the same length, rowptr(iup, idw) = rowbase[idw] + iup * rowcnt[idw];
     // when set the row pointer array is not read at all
     const int64_t *rowbase; const int32_t *rowcnt;
+    const int64_t *cpre;    // lane-major dw-type blocks stored tile-major (k_csr_il only): block (jb, idw) starts at jb*64*cpre[Qdw] + rows(jb)*cpre[idw]
 };
 
 // Row-block CSR product.  A workgroup owns `rows_per_block` consecutive rows of one idw row.  Their
@@ -1573,6 +1590,117 @@ struct CsrArgs {
 typedef double dbl2_t __attribute__((ext_vector_type(2)));
 typedef int int4_t __attribute__((ext_vector_type(4)));
 
+// blockIdx -> (local dw row, row block inside it) for the two sweep orders; false: idle block
+__device__ __forceinline__ bool csr_block_map(const CsrArgs &A, int64_t &idwl, int &jb)
+{
+    if (A.coltiles) {
+        // column tile jb is owned by XCD (jb % 8); that XCD walks all idw rows of the tile, so the
+        // x slab x(tile, all idw) that the dw hops gather from stays in its L2
+        // (32-bit arithmetic: blockIdx and the number of local dw rows both fit, and a 64-bit division costs hundreds of instructions per block)
+        const uint32_t xcd = blockIdx.x & 7u, sidx = blockIdx.x >> 3, q = (uint32_t)A.Qdw;
+        const uint32_t tl = sidx / q; idwl = sidx - tl * q; jb = (int)(tl * 8u + xcd);
+        return jb < A.blocks_per_row;
+    }
+    const int64_t per_tile = (int64_t)A.tile * A.Qdw;
+    const int nt_full = A.blocks_per_row / A.tile;
+    if (!A.xcd_rows && per_tile < ((int64_t)1 << 31)) {      // the common case in 32-bit arithmetic
+        const uint32_t b = blockIdx.x, pt = (uint32_t)per_tile;
+        uint32_t t, r, tw;
+        if (b < (uint32_t)nt_full * pt) { t = b / pt; r = b - t * pt; tw = (uint32_t)A.tile; }
+        else { t = (uint32_t)nt_full; r = b - (uint32_t)nt_full * pt; tw = (uint32_t)(A.blocks_per_row - nt_full * A.tile); }
+        const uint32_t q = r / tw; idwl = q; jb = (int)(t * (uint32_t)A.tile + (r - q * tw));
+        return true;
+    }
+    const int64_t b = blockIdx.x;
+    int64_t t, r; int tw;
+    if (b < (int64_t)nt_full * per_tile) { t = b / per_tile; r = b - t * per_tile; tw = A.tile; }
+    else { t = nt_full; r = b - (int64_t)nt_full * per_tile; tw = A.blocks_per_row - nt_full * A.tile; }
+    if (A.xcd_rows) {
+        // workgroups are dealt round-robin over the 8 XCDs: keep all row blocks of one idw row on
+        // one XCD (its L2 then serves that row's up-hop gathers).  Speed only, never correctness.
+        const int64_t q8 = A.Qdw & ~(int64_t)7, body = q8 * tw;
+        if (r < body) { const int64_t g = r / (8 * (int64_t)tw), w = r - g * 8 * tw; idwl = g * 8 + (w & 7); jb = (int)(t * A.tile + (w >> 3)); }
+        else { const int64_t w = r - body; idwl = q8 + w / tw; jb = (int)(t * A.tile + (w - (w / tw) * tw)); }
+    } else { idwl = r / tw; jb = (int)(t * A.tile + (r - idwl * tw)); }
+    return true;
+}
+
+// Row-block product on the LANE-MAJOR image of a block (csr_il): every row of the 64-row block has the same length, entry e
+// of the block's row lr sits at block_start + e*rows + lr, so lane lr reads its own row with coalesced loads (512 B of
+// values, 256 B of columns per instruction and wave) -- no LDS staging, no transposition, and every load of the block is in
+// flight before the first gather.  Occupancy is bounded by registers only, which is what keeps enough of the stream in
+// flight per CU.  The local block takes block start and row length from the streamed row pointer; dw-type blocks from the
+// factored form.
+template <int C, bool NT>
+__device__ __forceinline__ double csr_il_row(const double *__restrict__ pv, const int32_t *__restrict__ pc, int nr, const double *__restrict__ x)
+{
+    double v[C]; int32_t c[C];
+#pragma unroll
+    for (int e = 0; e < C; e++) {
+        if (NT) { v[e] = __builtin_nontemporal_load(pv + (int64_t)e * nr); c[e] = __builtin_nontemporal_load(pc + (int64_t)e * nr); }
+        else { v[e] = pv[(int64_t)e * nr]; c[e] = pc[(int64_t)e * nr]; }
+    }
+    double xv[C];
+#pragma unroll
+    for (int e = 0; e < C; e++) xv[e] = x[c[e]];
+    double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+    for (int e = 0; e < C; e++) { if (e & 1) a1 += v[e] * xv[e]; else a0 += v[e] * xv[e]; }
+    return a0 + a1;
+}
+
+template <bool NT, int BLK /* 0: local block, 1: a dw-type block -- keeps the two apart in kernel traces */>
+__global__ void __launch_bounds__(64) k_csr_il(CsrArgs A)
+{
+    __shared__ double red[4];
+    int64_t idwl; int jb;
+    if (!csr_block_map(A, idwl, jb)) { if (A.epi && (A.pass == 0 || A.pass == 2) && threadIdx.x == 0) A.partial[blockIdx.x] = 0.0; return; }
+    const int tid = threadIdx.x;
+    const int iup0 = jb * A.rows_per_block;
+    int nr = A.DimUp - iup0; if (nr > A.rows_per_block) nr = A.rows_per_block;
+    const int64_t row0 = idwl * A.DimUp + iup0;
+    const bool act = tid < nr;
+    int64_t p0; int cnt;
+    if (A.cpre) { cnt = A.rowcnt[idwl]; p0 = (int64_t)iup0 * A.cpre[A.Qdw] + (int64_t)nr * A.cpre[idwl]; }
+    else if (A.rowbase) { cnt = A.rowcnt[idwl]; p0 = A.rowbase[idwl] + (int64_t)iup0 * cnt; }
+    else {
+        // streamed row pointer: lane r holds rowptr[row0 + r] and the next one; block start = first lane's, length = difference
+        const int64_t ra = A.rowptr[row0 + (act ? tid : 0)], re = A.rowptr[row0 + (act ? tid : 0) + 1];
+        p0 = ((int64_t)__builtin_amdgcn_readfirstlane((int)(ra >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(ra & 0xffffffffll));
+        cnt = __builtin_amdgcn_readfirstlane((int)(re - ra));
+    }
+    double up_i = 0.0, xl_i = 0.0;
+    if (act) {
+        if (A.epi && A.pass < 2) up_i = A.uprev[row0 + tid];
+        if (A.epi && (A.pass == 0 || A.pass == 2)) xl_i = A.v_local[row0 + tid];
+        if (A.pass >= 2) up_i = A.y[row0 + tid];        // running value of the earlier blocks
+    }
+    double s_cur = 1.0, c_prev = 0.0, asum = 0.0;
+    if (A.epi) { s_cur = A.scal[SC_SCUR]; c_prev = A.scal[SC_BETA] * A.scal[SC_SPREV]; }
+    if (act) {
+        const double *pv = A.vals + p0 + tid; const int32_t *pc = A.cols + p0 + tid;
+        double acc;
+        switch (cnt) {
+        case 9: acc = csr_il_row<9, NT>(pv, pc, nr, A.x); break;
+        case 8: acc = csr_il_row<8, NT>(pv, pc, nr, A.x); break;
+        case 7: acc = csr_il_row<7, NT>(pv, pc, nr, A.x); break;
+        case 6: acc = csr_il_row<6, NT>(pv, pc, nr, A.x); break;
+        case 5: acc = csr_il_row<5, NT>(pv, pc, nr, A.x); break;
+        default: {
+            acc = 0.0; int e = 0;
+            for (; e + 4 <= cnt; e += 4) acc += csr_il_row<4, NT>(pv + (int64_t)e * nr, pc + (int64_t)e * nr, nr, A.x);
+            for (; e < cnt; e++) acc += csr_il_row<1, NT>(pv + (int64_t)e * nr, pc + (int64_t)e * nr, nr, A.x);
+        }
+        }
+        const int64_t row = row0 + tid;
+        if (A.epi) {
+            const double w = A.pass >= 2 ? up_i + s_cur * acc : s_cur * acc - c_prev * up_i;
+            A.y[row] = w; asum = (s_cur * xl_i) * w;
+        } else A.y[row] = A.pass >= 2 ? up_i + acc : acc;
+    }
+    if (A.epi && (A.pass == 0 || A.pass == 2)) { double r = block_sum(asum, red); if (tid == 0) A.partial[blockIdx.x] = r; }
+}
+
 template <int ROWS, int CAPN, bool NT>
 __global__ void __launch_bounds__(ROWS) k_csr_spmv2(CsrArgs A)
 {
@@ -1582,26 +1710,7 @@ __global__ void __launch_bounds__(ROWS) k_csr_spmv2(CsrArgs A)
     __shared__ __attribute__((aligned(16))) int32_t scol[CAPN + 4];
     __shared__ double red[4];
     int64_t idwl; int jb;
-    if (A.coltiles) {
-        // column tile jb is owned by XCD (jb % 8); that XCD walks all idw rows of the tile, so the
-        // x slab x(tile, all idw) that the dw hops gather from stays in its L2
-        const int xcd = blockIdx.x & 7; const int64_t sidx = blockIdx.x >> 3;
-        const int64_t tl = sidx / A.Qdw; idwl = sidx - tl * A.Qdw; jb = (int)(tl * 8 + xcd);
-        if (jb >= A.blocks_per_row) { if (A.epi && (A.pass == 0 || A.pass == 2) && threadIdx.x == 0) A.partial[blockIdx.x] = 0.0; return; }
-    } else {
-        const int64_t b = blockIdx.x, per_tile = (int64_t)A.tile * A.Qdw;
-        const int nt_full = A.blocks_per_row / A.tile;
-        int64_t t, r; int tw;
-        if (b < (int64_t)nt_full * per_tile) { t = b / per_tile; r = b - t * per_tile; tw = A.tile; }
-        else { t = nt_full; r = b - (int64_t)nt_full * per_tile; tw = A.blocks_per_row - nt_full * A.tile; }
-        if (A.xcd_rows) {
-            // workgroups are dealt round-robin over the 8 XCDs: keep all row blocks of one idw row on
-            // one XCD (its L2 then serves that row's up-hop gathers).  Speed only, never correctness.
-            const int64_t q8 = A.Qdw & ~(int64_t)7, body = q8 * tw;
-            if (r < body) { const int64_t g = r / (8 * (int64_t)tw), w = r - g * 8 * tw; idwl = g * 8 + (w & 7); jb = (int)(t * A.tile + (w >> 3)); }
-            else { const int64_t w = r - body; idwl = q8 + w / tw; jb = (int)(t * A.tile + (w - (w / tw) * tw)); }
-        } else { idwl = r / tw; jb = (int)(t * A.tile + (r - idwl * tw)); }
-    }
+    if (!csr_block_map(A, idwl, jb)) { if (A.epi && (A.pass == 0 || A.pass == 2) && threadIdx.x == 0) A.partial[blockIdx.x] = 0.0; return; }
     const int tid = threadIdx.x;
     const int iup0 = jb * A.rows_per_block;
     int nr = A.DimUp - iup0; if (nr > A.rows_per_block) nr = A.rows_per_block;

@@ -294,19 +294,23 @@ static int hxv(S *s, const double *v, double *out, bool epi, const double *uprev
         // slices x(:,iph), y(:,iph) (x-space of one block: Xel elements; phonon sectors of several ranks use the full gather)
         const int nph = H.DimPh;
         const int64_t Xel = H.DimUp * (multi ? s->nhalo : H.DimDw);
-        auto launch = [&](const CsrArgs &B0, bool small, bool nt, int64_t nb) {
+        auto launch = [&](const CsrArgs &B0, bool small, bool nt, int64_t nb, bool il = false) {
             for (int iph = 0; iph < nph; iph++) {
                 CsrArgs B = B0;
                 B.x += (int64_t)iph * Xel; B.y += (int64_t)iph * s->nloc_el; B.v_local += (int64_t)iph * s->nloc_el;
                 if (B.uprev) B.uprev += (int64_t)iph * s->nloc_el;
                 B.partial += (int64_t)iph * nb;
-                if (small) { if (nt) hipLaunchKernelGGL((k_csr_spmv2<64, 640, true>), dim3((unsigned)nb), dim3(64), 0, s->stream, B); else hipLaunchKernelGGL((k_csr_spmv2<64, 640, false>), dim3((unsigned)nb), dim3(64), 0, s->stream, B); }
+                if (il) {
+                    if (B.coltiles) { if (nt) hipLaunchKernelGGL((k_csr_il<true, 1>), dim3((unsigned)nb), dim3(64), 0, s->stream, B); else hipLaunchKernelGGL((k_csr_il<false, 1>), dim3((unsigned)nb), dim3(64), 0, s->stream, B); }
+                    else { if (nt) hipLaunchKernelGGL((k_csr_il<true, 0>), dim3((unsigned)nb), dim3(64), 0, s->stream, B); else hipLaunchKernelGGL((k_csr_il<false, 0>), dim3((unsigned)nb), dim3(64), 0, s->stream, B); }
+                }
+                else if (small) { if (nt) hipLaunchKernelGGL((k_csr_spmv2<64, 640, true>), dim3((unsigned)nb), dim3(64), 0, s->stream, B); else hipLaunchKernelGGL((k_csr_spmv2<64, 640, false>), dim3((unsigned)nb), dim3(64), 0, s->stream, B); }
                 else { if (nt) hipLaunchKernelGGL((k_csr_spmv2<64, 1152, true>), dim3((unsigned)nb), dim3(64), 0, s->stream, B); else hipLaunchKernelGGL((k_csr_spmv2<64, 1152, false>), dim3((unsigned)nb), dim3(64), 0, s->stream, B); }
             }
         };
         nblocks = (int64_t)s->csr_bpr * H.Qdw;
         A.pass = s->csr_split ? 1 : 0; A.coltiles = 0;
-        launch(A, s->csr_split && s->csrL_small, false, nblocks);
+        launch(A, s->csr_split && s->csrL_small, s->csr_il_loc && s->csrL_nt, nblocks, s->csr_split && s->csr_il_loc);
         HIPCHK(hipGetLastError());
         if (s->csr_split) {
             A.rows_per_block = s->csrD_rpb; A.blocks_per_row = s->csrD_bpr; A.coltiles = 1; A.xcd_rows = 0;
@@ -315,8 +319,8 @@ static int hxv(S *s, const double *v, double *out, bool epi, const double *uprev
                 // dw hops into the rank's own rows: their columns are the first Qdw rows of the x-space, i.e. the local
                 // shard itself -- this block too runs while the exchange is in flight
                 A.rowptr = s->csrO_rowptr.p; A.cols = s->csrO_cols.p; A.vals = s->csrO_vals.p; A.pass = 3;
-                if (s->csr_uni) { A.rowbase = s->csrO_base.p; A.rowcnt = s->csrO_cnt.p; }
-                launch(A, s->csrD_small, false, nblocks);
+                if (s->csr_uni) { A.rowbase = s->csrO_base.p; A.rowcnt = s->csrO_cnt.p; A.cpre = s->csr_tm ? s->csrO_cpre.p : nullptr; }
+                launch(A, s->csrD_small, s->csr_il_dw && s->csrD_nt != 0, nblocks, s->csr_il_dw);
                 HIPCHK(hipGetLastError());
             }
             if (overlap) { HIPCHK(hipStreamWaitEvent(s->stream, s->ev_gather, 0)); A.x = s->vfull.p; }
@@ -338,10 +342,10 @@ static int hxv(S *s, const double *v, double *out, bool epi, const double *uprev
                 HIPCHK(hipGetLastError());
             }
             A.rowptr = s->csrD_rowptr.p; A.cols = s->csrD_cols.p; A.vals = s->csrD_vals.p;
-            if (s->csr_uni) { A.rowbase = s->csrD_base.p; A.rowcnt = s->csrD_cnt.p; }
+            if (s->csr_uni) { A.rowbase = s->csrD_base.p; A.rowcnt = s->csrD_cnt.p; A.cpre = s->csr_tm ? s->csrD_cpre.p : nullptr; }
             A.pass = 2;
             nblocks = 8 * cdiv(s->csrD_bpr, 8) * H.Qdw;
-            launch(A, s->csrD_small, s->csrD_nt != 0, nblocks);
+            launch(A, s->csrD_small, s->csrD_nt != 0, nblocks, s->csr_il_dw);
             HIPCHK(hipGetLastError());
         }
         nblocks *= nph;      // one partial per workgroup and phonon block

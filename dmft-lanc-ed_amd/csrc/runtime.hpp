@@ -176,9 +176,13 @@ struct edgpu_sector_s {
     // form rowptr(iup, idw) = base[idw] + iup * cnt[idw] (the full arrays above stay for the row export only) and the
     // product streams no row pointer for them
     DevBuf<int64_t> csrD_base, csrO_base; DevBuf<int32_t> csrD_cnt, csrO_cnt; bool csr_uni = false;
+    // lane-major image of the 64-row blocks (k_csr_il): the local block when every up configuration has the same number of
+    // hops, the dw-type blocks always (their rows are uniform per idw row)
+    bool csr_il_loc = false, csr_il_dw = false; bool csrL_nt = true;
+    bool csr_tm = false; DevBuf<int64_t> csrD_cpre, csrO_cpre; std::vector<int32_t> h_cntD, h_cntO;      // tile-major order of the dw-type blocks
     // needed-rows exchange: the dw block is stored as two blocks, hops into the rank's own rows (runs while the exchange
     // is in flight) and hops into received rows (csrD_*: runs after it)
-    DevBuf<int64_t> csrO_rowptr, selpre_own, selpre_halo; DevBuf<int32_t> csrO_cols; DevBuf<double> csrO_vals; bool csr_three = false; int64_t csrO_nnz = 0;
+    DevBuf<int64_t> csrO_rowptr; DevBuf<int32_t> csrO_cols; DevBuf<double> csrO_vals; bool csr_three = false; int64_t csrO_nnz = 0;
     // non-local (Jx/Jp) block of the explicit storage, compressed rows: k_nd_build / k_csr_nd
     DevBuf<double> csr_gel;      // phonon sectors: electronic factor of the e-ph coupling (the reference's diagonal spH0e_eph)
     DevBuf<int64_t> nd_rows, nd_ptr; DevBuf<int32_t> nd_cols; DevBuf<double> nd_vals; DevBuf<uint8_t> nd_slot; int64_t nd_nr = 0, nd_nnz = 0;

@@ -293,58 +293,65 @@ static int build_csr(S *s)
         hipLaunchKernelGGL(k_csr_build, dim3(gb), dim3(256), 0, s->stream, A, 0);
     } else {
         CHK(s->csr_rowptr.alloc((size_t)s->nloc_el + 1)); CHK(s->csr_cols.alloc((size_t)s->csrL_nnz + 8)); CHK(s->csr_vals.alloc((size_t)s->csrL_nnz + 8));
-        s->csr_three = s->halo && !H.Jhflag && dbg_int("EDGPU_CSR_THREE", 1) != 0;      // the stored non-local block reads own and received rows from one x buffer: keep the own-row copy
-        if (!s->csr_three) { CHK(s->csrD_rowptr.alloc((size_t)s->nloc_el + 1)); CHK(s->csrD_cols.alloc((size_t)s->csrD_nnz + 8)); CHK(s->csrD_vals.alloc((size_t)s->csrD_nnz + 8)); }
-        A.rowptr = s->csr_rowptr.p; A.cols = s->csr_cols.p; A.vals = s->csr_vals.p;
-        hipLaunchKernelGGL(k_csr_build, dim3(gb), dim3(256), 0, s->stream, A, 1);
-        if (!s->csr_three) {
-            A.rowptr = s->csrD_rowptr.p; A.cols = s->csrD_cols.p; A.vals = s->csrD_vals.p;
-            hipLaunchKernelGGL(k_csr_build, dim3(gb), dim3(256), 0, s->stream, A, 2);
-        } else {
-            // per local dw row: how many of its hops stay inside the rank's own rows (x-space row < Qdw)
-            std::vector<int64_t> po(H.Qdw + 1, 0), ph(H.Qdw + 1, 0);
-            std::vector<int32_t> xc; { xc.resize(dw.cols.size()); HIPCHK(hipMemcpy(xc.data(), s->dw_cols_x.p, xc.size() * 4, hipMemcpyDeviceToHost)); }
-            for (int64_t q = 0; q < H.Qdw; q++) {
-                int64_t no = 0, nh = 0;
-                for (int64_t pp = dw.rowptr[H.dw0 + q]; pp < dw.rowptr[H.dw0 + q + 1]; pp++) (xc[pp] < H.Qdw ? no : nh)++;
-                po[q + 1] = po[q] + no * up.dim; ph[q + 1] = ph[q] + nh * up.dim;
-            }
-            s->csrO_nnz = po[H.Qdw]; s->csrD_nnz = ph[H.Qdw];
-            CHK(s->selpre_own.upload(po)); CHK(s->selpre_halo.upload(ph));
-            CHK(s->csrD_rowptr.alloc((size_t)s->nloc_el + 1)); CHK(s->csrD_cols.alloc((size_t)s->csrD_nnz + 8)); CHK(s->csrD_vals.alloc((size_t)s->csrD_nnz + 8));
-            CHK(s->csrO_rowptr.alloc((size_t)s->nloc_el + 1)); CHK(s->csrO_cols.alloc((size_t)s->csrO_nnz + 8)); CHK(s->csrO_vals.alloc((size_t)s->csrO_nnz + 8));
-            A.sel = 1; A.selpre = s->selpre_own.p; A.rowptr = s->csrO_rowptr.p; A.cols = s->csrO_cols.p; A.vals = s->csrO_vals.p;
-            hipLaunchKernelGGL(k_csr_build, dim3(gb), dim3(256), 0, s->stream, A, 2);
-            A.sel = 2; A.selpre = s->selpre_halo.p; A.rowptr = s->csrD_rowptr.p; A.cols = s->csrD_cols.p; A.vals = s->csrD_vals.p;
-            hipLaunchKernelGGL(k_csr_build, dim3(gb), dim3(256), 0, s->stream, A, 2);
-            A.sel = 0; A.selpre = nullptr;
+        {   // lane-major block images (k_csr_il): 64-row blocks whose rows all have the same length
+            bool up_uniform = true;
+            for (int i = 1; i < up.dim; i++) up_uniform = up_uniform && (up.rowptr[i + 1] - up.rowptr[i] == up.rowptr[1] - up.rowptr[0]);
+            const int il = dbg_int("EDGPU_CSR_IL", 3);      // bit 0: local block, bit 1: dw-type blocks
+            s->csr_il_loc = (il & 1) && up_uniform;
+            s->csr_il_dw = (il & 2) != 0;
         }
-        {   // factored row pointers of the dw-type blocks
-            std::vector<int64_t> bD(H.Qdw + 1, 0), bO(H.Qdw + 1, 0); std::vector<int32_t> cD(H.Qdw, 0), cO(H.Qdw, 0);
+        A.rpb = 64;
+        s->csr_three = s->halo && !H.Jhflag && dbg_int("EDGPU_CSR_THREE", 1) != 0;      // the stored non-local block reads own and received rows from one x buffer: keep the own-row copy
+        // per local dw row: its dw hops into the rank's own rows (x-space row < Qdw; three-block form only) and the others.
+        // Every row of one idw row holds the same number of them: factored row pointers base[idw] + iup * cnt[idw].
+        std::vector<int64_t> bD(H.Qdw + 1, 0), bO(H.Qdw + 1, 0), pD(H.Qdw + 1, 0), pO(H.Qdw + 1, 0); std::vector<int32_t> cD(H.Qdw, 0), cO(H.Qdw, 0);
+        {
             std::vector<int32_t> xc;
             if (s->csr_three) { xc.resize(dw.cols.size()); HIPCHK(hipMemcpy(xc.data(), s->dw_cols_x.p, xc.size() * 4, hipMemcpyDeviceToHost)); }
             for (int64_t q = 0; q < H.Qdw; q++) {
                 int32_t no = 0, nh = 0;
                 for (int64_t pp = dw.rowptr[H.dw0 + q]; pp < dw.rowptr[H.dw0 + q + 1]; pp++) (s->csr_three && xc[pp] < H.Qdw ? no : nh)++;
-                cD[q] = nh; cO[q] = no; bD[q + 1] = bD[q] + (int64_t)nh * up.dim; bO[q + 1] = bO[q] + (int64_t)no * up.dim;
+                cD[q] = nh; cO[q] = no; pD[q + 1] = pD[q] + nh; pO[q + 1] = pO[q] + no;
+                bD[q + 1] = bD[q] + (int64_t)nh * up.dim; bO[q + 1] = bO[q] + (int64_t)no * up.dim;
             }
-            CHK(s->csrD_base.upload(bD)); CHK(s->csrD_cnt.upload(cD));
-            if (s->csr_three) { CHK(s->csrO_base.upload(bO)); CHK(s->csrO_cnt.upload(cO)); }
-            s->csr_uni = dbg_int("EDGPU_CSR_UNI", 1) != 0;
         }
+        s->csr_uni = dbg_int("EDGPU_CSR_UNI", 1) != 0;
+        // tile-major storage of the lane-major dw-type blocks: the blocks of one column tile (all idw) are contiguous, in the
+        // order the XCD that owns the tile walks them -- block (jb, idw) starts at jb*64*ctot + rows(jb)*cpre[idw]
+        s->csr_tm = s->csr_il_dw && s->csr_uni && dbg_int("EDGPU_CSR_TM", 1) != 0;
+        s->h_cntD = cD; s->h_cntO = cO;
+        CHK(s->csrD_base.upload(bD)); CHK(s->csrD_cnt.upload(cD)); CHK(s->csrD_cpre.upload(pD));
+        if (s->csr_three) { CHK(s->csrO_base.upload(bO)); CHK(s->csrO_cnt.upload(cO)); CHK(s->csrO_cpre.upload(pO)); s->csrO_nnz = bO[H.Qdw]; s->csrD_nnz = bD[H.Qdw]; }
+        CHK(s->csrD_rowptr.alloc((size_t)s->nloc_el + 1)); CHK(s->csrD_cols.alloc((size_t)s->csrD_nnz + 8)); CHK(s->csrD_vals.alloc((size_t)s->csrD_nnz + 8));
+        if (s->csr_three) { CHK(s->csrO_rowptr.alloc((size_t)s->nloc_el + 1)); CHK(s->csrO_cols.alloc((size_t)s->csrO_nnz + 8)); CHK(s->csrO_vals.alloc((size_t)s->csrO_nnz + 8)); }
+        A.rowptr = s->csr_rowptr.p; A.cols = s->csr_cols.p; A.vals = s->csr_vals.p;
+        A.il = s->csr_il_loc ? 1 : 0;
+        hipLaunchKernelGGL(k_csr_build, dim3(gb), dim3(256), 0, s->stream, A, 1);
+        A.il = s->csr_il_dw ? 1 : 0; A.tm = s->csr_tm ? 1 : 0;
+        if (!s->csr_three) {
+            A.rowptr = s->csrD_rowptr.p; A.cols = s->csrD_cols.p; A.vals = s->csrD_vals.p; A.cpre = s->csrD_cpre.p;
+            hipLaunchKernelGGL(k_csr_build, dim3(gb), dim3(256), 0, s->stream, A, 2);
+        } else {
+            A.sel = 1; A.selpre = s->csrO_base.p; A.cpre = s->csrO_cpre.p; A.rowptr = s->csrO_rowptr.p; A.cols = s->csrO_cols.p; A.vals = s->csrO_vals.p;
+            hipLaunchKernelGGL(k_csr_build, dim3(gb), dim3(256), 0, s->stream, A, 2);
+            A.sel = 2; A.selpre = s->csrD_base.p; A.cpre = s->csrD_cpre.p; A.rowptr = s->csrD_rowptr.p; A.cols = s->csrD_cols.p; A.vals = s->csrD_vals.p;
+            hipLaunchKernelGGL(k_csr_build, dim3(gb), dim3(256), 0, s->stream, A, 2);
+            A.sel = 0; A.selpre = nullptr;
+        }
+        A.il = 0; A.tm = 0;
         int64_t ndmax = 0;
         for (int64_t q = 0; q < H.Qdw; q++) ndmax = std::max<int64_t>(ndmax, dw.rowptr[H.dw0 + q + 1] - dw.rowptr[H.dw0 + q]);
-        s->csrD_rpb = (int32_t)std::min<int64_t>(dbg_int("EDGPU_CSRD_ROWS", 64), 1152 / std::max<int64_t>(ndmax, 1));
+        s->csrD_rpb = s->csr_il_dw ? 64 : (int32_t)std::min<int64_t>(dbg_int("EDGPU_CSRD_ROWS", 64), 1152 / std::max<int64_t>(ndmax, 1));
         if (s->csrD_rpb < 1) return fail(EDGPU_EUNSUPPORTED, "edgpu: a CSR row exceeds the LDS tile");
         s->csrD_bpr = (int32_t)cdiv(H.DimUp, s->csrD_rpb);
-        s->csrD_nt = dbg_int("EDGPU_CSRD_NT", 1);
+        s->csrD_nt = dbg_int("EDGPU_CSRD_NT", 1); s->csrL_nt = dbg_int("EDGPU_CSRL_NT", 1) != 0;
         maxrow = 1 + upmax;
         s->csrL_small = (1 + upmax) * 64 <= 640 && dbg_int("EDGPU_CSR_SMALL", 1);     // smaller LDS image -> more resident workgroups
         s->csrD_small = ndmax * s->csrD_rpb <= 640 && dbg_int("EDGPU_CSR_SMALL", 1);
     }
     HIPCHK(hipGetLastError());
     s->csr_xcd_rows = dbg_int("EDGPU_CSR_XCD", 0);
-    s->csr_rpb = (int32_t)std::min<int64_t>(64, 1152 / std::max<int64_t>(maxrow, 1));      // one wave per row block
+    s->csr_rpb = s->csr_il_loc ? 64 : (int32_t)std::min<int64_t>(64, 1152 / std::max<int64_t>(maxrow, 1));      // one wave per row block
     if (s->csr_rpb < 1) return fail(EDGPU_EUNSUPPORTED, "edgpu: a CSR row exceeds the LDS tile");
     s->csr_bpr = (int32_t)cdiv(H.DimUp, s->csr_rpb);
     s->csr_tile = std::max(1, std::min(dbg_int("EDGPU_CSR_TILE", 1 << 20), s->csr_bpr));

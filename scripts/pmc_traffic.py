@@ -18,7 +18,7 @@ def source_stamp():      # same digest as bench.py: the summary is only quoted w
 
 
 STAMP = source_stamp()
-PRODUCT = {"csr": ("k_csr_spmv2",), "kron": ("k_uppass", "k_dwpass"), "direct": ("k_uppass", "k_dwpass", "k_direct_tables")}
+PRODUCT = {"csr": ("k_csr_spmv2", "k_csr_il"), "kron": ("k_uppass", "k_dwpass"), "direct": ("k_uppass", "k_dwpass", "k_direct_tables")}
 out = []
 for st, prefixes in PRODUCT.items():
     per = {}

@@ -30,6 +30,9 @@ template <int MODE> __global__ void __launch_bounds__(64) k(const dbl2 *__restri
         for (int j = 0; j < 7; j++) s += r[j].x + r[j].y;
         if (MODE == 2 || MODE == 4 || MODE == 6) y[c * 64 + lane] = s;
         if (MODE == 3 || MODE == 5 || MODE == 7 || MODE == 8) __builtin_nontemporal_store(s, y + c * 64 + lane);
+        if (MODE == 10) y[(c * 64 + lane) & ((1 << 17) - 1)] = s;          // ring of 1 MiB: stays in the L2s
+        if (MODE == 11) y[(c * 64 + lane) & ((1 << 23) - 1)] = s;          // ring of 64 MiB: beyond the L2s, inside the Infinity Cache
+        if (MODE == 12) y[(c * 64 + lane) & ((1 << 20) - 1)] = s;          // ring of 8 MiB
         acc += s; prev = s;
     }
     if (acc == 1.2345) y[0] = acc;
@@ -41,14 +44,14 @@ int main()
     CK(hipMalloc(&a, (size_t)nchunk * 6912)); CK(hipMalloc(&u, (size_t)nchunk * 512)); CK(hipMalloc(&y, (size_t)nchunk * 512));
     CK(hipMemset(a, 0, (size_t)nchunk * 6912)); CK(hipMemset(u, 0, (size_t)nchunk * 512)); CK(hipMemset(y, 0, (size_t)nchunk * 512));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    const char *nm[10] = {"entries only", "+u read", "+y write", "+y write nt", "+y rmw", "+y rmw nt-store", "+y write, contiguous chunks per wave", "+y write nt, contiguous chunks", "+u read +y write nt", "+y write (previous chunk's value, before the wait)"};
-    for (int grid : {256 * 8, 256 * 20}) {
-        for (int mode = 0; mode < 10; mode++) {
+    const char *nm[13] = {"entries only", "+u read", "+y write", "+y write nt", "+y rmw", "+y rmw nt-store", "+y write, contiguous chunks per wave", "+y write nt, contiguous chunks", "+u read +y write nt", "+y write (previous chunk's value, before the wait)", "+y write into a 1 MiB ring", "+y write into a 64 MiB ring", "+y write into an 8 MiB ring"};
+    for (int grid : {256 * 8}) {
+        for (int mode = 0; mode < 13; mode++) {
             float best = 1e9;
             for (int rep = 0; rep < 4; rep++) {
                 CK(hipEventRecord(e0));
 #define L(M) if (mode == M) hipLaunchKernelGGL(k<M>, dim3(grid), dim3(64), 0, 0, a, u, y, nchunk);
-                L(0) L(1) L(2) L(3) L(4) L(5) L(6) L(7) L(8) L(9)
+                L(0) L(1) L(2) L(3) L(4) L(5) L(6) L(7) L(8) L(9) L(10) L(11) L(12)
                 CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
                 float ms; CK(hipEventElapsedTime(&ms, e0, e1)); if (ms < best) best = ms;
             }

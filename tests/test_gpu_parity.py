@@ -132,6 +132,29 @@ def test_explicit_csr_rows_equal_dense(edgpu_mod):
     G.close()
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("il,tm", [("3", "1"), ("3", "0"), ("1", "1"), ("2", "1"), ("0", "1")])
+def test_explicit_csr_rows_of_the_split_lane_major_blocks(edgpu_mod, monkeypatch, il, tm):
+    """Split explicit CSR (local + dw block) with the 64-row blocks stored lane-major (k_csr_il): the row export undoes the
+    interleave -- whole matrix and windows that start / end inside a block (DimUp = 70: blocks of 64 and 6 rows)."""
+    from edgpu import model
+    m, nu, nd = model.half_filled_c(7)
+    S = oracle.Sector(m, nu, nd); H = S.hmat()
+    monkeypatch.setenv("EDGPU_CSR_SPLIT", "1"); monkeypatch.setenv("EDGPU_CSR_IL", il); monkeypatch.setenv("EDGPU_CSR_TM", tm)
+    G = edgpu_mod.HvSector(m, nu, nd, storage="csr")
+    for r0, n in ((0, S.Dim), (37, 200), (64, 6), (69, 2), (S.Dim - 5, 5)):
+        rp, cols, vals = G.csr_rows(r0, n)
+        for i in range(n):
+            c = cols[rp[i]:rp[i + 1]]
+            assert np.all(np.diff(c) > 0)
+            row = np.zeros(S.Dim); row[c] = vals[rp[i]:rp[i + 1]]
+            np.testing.assert_array_equal(row, H[r0 + i])
+    v = np.random.RandomState(5).uniform(-0.5, 0.5, S.Dim)
+    ref = S.spmatvec(v)
+    assert np.abs(G.spHtimesV(v) - ref).max() <= HXV_RTOL * np.abs(ref).max()
+    G.close()
+
+
 LANC = [z for z in ZOO if z[0] in ("c_nb5_half", "c_nb7_half", "norb2_normal_JxJp", "replica_sz_sx_JxJp", "orbs_norb2_nb3", "phonons_nb3_nph3", "nb6_even")]
 
 
@@ -224,8 +247,9 @@ def test_large_sector_code_paths_on_small_sectors(edgpu_mod, monkeypatch, name, 
     w = np.linalg.eigvalsh(S.hmat())
     for env in ({"EDGPU_KRON_SPLIT": "1", "EDGPU_CSR_SPLIT": "1"},
                 {"EDGPU_COMPOSITE": "0"},      # ed_total_ud=F through the generic mixed-radix kernel instead of the composite two-factor path (no CSR there)
-                {"EDGPU_KRON_SPLIT": "1", "EDGPU_CSR_SPLIT": "1", "EDGPU_DW_W": "8", "EDGPU_DW_ROWS": "16", "EDGPU_CSRD_ROWS": "16", "EDGPU_UP_GRID": "3"},
-                {"EDGPU_KRON_SPLIT": "1", "EDGPU_DW_VARIANT": "1", "EDGPU_UP_PERSISTENT": "0", "EDGPU_CSR_SPLIT": "1", "EDGPU_CSRD_NT": "0", "EDGPU_CSR_UNI": "0"},
+                {"EDGPU_KRON_SPLIT": "1", "EDGPU_CSR_SPLIT": "1", "EDGPU_DW_W": "8", "EDGPU_DW_ROWS": "16", "EDGPU_CSRD_ROWS": "16", "EDGPU_UP_GRID": "3", "EDGPU_CSR_IL": "0"},      # explicit CSR through the LDS-staged row-major kernels
+                {"EDGPU_CSR_SPLIT": "1", "EDGPU_CSR_IL": "2", "EDGPU_CSR_TM": "0"},      # lane-major dw block only, blocks in row order
+                {"EDGPU_KRON_SPLIT": "1", "EDGPU_DW_VARIANT": "1", "EDGPU_UP_PERSISTENT": "0", "EDGPU_CSR_SPLIT": "1", "EDGPU_CSRD_NT": "0", "EDGPU_CSR_UNI": "0", "EDGPU_CSR_IL": "1"},
                 {"EDGPU_CSR_SPLIT": "0", "EDGPU_KRON_SPLIT": "1", "EDGPU_UP_THREADS": "512", "EDGPU_UP_PAIRS": "0"},
                 {"EDGPU_KRON_SPLIT": "1", "EDGPU_DEBUG": "4"},                                  # long-row path: one workgroup per row segment, halo in LDS (k_uppass_halo)
                 {"EDGPU_KRON_SPLIT": "1", "EDGPU_DEBUG": "4", "EDGPU_UP_GRID": "24", "EDGPU_LZ_FUSED": "0"},     # ... with idle workgroups (3 per XCD, 2 segments)
