@@ -30,7 +30,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "dmft-lanc-ed_amd"))
 
 HBM_PEAK_GBPS = 8000.0  # MI355X spec, /opt/skills/guides/MI355X_MICROARCH.md
-KERNELS = {"csr": "k_csr_il<true,0> (local block) + k_csr_il<true,1> (dw block): one product of the split explicit CSR, 64-row blocks stored lane-major",
+KERNELS = {"csr": "k_csr_il<false,0> (local block) + k_csr_il<true,1> (dw block): one product of the split explicit CSR, 64-row blocks stored lane-major",
            "kron": "k_uppass2_ax + k_dwpass2 (fused Lanczos iteration over the stored factors: axpy+norm+local pass, dw pass+scale+dot)",
            "direct": "k_direct_tables_wave + k_uppass2_ax<DIRECT> + k_dwpass2 (fused Lanczos iteration, on-the-fly operator)"}
 

@@ -178,7 +178,7 @@ struct edgpu_sector_s {
     DevBuf<int64_t> csrD_base, csrO_base; DevBuf<int32_t> csrD_cnt, csrO_cnt; bool csr_uni = false;
     // lane-major image of the 64-row blocks (k_csr_il): the local block when every up configuration has the same number of
     // hops, the dw-type blocks always (their rows are uniform per idw row)
-    bool csr_il_loc = false, csr_il_dw = false; bool csrL_nt = true;
+    bool csr_il_loc = false, csr_il_dw = false; bool csrL_nt = false;
     bool csr_tm = false; DevBuf<int64_t> csrD_cpre, csrO_cpre; std::vector<int32_t> h_cntD, h_cntO;      // tile-major order of the dw-type blocks
     // needed-rows exchange: the dw block is stored as two blocks, hops into the rank's own rows (runs while the exchange
     // is in flight) and hops into received rows (csrD_*: runs after it)
