@@ -239,8 +239,15 @@ static int csr_rows_el(edgpu_handle h, int64_t row0, int64_t nrows, int64_t *row
         for (int64_t r = 0; r <= nrows; r++) hrp[r] = w[row0 + r - rA];
         hc.resize((size_t)(hrp[nrows] - hrp[0])); hv.resize(hc.size());
         for (int64_t r = 0; r < nrows; r++) {
+            // level e of a block holds the rows with more than e entries, packed in row order (equal lengths: e*rows + row)
             const int64_t g = row0 + r, b0 = blk0(g), nr = blkn(g), len = hrp[r + 1] - hrp[r], base = w[b0 - rA] - w[0];
-            for (int64_t e = 0; e < len; e++) { hc[hrp[r] - hrp[0] + e] = tc[base + e * nr + (g - b0)]; hv[hrp[r] - hrp[0] + e] = tv[base + e * nr + (g - b0)]; }
+            int64_t lev = base;
+            for (int64_t e = 0; e < len; e++) {
+                int64_t cnt = 0, before = 0;
+                for (int64_t i = 0; i < nr; i++) { const bool has = w[b0 - rA + i + 1] - w[b0 - rA + i] > e; cnt += has; before += has && (b0 + i < g); }
+                hc[hrp[r] - hrp[0] + e] = tc[lev + before]; hv[hrp[r] - hrp[0] + e] = tv[lev + before];
+                lev += cnt;
+            }
         }
         return EDGPU_OK;
     };

@@ -1555,7 +1555,20 @@ __global__ void __launch_bounds__(256) k_csr_build(CsrBuildArgs A, int part)
         q0 = (A.tm && part == 2 ? (int64_t)iup0 * A.cpre[A.Qdw] + (int64_t)nr * A.cpre[idwl] : rowstart(iup0)) + (iup - iup0); qs = nr;
     }
     int e = 0;
-    auto emit = [&](int32_t c, double v) { const int64_t q = q0 + (int64_t)e * qs; A.cols[q] = c; A.vals[q] = v; e++; };
+    // local block (part 1) in lane-major order with rows of DIFFERENT lengths inside a 64-row block: the rows that own an
+    // e-th entry are packed in row order, level after level: position = block_start + sum_i min(len_i, e) + #{i < r : len_i > e}
+    const bool jag = A.il && part == 1;
+    int jag0 = 0, jagn = 0; int64_t jlev = 0;
+    if (jag) { jag0 = (iup / A.rpb) * A.rpb; jagn = A.DimUp - jag0; if (jagn > A.rpb) jagn = A.rpb; jlev = rowstart(jag0); }
+    auto emit = [&](int32_t c, double v) {
+        int64_t q;
+        if (jag) {
+            int cnt = 0, before = 0;
+            for (int i = 0; i < jagn; i++) { const bool has = (int)(A.uppre[jag0 + i + 1] - A.uppre[jag0 + i]) > e; cnt += has; before += has && (jag0 + i < iup); }
+            q = jlev + before; jlev += cnt;
+        } else q = q0 + (int64_t)e * qs;
+        A.cols[q] = c; A.vals[q] = v; e++;
+    };
     const int64_t xrow = idw - A.rowshift;     // index of this dw row in the column (x) space
     if (part != 1) for (int32_t q = d0; q < d1; q++) if (A.dwc[q] < xrow && keep(A.dwc[q])) emit((int32_t)((int64_t)A.dwc[q] * A.DimUp + iup), A.dwv[q]);
     if (part != 2) {
@@ -1660,14 +1673,14 @@ __global__ void __launch_bounds__(64) k_csr_il(CsrArgs A)
     int nr = A.DimUp - iup0; if (nr > A.rows_per_block) nr = A.rows_per_block;
     const int64_t row0 = idwl * A.DimUp + iup0;
     const bool act = tid < nr;
-    int64_t p0; int cnt;
+    int64_t p0; int cnt, len = 0;
     if (A.cpre) { cnt = A.rowcnt[idwl]; p0 = (int64_t)iup0 * A.cpre[A.Qdw] + (int64_t)nr * A.cpre[idwl]; }
     else if (A.rowbase) { cnt = A.rowcnt[idwl]; p0 = A.rowbase[idwl] + (int64_t)iup0 * cnt; }
     else {
         // streamed row pointer: lane r holds rowptr[row0 + r] and the next one; block start = first lane's, length = difference
         const int64_t ra = A.rowptr[row0 + (act ? tid : 0)], re = A.rowptr[row0 + (act ? tid : 0) + 1];
         p0 = ((int64_t)__builtin_amdgcn_readfirstlane((int)(ra >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(ra & 0xffffffffll));
-        cnt = __builtin_amdgcn_readfirstlane((int)(re - ra));
+        cnt = __builtin_amdgcn_readfirstlane((int)(re - ra)); len = act ? (int)(re - ra) : 0;
     }
     double up_i = 0.0, xl_i = 0.0;
     if (act) {
@@ -1677,10 +1690,34 @@ __global__ void __launch_bounds__(64) k_csr_il(CsrArgs A)
     }
     double s_cur = 1.0, c_prev = 0.0, asum = 0.0;
     if (A.epi) { s_cur = A.scal[SC_SCUR]; c_prev = A.scal[SC_BETA] * A.scal[SC_SPREV]; }
+    double accj = 0.0; bool jag = false;
+    if (BLK == 0 && !A.rowbase) {
+        // rows of different lengths inside the block (up configurations with different numbers of hops): level e holds the
+        // rows with more than e entries, packed in row order -- positions from a ballot, two levels in flight per step
+        jag = __ballot(act && len != cnt) != 0ull;
+        if (jag) {
+            const uint64_t lt = (tid == 0) ? 0ull : (~0ull >> (64 - tid));
+            int64_t base = p0;
+            for (int e = 0;; e += 2) {
+                const bool h0 = e < len, h1 = e + 1 < len;
+                const uint64_t m0 = __ballot(h0), m1 = __ballot(h1);
+                if (!m0) break;
+                const int n0 = __popcll(m0);
+                double v0 = 0.0, v1 = 0.0, x0 = 0.0, x1 = 0.0; int32_t c0 = 0, c1 = 0;
+                if (h0) { const int64_t q = base + __popcll(m0 & lt); v0 = A.vals[q]; c0 = A.cols[q]; }
+                if (h1) { const int64_t q = base + n0 + __popcll(m1 & lt); v1 = A.vals[q]; c1 = A.cols[q]; }
+                if (h0) x0 = A.x[c0];
+                if (h1) x1 = A.x[c1];
+                accj += v0 * x0; accj += v1 * x1;
+                base += n0 + __popcll(m1);
+            }
+        }
+    }
     if (act) {
         const double *pv = A.vals + p0 + tid; const int32_t *pc = A.cols + p0 + tid;
         double acc;
-        switch (cnt) {
+        if (jag) acc = accj;
+        else switch (cnt) {
         case 9: acc = csr_il_row<9, NT>(pv, pc, nr, A.x); break;
         case 8: acc = csr_il_row<8, NT>(pv, pc, nr, A.x); break;
         case 7: acc = csr_il_row<7, NT>(pv, pc, nr, A.x); break;

@@ -297,7 +297,7 @@ static int build_csr(S *s)
             bool up_uniform = true;
             for (int i = 1; i < up.dim; i++) up_uniform = up_uniform && (up.rowptr[i + 1] - up.rowptr[i] == up.rowptr[1] - up.rowptr[0]);
             const int il = dbg_int("EDGPU_CSR_IL", 3);      // bit 0: local block, bit 1: dw-type blocks
-            s->csr_il_loc = (il & 1) && up_uniform;
+            s->csr_il_loc = (il & 1) && (up_uniform || dbg_int("EDGPU_CSR_JAG", 1) != 0);      // rows of different lengths: packed level by level (k_csr_il, jagged path)
             s->csr_il_dw = (il & 2) != 0;
         }
         A.rpb = 64;

@@ -155,6 +155,29 @@ def test_explicit_csr_rows_of_the_split_lane_major_blocks(edgpu_mod, monkeypatch
     G.close()
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("nu,nd,jag", [(4, 5, "1"), (4, 5, "0"), (6, 3, "1"), (3, 3, "1")])
+def test_split_csr_with_rows_of_different_lengths(edgpu_mod, monkeypatch, nu, nd, jag):
+    """Away from half filling the up configurations differ in their number of hops (impurity level occupied or not), so the
+    rows of a 64-row block of the local block differ in length: they are packed level by level (k_csr_il, jagged path;
+    EDGPU_CSR_JAG=0: row-major block + LDS-staged kernel).  Ns=10: DimUp = 210 (3 blocks of 64 and one of 18) / 120."""
+    from edgpu import model
+    m = model.make_model(Norb=1, Nbath=9, Uloc=(2.0,), xmu=0.1, hfmode=False)
+    S = oracle.Sector(m, [nu], [nd])
+    v = np.random.RandomState(11).uniform(-0.5, 0.5, S.Dim)
+    ref = S.spmatvec(v)
+    monkeypatch.setenv("EDGPU_CSR_SPLIT", "1"); monkeypatch.setenv("EDGPU_CSR_JAG", jag)
+    G = edgpu_mod.HvSector(m, [nu], [nd], storage="csr")
+    assert ("lane-major-blocks=local" in G.describe()) == (jag == "1")
+    assert np.abs(G.spHtimesV(v) - ref).max() <= HXV_RTOL * np.abs(ref).max()
+    for r0, n in ((0, 700), (61, 9), (S.Dim - 300, 300), (12345 % S.Dim, 257)):
+        rp, cols, vals = G.csr_rows(r0, n)
+        y = np.array([vals[rp[i]:rp[i + 1]] @ v[cols[rp[i]:rp[i + 1]]] for i in range(n)])
+        assert all(np.all(np.diff(cols[rp[i]:rp[i + 1]]) > 0) for i in range(n))
+        assert np.abs(y - ref[r0:r0 + n]).max() <= 1e-12 * np.abs(ref).max()
+    G.close()
+
+
 LANC = [z for z in ZOO if z[0] in ("c_nb5_half", "c_nb7_half", "norb2_normal_JxJp", "replica_sz_sx_JxJp", "orbs_norb2_nb3", "phonons_nb3_nph3", "nb6_even")]
 
 
