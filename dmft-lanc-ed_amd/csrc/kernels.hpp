@@ -818,13 +818,24 @@ struct DwArgs {
     const double *uprev2;      // fused Lanczos iteration (EPI only): out holds the UNSCALED local part; out = s_cur*(out + dw part) - beta*s_prev*uprev2
 };
 
+// Column tiles dealt to the XCDs (workgroups go round-robin over the 8 XCDs): XCD x owns tiles x, x+8, ... and walks all row
+// chunks of a tile, so the slab x(tile, all idw) the dw hops gather from is shared through that XCD's L2.  Only whole groups
+// of 8 tiles are dealt that way; the ntiles % 8 left-over tiles are swept by all XCDs together (consecutive blocks =
+// consecutive chunks), so that no XCD carries one tile more than the others (c3: 202 tiles = 25 per XCD + 2 shared instead
+// of 26 / 25) and no block is idle.  Grid = ntiles * chunks.
+__device__ __forceinline__ void xcd_tile_map(uint32_t b, uint32_t ntiles, uint32_t chunks, int &tile, uint32_t &chunk)
+{
+    const uint32_t t8 = ntiles & ~7u, nmain = t8 * chunks;
+    if (b < nmain) { const uint32_t xcd = b & 7u, sidx = b >> 3, tl = sidx / chunks; chunk = sidx - tl * chunks; tile = (int)(tl * 8u + xcd); }
+    else { const uint32_t r = b - nmain, tl = r / chunks; chunk = r - tl * chunks; tile = (int)(t8 + tl); }
+}
+
 template <bool EPI>
 __global__ void __launch_bounds__(256) k_dwpass(DwArgs A)
 {
     __shared__ double red[4];
-    const int xcd = blockIdx.x & 7; const int64_t sidx = blockIdx.x >> 3;
-    const int64_t tl = sidx / A.chunks; const int chunk = (int)(sidx - tl * A.chunks);
-    const int tile = (int)(tl * 8 + xcd);
+    int tile; uint32_t chunk;
+    xcd_tile_map(blockIdx.x, (uint32_t)A.ntiles, (uint32_t)A.chunks, tile, chunk);
     double asum = 0.0;
     if (tile < A.ntiles) {
         const int j = threadIdx.x & (A.w - 1), r = threadIdx.x >> A.wshift;
@@ -857,9 +868,8 @@ __global__ void __launch_bounds__(256) k_dwpass2(DwArgs A)
     __shared__ int32_t tn[64];
     double *tv = dyn_lds;                                               // [row in block][k]
     int32_t *tc = reinterpret_cast<int32_t *>(dyn_lds + A.R * A.dww);
-    const int xcd = blockIdx.x & 7; const int64_t sidx = blockIdx.x >> 3;
-    const int64_t tl = sidx / A.chunks; const int chunk = (int)(sidx - tl * A.chunks);
-    const int tile = (int)(tl * 8 + xcd);
+    int tile; uint32_t chunk;
+    xcd_tile_map(blockIdx.x, (uint32_t)A.ntiles, (uint32_t)A.chunks, tile, chunk);
     double asum = 0.0;
     if (tile < A.ntiles) {
         const int64_t nrows = A.Qdw * A.DimPh, row0 = (int64_t)chunk * A.R;
@@ -1610,9 +1620,8 @@ __device__ __forceinline__ bool csr_block_map(const CsrArgs &A, int64_t &idwl, i
         // column tile jb is owned by XCD (jb % 8); that XCD walks all idw rows of the tile, so the
         // x slab x(tile, all idw) that the dw hops gather from stays in its L2
         // (32-bit arithmetic: blockIdx and the number of local dw rows both fit, and a 64-bit division costs hundreds of instructions per block)
-        const uint32_t xcd = blockIdx.x & 7u, sidx = blockIdx.x >> 3, q = (uint32_t)A.Qdw;
-        const uint32_t tl = sidx / q; idwl = sidx - tl * q; jb = (int)(tl * 8u + xcd);
-        return jb < A.blocks_per_row;
+        uint32_t ch; xcd_tile_map(blockIdx.x, (uint32_t)A.blocks_per_row, (uint32_t)A.Qdw, jb, ch); idwl = ch;
+        return true;
     }
     const int64_t per_tile = (int64_t)A.tile * A.Qdw;
     const int nt_full = A.blocks_per_row / A.tile;

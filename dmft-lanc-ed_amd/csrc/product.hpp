@@ -240,7 +240,7 @@ static int fused_dw(S *s, const double *u, double *t, const double *uprev)
     D.ntiles = (int32_t)cdiv(H.DimUp, D.w);
     D.R = std::min(64, s->dw_rows);
     D.chunks = (int32_t)cdiv(H.Qdw * H.DimPh, D.R);
-    const int64_t nblocks = 8 * cdiv(D.ntiles, 8) * (int64_t)D.chunks;
+    const int64_t nblocks = (int64_t)D.ntiles * D.chunks;
     const bool nt = s->dw_variant != 2, rag = s->dwf->ragged;
     const size_t dlds = std::max<size_t>((size_t)D.R * D.dww * 12 + 16, (size_t)s->dw_lds_kb * 1024);
 #define DW2_LAUNCH(N_, R_)                                                                                                      \
@@ -314,7 +314,7 @@ static int hxv(S *s, const double *v, double *out, bool epi, const double *uprev
         HIPCHK(hipGetLastError());
         if (s->csr_split) {
             A.rows_per_block = s->csrD_rpb; A.blocks_per_row = s->csrD_bpr; A.coltiles = 1; A.xcd_rows = 0;
-            nblocks = 8 * cdiv(s->csrD_bpr, 8) * H.Qdw;
+            nblocks = (int64_t)s->csrD_bpr * H.Qdw;
             if (s->csr_three) {
                 // dw hops into the rank's own rows: their columns are the first Qdw rows of the x-space, i.e. the local
                 // shard itself -- this block too runs while the exchange is in flight
@@ -344,7 +344,7 @@ static int hxv(S *s, const double *v, double *out, bool epi, const double *uprev
             A.rowptr = s->csrD_rowptr.p; A.cols = s->csrD_cols.p; A.vals = s->csrD_vals.p;
             if (s->csr_uni) { A.rowbase = s->csrD_base.p; A.rowcnt = s->csrD_cnt.p; A.cpre = s->csr_tm ? s->csrD_cpre.p : nullptr; }
             A.pass = 2;
-            nblocks = 8 * cdiv(s->csrD_bpr, 8) * H.Qdw;
+            nblocks = (int64_t)s->csrD_bpr * H.Qdw;
             launch(A, s->csrD_small, s->csrD_nt != 0, nblocks, s->csr_il_dw);
             HIPCHK(hipGetLastError());
         }
@@ -493,7 +493,7 @@ static int hxv(S *s, const double *v, double *out, bool epi, const double *uprev
                 D.ntiles = (int32_t)cdiv(H.DimUp, D.w);
                 D.R = vec2 ? std::min(64, s->dw_rows) : 256 / D.w;
                 D.chunks = (int32_t)cdiv(H.Qdw * H.DimPh, D.R);
-                nblocks = 8 * cdiv(D.ntiles, 8) * (int64_t)D.chunks;
+                nblocks = (int64_t)D.ntiles * D.chunks;
                 if (!vec2) {
                     if (epi) hipLaunchKernelGGL(k_dwpass<true>, dim3((unsigned)nblocks), dim3(256), 0, s->stream, D);
                     else hipLaunchKernelGGL(k_dwpass<false>, dim3((unsigned)nblocks), dim3(256), 0, s->stream, D);
