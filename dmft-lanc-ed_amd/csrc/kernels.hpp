@@ -1525,6 +1525,7 @@ struct CsrBuildArgs {
     int64_t *rowptr; int32_t *cols; double *vals;
     int32_t sel; const int64_t *selpre;   // part 2 only: 0 all dw hops; 1 those into the rank's own rows; 2 those into received (halo)
                                           // rows.  selpre[idwl] = entries of the selected kind in the rows before idwl (times DimUp)
+    int64_t ld;                           // row pitch of the vectors the columns index (DimUp, or DimUp rounded up to the 128-B line)
     int32_t tm; const int64_t *cpre;      // tm (dw-type blocks, with il): blocks stored tile-major, block (jb, idw) at jb*rpb*cpre[Qdw] + rows(jb)*cpre[idw]
     int32_t il, rpb;                      // il: entries of each block of `rpb` consecutive rows of one idw row are stored lane-major
                                           // (entry e of the block's row lr at block_start + e*rows_in_block + lr); all rows of a block
@@ -1580,14 +1581,14 @@ __global__ void __launch_bounds__(256) k_csr_build(CsrBuildArgs A, int part)
         A.cols[q] = c; A.vals[q] = v; e++;
     };
     const int64_t xrow = idw - A.rowshift;     // index of this dw row in the column (x) space
-    if (part != 1) for (int32_t q = d0; q < d1; q++) if (A.dwc[q] < xrow && keep(A.dwc[q])) emit((int32_t)((int64_t)A.dwc[q] * A.DimUp + iup), A.dwv[q]);
+    if (part != 1) for (int32_t q = d0; q < d1; q++) if (A.dwc[q] < xrow && keep(A.dwc[q])) emit((int32_t)((int64_t)A.dwc[q] * A.ld + iup), A.dwv[q]);
     if (part != 2) {
         int32_t r = u0;
-        for (; r < u1 && A.upc[r] < iup; r++) emit((int32_t)(xrow * A.DimUp + A.upc[r]), A.upv[r]);
-        emit((int32_t)(xrow * A.DimUp + iup), A.diag[il]);
-        for (; r < u1; r++) emit((int32_t)(xrow * A.DimUp + A.upc[r]), A.upv[r]);
+        for (; r < u1 && A.upc[r] < iup; r++) emit((int32_t)(xrow * A.ld + A.upc[r]), A.upv[r]);
+        emit((int32_t)(xrow * A.ld + iup), A.diag[il]);
+        for (; r < u1; r++) emit((int32_t)(xrow * A.ld + A.upc[r]), A.upv[r]);
     }
-    if (part != 1) for (int32_t q = d0; q < d1; q++) if (A.dwc[q] >= xrow && keep(A.dwc[q])) emit((int32_t)((int64_t)A.dwc[q] * A.DimUp + iup), A.dwv[q]);
+    if (part != 1) for (int32_t q = d0; q < d1; q++) if (A.dwc[q] >= xrow && keep(A.dwc[q])) emit((int32_t)((int64_t)A.dwc[q] * A.ld + iup), A.dwv[q]);
 }
 
 struct CsrArgs {
@@ -1602,6 +1603,7 @@ struct CsrArgs {
     // dw-type blocks: every row of one idw row has the same length, rowptr(iup, idw) = rowbase[idw] + iup * rowcnt[idw];
     // when set the row pointer array is not read at all
     const int64_t *rowbase; const int32_t *rowcnt;
+    int64_t ld;             // row pitch of x / y / uprev / v_local in doubles (the stored columns index that space); rowptr stays dense
     const int64_t *cpre;    // lane-major dw-type blocks stored tile-major (k_csr_il only): block (jb, idw) starts at jb*64*cpre[Qdw] + rows(jb)*cpre[idw]
 };
 
@@ -1680,7 +1682,7 @@ __global__ void __launch_bounds__(64) k_csr_il(CsrArgs A)
     const int tid = threadIdx.x;
     const int iup0 = jb * A.rows_per_block;
     int nr = A.DimUp - iup0; if (nr > A.rows_per_block) nr = A.rows_per_block;
-    const int64_t row0 = idwl * A.DimUp + iup0;
+    const int64_t row0 = idwl * A.DimUp + iup0, vrow0 = idwl * A.ld + iup0;      // row pointer index / vector index
     const bool act = tid < nr;
     int64_t p0; int cnt, len = 0;
     if (A.cpre) { cnt = A.rowcnt[idwl]; p0 = (int64_t)iup0 * A.cpre[A.Qdw] + (int64_t)nr * A.cpre[idwl]; }
@@ -1693,9 +1695,9 @@ __global__ void __launch_bounds__(64) k_csr_il(CsrArgs A)
     }
     double up_i = 0.0, xl_i = 0.0;
     if (act) {
-        if (A.epi && A.pass < 2) up_i = A.uprev[row0 + tid];
-        if (A.epi && (A.pass == 0 || A.pass == 2)) xl_i = A.v_local[row0 + tid];
-        if (A.pass >= 2) up_i = A.y[row0 + tid];        // running value of the earlier blocks
+        if (A.epi && A.pass < 2) up_i = A.uprev[vrow0 + tid];
+        if (A.epi && (A.pass == 0 || A.pass == 2)) xl_i = A.v_local[vrow0 + tid];
+        if (A.pass >= 2) up_i = A.y[vrow0 + tid];        // running value of the earlier blocks
     }
     double s_cur = 1.0, c_prev = 0.0, asum = 0.0;
     if (A.epi) { s_cur = A.scal[SC_SCUR]; c_prev = A.scal[SC_BETA] * A.scal[SC_SPREV]; }
@@ -1738,7 +1740,7 @@ __global__ void __launch_bounds__(64) k_csr_il(CsrArgs A)
             for (; e < cnt; e++) acc += csr_il_row<1, NT>(pv + (int64_t)e * nr, pc + (int64_t)e * nr, nr, A.x);
         }
         }
-        const int64_t row = row0 + tid;
+        const int64_t row = vrow0 + tid;
         if (A.epi) {
             const double w = A.pass >= 2 ? up_i + s_cur * acc : s_cur * acc - c_prev * up_i;
             A.y[row] = w; asum = (s_cur * xl_i) * w;
@@ -1760,7 +1762,7 @@ __global__ void __launch_bounds__(ROWS) k_csr_spmv2(CsrArgs A)
     const int tid = threadIdx.x;
     const int iup0 = jb * A.rows_per_block;
     int nr = A.DimUp - iup0; if (nr > A.rows_per_block) nr = A.rows_per_block;
-    const int64_t row0 = idwl * A.DimUp + iup0;
+    const int64_t row0 = idwl * A.DimUp + iup0, vrow0 = idwl * A.ld + iup0;      // row pointer index / vector index
     int64_t p0; int n, ucnt = 0;
     if (A.rowbase) { ucnt = A.rowcnt[idwl]; p0 = A.rowbase[idwl] + (int64_t)iup0 * ucnt; n = nr * ucnt; }
     else { p0 = A.rowptr[row0]; n = (int)(A.rowptr[row0 + nr] - p0); }
@@ -1770,9 +1772,9 @@ __global__ void __launch_bounds__(ROWS) k_csr_spmv2(CsrArgs A)
     if (tid < nr) {
         if (A.rowbase) { ra = tid * ucnt + sh; re = ra + ucnt; }
         else { ra = (int)(A.rowptr[row0 + tid] - p0) + sh; re = (int)(A.rowptr[row0 + tid + 1] - p0) + sh; }
-        if (A.epi && A.pass < 2) up_i = A.uprev[row0 + tid];
-        if (A.epi && (A.pass == 0 || A.pass == 2)) xl_i = A.v_local[row0 + tid];
-        if (A.pass >= 2) up_i = A.y[row0 + tid];        // running value of the earlier blocks
+        if (A.epi && A.pass < 2) up_i = A.uprev[vrow0 + tid];
+        if (A.epi && (A.pass == 0 || A.pass == 2)) xl_i = A.v_local[vrow0 + tid];
+        if (A.pass >= 2) up_i = A.y[vrow0 + tid];        // running value of the earlier blocks
     }
     {
         const double *gv = A.vals + (p0 - sh); const int32_t *gc = A.cols + (p0 - sh);   // 4-aligned base
@@ -1797,7 +1799,7 @@ __global__ void __launch_bounds__(ROWS) k_csr_spmv2(CsrArgs A)
     double s_cur = 1.0, c_prev = 0.0, asum = 0.0;
     if (A.epi) { s_cur = A.scal[SC_SCUR]; c_prev = A.scal[SC_BETA] * A.scal[SC_SPREV]; }
     if (tid < nr) {
-        const int64_t row = row0 + tid;
+        const int64_t row = vrow0 + tid;
         double acc0 = 0.0, acc1 = 0.0;
         int k = ra;
         for (; k + 4 <= re; k += 4) {

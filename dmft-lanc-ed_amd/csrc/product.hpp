@@ -159,7 +159,8 @@ static int transposed_dw_pass(S *s, const double *v, hipStream_t st)
 static bool pitch_ok(const S *s)
 {
     const SectorHost &H = s->H;
-    if (s->multi || !s->kron2 || !s->kron_split || H.desc.storage == EDGPU_STORE_CSR || H.DimPh != 1 || s->tr_on) return false;
+    if (H.desc.storage == EDGPU_STORE_CSR) return s->csr_ld > H.DimUp;      // explicit CSR whose columns index the pitched space (single rank)
+    if (s->multi || !s->kron2 || !s->kron_split || H.DimPh != 1 || s->tr_on) return false;
     if (s->extra && !(s->has_nd && !s->has_ph && s->nd_split)) return false;
     if (!(s->dw_variant >= 2 && (H.DimUp % 2 == 0) && s->dw_w >= 4 && s->dwf->width <= 64)) return false;
     const bool persistent = s->up_persistent && s->upf->packed && s->upf->width <= 16 && s->use_lds && H.DimUp <= 13312;
@@ -285,7 +286,18 @@ static int hxv(S *s, const double *v, double *out, bool epi, const double *uprev
         // shard itself (pointer shifted to global column numbering) while the exchange is in flight
         const bool overlap = multi && s->csr_split && H.DimPh == 1;
         if (multi && !overlap) HIPCHK(hipStreamWaitEvent(s->stream, s->ev_gather, 0));
+        // columns stored in the pitched space: a caller's dense vectors (plain products only) go through pitched scratch copies
+        const bool via_scratch = s->csr_ld > H.DimUp && ld == 0;
+        double *dense_out = out;
+        if (via_scratch) {
+            if (epi) return fail(EDGPU_EINVAL, "edgpu: internal: Lanczos epilogue on dense vectors with pitched CSR columns");
+            const size_t rows = (size_t)(s->nloc / H.DimUp), vl = rows * (size_t)s->csr_ld;
+            if (!s->csr_xs.p) { CHK(s->csr_xs.alloc(vl)); CHK(s->csr_ys.alloc(vl)); HIPCHK(hipMemsetAsync(s->csr_xs.p, 0, vl * 8, s->stream)); HIPCHK(hipMemsetAsync(s->csr_ys.p, 0, vl * 8, s->stream)); }
+            HIPCHK(hipMemcpy2DAsync(s->csr_xs.p, (size_t)s->csr_ld * 8, v, (size_t)H.DimUp * 8, (size_t)H.DimUp * 8, rows, hipMemcpyDeviceToDevice, s->stream));
+            v = s->csr_xs.p; out = s->csr_ys.p;
+        }
         CsrArgs A{};
+        A.ld = s->csr_ld;
         A.nrows = s->nloc_el; A.rows_per_block = s->csr_rpb; A.DimUp = (int32_t)H.DimUp; A.blocks_per_row = s->csr_bpr; A.Qdw = H.Qdw; A.tile = s->csr_tile;
         A.rowptr = s->csr_rowptr.p; A.cols = s->csr_cols.p; A.vals = s->csr_vals.p;
         A.x = overlap ? (s->halo ? v : v - H.dw0 * H.DimUp) : (multi ? s->vfull.p : v); A.y = out; A.v_local = v; A.uprev = uprev; A.scal = s->scal.p; A.partial = s->partial.p; A.epi = epi; A.xcd_rows = s->csr_xcd_rows;
@@ -349,6 +361,7 @@ static int hxv(S *s, const double *v, double *out, bool epi, const double *uprev
             HIPCHK(hipGetLastError());
         }
         nblocks *= nph;      // one partial per workgroup and phonon block
+        if (via_scratch) HIPCHK(hipMemcpy2DAsync(dense_out, (size_t)H.DimUp * 8, out, (size_t)s->csr_ld * 8, (size_t)H.DimUp * 8, (size_t)(s->nloc / H.DimUp), hipMemcpyDeviceToDevice, s->stream));
     } else if (s->kron2) {
         Kron2Args A{};
         A.DimUp = (int32_t)H.DimUp; A.DimDw = (int32_t)(s->halo ? s->nhalo : H.DimDw); A.DimPh = H.DimPh; A.Norb = d.Norb; A.Qdw = H.Qdw; A.dw0 = H.dw0;

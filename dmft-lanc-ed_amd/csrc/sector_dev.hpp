@@ -280,7 +280,13 @@ static int build_csr(S *s)
     // cache resident (rows for the up hops, XCD-owned column tiles for the dw hops).
     s->csr_split = dbg_int("EDGPU_CSR_SPLIT", (H.DimUp * H.DimDw * 8 > ((int64_t)48 << 20)) ? 1 : 0) != 0 || H.Jhflag || H.DimPh > 1;      // the non-local / phonon passes go between the local and the dw block
     s->csrL_nnz = H.Qdw * uppre[up.dim]; s->csrD_nnz = s->csr_nnz - s->csrL_nnz;
+    s->csr_ld = H.DimUp;
+    if (!s->multi && s->csr_split && !H.Jhflag && H.DimPh == 1 && (H.DimUp % 16) != 0 && dbg_int("EDGPU_PAD", 1) != 0 && dbg_int("EDGPU_CSR_PITCH", 1) != 0) {
+        const int64_t ld = (H.DimUp + 15) & ~(int64_t)15;
+        if (ld * s->nhalo < ((int64_t)1 << 31)) s->csr_ld = ld;
+    }
     CsrBuildArgs A{};
+    A.ld = s->csr_ld;
     A.DimUp = (int32_t)H.DimUp; A.DimDw = (int32_t)H.DimDw; A.Qdw = H.Qdw; A.dw0 = H.dw0;
     A.uprp = s->upf->rowptr.p; A.upc = s->upf->cols.p; A.upv = s->upf->vals.p;
     A.dwrp = s->dwf->rowptr.p; A.dwc = s->halo ? s->dw_cols_x.p : s->dwf->cols.p; A.dwv = s->dwf->vals.p;

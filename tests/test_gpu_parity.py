@@ -274,6 +274,7 @@ def test_large_sector_code_paths_on_small_sectors(edgpu_mod, monkeypatch, name, 
                 {"EDGPU_CSR_SPLIT": "1", "EDGPU_CSR_IL": "2", "EDGPU_CSR_TM": "0"},      # lane-major dw block only, blocks in row order
                 {"EDGPU_KRON_SPLIT": "1", "EDGPU_DW_VARIANT": "1", "EDGPU_UP_PERSISTENT": "0", "EDGPU_CSR_SPLIT": "1", "EDGPU_CSRD_NT": "0", "EDGPU_CSR_UNI": "0", "EDGPU_CSR_IL": "1"},
                 {"EDGPU_CSR_SPLIT": "0", "EDGPU_KRON_SPLIT": "1", "EDGPU_UP_THREADS": "512", "EDGPU_UP_PAIRS": "0"},
+                {"EDGPU_CSR_SPLIT": "1", "EDGPU_CSR_PITCH": "0", "EDGPU_KRON_SPLIT": "1"},      # explicit CSR with columns in the dense vector space
                 {"EDGPU_KRON_SPLIT": "1", "EDGPU_DEBUG": "4"},                                  # long-row path: one workgroup per row segment, halo in LDS (k_uppass_halo)
                 {"EDGPU_KRON_SPLIT": "1", "EDGPU_DEBUG": "4", "EDGPU_UP_GRID": "24", "EDGPU_LZ_FUSED": "0"},     # ... with idle workgroups (3 per XCD, 2 segments)
                 {"EDGPU_KRON_SPLIT": "1", "EDGPU_DEBUG": "4", "EDGPU_UP_HALO": "0", "EDGPU_ROW_SPLIT": "3"},       # long-row fallback: no LDS staging, packed 8-dword image (k_uppass_big)
