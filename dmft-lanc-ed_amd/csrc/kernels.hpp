@@ -1528,8 +1528,9 @@ struct CsrBuildArgs {
     int64_t ld;                           // row pitch of the vectors the columns index (DimUp, or DimUp rounded up to the 128-B line)
     int32_t tm; const int64_t *cpre;      // tm (dw-type blocks, with il): blocks stored tile-major, block (jb, idw) at jb*rpb*cpre[Qdw] + rows(jb)*cpre[idw]
     int32_t il, rpb;                      // il: entries of each block of `rpb` consecutive rows of one idw row are stored lane-major
-                                          // (entry e of the block's row lr at block_start + e*rows_in_block + lr); all rows of a block
-                                          // have the same length.  rowptr keeps the row-major numbers (block start, row lengths).
+                                          // (entry e of the block's row lr at block_start + e*rows_in_block + lr when the rows of the
+                                          // block have equal lengths; level by level otherwise, see `jag` below).  rowptr keeps the
+                                          // row-major numbers (block start, row lengths).
 };
 
 // row (iup, idw) holds, in ascending column order: dw hops to jdw<idw, up hops jup<iup, the
