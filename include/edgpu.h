@@ -108,7 +108,9 @@ int edgpu_diag_export(edgpu_handle h, double *d_host);
  * With more than one rank the rows are summed over the ranks (mpi_sp_dump_matrix, ED_SPARSE_MATRIX.f90:408-437):
  * every rank gets the full matrix. */
 int edgpu_sector_hmat(edgpu_handle h, double *hmat);
-/* explicit CSR (storage=CSR only): sizes and a window of rows [row0,row0+nrows) copied to the host */
+/* explicit CSR (storage=CSR only): sizes and a window of rows [row0,row0+nrows) copied to the host as plain CSR rows --
+ * ascending columns in the dense numbering jup + jdw*DimUp, whatever the device layout (blocks, lane-major 64-row blocks,
+ * tile-major dw storage, pitched column space) */
 int edgpu_csr_rows(edgpu_handle h, int64_t row0, int64_t nrows, int64_t *row_ptr, int32_t *cols, double *vals, int64_t cap);
 
 /* ---- the operator: dd_sparse_HxV(Nloc,v,Hv), ED_VARS_GLOBAL.f90:75-81 ----------------
