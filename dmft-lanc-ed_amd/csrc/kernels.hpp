@@ -2145,22 +2145,46 @@ constexpr int kMaxBasis = 48;
 struct BasisArgs { const double *V[kMaxBasis + 1]; int32_t nv; };
 
 // partial[b*nv + i] = sum over the block's elements of V_i . w     (one pass over w)
+// Two elements per lane (16-B loads) and the basis in groups of four vectors whose loads are issued together: a guard per
+// vector would put every load in its own basic block and serialise them (the first form of this kernel ran at 2.6-3.6 TB/s).
+constexpr int kBasisGroups = (kMaxBasis + 1 + 3) / 4;
 __global__ void __launch_bounds__(256) k_multidot(BasisArgs B, const double *__restrict__ w, int64_t n, double *__restrict__ partial)
 {
     __shared__ double red[4];
-    double acc[kMaxBasis + 1];
+    double acc[kBasisGroups * 4];
 #pragma unroll
-    for (int i = 0; i <= kMaxBasis; i++) acc[i] = 0.0;
-    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
-        const double x = w[e];
+    for (int i = 0; i < kBasisGroups * 4; i++) acc[i] = 0.0;
+    const int nv = B.nv;
+    const int64_t n2 = n >> 1;
+    const dbl2_t *w2 = reinterpret_cast<const dbl2_t *>(w);
+    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < n2; p += (int64_t)gridDim.x * blockDim.x) {
+        const dbl2_t x = w2[p];
 #pragma unroll
-        for (int i = 0; i <= kMaxBasis; i++) if (i < B.nv) acc[i] += B.V[i][e] * x;
+        for (int g = 0; g < kBasisGroups; g++) {
+            constexpr int dummy = 0; (void)dummy;
+            const int lim = (kMaxBasis + 1 - g * 4) < 4 ? (kMaxBasis + 1 - g * 4) : 4;      // compile time after unrolling
+            if (lim == 4 && (g + 1) * 4 <= nv) {
+                dbl2_t v[4];
+#pragma unroll
+                for (int j = 0; j < 4; j++) v[j] = reinterpret_cast<const dbl2_t *>(B.V[g * 4 + j < kMaxBasis + 1 ? g * 4 + j : 0])[p];
+#pragma unroll
+                for (int j = 0; j < 4; j++) acc[g * 4 + j] += v[j].x * x.x + v[j].y * x.y;
+            } else if (g * 4 < nv) {
+#pragma unroll
+                for (int j = 0; j < 4; j++) if (j < lim && g * 4 + j < nv) { const dbl2_t v = reinterpret_cast<const dbl2_t *>(B.V[g * 4 + j < kMaxBasis + 1 ? g * 4 + j : 0])[p]; acc[g * 4 + j] += v.x * x.x + v.y * x.y; }
+            }
+        }
+    }
+    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {     // odd length: the last element
+        const double x = w[n - 1];
+#pragma unroll
+        for (int i = 0; i <= kMaxBasis; i++) if (i < nv) acc[i] += B.V[i][n - 1] * x;
     }
 #pragma unroll
     for (int i = 0; i <= kMaxBasis; i++) {     // unrolled with a uniform guard: acc[] stays in registers (no scratch)
-        if (i < B.nv) {
+        if (i < nv) {
             double r = block_sum(acc[i], red);
-            if (threadIdx.x == 0) partial[(int64_t)blockIdx.x * B.nv + i] = r;
+            if (threadIdx.x == 0) partial[(int64_t)blockIdx.x * nv + i] = r;
         }
     }
 }
@@ -2176,36 +2200,55 @@ __global__ void __launch_bounds__(256) k_multidot_final(const double *__restrict
         __syncthreads();
     }
 }
-// w -= sum_i h[i] V_i
-__global__ void __launch_bounds__(256) k_multiaxpy(BasisArgs B, const double *__restrict__ h, double *__restrict__ w, int64_t n)
-{
-    double c[kMaxBasis + 1];
-#pragma unroll
-    for (int i = 0; i <= kMaxBasis; i++) c[i] = i < B.nv ? h[i] : 0.0;
-    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
-        double x = w[e];
-#pragma unroll
-        for (int i = 0; i <= kMaxBasis; i++) if (i < B.nv) x -= c[i] * B.V[i][e];
-        w[e] = x;
-    }
-}
-// the same update with |w_new|^2 accumulated on the way (block partials, fixed order): saves the separate norm pass
-__global__ void __launch_bounds__(256) k_multiaxpy_norm(BasisArgs B, const double *__restrict__ h, double *__restrict__ w, int64_t n, double *__restrict__ partial)
+// w -= sum_i h[i] V_i      (NORM: |w_new|^2 accumulated on the way, block partials in fixed order: saves the separate norm pass)
+// Same shape as k_multidot: two elements per lane, groups of four vectors loaded together; coefficients from LDS (a uniform
+// read is a broadcast) instead of ~100 scalar registers.
+template <bool NORM>
+__device__ __forceinline__ void multiaxpy_body(const BasisArgs &B, const double *__restrict__ h, double *__restrict__ w, int64_t n, double *__restrict__ partial)
 {
     __shared__ double red[4];
-    double c[kMaxBasis + 1];
-#pragma unroll
-    for (int i = 0; i <= kMaxBasis; i++) c[i] = i < B.nv ? h[i] : 0.0;
+    __shared__ double cs[kBasisGroups * 4];
+    const int nv = B.nv;
+    for (int i = threadIdx.x; i < kBasisGroups * 4; i += blockDim.x) cs[i] = i < nv ? h[i] : 0.0;
+    __syncthreads();
+    const int64_t n2 = n >> 1;
+    dbl2_t *w2 = reinterpret_cast<dbl2_t *>(w);
     double ss = 0.0;
-    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
-        double x = w[e];
+    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < n2; p += (int64_t)gridDim.x * blockDim.x) {
+        dbl2_t x = w2[p];
 #pragma unroll
-        for (int i = 0; i <= kMaxBasis; i++) if (i < B.nv) x -= c[i] * B.V[i][e];
-        w[e] = x;
-        ss += x * x;
+        for (int g = 0; g < kBasisGroups; g++) {
+            const int lim = (kMaxBasis + 1 - g * 4) < 4 ? (kMaxBasis + 1 - g * 4) : 4;
+            if (lim == 4 && (g + 1) * 4 <= nv) {
+                dbl2_t v[4];
+#pragma unroll
+                for (int j = 0; j < 4; j++) v[j] = reinterpret_cast<const dbl2_t *>(B.V[g * 4 + j < kMaxBasis + 1 ? g * 4 + j : 0])[p];
+#pragma unroll
+                for (int j = 0; j < 4; j++) { const double c = cs[g * 4 + j]; x.x -= c * v[j].x; x.y -= c * v[j].y; }
+            } else if (g * 4 < nv) {
+#pragma unroll
+                for (int j = 0; j < 4; j++) if (j < lim && g * 4 + j < nv) { const dbl2_t v = reinterpret_cast<const dbl2_t *>(B.V[g * 4 + j < kMaxBasis + 1 ? g * 4 + j : 0])[p]; const double c = cs[g * 4 + j]; x.x -= c * v.x; x.y -= c * v.y; }
+            }
+        }
+        w2[p] = x;
+        if (NORM) ss += x.x * x.x + x.y * x.y;
     }
-    double r = block_sum(ss, red);
-    if (threadIdx.x == 0) partial[blockIdx.x] = r;
+    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+        double x = w[n - 1];
+#pragma unroll
+        for (int i = 0; i <= kMaxBasis; i++) if (i < nv) x -= cs[i] * B.V[i][n - 1];
+        w[n - 1] = x;
+        if (NORM) ss += x * x;
+    }
+    if (NORM) { double r = block_sum(ss, red); if (threadIdx.x == 0) partial[blockIdx.x] = r; }
+}
+__global__ void __launch_bounds__(256) k_multiaxpy(BasisArgs B, const double *__restrict__ h, double *__restrict__ w, int64_t n)
+{
+    multiaxpy_body<false>(B, h, w, n, nullptr);
+}
+__global__ void __launch_bounds__(256) k_multiaxpy_norm(BasisArgs B, const double *__restrict__ h, double *__restrict__ w, int64_t n, double *__restrict__ partial)
+{
+    multiaxpy_body<true>(B, h, w, n, partial);
 }
 // in-place rotation of the basis: V_j <- sum_i V_i Y[i + nv*j], j < nout  (row by row: all nv values of an element sit in
 // registers, so the capacity is a template parameter: 48 for the usual bases, 96 for the large ones of finite-T runs)
