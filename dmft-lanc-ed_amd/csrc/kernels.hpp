@@ -2262,9 +2262,19 @@ __global__ void __launch_bounds__(256) k_basis_rotate(RotArgsT<MAXB> R, int64_t 
     for (int t = threadIdx.x; t < R.nv * R.nout; t += blockDim.x) ysh[t] = R.Y[t];
     __syncthreads();
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
-        double x[MAXB + 1];
+        double x[((MAXB + 1 + 3) / 4) * 4];
+        // the basis in groups of four vectors whose loads are issued together (a guard per vector serialises the loads)
 #pragma unroll
-        for (int i = 0; i <= MAXB; i++) x[i] = i < R.nv ? R.V[i][e] : 0.0;
+        for (int g = 0; g < (MAXB + 1 + 3) / 4; g++) {
+            const int lim = (MAXB + 1 - g * 4) < 4 ? (MAXB + 1 - g * 4) : 4;
+            if (lim == 4 && (g + 1) * 4 <= R.nv) {
+#pragma unroll
+                for (int j = 0; j < 4; j++) x[g * 4 + j] = R.V[g * 4 + j <= MAXB ? g * 4 + j : 0][e];
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; j++) x[g * 4 + j] = (j < lim && g * 4 + j < R.nv) ? R.V[g * 4 + j <= MAXB ? g * 4 + j : 0][e] : 0.0;
+            }
+        }
         for (int j = 0; j < R.nout; j++) {
             double s = 0.0;
 #pragma unroll
@@ -2281,20 +2291,50 @@ __global__ void __launch_bounds__(256) k_basis_rotate(RotArgsT<MAXB> R, int64_t 
 struct DvdArgs { const double *V[kMaxBasis + 1]; const double *W[kMaxBasis + 1]; int32_t nv; const double *y; double theta; const double *diag; int64_t nel; double w0; };
 __global__ void __launch_bounds__(256) k_dvd_resid(DvdArgs A, double *__restrict__ t, int64_t n, double *__restrict__ partial)
 {
+    // two elements per lane, the two bases in groups of four vector pairs loaded together, coefficients from LDS (as k_multidot)
     __shared__ double red[4];
-    double c[kMaxBasis + 1];
-#pragma unroll
-    for (int i = 0; i <= kMaxBasis; i++) c[i] = i < A.nv ? A.y[i] : 0.0;
-    double rr = 0.0;
-    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
-        double r = 0.0;
-#pragma unroll
-        for (int i = 0; i <= kMaxBasis; i++) if (i < A.nv) r += c[i] * (A.W[i][e] - A.theta * A.V[i][e]);
-        const int64_t iph = e / A.nel;
-        double den = A.theta - (A.diag[e - iph * A.nel] + A.w0 * (double)iph);
+    __shared__ double cs[kBasisGroups * 4];
+    const int nv = A.nv;
+    for (int i = threadIdx.x; i < kBasisGroups * 4; i += blockDim.x) cs[i] = i < nv ? A.y[i] : 0.0;
+    __syncthreads();
+    const double theta = A.theta;
+    auto finish = [&](int64_t e, double r) -> double {
+        const int64_t iph = A.nel >= n ? 0 : e / A.nel;
+        double den = theta - (A.diag[e - iph * A.nel] + A.w0 * (double)iph);
         if (fabs(den) < 1e-8) den = den < 0.0 ? -1e-8 : 1e-8;
-        t[e] = r / den;
-        rr += r * r;
+        return r / den;
+    };
+    double rr = 0.0;
+    const int64_t n2 = n >> 1;
+    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < n2; p += (int64_t)gridDim.x * blockDim.x) {
+        dbl2_t r; r.x = 0.0; r.y = 0.0;
+#pragma unroll
+        for (int g = 0; g < kBasisGroups; g++) {
+            const int lim = (kMaxBasis + 1 - g * 4) < 4 ? (kMaxBasis + 1 - g * 4) : 4;
+            if (lim == 4 && (g + 1) * 4 <= nv) {
+                dbl2_t wv[4], vv[4];
+#pragma unroll
+                for (int j = 0; j < 4; j++) { const int i = g * 4 + j <= kMaxBasis ? g * 4 + j : 0; wv[j] = reinterpret_cast<const dbl2_t *>(A.W[i])[p]; vv[j] = reinterpret_cast<const dbl2_t *>(A.V[i])[p]; }
+#pragma unroll
+                for (int j = 0; j < 4; j++) { const double c = cs[g * 4 + j]; r.x += c * (wv[j].x - theta * vv[j].x); r.y += c * (wv[j].y - theta * vv[j].y); }
+            } else if (g * 4 < nv) {
+#pragma unroll
+                for (int j = 0; j < 4; j++) if (j < lim && g * 4 + j < nv) {
+                    const int i = g * 4 + j <= kMaxBasis ? g * 4 + j : 0;
+                    const dbl2_t wv = reinterpret_cast<const dbl2_t *>(A.W[i])[p], vv = reinterpret_cast<const dbl2_t *>(A.V[i])[p];
+                    const double c = cs[g * 4 + j]; r.x += c * (wv.x - theta * vv.x); r.y += c * (wv.y - theta * vv.y);
+                }
+            }
+        }
+        dbl2_t o; o.x = finish(2 * p, r.x); o.y = finish(2 * p + 1, r.y);
+        reinterpret_cast<dbl2_t *>(t)[p] = o;
+        rr += r.x * r.x + r.y * r.y;
+    }
+    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+        const int64_t e = n - 1; double r = 0.0;
+#pragma unroll
+        for (int i = 0; i <= kMaxBasis; i++) if (i < nv) r += cs[i] * (A.W[i][e] - theta * A.V[i][e]);
+        t[e] = finish(e, r); rr += r * r;
     }
     double s = block_sum(rr, red);
     if (threadIdx.x == 0) partial[blockIdx.x] = s;
