@@ -2147,21 +2147,23 @@ struct BasisArgs { const double *V[kMaxBasis + 1]; int32_t nv; };
 // partial[b*nv + i] = sum over the block's elements of V_i . w     (one pass over w)
 // Two elements per lane (16-B loads) and the basis in groups of four vectors whose loads are issued together: a guard per
 // vector would put every load in its own basic block and serialise them (the first form of this kernel ran at 2.6-3.6 TB/s).
+// NG: groups compiled in (nv <= 4*NG): small bases get a small register footprint, i.e. more resident waves -- a 3-vector
+// dot through the 13-group instance keeps only 24 KB per CU in flight.
 constexpr int kBasisGroups = (kMaxBasis + 1 + 3) / 4;
+template <int NG>
 __global__ void __launch_bounds__(256) k_multidot(BasisArgs B, const double *__restrict__ w, int64_t n, double *__restrict__ partial)
 {
     __shared__ double red[4];
-    double acc[kBasisGroups * 4];
+    double acc[NG * 4];
 #pragma unroll
-    for (int i = 0; i < kBasisGroups * 4; i++) acc[i] = 0.0;
+    for (int i = 0; i < NG * 4; i++) acc[i] = 0.0;
     const int nv = B.nv;
     const int64_t n2 = n >> 1;
     const dbl2_t *w2 = reinterpret_cast<const dbl2_t *>(w);
     for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < n2; p += (int64_t)gridDim.x * blockDim.x) {
         const dbl2_t x = w2[p];
 #pragma unroll
-        for (int g = 0; g < kBasisGroups; g++) {
-            constexpr int dummy = 0; (void)dummy;
+        for (int g = 0; g < NG; g++) {
             const int lim = (kMaxBasis + 1 - g * 4) < 4 ? (kMaxBasis + 1 - g * 4) : 4;      // compile time after unrolling
             if (lim == 4 && (g + 1) * 4 <= nv) {
                 dbl2_t v[4];
@@ -2178,10 +2180,10 @@ __global__ void __launch_bounds__(256) k_multidot(BasisArgs B, const double *__r
     if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {     // odd length: the last element
         const double x = w[n - 1];
 #pragma unroll
-        for (int i = 0; i <= kMaxBasis; i++) if (i < nv) acc[i] += B.V[i][n - 1] * x;
+        for (int i = 0; i < NG * 4 && i <= kMaxBasis; i++) if (i < nv) acc[i] += B.V[i][n - 1] * x;
     }
 #pragma unroll
-    for (int i = 0; i <= kMaxBasis; i++) {     // unrolled with a uniform guard: acc[] stays in registers (no scratch)
+    for (int i = 0; i < NG * 4 && i <= kMaxBasis; i++) {     // unrolled with a uniform guard: acc[] stays in registers (no scratch)
         if (i < nv) {
             double r = block_sum(acc[i], red);
             if (threadIdx.x == 0) partial[(int64_t)blockIdx.x * nv + i] = r;
@@ -2203,7 +2205,7 @@ __global__ void __launch_bounds__(256) k_multidot_final(const double *__restrict
 // w -= sum_i h[i] V_i      (NORM: |w_new|^2 accumulated on the way, block partials in fixed order: saves the separate norm pass)
 // Same shape as k_multidot: two elements per lane, groups of four vectors loaded together; coefficients from LDS (a uniform
 // read is a broadcast) instead of ~100 scalar registers.
-template <bool NORM>
+template <bool NORM, int NG>
 __device__ __forceinline__ void multiaxpy_body(const BasisArgs &B, const double *__restrict__ h, double *__restrict__ w, int64_t n, double *__restrict__ partial)
 {
     __shared__ double red[4];
@@ -2217,7 +2219,7 @@ __device__ __forceinline__ void multiaxpy_body(const BasisArgs &B, const double 
     for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < n2; p += (int64_t)gridDim.x * blockDim.x) {
         dbl2_t x = w2[p];
 #pragma unroll
-        for (int g = 0; g < kBasisGroups; g++) {
+        for (int g = 0; g < NG; g++) {
             const int lim = (kMaxBasis + 1 - g * 4) < 4 ? (kMaxBasis + 1 - g * 4) : 4;
             if (lim == 4 && (g + 1) * 4 <= nv) {
                 dbl2_t v[4];
@@ -2242,13 +2244,35 @@ __device__ __forceinline__ void multiaxpy_body(const BasisArgs &B, const double 
     }
     if (NORM) { double r = block_sum(ss, red); if (threadIdx.x == 0) partial[blockIdx.x] = r; }
 }
+template <int NG>
 __global__ void __launch_bounds__(256) k_multiaxpy(BasisArgs B, const double *__restrict__ h, double *__restrict__ w, int64_t n)
 {
-    multiaxpy_body<false>(B, h, w, n, nullptr);
+    multiaxpy_body<false, NG>(B, h, w, n, nullptr);
 }
+template <int NG>
 __global__ void __launch_bounds__(256) k_multiaxpy_norm(BasisArgs B, const double *__restrict__ h, double *__restrict__ w, int64_t n, double *__restrict__ partial)
 {
-    multiaxpy_body<true>(B, h, w, n, partial);
+    multiaxpy_body<true, NG>(B, h, w, n, partial);
+}
+// host-side dispatch on the number of vectors
+#define EDGPU_NG_DISPATCH(nv, CALL) do { const int ng_ = ((nv) + 3) / 4; if (ng_ <= 1) { CALL(1); } else if (ng_ <= 2) { CALL(2); } else if (ng_ <= 4) { CALL(4); } else if (ng_ <= 6) { CALL(6); } else { CALL(kBasisGroups); } } while (0)
+static inline void launch_multidot(hipStream_t st, int nb, const BasisArgs &B, const double *w, int64_t n, double *partial)
+{
+#define C_(NG) hipLaunchKernelGGL((k_multidot<NG>), dim3(nb), dim3(256), 0, st, B, w, n, partial)
+    EDGPU_NG_DISPATCH(B.nv, C_);
+#undef C_
+}
+static inline void launch_multiaxpy(hipStream_t st, int nb, const BasisArgs &B, const double *h, double *w, int64_t n)
+{
+#define C_(NG) hipLaunchKernelGGL((k_multiaxpy<NG>), dim3(nb), dim3(256), 0, st, B, h, w, n)
+    EDGPU_NG_DISPATCH(B.nv, C_);
+#undef C_
+}
+static inline void launch_multiaxpy_norm(hipStream_t st, int nb, const BasisArgs &B, const double *h, double *w, int64_t n, double *partial)
+{
+#define C_(NG) hipLaunchKernelGGL((k_multiaxpy_norm<NG>), dim3(nb), dim3(256), 0, st, B, h, w, n, partial)
+    EDGPU_NG_DISPATCH(B.nv, C_);
+#undef C_
 }
 // in-place rotation of the basis: V_j <- sum_i V_i Y[i + nv*j], j < nout  (row by row: all nv values of an element sit in
 // registers, so the capacity is a template parameter: 48 for the usual bases, 96 for the large ones of finite-T runs)

@@ -353,7 +353,7 @@ static int lanczos_gs_impl(S *s, int nitermax, double threshold, int ncheck, dou
             for (int i = 0; i < B.nv; i++) B.V[i] = ring_get(k0 + i);
             HIPCHK(hipMemcpyAsync(s->eig_h.p, coef.data() + k0, (size_t)B.nv * 8, hipMemcpyHostToDevice, s->stream));
             HIPCHK(hipStreamSynchronize(s->stream));      // coef lives on the host stack of this call
-            hipLaunchKernelGGL(k_multiaxpy, dim3(nbk), dim3(256), 0, s->stream, B, (const double *)s->eig_h.p, acc, vlen);
+            launch_multiaxpy(s->stream, (int)nbk, B, (const double *)s->eig_h.p, acc, vlen);
             HIPCHK(hipGetLastError());
         }
     } else {
@@ -451,7 +451,7 @@ static int orthogonalise_cgs(S *s, double *const *basis, int nv, int first_from,
             BasisArgs B{}; B.nv = gc + (lastg ? 1 : 0);
             for (int i = 0; i < gc; i++) B.V[i] = basis[from + g0 + i];
             if (lastg) B.V[gc] = w;                           // w rides along once: |w|^2 before the update
-            hipLaunchKernelGGL(k_multidot, dim3(nb), dim3(256), 0, s->stream, B, (const double *)w, n, s->eig_partial.p);
+            launch_multidot(s->stream, nb, B, (const double *)w, n, s->eig_partial.p);
             hipLaunchKernelGGL(k_multidot_final, dim3(1), dim3(256), 0, s->stream, (const double *)s->eig_partial.p, nb, B.nv, s->eig_h.p + g0);
             HIPCHK(hipGetLastError());
         }
@@ -460,8 +460,8 @@ static int orthogonalise_cgs(S *s, double *const *basis, int nv, int first_from,
             const int g0 = g * kMaxBasis, gc = std::min(kMaxBasis, cnt - g0);
             BasisArgs Bu{}; Bu.nv = gc;
             for (int i = 0; i < gc; i++) Bu.V[i] = basis[from + g0 + i];
-            if (g == ngroups - 1) hipLaunchKernelGGL(k_multiaxpy_norm, dim3(nb), dim3(256), 0, s->stream, Bu, (const double *)(s->eig_h.p + g0), w, n, s->eig_partial.p);
-            else hipLaunchKernelGGL(k_multiaxpy, dim3(nb), dim3(256), 0, s->stream, Bu, (const double *)(s->eig_h.p + g0), w, n);
+            if (g == ngroups - 1) launch_multiaxpy_norm(s->stream, nb, Bu, (const double *)(s->eig_h.p + g0), w, n, s->eig_partial.p);
+            else launch_multiaxpy(s->stream, nb, Bu, (const double *)(s->eig_h.p + g0), w, n);
             HIPCHK(hipGetLastError());
         }
         hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(1024), 0, s->stream, (const double *)s->eig_partial.p, (int64_t)nb, s->scal.p + SC_TMP);
@@ -646,7 +646,7 @@ static int dvdson(S *s, int nev, int maxiter, double tol, double *evals, double 
     std::vector<double> h2(mmax + 1);
     auto dots = [&](int nv, const double *w, bool with_W) -> int {
         BasisArgs B{}; B.nv = nv; for (int i = 0; i < nv; i++) B.V[i] = with_W ? Wp(i) : Vp(i);
-        hipLaunchKernelGGL(k_multidot, dim3(nb), dim3(256), 0, s->stream, B, w, n, s->eig_partial.p);
+        launch_multidot(s->stream, nb, B, w, n, s->eig_partial.p);
         hipLaunchKernelGGL(k_multidot_final, dim3(1), dim3(256), 0, s->stream, (const double *)s->eig_partial.p, nb, nv, s->eig_h.p);
         HIPCHK(hipGetLastError());
         CHK(allreduce_dev(s, s->eig_h.p, nv));
