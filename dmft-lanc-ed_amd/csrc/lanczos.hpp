@@ -115,7 +115,7 @@ static int lz_iter_tail(S *s, LzVecs &V, int k, double *acc, bool alpha_done = f
         hipLaunchKernelGGL(k_scalar_step, dim3(1), dim3(1), 0, s->stream, s->scal.p, s->alphas.p, s->betas.p, (const double *)nullptr, k, 0);
         if (acc) hipLaunchKernelGGL(k_scalar_step, dim3(1), dim3(1), 0, s->stream, s->scal.p, s->alphas.p, s->betas.p, (const double *)s->zvec.p, k, 3);
     }
-    int nb = (int)std::max<int64_t>(1, std::min<int64_t>(cdiv(s->vlen, 256 * 4), 4096));
+    int nb = (int)std::max<int64_t>(1, std::min<int64_t>(cdiv(s->vlen, 256 * 4), (int64_t)s->axpy_nb));      // measured at c3: 512 blocks 0.70 ms, 1024 0.73, 4096 0.82-0.88, one pair per lane 0.76
     hipLaunchKernelGGL(k_axpy_norm, dim3(nb), dim3(256), 0, s->stream, V.w, V.ucur, acc, s->scal.p, s->vlen, s->partial.p);      // padding columns are zero and stay zero
     if (!s->multi) {   // no all-reduce between the sum and the step that uses it: one launch
         hipLaunchKernelGGL(k_reduce_final_step, dim3(1), dim3(1024), 0, s->stream, s->partial.p, (int64_t)nb, s->scal.p, s->alphas.p, s->betas.p, (const double *)nullptr, 1);

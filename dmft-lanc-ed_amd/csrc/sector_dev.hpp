@@ -475,6 +475,7 @@ static int create(const edgpu_desc *desc, S **out)
         s->nnz_total += s->nd_nnz;
     }
     if (s->multi && !s->tr_on) CHK(s->vfull.alloc((size_t)(H.DimUp * s->nhalo * H.DimPh)));
+    s->axpy_nb = std::max(1, dbg_int("EDGPU_AXPY_NB", 512));
     s->vld = H.DimUp; s->vlen = s->nloc;
     s->pad_on = (fused_ok(s.get()) || pitch_ok(s.get())) && (H.DimUp % 16) != 0 && dbg_int("EDGPU_PAD", 1) != 0;
     if (s->pad_on) { s->vld = (H.DimUp + 15) & ~(int64_t)15; s->vlen = (s->nloc / H.DimUp) * s->vld; }
