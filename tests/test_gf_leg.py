@@ -22,8 +22,12 @@ def _gf_from_lanczos(z, norm2, a, b, n, e0, sign):
 CASES = [("c_nb5_half", 1, 1), ("c_nb5_half", 1, 2), ("norb2_normal_JxJp", 2, 1), ("orbs_norb2_nb3", 2, 2), ("phonons_nb3_nph3", 1, 1)]
 
 
-@pytest.mark.parametrize("case,iorb,ispin", CASES)
-def test_gf_leg_matches_oracle_and_dense(edgpu_mod, case, iorb, ispin):
+@pytest.mark.parametrize("case,iorb,ispin,tstore", [c + ("kron",) for c in CASES] + [("c_nb5_half", 1, 1, "csr"), ("c_nb5_half", 1, 2, "csr"), ("phonons_nb3_nph3", 1, 1, "csr")])
+def test_gf_leg_matches_oracle_and_dense(edgpu_mod, monkeypatch, case, iorb, ispin, tstore):
+    """tstore: storage of the target sector the tridiagonalisation runs in; "csr" = the split explicit CSR (lane-major blocks,
+    pitched columns on one rank), forced on these small sectors."""
+    if tstore == "csr":
+        monkeypatch.setenv("EDGPU_CSR_SPLIT", "1")
     name, m, nu, nd = [z for z in cases.zoo() if z[0] == case][0]
     S = oracle.Sector(m, nu, nd)
     H = S.hmat(); w, U = np.linalg.eigh(H); e0, gs = w[0], U[:, 0]
@@ -35,7 +39,7 @@ def test_gf_leg_matches_oracle_and_dense(edgpu_mod, case, iorb, ispin):
         (nu2 if ispin == 1 else nd2)[ia] += 1 if dagger else -1
         St = oracle.Sector(m, nu2, nd2)
         vref, n2ref = oracle.apply_op(S, St, iorb, ispin, dagger, gs)
-        Gt = edgpu_mod.HvSector(m, nu2, nd2, storage="kron")
+        Gt = edgpu_mod.HvSector(m, nu2, nd2, storage=tstore)
         din, dout = edgpu_mod.DeviceVector(S.Dim).upload(gs), edgpu_mod.DeviceVector(St.Dim)
         n2 = edgpu_mod.apply_op(G0, Gt, iorb, ispin, dagger, din, dout)
         assert abs(n2 - n2ref) <= 1e-13
