@@ -30,7 +30,7 @@ python3 scripts/pmc_summary.py $OUT 2>/dev/null | grep -A3 "pmc_ns18" > $OUT/ns1
 python3 scripts/microbench.py 17 kron 3 lanczos > $OUT/ns18_kron_iteration.txt 2>&1
 echo "done ns18"
 # config 5 and ed_total_ud=F
-for st in kron direct; do python3 scripts/bench_c5.py 7 $st; done > $OUT/c5_times.txt 2>&1
+for st in kron direct csr; do python3 scripts/bench_c5.py 7 $st; done > $OUT/c5_times.txt 2>&1
 python3 scripts/microbench.py 15 csr 5 > $OUT/c3_isolated_products.txt 2>&1
 python3 scripts/microbench.py 15 kron 10 >> $OUT/c3_isolated_products.txt 2>&1
 python3 scripts/microbench.py 15 direct 10 >> $OUT/c3_isolated_products.txt 2>&1
