@@ -558,35 +558,38 @@ int edgpu_imp_density_offdiag(edgpu_handle h, const double *vec_host, double *dm
 // rank's shard of sector A, vout its shard of the twin sector B (dw split of DimDw_B = DimUp_A); the state is
 // all-gathered once, vout must hold DimDw_A * Qdw_B * DimPh doubles, Qdw_B = this rank's share of DimUp_A
 // (same rule as ED_HAMILTONIAN.f90:96-110).
-int edgpu_twin_reorder(edgpu_handle h, const double *vin_host, double *vout_host)
+int edgpu_twin_reorder(edgpu_handle h, const double *vin, double *vout)
 {
-    if (!h || !vin_host || !vout_host) return fail(EDGPU_EINVAL, "edgpu_twin_reorder: null argument");
+    if (!h || !vin || !vout) return fail(EDGPU_EINVAL, "edgpu_twin_reorder: null argument");
+    if (vin == vout) return fail(EDGPU_EINVAL, "edgpu_twin_reorder: the reorder is out of place, vin == vout");
     HIPCHK(hipSetDevice(h->device));
     const SectorHost &H = h->H;
-    if (h->tmp_in.n != (size_t)h->nloc) { CHK(h->tmp_in.alloc((size_t)h->nloc)); CHK(h->tmp_out.alloc((size_t)h->nloc)); }
-    HIPCHK(hipMemcpy(h->tmp_in.p, vin_host, (size_t)h->nloc * 8, hipMemcpyHostToDevice));
+    const bool in_dev = is_device_ptr(vin), out_dev = is_device_ptr(vout);
+    if (!(in_dev && out_dev) && h->tmp_in.n != (size_t)h->nloc) { CHK(h->tmp_in.alloc((size_t)h->nloc)); CHK(h->tmp_out.alloc((size_t)h->nloc)); }
+    if (!in_dev) HIPCHK(hipMemcpy(h->tmp_in.p, vin, (size_t)h->nloc * 8, hipMemcpyHostToDevice));
+    const double *src = in_dev ? vin : h->tmp_in.p;
     const bool dist = h->multi && h->comm.size > 1;
     const int64_t nelG = H.DimUp * H.DimDw;
     TwinArgs A{}; A.nud = H.Ns_Ud; A.DimPh = H.DimPh; A.nel = dist ? nelG : h->nloc_el; A.nel_out = h->nloc_el; A.row0_out = 0;
-    A.vin = h->tmp_in.p; A.vout = h->tmp_out.p;
+    A.vin = src; A.vout = out_dev ? vout : h->tmp_out.p;
     for (int k = 0; k < 2 * H.Ns_Ud; k++) A.dimsA[k] = H.fac[k].dim;
     DevBuf<double> full, outb;
     int64_t nout = h->nloc;
     if (dist) {
         CHK(full.alloc((size_t)(nelG * H.DimPh)));
-        CHK(gather_full(h, h->tmp_in.p, full.p, h->stream));
+        CHK(gather_full(h, src, full.p, h->stream));
         // shard of the twin sector: DimUp_B = DimDw_A rows long, dw columns of B = up index of A split over the ranks
         const int64_t P = h->comm.size, r = h->comm.rank, q = H.DimUp / P, rem = H.DimUp % P;
         if (H.DimUp < P) return fail(EDGPU_EUNSUPPORTED, "edgpu_twin_reorder: twin sector has fewer dw columns than ranks");
         const int64_t qb = r < rem ? q + 1 : q, b0 = r < rem ? r * (q + 1) : r * q + rem;
         A.vin = full.p; A.nel_out = H.DimDw * qb; A.row0_out = H.DimDw * b0;
         nout = A.nel_out * H.DimPh;
-        CHK(outb.alloc((size_t)nout)); A.vout = outb.p;
+        if (!out_dev) { CHK(outb.alloc((size_t)nout)); A.vout = outb.p; }
     }
     const int nb = (int)std::max<int64_t>(1, std::min<int64_t>(cdiv(nout, 256), 8192));
     hipLaunchKernelGGL(k_twin_reorder, dim3(nb), dim3(256), 0, h->stream, A);
     HIPCHK(hipGetLastError());
-    HIPCHK(hipMemcpyAsync(vout_host, A.vout, (size_t)nout * 8, hipMemcpyDeviceToHost, h->stream));
+    if (!out_dev) HIPCHK(hipMemcpyAsync(vout, A.vout, (size_t)nout * 8, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     return EDGPU_OK;
 }
@@ -1206,6 +1209,7 @@ int edgpu_malloc(void **dev, size_t bytes)
 int edgpu_free(void *dev) { if (dev) HIPCHK(hipFree(dev)); return EDGPU_OK; }
 int edgpu_memcpy_h2d(void *dev, const void *host, size_t bytes) { HIPCHK(hipMemcpy(dev, host, bytes, hipMemcpyHostToDevice)); return EDGPU_OK; }
 int edgpu_memcpy_d2h(void *host, const void *dev, size_t bytes) { HIPCHK(hipMemcpy(host, dev, bytes, hipMemcpyDeviceToHost)); return EDGPU_OK; }
+int edgpu_memset(void *dev, int32_t byte_value, size_t bytes) { HIPCHK(hipMemset(dev, byte_value, bytes)); return EDGPU_OK; }
 int edgpu_device_synchronize(void) { HIPCHK(hipDeviceSynchronize()); return EDGPU_OK; }
 
 }  // extern "C"

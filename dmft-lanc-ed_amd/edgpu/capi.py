@@ -26,7 +26,7 @@ SYMBOLS = [
     "edgpu_comm_unique_id", "edgpu_comm_init_rccl", "edgpu_comm_init_callbacks",
     "edgpu_comm_create_rccl", "edgpu_comm_create_callbacks", "edgpu_comm_sub", "edgpu_comm_destroy", "edgpu_sector_attach_comm",
     "edgpu_comm_count", "edgpu_comm_allreduce_sum", "edgpu_sector_exchange_info",
-    "edgpu_device_count", "edgpu_malloc", "edgpu_free", "edgpu_memcpy_h2d", "edgpu_memcpy_d2h",
+    "edgpu_device_count", "edgpu_malloc", "edgpu_free", "edgpu_memcpy_h2d", "edgpu_memcpy_d2h", "edgpu_memset",
     "edgpu_device_synchronize", "edgpu_last_error", "edgpu_abi_version",
 ]
 
@@ -139,6 +139,7 @@ def lib():
         "edgpu_free": (C.c_int, [vp]),
         "edgpu_memcpy_h2d": (C.c_int, [vp, vp, C.c_size_t]),
         "edgpu_memcpy_d2h": (C.c_int, [vp, vp, C.c_size_t]),
+        "edgpu_memset": (C.c_int, [vp, i32, C.c_size_t]),
         "edgpu_device_synchronize": (C.c_int, []),
         "edgpu_last_error": (C.c_char_p, []),
         "edgpu_abi_version": (C.c_int, []),

@@ -36,6 +36,11 @@ class DeviceVector:
         check(capi.lib().edgpu_memcpy_h2d(self.ptr, a.ctypes.data, self.n * 8))
         return self
 
+    def zero(self):
+        """all-zero vector (the start vector ED_DIAG.f90:147 passes: the library then seeds it itself) without a host copy"""
+        check(capi.lib().edgpu_memset(self.ptr, 0, self.n * 8))
+        return self
+
     def download(self):
         out = np.empty(self.n, np.float64)
         check(capi.lib().edgpu_memcpy_d2h(out.ctypes.data, self.ptr, self.n * 8))
@@ -225,12 +230,17 @@ class HvSector:
 
     def twin_reorder(self, vec):
         """State of the twin sector (ndw,nup) from a state of this sector (es_return_cvector, itwin branch)."""
-        vec = np.ascontiguousarray(vec, np.float64)
-        out = np.empty_like(vec)
+        nout = int(self.vecDim)
         if int(self._desc.mpi_size) > 1:   # shard of the twin sector: its dw columns are this sector's up index
             from .model import dw_partition
             qb, _ = dw_partition(int(self.info.DimUp), int(self._desc.mpi_size), int(self._desc.mpi_rank))
-            out = np.empty(int(self.info.DimDw) * qb * int(self.info.DimPh))
+            nout = int(self.info.DimDw) * qb * int(self.info.DimPh)
+        if isinstance(vec, DeviceVector):          # stays in HBM: returns a DeviceVector
+            out = DeviceVector(nout)
+            check(capi.lib().edgpu_twin_reorder(self._h, vec.ptr, out.ptr))
+            return out
+        vec = np.ascontiguousarray(vec, np.float64)
+        out = np.empty(nout)
         check(capi.lib().edgpu_twin_reorder(self._h, vec.ctypes.data, out.ctypes.data))
         return out
 

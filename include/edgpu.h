@@ -188,10 +188,11 @@ int edgpu_local_energy(edgpu_handle h, const double *state_host, double *out7);
 
 /* eigenvector hand-off for twin sectors (ed_twin): the state of sector B(ndw,nup) from the state of this
  * sector A(nup,ndw), vector_B(i) = cvec_A(Order(i)), Order = twin_sector_order (ED_SETUP.f90:852-880,
- * ED_EIGENSPACE.f90:486-497).  Host vectors of getDim doubles.  With more than one rank vin is the rank's shard of
- * A and vout its shard of B: DimDw_A * Qdw_B * DimPh doubles, Qdw_B = the rank's share of DimUp_A under the dw split
- * of ED_HAMILTONIAN.f90:96-110 (the state is all-gathered once on the device). */
-int edgpu_twin_reorder(edgpu_handle h, const double *vin_host, double *vout_host);
+ * ED_EIGENSPACE.f90:486-497).  Vectors of getDim doubles, each either a host pointer or a device pointer (e.g. the
+ * state edgpu_lanczos_gs_device left in HBM: nothing crosses PCIe then); out of place.  With more than one rank vin is
+ * the rank's shard of A and vout its shard of B: DimDw_A * Qdw_B * DimPh doubles, Qdw_B = the rank's share of DimUp_A
+ * under the dw split of ED_HAMILTONIAN.f90:96-110 (the state is all-gathered once on the device). */
+int edgpu_twin_reorder(edgpu_handle h, const double *vin, double *vout);
 
 /* ---- Green's-function leg: O|state> between two live sectors, in HBM ------
  * vout(j) = sgn * vin(i) with |j> = c^+_{iorb,ispin}|i> (dagger=1) or c_{iorb,ispin}|i> (dagger=0),
@@ -308,6 +309,7 @@ int edgpu_malloc(void **dev, size_t bytes);
 int edgpu_free(void *dev);
 int edgpu_memcpy_h2d(void *dev, const void *host, size_t bytes);
 int edgpu_memcpy_d2h(void *host, const void *dev, size_t bytes);
+int edgpu_memset(void *dev, int32_t byte_value, size_t bytes);   /* hipMemset: e.g. the all-zero start vector of ED_DIAG.f90:147 without a host copy */
 int edgpu_device_synchronize(void);
 
 const char *edgpu_last_error(void);

@@ -343,6 +343,40 @@ def apply_op(S_from, S_to, iorb, ispin, dagger, state):
     return (vv / np.sqrt(norm2) if norm2 > 0 else vv), norm2
 
 
+def apply_op_vec(S_from, S_to, iorb, ispin, dagger, state, normalise=True):
+    """The same statements as apply_op (ED_GF_NORMAL.f90:190-213, 264-283) evaluated for whole index slices with numpy,
+    so that the Ns=16 target sectors are within reach: the operator acts on ONE of the sector's index factors
+    (state2indices), every other index is carried along.  Bit-equal to apply_op (tests/test_analytic_cpu.py)."""
+    Ns_Ud = S_from.Ns_Ud
+    total_ud = S_from.model.get("ed_total_ud", True)
+    ialfa, iorb1 = (1, iorb) if total_ud else (iorb, 1)
+    ibeta = ialfa + (ispin - 1) * Ns_Ud
+    idims = [int(x) for x in list(S_from.DimUps) + list(S_from.DimDws)]
+    jdims = [int(x) for x in list(S_to.DimUps) + list(S_to.DimDws)]
+    HI = S_from.map(ibeta - 1).astype(np.int64); HJ = S_to.map(ibeta - 1).astype(np.int64)
+    bit = 1 << (iorb1 - 1)
+    occ = (HI & bit) != 0
+    src = np.nonzero(~occ if dagger else occ)[0]
+    r = HI[src] ^ bit                                  # cdg sets / c clears bit pos-1 (ED_SETUP.f90:805-831)
+    low = HI[src] & (bit - 1)
+    par = np.zeros(src.size, np.int64)
+    for q in range(iorb1 - 1):
+        par += (low >> q) & 1
+    sgn = np.where(par % 2 == 0, 1.0, -1.0)
+    dst = np.searchsorted(HJ, r)
+    assert np.array_equal(HJ[dst], r)
+    ax = len(idims) - ibeta + 1                        # C-order axis of index factor ibeta behind the phonon axis
+    vin = np.asarray(state, np.float64).reshape([S_from.DimPh] + idims[::-1])
+    vv = np.zeros([S_to.DimPh] + jdims[::-1])
+    a, b = np.moveaxis(vv, ax, -1), np.moveaxis(vin, ax, -1)
+    a[..., dst] = b[..., src] * sgn
+    vv = vv.reshape(-1)
+    if not normalise:
+        return vv
+    norm2 = float(vv @ vv)
+    return (vv / np.sqrt(norm2) if norm2 > 0 else vv), norm2
+
+
 def lanc_observables(S, state, peso=1.0):
     """Restatement of the per-state loop of lanc_observables (ED_OBSERVABLES.f90:150-215): loops over
     all basis states of sector S and accumulates the local observables with weight peso*|state_i|^2."""

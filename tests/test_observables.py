@@ -37,6 +37,11 @@ def test_twin_sector_vector(edgpu_mod, name, m, nu, nd):
     order = oracle.twin_sector_order(S)
     G = edgpu_mod.HvSector(m, nu, nd, storage="direct")
     np.testing.assert_array_equal(G.twin_reorder(v), v[order - 1])
+    # the same with the state resident in HBM (device pointers in and out, nothing crosses PCIe inside the call)
+    dv = edgpu_mod.DeviceVector(S.Dim).upload(v)
+    dt = G.twin_reorder(dv)
+    np.testing.assert_array_equal(dt.download(), v[order - 1])
+    dt.free(); dv.free()
     G.close()
 
 
