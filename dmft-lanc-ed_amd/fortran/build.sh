@@ -12,7 +12,7 @@ LINK=(-L"$HERE/../edgpu" -ledgpu -Wl,-rpath,'$ORIGIN/../../edgpu')
 "$FC" -O2 -c "$HERE/edgpu_c_api.f90" -o edgpu_c_api.o
 "$FC" -O2 -c "$HERE/dropin/EDGPU_LIVE.f90" -o EDGPU_LIVE.o
 # same-name replacement of the reference module ED_SPARSE_MATRIX (one layer over the C ABI) + a host-only demo of it
-"$FC" -O2 -c "$HERE/dropin/ED_SPARSE_MATRIX.f90" -o ED_SPARSE_MATRIX.o
+"$FC" -O2 -cpp -c "$HERE/dropin/ED_SPARSE_MATRIX.f90" -o ED_SPARSE_MATRIX.o
 "$FC" -O2 "$HERE/dropin/demo_sparse_dropin.f90" edgpu_c_api.o EDGPU_LIVE.o ED_SPARSE_MATRIX.o "${LINK[@]}" -o demo_sparse_dropin
 # explicit-argument operator module + the config-1 demo driver
 "$FC" -O2 -c "$HERE/ED_HAMILTONIAN_GPU.f90" -o ED_HAMILTONIAN_GPU.o
@@ -20,12 +20,17 @@ LINK=(-L"$HERE/../edgpu" -ledgpu -Wl,-rpath,'$ORIGIN/../../edgpu')
 # same-name operator modules (ED_HAMILTONIAN_SPARSE_HxV, ED_HAMILTONIAN_DIRECT_HxV) and the SF_SP_LINALG stand-in, compile-
 # checked and run against test-only scaffold modules that carry the reference's module names and variables
 if [ -d "$ROOT/tests/fortran_scaffold" ]; then
-  "$FC" -O2 -c "$ROOT/tests/fortran_scaffold/scaffold_modules.f90" -o scaffold_modules.o
-  "$FC" -O2 -c "$HERE/dropin/ED_HAMILTONIAN_GPU_BUILD.f90" -o ED_HAMILTONIAN_GPU_BUILD.o
-  "$FC" -O2 -c "$HERE/dropin/ED_HAMILTONIAN_SPARSE_HxV.f90" -o ED_HAMILTONIAN_SPARSE_HxV.o
-  "$FC" -O2 -c "$HERE/dropin/ED_HAMILTONIAN_DIRECT_HxV.f90" -o ED_HAMILTONIAN_DIRECT_HxV.o
-  "$FC" -O2 -c "$HERE/dropin/SF_SP_LINALG.f90" -o SF_SP_LINALG.o
-  "$FC" -O2 "$ROOT/tests/fortran_scaffold/host_like_driver.f90" edgpu_c_api.o EDGPU_LIVE.o ED_SPARSE_MATRIX.o scaffold_modules.o \
+  # an MPI build of the host (-D_MPI): the scaffold supplies `MODULE MPI` with MPI_COMM_NULL, the drop-ins are compiled
+  # with the host's preprocessor flags as INTEGRATION.md asks
+  MPIF=(-O2 -cpp -D_MPI)
+  "$FC" "${MPIF[@]}" -c "$ROOT/tests/fortran_scaffold/scaffold_mpi.f90" -o scaffold_mpi.o
+  "$FC" "${MPIF[@]}" -c "$HERE/dropin/ED_SPARSE_MATRIX.f90" -o ED_SPARSE_MATRIX_mpi.o      # replaces the serial .mod from here on
+  "$FC" "${MPIF[@]}" -c "$ROOT/tests/fortran_scaffold/scaffold_modules.f90" -o scaffold_modules.o
+  "$FC" "${MPIF[@]}" -c "$HERE/dropin/ED_HAMILTONIAN_GPU_BUILD.f90" -o ED_HAMILTONIAN_GPU_BUILD.o
+  "$FC" "${MPIF[@]}" -c "$HERE/dropin/ED_HAMILTONIAN_SPARSE_HxV.f90" -o ED_HAMILTONIAN_SPARSE_HxV.o
+  "$FC" "${MPIF[@]}" -c "$HERE/dropin/ED_HAMILTONIAN_DIRECT_HxV.f90" -o ED_HAMILTONIAN_DIRECT_HxV.o
+  "$FC" "${MPIF[@]}" -c "$HERE/dropin/SF_SP_LINALG.f90" -o SF_SP_LINALG.o
+  "$FC" "${MPIF[@]}" "$ROOT/tests/fortran_scaffold/host_like_driver.f90" edgpu_c_api.o EDGPU_LIVE.o scaffold_mpi.o ED_SPARSE_MATRIX_mpi.o scaffold_modules.o \
         ED_HAMILTONIAN_GPU_BUILD.o ED_HAMILTONIAN_SPARSE_HxV.o ED_HAMILTONIAN_DIRECT_HxV.o SF_SP_LINALG.o "${LINK[@]}" -o host_like_driver
 fi
 echo "built $HERE/_build/demo_c1"

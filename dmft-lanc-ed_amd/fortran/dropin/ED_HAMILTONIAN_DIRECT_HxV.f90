@@ -22,6 +22,9 @@ contains
     integer                  :: Nloc
     real(8), dimension(Nloc) :: vin, Hv
     character(len=*)         :: who
+#ifdef _MPI
+    if (MpiStatus .and. MpiComm == MPI_COMM_NULL) return                      ! a rank outside the shrunk communicator holds no rows
+#endif
     if (.not. Hstatus) stop "directMatVec_cc ERROR: Hsector NOT set"          ! reference 30
     if (.not. gpu_live_is_current(EDGPU_STORE_DIRECT)) call gpu_build_live(EDGPU_STORE_DIRECT)
     if (Nloc /= live_info%vecDim) then

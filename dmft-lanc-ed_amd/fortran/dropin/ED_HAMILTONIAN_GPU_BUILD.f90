@@ -57,6 +57,9 @@ contains
     type(c_ptr)      :: h
     integer          :: Nups(Ns_Ud), Ndws(Ns_Ud)
     if (.not. Hstatus) stop "gpu_build_live ERROR: Hsector NOT set"
+#ifdef _MPI
+    if (MpiStatus .and. MpiComm == MPI_COMM_NULL) stop "gpu_build_live ERROR: called on a rank outside the sector's communicator"
+#endif
     call resolve_bath()
     call get_Nup(Hsector, Nups)
     call get_Ndw(Hsector, Ndws)

@@ -2,7 +2,8 @@
 !  sector operator is built and applied on the GPU through the C ABI of include/edgpu.h.  ED_HAMILTONIAN.f90 binds these
 !  names unmodified (139-166):   call ed_buildh_main(isector) ;  spHtimesV_p => spMatVec_main   (or _MPI_ / _orbs).
 !  Compile this file INSTEAD of the reference's, together with EDGPU_C_API, EDGPU_LIVE, ED_HAMILTONIAN_GPU_BUILD and the
-!  same-name ED_SPARSE_MATRIX / ED_HAMILTONIAN_DIRECT_HxV.
+!  same-name ED_SPARSE_MATRIX / ED_HAMILTONIAN_DIRECT_HxV, with the host's own preprocessor flags (-cpp, -D_MPI for an MPI
+!  build: MPI_COMM_NULL then arrives through ED_VARS_GLOBAL's USE MPI as it does for the reference's file).
 MODULE ED_HAMILTONIAN_SPARSE_HxV
   use, intrinsic :: iso_c_binding
   USE ED_HAMILTONIAN_COMMON
@@ -46,6 +47,11 @@ contains
     real(8), dimension(:,:), optional :: Hmat
     character(len=*)                  :: who
     real(8), allocatable, target      :: dense(:,:)
+#ifdef _MPI
+    ! ranks the shrunk communicator of a sector with DimDw < MpiSize leaves out (ED_HAMILTONIAN.f90:65-93) return at once,
+    ! exactly as the reference's builders do (35-37, 218-220): no GPU sector, no collective
+    if (MpiStatus .and. MpiComm == MPI_COMM_NULL) return
+#endif
     if (.not. Hstatus) stop "ed_buildh ERROR: Hsector NOT set"
     isector = Hsector                                       ! as the reference does (40)
     if (present(Hmat)) then

@@ -6,6 +6,9 @@
 !  sp_dump_matrix instead.  Compile this file INSTEAD of the reference's ED_SPARSE_MATRIX.f90.
 module ED_SPARSE_MATRIX
   use, intrinsic :: iso_c_binding
+#ifdef _MPI
+  use MPI, only: MPI_COMM_NULL          ! as the reference's module does (ED_SPARSE_MATRIX.f90:2-5)
+#endif
   use EDGPU_C_API
   use EDGPU_LIVE, only: edgpu_live_invalidate
   implicit none
@@ -28,7 +31,11 @@ module ED_SPARSE_MATRIX
      end subroutine sp_allreduce_interface
   end interface
 
-  integer, save :: comm_null = -1     !< value of MPI_COMM_NULL of the host's MPI (sp_set_comm_null); calls on it return at once
+#ifdef _MPI
+  integer, save :: comm_null = MPI_COMM_NULL   !< calls on the null communicator return at once (ED_SPARSE_MATRIX.f90:160,...)
+#else
+  integer, save :: comm_null = -1     !< value of MPI_COMM_NULL of the host's MPI (sp_set_comm_null) when built without -D_MPI
+#endif
   procedure(sp_allreduce_interface), pointer, save :: allreduce_hook => null()
 
   interface sp_init_matrix

@@ -10,6 +10,9 @@
 !  first product, so MatVec is called once, on the start vector, to bring it to life.
 module SF_SP_LINALG
   use, intrinsic :: iso_c_binding
+#ifdef _MPI
+  use MPI, only: MPI_COMM_NULL
+#endif
   use EDGPU_C_API
   use EDGPU_LIVE
   implicit none
@@ -38,6 +41,16 @@ module SF_SP_LINALG
   public :: sp_eigh, sp_lanc_eigh, sp_dvdson_eigh, sp_lanc_tridiag
 
 contains
+
+  !> SciFortran's MPI forms return at once on a rank whose communicator is MPI_COMM_NULL -- the ranks a sector with
+  !  DimDw < MpiSize leaves out call them all the same (ED_DIAG.f90:153-185 runs on every rank)
+  logical function left_out(MpiComm)
+    integer, intent(in) :: MpiComm
+    left_out = .false.
+#ifdef _MPI
+    left_out = MpiComm == MPI_COMM_NULL
+#endif
+  end function left_out
 
   subroutine wake(MatVec, n, v)
     procedure(sf_matvec)   :: MatVec
@@ -81,6 +94,7 @@ contains
     real(8), optional             :: v0(size(evec,1))
     real(8), optional             :: tol
     logical, optional             :: iverbose
+    if (left_out(MpiComm)) return
     call sp_eigh_serial(MatVec, eval, evec, Nblock, Nitermax, v0, tol, iverbose)   ! the sector carries its communicator
   end subroutine sp_eigh_mpi
 
@@ -115,6 +129,7 @@ contains
     logical, optional             :: iverbose
     real(8), optional             :: threshold
     integer, optional             :: ncheck
+    if (left_out(MpiComm)) return
     call sp_lanc_eigh_serial(MatVec, egs, vect, Nitermax, iverbose, threshold, ncheck)
   end subroutine sp_lanc_eigh_mpi
 
@@ -155,6 +170,7 @@ contains
     real(8)                       :: vin(:)
     real(8)                       :: alanc(:), blanc(:)
     real(8), optional             :: threshold
+    if (left_out(MpiComm)) return
     call sp_lanc_tridiag_serial(MatVec, vin, alanc, blanc, threshold)
   end subroutine sp_lanc_tridiag_mpi
 

@@ -9,6 +9,7 @@ program host_like_driver
   USE ED_HAMILTONIAN_SPARSE_HxV
   USE ED_HAMILTONIAN_DIRECT_HxV
   USE SF_SP_LINALG
+  use EDGPU_LIVE, only: live_status
   implicit none
   real(8), allocatable :: v(:), Hv(:), vect(:), eval(:), evec(:,:), Hmat(:,:), alanc(:), blanc(:)
   real(8) :: egs
@@ -55,6 +56,29 @@ program host_like_driver
   write(*,"(A,3ES24.16)") "Hmat_trace_sum_11=", sum([(Hmat(i,i), i=1,N)]), sum(Hmat), Hmat(1,1)
   write(*,"(A,L1)") "Hmat_symmetric=", maxval(abs(Hmat - transpose(Hmat))) == 0d0
   call host_delete(); deallocate(Hmat)
+
+  ! ---- a rank the shrunk communicator leaves out: sector (3,0) has DimDw = 1 < MpiSize = 4, build_Hv_sector gives ranks 1..3
+  !      MpiComm = MPI_COMM_NULL and leaves their MpiRank/MpiSize alone (ED_HAMILTONIAN.f90:65-93); they still call the
+  !      builder and the solver (ED_DIAG.f90:143-185), which must return at once without creating a GPU sector
+  MpiStatus = .true.; MpiComm = MPI_COMM_NULL; MpiRank = 2; MpiSize = 4
+  isector = 1 + 3*(Ns_Orb+1) + 0
+  do imode = 1, 2
+     ed_sparse_H = (imode == 1)
+     call host_build(isector)
+     allocate(eval(1), evec(0,1), vect(0), alanc(3), blanc(3))        ! vecDim_Hv_sector = 0 on such a rank
+     eval = -77d0; alanc = -77d0
+     call sp_eigh(MpiComm, spHtimesV_p, eval, evec, 1, 10, tol=1d-12)
+     call sp_lanc_eigh(MpiComm, spHtimesV_p, eval(1), vect, 10)
+     call sp_lanc_tridiag(MpiComm, spHtimesV_p, vect, alanc, blanc)
+     write(*,"(A,L1,A,L1)") "left_out_rank_untouched=", (.not. live_status) .and. eval(1) == -77d0 .and. alanc(1) == -77d0, " sparse=", ed_sparse_H
+     call host_delete()
+     deallocate(eval, evec, vect, alanc, blanc)
+  end do
+  N = getDim(isector); allocate(Hmat(N,N)); Hmat = -77d0
+  call host_build(isector, Hmat)                                      ! LAPACK form: ed_buildh_main(isector,Hmat) returns too (35-37)
+  write(*,"(A,L1)") "left_out_rank_hmat_untouched=", (.not. live_status) .and. all(Hmat == -77d0)
+  call host_delete(); deallocate(Hmat)
+  MpiStatus = .false.; MpiRank = 0; MpiSize = 1
 
   ! ---- 2-orbital replica bath, H_basis={sigma_z}, lambda_imp=1, Jx=Jp=0.25 (golden record replica_Nbath2_J) ------
   deallocate(impHloc, dmft_bath%e, dmft_bath%v)

@@ -18,6 +18,7 @@ END MODULE ED_INPUT_VARS
 
 MODULE ED_VARS_GLOBAL
   USE ED_SPARSE_MATRIX
+  USE MPI                                                   ! ED_VARS_GLOBAL.f90:4-7 (#ifdef _MPI)
   implicit none
   type H_operator
      real(8),dimension(:,:,:,:),allocatable :: O
@@ -54,7 +55,8 @@ MODULE ED_VARS_GLOBAL
   type(sparse_matrix_csr)                          :: spH0_ph, spH0e_eph, spH0ph_eph
   procedure(dd_sparse_HxV),pointer                 :: spHtimesV_p=>null()
   logical                                          :: Jhflag
-  integer                                          :: MpiComm = -1
+  integer                                          :: MpiComm_Global = MPI_COMM_NULL    ! ED_VARS_GLOBAL.f90:265-266
+  integer                                          :: MpiComm = MPI_COMM_NULL
   logical                                          :: MpiStatus = .false.
   integer                                          :: MpiRank = 0, MpiSize = 1
 END MODULE ED_VARS_GLOBAL

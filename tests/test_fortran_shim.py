@@ -162,6 +162,9 @@ def test_unchanged_host_flow_through_same_name_modules():
     tr, tot, h11 = f("Hmat_trace_sum_11")
     assert abs(tr - np.trace(H)) < 1e-10 and abs(tot - H.sum()) < 1e-10 and abs(h11 - H[0, 0]) < 1e-14
     assert "Hmat_symmetric=T" in out
+    # ranks outside a shrunk communicator (MpiStatus=T, MpiComm=MPI_COMM_NULL: ED_HAMILTONIAN.f90:65-93) return from the
+    # builders and the SF_SP_LINALG entry points without creating a GPU sector or touching their arguments
+    assert out.count("left_out_rank_untouched=T") == 2 and "left_out_rank_hmat_untouched=T" in out, out
     gr = [c for c in cases.golden_cases() if c["name"] == "replica_Nbath2_J"][0]
     assert "replica N=   400" in out
     assert abs(f("replica_sum_Hv")[0] - gr["sum_Hv"]) < 1e-11 and abs(f("replica_v_Hv")[0] - gr["v_Hv"]) < 1e-10
