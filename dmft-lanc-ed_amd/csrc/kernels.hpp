@@ -675,9 +675,12 @@ struct UpHaloArgs {
     const double *diag, *Eup, *Edw, *cross; const int32_t *mapup, *mapdw; int32_t impmask, nI; double econst;
     const double *v; double *out;
     int32_t ld;              // row pitch of v / out in doubles (0: DimUp)
+    // ADD: `out` already holds the dw part (k_dwpass2<..., WR>): this pass adds to it.  EPI: Lanczos epilogue on top,
+    // out = s_cur*(local + dw) - beta*s_prev*uprev and the alpha partial sums (s_cur*v).out per workgroup
+    const double *uprev, *scal; double *partial;
 };
 constexpr int kHaloSegMax = 6144, kHaloMax = 12288;     // up to 3 pairs and 12 halo values per lane of a 1024-thread workgroup
-template <bool DIRECT, int NQ, int MAXH>      // NQ: pairs per lane = steps per (row, segment) item; MAXH: halo values per lane
+template <bool DIRECT, int NQ, int MAXH, bool ADD = false, bool EPI = false>      // NQ: pairs per lane = steps per (row, segment) item; MAXH: halo values per lane
 __global__ void __launch_bounds__(1024) k_uppass_halo(UpHaloArgs A)
 {
     extern __shared__ double lds[];
@@ -692,8 +695,11 @@ __global__ void __launch_bounds__(1024) k_uppass_halo(UpHaloArgs A)
     double *halo = lds + A.seglen;
     double *tv = halo + A.halocap;
     double *crow = tv + 128;
+    double *red = crow + 32;
     for (int t = tid; t < A.nterms && t < 128; t += NT) tv[t] = A.tval[t];
-    if (g >= G) return;
+    if (g >= G) { if (EPI && tid == 0) A.partial[blockIdx.x] = 0.0; return; }
+    const double s_cur = EPI ? A.scal[SC_SCUR] : 1.0, c_prev = (EPI && A.uprev) ? A.scal[SC_BETA] * A.scal[SC_SPREV] : 0.0;
+    double asum = 0.0;
     uint32_t hc[MAXH / 2];                               // this lane's halo columns, two 16-bit values per register: the same for every row
 #pragma unroll
     for (int h = 0; h < MAXH; h += 2) {
@@ -712,7 +718,7 @@ __global__ void __launch_bounds__(1024) k_uppass_halo(UpHaloArgs A)
     // Operand ring of two slots, continuous across items: the image slice of a workgroup is the same for every row, so the
     // operands of linear step L+2 (possibly of the next row) are requested as soon as step L has used its slot.  Loads return
     // in order: requests a step waits for are issued BEFORE the next row's prefetch, never behind it.
-    struct Ops { dbl2v d; uint4 w0, w1, w2, w3; };       // d: stored diagonal (KRON) or Eup (DIRECT)
+    struct Ops { dbl2v d; uint4 w0, w1, w2, w3; dbl2v od, up; };       // d: stored diagonal (KRON) or Eup (DIRECT); od: dw part already in out (ADD); up: u_prev (EPI)
     Ops o[2];
     auto load_ops = [&](int64_t rw, int q, Ops &t) {
         const int p = tid + q * NT;
@@ -721,6 +727,8 @@ __global__ void __launch_bounds__(1024) k_uppass_halo(UpHaloArgs A)
             if (!DIRECT) t.d = *reinterpret_cast<const dbl2v *>(A.diag + (rw % A.Qdw) * DimUp + i);
             else t.d = *reinterpret_cast<const dbl2v *>(A.Eup + i);
             t.w0 = A.pseg8[2 * i]; t.w1 = A.pseg8[2 * i + 1]; t.w2 = A.pseg8[2 * i + 2]; t.w3 = A.pseg8[2 * i + 3];
+            if (ADD) t.od = *reinterpret_cast<const dbl2v *>(A.out + rw * ld + i);      // this lane alone writes that position, two steps from now
+            if (EPI && A.uprev) t.up = *reinterpret_cast<const dbl2v *>(A.uprev + rw * ld + i);
         }
     };
     auto step = [&](int64_t rw, int q, const Ops &cur) {
@@ -742,6 +750,12 @@ __global__ void __launch_bounds__(1024) k_uppass_halo(UpHaloArgs A)
                 double t0 = tv[code0 & 0x7fu], t1 = tv[code1 & 0x7fu];
                 t0 = (code0 & 0x80u) ? -t0 : t0; t1 = (code1 & 0x80u) ? -t1 : t1;
                 a0 += t0 * lds[col0]; a1 += t1 * lds[col1];
+            }
+            if (ADD) { a0 += cur.od.x; a1 += cur.od.y; }
+            if (EPI) {
+                a0 *= s_cur; a1 *= s_cur;
+                if (A.uprev) { a0 -= c_prev * cur.up.x; a1 -= c_prev * cur.up.y; }
+                asum += (s_cur * xx.x) * a0 + (s_cur * xx.y) * a1;
             }
             dbl2v r; r.x = a0; r.y = a1;
             *reinterpret_cast<dbl2v *>(A.out + rw * ld + lo + 2 * p) = r;
@@ -773,6 +787,7 @@ __global__ void __launch_bounds__(1024) k_uppass_halo(UpHaloArgs A)
         item(std::integral_constant<int, 0>{}, row); row += rstep;
         if (NQ & 1) { if (row >= A.nrows) break; item(std::integral_constant<int, 1>{}, row); row += rstep; }
     }
+    if (EPI) { const double rr = block_sum(asum, red); if (tid == 0) A.partial[blockIdx.x] = rr; }
 }
 
 // pelem8 (columns) -> pseg8 (positions in the [segment | halo] LDS image of the segment that owns the element)
@@ -858,7 +873,15 @@ __global__ void __launch_bounds__(256) k_dwpass(DwArgs A)
 // Same pass with two iup per lane (16-byte loads/stores; needs DimUp even) and the Hdw rows of
 // the block staged in LDS once, which removes the per-lane table loads: ~5x fewer vector-memory
 // instructions per element than k_dwpass.
-template <bool EPI, bool NT, bool RAGGED>   // RAGGED: rows have different hop counts (multi-orbital models): skip the ELL padding
+// write-through store: the line leaves the XCD's L2 (plain and nt stores keep it there, MI355X_MICROARCH.md "stores of each
+// flavour"), so a result stream that nobody on this XCD reads again does not push the gathered slab out of the L2
+__device__ __forceinline__ void store_through(dbl2v *p, dbl2v v)
+{
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(p), "v"(v) : "memory");
+}
+// WR = 0: out += dw hops (read-modify-write, optionally with the Lanczos epilogue).  WR = 1 / 2: out = dw hops, nothing of
+// `out` is read (the local pass that follows adds to it and carries the epilogue: hxv(), "dw first"); 2 stores write-through.
+template <bool EPI, bool NT, bool RAGGED, int WR = 0>   // RAGGED: rows have different hop counts (multi-orbital models): skip the ELL padding
 __global__ void __launch_bounds__(256) k_dwpass2(DwArgs A)
 {
     // dynamic LDS sized by the launch to R*dww entries (was a fixed 64x64 image = 48 KB, i.e. 3 workgroups per CU whatever
@@ -903,6 +926,7 @@ __global__ void __launch_bounds__(256) k_dwpass2(DwArgs A)
                     acc += tvr[k] * x;
                 }
                 dbl2v *po = reinterpret_cast<dbl2v *>(A.out + e);
+                if (WR) { if (WR == 2) store_through(po, acc); else if (NT) __builtin_nontemporal_store(acc, po); else *po = acc; continue; }
                 dbl2v o = NT ? __builtin_nontemporal_load(po) : *po;
                 if (EPI) {
                     const dbl2v vl = *reinterpret_cast<const dbl2v *>(A.v + e);
@@ -1956,6 +1980,11 @@ __device__ __forceinline__ void scalar_step(double *scal, double *alphas, double
         if (k == 0) { scal[SC_SCUR] = b > 0.0 ? 1.0 / b : 0.0; scal[SC_SPREV] = 0.0; scal[SC_BETA] = 0.0; }
         else { betas[k] = b; scal[SC_BETA] = b; scal[SC_SPREV] = scal[SC_SCUR]; scal[SC_SCUR] = b > 0.0 ? 1.0 / b : 0.0; }
     } else if (mode == 5) { scal[SC_ALPHA] = scal[SC_TMP]; alphas[k] = scal[SC_TMP]; scal[SC_K] = (double)(k + 1); }   // after the dw pass: alpha_k
+    // multi-eigenpair solver (eigsh): the newest Lanczos vector was re-orthogonalised in place, TMP = its new |.|^2:
+    // beta of the iteration just completed and the scale of that vector follow it; nothing rotates, the counter stays
+    else if (mode == 6) { const double b = sqrt(scal[SC_TMP]); const int kk = k > 0 ? k - 1 : 0; betas[kk + 1] = b; scal[SC_BETA] = b; scal[SC_SCUR] = b > 0.0 ? 1.0 / b : 0.0; }
+    // thick restart: the current vector keeps its scale, the recurrence starts afresh (no previous vector), counter 0
+    else if (mode == 7) { scal[SC_SPREV] = 0.0; scal[SC_BETA] = 0.0; scal[SC_ALPHA] = 0.0; scal[SC_K] = 0.0; }
 }
 __global__ void k_scalar_step(double *scal, double *alphas, double *betas, const double *zvec, int k, int mode)
 {

@@ -512,7 +512,273 @@ static void jacobi_eig(std::vector<double> &A, int m, std::vector<double> &w, st
     for (int j = 0; j < m; j++) { w[j] = A[(size_t)idx[j] * m + idx[j]]; for (int i = 0; i < m; i++) Y[i + (size_t)m * j] = V[(size_t)i * m + idx[j]]; }
 }
 
+// ---------------------------------------------------------------------------------------
+// The same solver with PARTIAL re-orthogonalisation (the default; EDGPU_EIGSH_PRO=0 selects the form below that
+// re-orthogonalises every vector against the whole basis).  Between restarts the basis grows by the plain three-term
+// recurrence on the device-resident Lanczos engine (lz_iter: product fused with -beta*v_prev and the alpha dot, one
+// axpy+norm pass, scales carried as device scalars -- no pass over the basis, no separate normalisation).  The loss of
+// orthogonality is tracked on the host by the omega recurrence (H. Simon, Math. Comp. 42 (1984) 115) written for the
+// general projected matrix T of a thick-restarted basis (diagonal Ritz block + arrow + tridiagonal tail):
+//     beta_j w(j+1,k) = sum_i T(i,k) w(i,j) - sum_{i<=j} T(i,j) w(i,k) + (eps |T| + eta_k + eta_j)
+// When estimates pass sqrt(eps) the new vector is orthogonalised -- against the kept Ritz vectors they concern when only
+// those are concerned (orthogonality is lost along converging Ritz directions, which a thick-restarted basis holds as
+// explicit vectors), against the whole basis otherwise; and always the first vector after a restart, whose image couples
+// to every kept Ritz vector.  eta is what makes this safe across restarts: the coefficients such a pass removes are not
+// part of T, so the relation H y_k = theta_k y_k + sigma_k v_l of a Ritz vector formed afterwards holds only up to
+// eta_k = |F s_k| (F: the removed coefficients, kept on the host); the new Lanczos vectors overlap with the discarded
+// Ritz directions, so that defect feeds the recurrence at every step.  A first form without the term had estimates of 1e-12
+// while the true loss reached 1e-3 after a handful of restarts, and T produced values far below the spectrum (a 400-state
+// sector and Ns=16 with 20 vectors; tests/eigsh_model.py is the numpy model of this routine, tests/test_eigsh_model_cpu.py runs it).
+// A semi-orthogonal basis reproduces the Ritz values of the orthogonal one to O(eps |H|); the returned Ritz vectors are
+// orthonormalised among themselves at the end.  Basis vectors stay unnormalised (v_i = sc_i * B_i), the scales are folded
+// into the rotation and projection coefficients.
+// ---------------------------------------------------------------------------------------
+static int eigsh_pro(S *s, int nev, int ncv, int maxiter, double tol, double *evals, double *evecs_host, int *nconv_out, int *nrestart_out, int *nmatvec_out)
+{
+    const int64_t Dim = s->H.Dim, n = s->nloc, vlen = s->vlen;
+    if (nev < 1) return fail(EDGPU_EINVAL, "edgpu_eigsh: nev < 1");
+    if ((int64_t)nev >= Dim) return fail(EDGPU_EINVAL, "edgpu_eigsh: nev must be smaller than the sector dimension (the reference switches to LAPACK there, ED_DIAG.f90:105-107)");
+    if (nev >= kMaxBasisBig) return fail(EDGPU_EUNSUPPORTED, "edgpu_eigsh: nev must be below the basis capacity (edgpu_eigsh_ncv_cap)");
+    if (ncv > kMaxBasisBig) ncv = kMaxBasisBig;
+    if ((int64_t)ncv > Dim) ncv = (int)Dim;
+    if (ncv <= nev) ncv = (int)std::min<int64_t>(std::min<int64_t>(2 * nev + 1, kMaxBasisBig), Dim);
+    if (ncv <= nev) return fail(EDGPU_EINVAL, "edgpu_eigsh: ncv must exceed nev");
+    s->eig_ncv_used = ncv;
+    if (maxiter < 1) maxiter = 1;
+    const double eps = 2.220446049250313e-16, tol_eff = std::max(tol, 1e-12), eps23 = std::pow(eps, 2.0 / 3.0);
+    const double tau = std::sqrt(eps) * (double)std::max(1, dbg_int("EDGPU_EIGSH_OMEGA_PCT", 100)) / 100.0;
+    const int m = ncv, M = m + 2;
+    CHK(lz_prepare(s, m + 4));
+    if (s->lz[3].n != (size_t)n) CHK(s->lz[3].alloc((size_t)n));
+    while ((int)s->eigV.size() < m + 1) s->eigV.push_back(std::make_unique<DevBuf<double>>());
+    for (int i = 0; i <= m; i++) {
+        if (s->eigV[i]->n < (size_t)vlen) CHK(s->eigV[i]->alloc((size_t)vlen));
+        if (s->pad_on) HIPCHK(hipMemsetAsync(s->eigV[i]->p, 0, (size_t)vlen * 8, s->stream));      // padding columns must hold zeros
+    }
+    const int nb = (int)std::max<int64_t>(1, std::min<int64_t>(cdiv(vlen, 256 * 8), 1024));
+    const int gs = (int)std::max<int64_t>(1, std::min<int64_t>(cdiv(vlen, 256 * 4), 4096));
+    if (s->eig_h.n < (size_t)(m + 3)) CHK(s->eig_h.alloc((size_t)m + 3));
+    if (s->eig_partial.n < (size_t)nb * (kMaxBasis + 2)) CHK(s->eig_partial.alloc((size_t)nb * (kMaxBasis + 2)));
+    if (s->eig_y.n < (size_t)m * m) CHK(s->eig_y.alloc((size_t)m * m));
+    auto B = [&](int i) { return s->eigV[i]->p; };
+    const SectorHost &H = s->H;
+    std::vector<double> sc((size_t)M, 1.0), T((size_t)M * M, 0.0), W((size_t)M * M, 0.0), F((size_t)M * M, 0.0), eta((size_t)M, 0.0), theta, Y, coef((size_t)M);
+    auto Tm = [&](int i, int j) -> double & { return T[(size_t)i * M + j]; };
+    auto Wm = [&](int i, int j) -> double & { return W[(size_t)i * M + j]; };
+    auto Fm = [&](int i, int j) -> double & { return F[(size_t)i * M + j]; };
+    auto rotate = [&](int nv, int nout, const std::vector<double> &Yc) -> int {      // B_a <- sum_k B_k Yc(k,a), a < nout (in place)
+        HIPCHK(hipMemcpyAsync(s->eig_y.p, Yc.data(), (size_t)nv * nout * 8, hipMemcpyHostToDevice, s->stream));
+        HIPCHK(hipStreamSynchronize(s->stream));      // Yc may be a temporary of the caller
+        if (nv <= kMaxBasis) { RotArgs R{}; R.nv = nv; R.nout = nout; R.Y = s->eig_y.p; for (int i = 0; i < nv; i++) R.V[i] = B(i);
+            hipLaunchKernelGGL(k_basis_rotate<kMaxBasis>, dim3(gs), dim3(256), (size_t)nv * nout * 8, s->stream, R, vlen); }
+        else { RotArgsT<kMaxBasisBig> R{}; R.nv = nv; R.nout = nout; R.Y = s->eig_y.p; for (int i = 0; i < nv; i++) R.V[i] = B(i);
+            static OncePerDevice once;
+            if (once.first(s->device)) HIPCHK(hipFuncSetAttribute((const void *)k_basis_rotate<kMaxBasisBig>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 96 * 8));
+            hipLaunchKernelGGL(k_basis_rotate<kMaxBasisBig>, dim3(gs), dim3(256), (size_t)nv * nout * 8, s->stream, R, vlen); }
+        HIPCHK(hipGetLastError());
+        return EDGPU_OK;
+    };
+    // w <- w - sum_{i in idx} <v_i,w> v_i with v_i = sc[i]*B_i (classical Gram-Schmidt, a second pass when the first one
+    // removed more than half of |w|^2); |w|^2 afterwards in scal[TMP] and in nrm2; removed[t] = coefficient of v_idx[t]
+    std::vector<double> removed;
+    auto project_out = [&](const std::vector<int> &idx, const double *scl, double *w, double &nrm2) -> int {
+        const int nv = (int)idx.size();
+        removed.assign((size_t)nv, 0.0);
+        double before = -1.0;
+        for (int pass = 0; pass < 2; pass++) {
+            const int ngroups = std::max(1, (int)cdiv(nv, kMaxBasis));
+            for (int g = 0; g < ngroups; g++) {
+                const int g0 = g * kMaxBasis, gc = std::min(kMaxBasis, nv - g0); const bool lastg = g == ngroups - 1;
+                BasisArgs Ba{}; Ba.nv = gc + (lastg ? 1 : 0);
+                for (int i = 0; i < gc; i++) Ba.V[i] = B(idx[g0 + i]);
+                if (lastg) Ba.V[gc] = w;                      // |w|^2 before the update rides along
+                launch_multidot(s->stream, nb, Ba, (const double *)w, vlen, s->eig_partial.p);
+                hipLaunchKernelGGL(k_multidot_final, dim3(1), dim3(256), 0, s->stream, (const double *)s->eig_partial.p, nb, Ba.nv, s->eig_h.p + g0);
+                HIPCHK(hipGetLastError());
+            }
+            CHK(allreduce_dev(s, s->eig_h.p, nv + 1));
+            HIPCHK(hipMemcpyAsync(coef.data(), s->eig_h.p, (size_t)(nv + 1) * 8, hipMemcpyDeviceToHost, s->stream)); HIPCHK(hipStreamSynchronize(s->stream));
+            before = coef[nv];
+            for (int i = 0; i < nv; i++) { removed[i] += coef[i] * scl[i]; coef[i] *= scl[i] * scl[i]; }
+            HIPCHK(hipMemcpyAsync(s->eig_h.p, coef.data(), (size_t)nv * 8, hipMemcpyHostToDevice, s->stream));
+            for (int g = 0; g < ngroups; g++) {
+                const int g0 = g * kMaxBasis, gc = std::min(kMaxBasis, nv - g0);
+                BasisArgs Bu{}; Bu.nv = gc; for (int i = 0; i < gc; i++) Bu.V[i] = B(idx[g0 + i]);
+                if (g == ngroups - 1) launch_multiaxpy_norm(s->stream, nb, Bu, (const double *)(s->eig_h.p + g0), w, vlen, s->eig_partial.p);
+                else launch_multiaxpy(s->stream, nb, Bu, (const double *)(s->eig_h.p + g0), w, vlen);
+                HIPCHK(hipGetLastError());
+            }
+            hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(1024), 0, s->stream, (const double *)s->eig_partial.p, (int64_t)nb, s->scal.p + SC_TMP);
+            HIPCHK(hipGetLastError());
+            CHK(allreduce_tmp(s));
+            HIPCHK(hipMemcpyAsync(&nrm2, s->scal.p + SC_TMP, 8, hipMemcpyDeviceToHost, s->stream)); HIPCHK(hipStreamSynchronize(s->stream));
+            if (nrm2 >= 0.5 * before) break;
+        }
+        return EDGPU_OK;
+    };
+    auto scalar_mode = [&](int mode) -> int {
+        hipLaunchKernelGGL(k_scalar_step, dim3(1), dim3(1), 0, s->stream, s->scal.p, s->alphas.p, s->betas.p, (const double *)nullptr, -1, mode);
+        HIPCHK(hipGetLastError());
+        return EDGPU_OK;
+    };
+    auto all_upto = [](int j) { std::vector<int> v((size_t)j + 1); for (int i = 0; i <= j; i++) v[i] = i; return v; };
+    double *dense = s->lz[3].p;
+    hipLaunchKernelGGL(k_random_start, dim3(2048), dim3(256), 0, s->stream, dense, H.DimUp, H.Qdw, H.dw0, H.DimDw, H.DimPh, (uint64_t)1234567);
+    HIPCHK(hipGetLastError());
+    CHK(lzf_copy_in(s, B(0), dense));
+    LzVecs V{s->lz[0].p, B(0), B(1)};
+    CHK(lz_start(s, V));                                  // zeroes the dummy previous vector, scale of u_0 -> scal[SCUR]
+    HIPCHK(hipMemcpyAsync(&sc[0], s->scal.p + SC_SCUR, 8, hipMemcpyDeviceToHost, s->stream)); HIPCHK(hipStreamSynchronize(s->stream));
+    Wm(0, 0) = 1.0;
+    int l = 0, j = 0, kloc = 0, nconv = 0, it = 0, nmv = 0, meff = m, n_full = 0, n_sel = 0; int64_t nreads = 0;
+    bool exact = false; double normT = 0.0, beta_last = 0.0;
+    uint64_t seed = 7654321;
+    for (it = 0; it < maxiter; it++) {
+        meff = m; exact = false;
+        for (; j < m; j++) {
+            V.ucur = B(j); V.w = B(j + 1);
+            CHK(lz_iter(s, V, kloc, nullptr)); nmv++;      // afterwards V.uprev = B(j), V.ucur = B(j+1)
+            double ab[2];
+            HIPCHK(hipMemcpyAsync(&ab[0], s->alphas.p + kloc, 8, hipMemcpyDeviceToHost, s->stream));
+            HIPCHK(hipMemcpyAsync(&ab[1], s->betas.p + kloc + 1, 8, hipMemcpyDeviceToHost, s->stream));
+            HIPCHK(hipStreamSynchronize(s->stream));
+            kloc++;
+            double alpha = ab[0], beta = ab[1];
+            Tm(j, j) = alpha;
+            normT = std::max(normT, std::fabs(alpha) + beta + (j > 0 ? std::fabs(Tm(j, j - 1)) : 0.0));
+            const bool arrow = l > 0 && j == l;            // H v_l couples to every kept Ritz vector
+            std::vector<int> idx;
+            if (arrow) idx = all_upto(j);
+            else {
+                // omega recurrence: estimates w(j+1,k), k < j
+                const double psi = 2.0 * eps * normT;
+                bool any = false, beyond = false;
+                for (int k = 0; k < j; k++) {
+                    double num = 0.0;
+                    for (int i = 0; i <= j; i++) { const double t1 = Tm(i, k), t2 = Tm(i, j); if (t1 != 0.0) num += t1 * Wm(i, j); if (t2 != 0.0) num -= t2 * Wm(i, k); }
+                    const double w = (num + std::copysign(psi + eta[k] + eta[j], num)) / std::max(beta, 1e-300);
+                    Wm(j + 1, k) = Wm(k, j + 1) = w;
+                    if (!(std::fabs(w) <= tau)) { any = true; if (k >= l) beyond = true; }      // also catches NaN
+                }
+                Wm(j + 1, j) = Wm(j, j + 1) = eps * normT / std::max(beta, 1e-300); Wm(j + 1, j + 1) = 1.0;
+                if (any && beyond) { idx = all_upto(j); n_full++; }
+                else if (any) { for (int k = 0; k < l; k++) if (!(std::fabs(Wm(j + 1, k)) <= 0.1 * tau)) idx.push_back(k); n_sel++; }
+            }
+            if (!idx.empty() && beta > 0.0) {
+                double nrm2 = 0.0;
+                std::vector<double> scl(idx.size()); for (size_t t = 0; t < idx.size(); t++) scl[t] = sc[idx[t]];
+                CHK(project_out(idx, scl.data(), B(j + 1), nrm2)); nreads += 2 * (int64_t)idx.size();
+                CHK(scalar_mode(6));                       // beta_j and the scale of u_{j+1} follow the new norm
+                beta = std::sqrt(std::max(nrm2, 0.0));
+                for (size_t t = 0; t < idx.size(); t++) {
+                    Wm(j + 1, idx[t]) = Wm(idx[t], j + 1) = eps;
+                    if (!arrow) Fm(idx[t], j) += removed[t];      // the arrow coefficients ARE in T (theoretical values)
+                }
+            }
+            Tm(j + 1, j) = Tm(j, j + 1) = beta; beta_last = beta;
+            sc[j + 1] = beta > 0.0 ? 1.0 / beta : 0.0;
+            if (beta <= 1e-13 * std::max(1.0, normT)) {
+                // invariant subspace: every Ritz pair of T(0..j) is exact.  Enough of them -> done; else continue with a fresh
+                // random direction orthogonal to the basis (finds further copies of degenerate levels in tiny sectors)
+                Tm(j + 1, j) = Tm(j, j + 1) = 0.0; beta_last = 0.0;
+                if (j + 1 >= nev || (int64_t)(j + 1) >= Dim) { meff = j + 1; exact = true; break; }
+                hipLaunchKernelGGL(k_random_start, dim3(2048), dim3(256), 0, s->stream, dense, H.DimUp, H.Qdw, H.dw0, H.DimDw, H.DimPh, seed++);
+                HIPCHK(hipGetLastError());
+                CHK(lzf_copy_in(s, B(j + 1), dense));
+                double nrm2 = 0.0; const std::vector<int> all = all_upto(j);
+                std::vector<double> scl(sc.begin(), sc.begin() + j + 1);
+                CHK(project_out(all, scl.data(), B(j + 1), nrm2));
+                CHK(project_out(all, scl.data(), B(j + 1), nrm2));
+                if (!(nrm2 > 0.0)) { meff = j + 1; exact = true; break; }
+                CHK(scalar_mode(6)); CHK(scalar_mode(7));
+                sc[j + 1] = 1.0 / std::sqrt(nrm2); kloc = 0; V.uprev = B(j);
+                for (int k = 0; k <= j; k++) Wm(j + 1, k) = Wm(k, j + 1) = eps;
+                Wm(j + 1, j + 1) = 1.0;
+            }
+        }
+        std::vector<double> Hs((size_t)meff * meff);
+        for (int a = 0; a < meff; a++) for (int b = 0; b < meff; b++) Hs[(size_t)a * meff + b] = Tm(a, b);
+        jacobi_eig(Hs, meff, theta, Y);
+        nconv = 0;
+        const int want = std::min(nev, meff);
+        for (int i = 0; i < want; i++) {
+            const double resid = std::fabs(beta_last * Y[(meff - 1) + (size_t)meff * i]);
+            if (exact || resid <= tol_eff * std::max(eps23, std::fabs(theta[i]))) nconv++;
+        }
+        if (nconv >= want || exact || it + 1 >= maxiter) break;
+        // thick restart: lowest l Ritz vectors (scales folded into the rotation), then the residual direction u_m
+        const int lnew = std::min(m - 1, nev + std::max(1, (m - nev) / 2));
+        std::vector<double> Yc((size_t)m * lnew);
+        for (int a = 0; a < lnew; a++) for (int k = 0; k < m; k++) Yc[k + (size_t)m * a] = sc[k] * Y[k + (size_t)m * a];
+        CHK(rotate(m, lnew, Yc)); nreads += m + lnew;
+        std::swap(s->eigV[lnew], s->eigV[m]);            // B(lnew) <- u_m, no copy
+        std::vector<double> Wn((size_t)M * M, 0.0), etan((size_t)M, 0.0);
+        for (int a = 0; a < lnew; a++) {
+            for (int b = 0; b <= a; b++) {
+                double x = 0.0;
+                for (int p = 0; p < m; p++) { double r = 0.0; for (int q = 0; q < m; q++) r += Wm(p, q) * Y[q + (size_t)m * b]; x += Y[p + (size_t)m * a] * r; }
+                Wn[(size_t)a * M + b] = Wn[(size_t)b * M + a] = a == b ? 1.0 : x;
+            }
+            double x = 0.0, f2 = 0.0, e1 = 0.0;
+            for (int p = 0; p < m; p++) {
+                x += Wm(m, p) * Y[p + (size_t)m * a];
+                double r = 0.0; for (int q = 0; q < m; q++) r += Fm(p, q) * Y[q + (size_t)m * a];
+                f2 += r * r; e1 += std::fabs(Y[p + (size_t)m * a]) * eta[p];
+            }
+            Wn[(size_t)lnew * M + a] = Wn[(size_t)a * M + lnew] = x;
+            etan[a] = std::sqrt(f2) + e1;                 // defect of H y_a = theta_a y_a + sigma_a v_l
+        }
+        Wn[(size_t)lnew * M + lnew] = 1.0;
+        W.swap(Wn); eta.swap(etan); std::fill(F.begin(), F.end(), 0.0);
+        const double scm = sc[m];
+        std::fill(T.begin(), T.end(), 0.0);
+        for (int a = 0; a < lnew; a++) { Tm(a, a) = theta[a]; Tm(a, lnew) = Tm(lnew, a) = beta_last * Y[(m - 1) + (size_t)m * a]; sc[a] = 1.0; }
+        sc[lnew] = scm;
+        CHK(scalar_mode(7));                              // scal[SCUR] already is the scale of u_m
+        l = lnew; j = l; kloc = 0;
+        V.uprev = B(l - 1);                               // any finite vector: its coefficient is zero
+    }
+    const int nout = std::min(nev, meff);
+    {
+        std::vector<double> Yc((size_t)meff * nout);
+        for (int a = 0; a < nout; a++) for (int k = 0; k < meff; k++) Yc[k + (size_t)meff * a] = sc[k] * Y[k + (size_t)meff * a];
+        CHK(rotate(meff, nout, Yc));
+    }
+    // the Ritz vectors of a semi-orthogonal basis are orthonormal to sqrt(eps) only: Gram-Schmidt among the nout of them
+    for (int i = 0; i < nout; i++) {
+        double nrm2 = 0.0;
+        std::vector<double> ones((size_t)std::max(i, 1), 1.0);
+        std::vector<int> prev((size_t)i); for (int t = 0; t < i; t++) prev[t] = t;
+        if (i > 0) CHK(project_out(prev, ones.data(), B(i), nrm2));
+        else { CHK(reduce_dot(s, B(0), B(0), vlen)); HIPCHK(hipMemcpyAsync(&nrm2, s->scal.p + SC_TMP, 8, hipMemcpyDeviceToHost, s->stream)); HIPCHK(hipStreamSynchronize(s->stream)); }
+        hipLaunchKernelGGL(k_scale_copy, dim3(gs), dim3(256), 0, s->stream, B(i), (const double *)B(i), nrm2 > 0.0 ? 1.0 / std::sqrt(nrm2) : 0.0, vlen);
+        HIPCHK(hipGetLastError());
+    }
+    for (int i = 0; i < nev; i++) evals[i] = i < nout ? theta[i] : 0.0;
+    if (evecs_host)
+        for (int i = 0; i < nout; i++) {
+            CHK(lzf_copy_out(s, dense, B(i)));
+            HIPCHK(hipMemcpyAsync(evecs_host + (int64_t)i * n, dense, (size_t)n * 8, hipMemcpyDeviceToHost, s->stream));
+            HIPCHK(hipStreamSynchronize(s->stream));
+        }
+    HIPCHK(hipStreamSynchronize(s->stream));
+    if (s->dbg & 8) fprintf(stderr, "edgpu_eigsh: %d products, %d restarts, basis %d; re-orthogonalisations: %d whole basis, %d kept Ritz vectors only; %.1f basis-vector reads per product\n",
+                            nmv, it + 1, m, n_full, n_sel, nmv ? (double)nreads / nmv : 0.0);
+    if (nconv_out) *nconv_out = nconv;
+    if (nrestart_out) *nrestart_out = it + 1;
+    if (nmatvec_out) *nmatvec_out = nmv;
+    if (nconv < nev) return fail(EDGPU_ENOTCONVERGED, "edgpu_eigsh: " + std::to_string(nconv) + " of " + std::to_string(nev) + " pairs converged within maxiter restarts");
+    return EDGPU_OK;
+}
+
+static int eigsh_full(S *s, int nev, int ncv, int maxiter, double tol, double *evals, double *evecs_host, int *nconv_out, int *nrestart_out, int *nmatvec_out);
 static int eigsh(S *s, int nev, int ncv, int maxiter, double tol, double *evals, double *evecs_host, int *nconv_out, int *nrestart_out, int *nmatvec_out)
+{
+    if (dbg_int("EDGPU_EIGSH_PRO", 1)) return eigsh_pro(s, nev, ncv, maxiter, tol, evals, evecs_host, nconv_out, nrestart_out, nmatvec_out);
+    return eigsh_full(s, nev, ncv, maxiter, tol, evals, evecs_host, nconv_out, nrestart_out, nmatvec_out);
+}
+
+static int eigsh_full(S *s, int nev, int ncv, int maxiter, double tol, double *evals, double *evecs_host, int *nconv_out, int *nrestart_out, int *nmatvec_out)
 {
     const int64_t Dim = s->H.Dim, n = s->nloc;
     if (nev < 1) return fail(EDGPU_EINVAL, "edgpu_eigsh: nev < 1");
@@ -526,7 +792,8 @@ static int eigsh(S *s, int nev, int ncv, int maxiter, double tol, double *evals,
     if (maxiter < 1) maxiter = 1;
     const double tol_eff = std::max(tol, 1e-12), eps23 = std::pow(2.220446049250313e-16, 2.0 / 3.0);
     const int m = ncv;
-    while ((int)s->eigV.size() < m + 1) { auto b = std::make_unique<DevBuf<double>>(); CHK(b->alloc((size_t)n)); s->eigV.push_back(std::move(b)); }
+    while ((int)s->eigV.size() < m + 1) s->eigV.push_back(std::make_unique<DevBuf<double>>());
+    for (int i = 0; i <= m; i++) if (s->eigV[i]->n < (size_t)n) CHK(s->eigV[i]->alloc((size_t)n));
     const int nb = (int)std::max<int64_t>(1, std::min<int64_t>(cdiv(n, 256 * 8), 1024));
     if (s->eig_h.n < (size_t)(m + 3)) CHK(s->eig_h.alloc((size_t)m + 3));
     if (s->eig_partial.n < (size_t)nb * (kMaxBasis + 2)) CHK(s->eig_partial.alloc((size_t)nb * (kMaxBasis + 2)));
@@ -581,7 +848,7 @@ static int eigsh(S *s, int nev, int ncv, int maxiter, double tol, double *evals,
         const int want = std::min(nev, meff);
         for (int i = 0; i < want; i++) {
             const double resid = std::fabs(beta_last * Y[(meff - 1) + (size_t)meff * i]);
-            if (resid <= tol_eff * std::max(eps23, std::fabs(theta[i]))) nconv++;
+            if (meff < m || resid <= tol_eff * std::max(eps23, std::fabs(theta[i]))) nconv++;      // invariant subspace: every Ritz pair is exact
         }
         if (nconv >= want || meff < m || it + 1 >= maxiter) break;
         // thick restart: keep the lowest l Ritz vectors, append the residual direction
@@ -626,7 +893,8 @@ static int dvdson(S *s, int nev, int maxiter, double tol, double *evals, double 
     const double tol_eff = std::max(tol, 1e-11);
     // the diagonal of H: stored formats hold it, the on-the-fly format derives it once here
     if (s->diag.n != (size_t)s->nloc_el) CHK(build_diag(s));
-    while ((int)s->eigV.size() < 2 * mmax + 1) { auto b = std::make_unique<DevBuf<double>>(); CHK(b->alloc((size_t)n)); s->eigV.push_back(std::move(b)); }
+    while ((int)s->eigV.size() < 2 * mmax + 1) s->eigV.push_back(std::make_unique<DevBuf<double>>());
+    for (int i = 0; i <= 2 * mmax; i++) if (s->eigV[i]->n < (size_t)n) CHK(s->eigV[i]->alloc((size_t)n));
     auto Vp = [&](int i) { return s->eigV[i]->p; };
     auto Wp = [&](int i) { return s->eigV[mmax + i]->p; };
     double *t = s->eigV[2 * mmax]->p;

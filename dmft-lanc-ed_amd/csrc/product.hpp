@@ -387,6 +387,49 @@ static int hxv(S *s, const double *v, double *out, bool epi, const double *uprev
             const bool halo_can = !s->use_lds && plain && s->upf->seg_ok && s->up_halo && (!epi || (dw_vec2 && !s->extra && !s->tr_on));
             bool halo_epi = false;
             const bool persistent = s->up_persistent && plain && s->upf->packed && s->upf->width <= 16 && s->use_lds && H.DimUp <= 13312;
+            // the column-tiled dw pass; wr > 0: write-only form (out = dw hops), see k_dwpass2
+            auto run_dw = [&](int wr, bool dw_epi, const double *uprev2) -> int {
+                DwArgs D{};
+                D.DimUp = A.DimUp; D.DimDw = A.DimDw; D.DimPh = A.DimPh; D.Qdw = A.Qdw; D.dw0 = A.dw0;
+                D.dwc = A.dwc; D.dwv = A.dwv; D.dww = A.dww; D.v = v; D.vfull = A.vfull; D.out = out; D.scal = s->scal.p; D.partial = s->partial.p;
+                D.uprev2 = uprev2; D.ld = (int32_t)ld;
+                D.w = s->dw_w; D.wshift = 0; while ((1 << D.wshift) < D.w) D.wshift++;
+                const int dv = s->dw_variant;
+                const bool vec2 = dv >= 2 && (H.DimUp % 2 == 0) && D.w >= 4 && D.dww <= 64;
+                D.ntiles = (int32_t)cdiv(H.DimUp, D.w);
+                D.R = vec2 ? std::min(64, s->dw_rows) : 256 / D.w;
+                D.chunks = (int32_t)cdiv(H.Qdw * H.DimPh, D.R);
+                nblocks = (int64_t)D.ntiles * D.chunks;
+                if (!vec2) {
+                    if (wr) return fail(EDGPU_EINVAL, "edgpu: internal: write-only dw pass needs the vectorised kernel");
+                    if (dw_epi) hipLaunchKernelGGL(k_dwpass<true>, dim3((unsigned)nblocks), dim3(256), 0, s->stream, D);
+                    else hipLaunchKernelGGL(k_dwpass<false>, dim3((unsigned)nblocks), dim3(256), 0, s->stream, D);
+                } else {
+                    const bool nt = dv != 2, rag = s->dwf->ragged;
+                    // extra LDS (EDGPU_DW_LDS_KB) caps the workgroups per CU; with 16-row chunks full residency measured best (Ns=16 and Ns=18 sweeps, round 2)
+                    const size_t dlds = std::max<size_t>((size_t)D.R * D.dww * 12 + 16, (size_t)s->dw_lds_kb * 1024);
+#define DW_LAUNCH(E_, N_, R_, W_)                                                                                               \
+    do {                                                                                                                            \
+        static OncePerDevice once_;                                                                                                 \
+        if (dlds > 60 * 1024 && once_.first(s->device)) {      /* static LDS of the kernel comes on top: stay below the 160 KB of a CU */ \
+            if (hipFuncSetAttribute((const void *)k_dwpass2<E_, N_, R_, W_>, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024) != hipSuccess) (void)hipGetLastError(); \
+        }                                                                                                                           \
+        hipLaunchKernelGGL((k_dwpass2<E_, N_, R_, W_>), dim3((unsigned)nblocks), dim3(256), dlds, s->stream, D);                    \
+    } while (0)
+                    if (wr == 2) { if (rag) DW_LAUNCH(false, false, true, 2); else DW_LAUNCH(false, false, false, 2); }
+                    else if (wr == 1) { if (rag) DW_LAUNCH(false, false, true, 1); else DW_LAUNCH(false, false, false, 1); }
+                    else if (dw_epi) { if (nt) { if (rag) DW_LAUNCH(true, true, true, 0); else DW_LAUNCH(true, true, false, 0); } else { if (rag) DW_LAUNCH(true, false, true, 0); else DW_LAUNCH(true, false, false, 0); } }
+                    else { if (nt) { if (rag) DW_LAUNCH(false, true, true, 0); else DW_LAUNCH(false, true, false, 0); } else { if (rag) DW_LAUNCH(false, false, true, 0); else DW_LAUNCH(false, false, false, 0); } }
+#undef DW_LAUNCH
+                }
+                HIPCHK(hipGetLastError());
+                return EDGPU_OK;
+            };
+            // Rows beyond LDS on one rank: the dw pass goes FIRST and only writes (no read-modify-write of the result, stores
+            // that leave the L2), so the XCD's L2 holds nothing but the slab the dw hops gather from; the local pass, which
+            // streams whole rows through LDS and has bandwidth to spare, adds its part on top and carries the Lanczos epilogue.
+            const bool dw_first = halo_can && !persistent && !multi && !nd_pass && dw_vec2 && !s->tr_on && s->dw_first > 0 && !(s->dbg & 2);
+            bool dw_done = false;
             if (persistent && s->up_pairs && s->upf->packed_elem) {
                 UpArgs2 U{};
                 U.DimUp = A.DimUp; U.DimPh = A.DimPh; U.Qdw = A.Qdw; U.dw0 = A.dw0; U.nrows = H.Qdw * H.DimPh;
@@ -446,20 +489,24 @@ static int hxv(S *s, const double *v, double *out, bool epi, const double *uprev
                 U.pseg8 = reinterpret_cast<const uint4 *>(f0.pseg8.p); U.ext = f0.seg_ext.p; U.ext_off = f0.seg_ext_off.p; U.tval = f0.ptval.p; U.nterms = f0.pterms;
                 U.diag = A.diag; U.Eup = A.Eup; U.Edw = A.Edw; U.cross = A.cross; U.mapup = A.mapup; U.mapdw = A.mapdw; U.impmask = A.impmask; U.nI = A.nI; U.econst = A.econst;
                 U.v = v; U.out = out; U.ld = (int32_t)ld;
-                halo_epi = epi;     // the scale and the -beta*u_prev term move to the dw pass (DwArgs.uprev2): this pass writes the unscaled local part
-                const size_t lds = ((size_t)U.seglen + U.halocap + 128 + 32) * 8;
+                U.uprev = uprev; U.scal = s->scal.p; U.partial = s->partial.p;
+                const size_t lds = ((size_t)U.seglen + U.halocap + 128 + 32 + 16) * 8;
                 const unsigned grid = (unsigned)std::max(8 * U.nseg, s->up_grid & ~7);
-#define HALO_LAUNCH(D_, Q_, H_)                                                                                                 \
+                if (dw_first) { CHK(run_dw(s->dw_first, false, nullptr)); dw_done = true; nblocks = grid; }
+                else halo_epi = epi;     // the scale and the -beta*u_prev term move to the dw pass (DwArgs.uprev2): this pass writes the unscaled local part
+#define HALO_LAUNCH(D_, Q_, H_, A_, E_)                                                                                         \
     do {                                                                                                                            \
         static OncePerDevice once_;                                                                                                 \
-        if (once_.first(s->device)) (void)hipFuncSetAttribute((const void *)k_uppass_halo<D_, Q_, H_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
-        hipLaunchKernelGGL((k_uppass_halo<D_, Q_, H_>), dim3(grid), dim3(1024), lds, s->stream, U);                                 \
+        if (once_.first(s->device)) (void)hipFuncSetAttribute((const void *)k_uppass_halo<D_, Q_, H_, A_, E_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+        hipLaunchKernelGGL((k_uppass_halo<D_, Q_, H_, A_, E_>), dim3(grid), dim3(1024), lds, s->stream, U);                         \
     } while (0)
-#define HALO_Q(D_, H_) do { if (nq == 1) HALO_LAUNCH(D_, 1, H_); else if (nq == 2) HALO_LAUNCH(D_, 2, H_); else HALO_LAUNCH(D_, 3, H_); } while (0)
+#define HALO_AE(D_, Q_, H_) do { if (!dw_first) HALO_LAUNCH(D_, Q_, H_, false, false); else if (epi) HALO_LAUNCH(D_, Q_, H_, true, true); else HALO_LAUNCH(D_, Q_, H_, true, false); } while (0)
+#define HALO_Q(D_, H_) do { if (nq == 1) HALO_AE(D_, 1, H_); else if (nq == 2) HALO_AE(D_, 2, H_); else HALO_AE(D_, 3, H_); } while (0)
                 const int nq = (int)cdiv(U.seglen / 2, 1024);
                 if (U.halocap <= 8 * 1024) { if (direct) HALO_Q(true, 8); else HALO_Q(false, 8); }
                 else { if (direct) HALO_Q(true, 12); else HALO_Q(false, 12); }
 #undef HALO_Q
+#undef HALO_AE
 #undef HALO_LAUNCH
                 HIPCHK(hipGetLastError());
             } else if (ld) {
@@ -496,37 +543,7 @@ static int hxv(S *s, const double *v, double *out, bool epi, const double *uprev
                     else hipLaunchKernelGGL(k_ndpass<false>, dim3((unsigned)(H.Qdw * H.DimPh)), dim3(256), 0, s->stream, Nd);
                     HIPCHK(hipGetLastError());
                 }
-                DwArgs D{};
-                D.DimUp = A.DimUp; D.DimDw = A.DimDw; D.DimPh = A.DimPh; D.Qdw = A.Qdw; D.dw0 = A.dw0;
-                D.dwc = A.dwc; D.dwv = A.dwv; D.dww = A.dww; D.v = v; D.vfull = A.vfull; D.out = out; D.scal = s->scal.p; D.partial = s->partial.p;
-                D.uprev2 = halo_epi ? uprev : nullptr; D.ld = (int32_t)ld;
-                D.w = s->dw_w; D.wshift = 0; while ((1 << D.wshift) < D.w) D.wshift++;
-                const int dv = s->dw_variant;
-                const bool vec2 = dv >= 2 && (H.DimUp % 2 == 0) && D.w >= 4 && D.dww <= 64;
-                D.ntiles = (int32_t)cdiv(H.DimUp, D.w);
-                D.R = vec2 ? std::min(64, s->dw_rows) : 256 / D.w;
-                D.chunks = (int32_t)cdiv(H.Qdw * H.DimPh, D.R);
-                nblocks = (int64_t)D.ntiles * D.chunks;
-                if (!vec2) {
-                    if (epi) hipLaunchKernelGGL(k_dwpass<true>, dim3((unsigned)nblocks), dim3(256), 0, s->stream, D);
-                    else hipLaunchKernelGGL(k_dwpass<false>, dim3((unsigned)nblocks), dim3(256), 0, s->stream, D);
-                } else {
-                    const bool nt = dv != 2, rag = s->dwf->ragged;
-                    // extra LDS (EDGPU_DW_LDS_KB) caps the workgroups per CU; with 16-row chunks full residency measured best (Ns=16 and Ns=18 sweeps, round 2)
-                    const size_t dlds = std::max<size_t>((size_t)D.R * D.dww * 12 + 16, (size_t)s->dw_lds_kb * 1024);
-#define DW_LAUNCH(E_, N_, R_)                                                                                                   \
-    do {                                                                                                                            \
-        static OncePerDevice once_;                                                                                                 \
-        if (dlds > 60 * 1024 && once_.first(s->device)) {      /* static LDS of the kernel comes on top: stay below the 160 KB of a CU */ \
-            if (hipFuncSetAttribute((const void *)k_dwpass2<E_, N_, R_>, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024) != hipSuccess) (void)hipGetLastError(); \
-        }                                                                                                                           \
-        hipLaunchKernelGGL((k_dwpass2<E_, N_, R_>), dim3((unsigned)nblocks), dim3(256), dlds, s->stream, D);                        \
-    } while (0)
-                    if (epi) { if (nt) { if (rag) DW_LAUNCH(true, true, true); else DW_LAUNCH(true, true, false); } else { if (rag) DW_LAUNCH(true, false, true); else DW_LAUNCH(true, false, false); } }
-                    else { if (nt) { if (rag) DW_LAUNCH(false, true, true); else DW_LAUNCH(false, true, false); } else { if (rag) DW_LAUNCH(false, false, true); else DW_LAUNCH(false, false, false); } }
-#undef DW_LAUNCH
-                }
-                HIPCHK(hipGetLastError());
+                if (!dw_done) CHK(run_dw(0, epi, halo_epi ? uprev : nullptr));
             }
         }
     } else {

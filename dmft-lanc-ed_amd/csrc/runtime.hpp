@@ -7,6 +7,7 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <map>
 #include <memory>
 #include <string>
@@ -32,8 +33,39 @@ static int fail(int code, const std::string &msg) { g_err = msg; return code; }
     } while (0)
 #define CHK(expr) do { int r_ = (expr); if (r_ != EDGPU_OK) return r_; } while (0)
 
+// Two copies of the HIP runtime in one process (e.g. this library bound to /opt/rocm's libamdhip64 and an embedding PyTorch
+// that then maps the copy it ships) each initialise the driver and each run exit handlers over the other's state: such a
+// process computes correctly and then dies at exit with "double free or corruption".  This library holds no static object
+// whose destructor calls HIP (g_kpool, g_rccl are plain data), so the only cure is not to get into that state: every entry
+// that would first touch the device refuses while more than one libamdhip64 is mapped.  The distinct paths are read from
+// /proc/self/maps (≈0.2 ms; entries that create sectors / communicators / device memory only).
+static int single_hip_runtime()
+{
+    std::vector<std::string> seen;
+    if (FILE *f = fopen("/proc/self/maps", "r")) {
+        char line[4096];
+        while (fgets(line, sizeof(line), f)) {
+            if (!strstr(line, "libamdhip64")) continue;
+            char *path = strchr(line, '/');
+            if (!path) continue;
+            path[strcspn(path, "\n")] = 0;
+            bool dup = false;
+            for (auto &s : seen) dup = dup || s == path;
+            if (!dup) seen.push_back(path);
+        }
+        fclose(f);
+    }
+    if (seen.size() <= 1) return EDGPU_OK;
+    std::string msg = "edgpu: " + std::to_string(seen.size()) + " copies of the HIP runtime are mapped in this process (";
+    for (size_t i = 0; i < seen.size(); i++) msg += (i ? ", " : "") + seen[i];
+    msg += "): load the embedding framework (e.g. `import torch`) BEFORE libedgpu.so so that both bind to one runtime, "
+           "or preload that runtime (LD_PRELOAD); continuing would end in heap corruption at process exit";
+    return fail(EDGPU_EHIP, msg);
+}
+
 static int require_device()
 {
+    CHK(single_hip_runtime());
     int n = 0;
     hipError_t e = hipGetDeviceCount(&n);
     if (e != hipSuccess || n < 1) return fail(EDGPU_ENODEVICE, "edgpu: no HIP device visible (this library has no CPU fallback)");
@@ -214,6 +246,7 @@ struct edgpu_sector_s {
     int64_t npartial = 0;
     // knobs read from the environment ONCE, at sector creation (never inside a product)
     int dbg = 0; bool tables_wave = true; int dw_lds_kb = 0; bool lz_fused_on = true;
+    int dw_first = 2;         // rows beyond LDS, one rank: dw pass first as a write-only pass (1: plain stores, 2: write-through), local pass adds + epilogue; 0: local pass first
     int eig_ncv_used = 0;     // basis size the last edgpu_eigsh call actually ran with
     // Lanczos iteration fusion (single rank)
     int fuse_mode = -1; const double *fuse_zvec = nullptr;   // >= 0: the product's final reduction also performs this scalar step

@@ -57,6 +57,7 @@ ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_int32
 EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.c_int32)
 
 _lib = None
+_hip_keep = None
 
 
 class EdgpuError(RuntimeError):
@@ -65,14 +66,62 @@ class EdgpuError(RuntimeError):
         self.code = code
 
 
+def mapped_hip_runtimes():
+    """distinct libamdhip64 files mapped into this process (/proc/self/maps)"""
+    seen = []
+    try:
+        with open("/proc/self/maps") as f:
+            for line in f:
+                if "libamdhip64" in line:
+                    path = line[line.index("/"):].strip()
+                    if path not in seen:
+                        seen.append(path)
+    except OSError:
+        pass
+    return seen
+
+
+def _preload_embedding_hip_runtime():
+    """One HIP runtime per process.  libedgpu.so is linked against libamdhip64.so.7 and the dynamic loader binds it to the
+    copy the process already holds -- PyTorch's own when `import torch` came first.  In the other order libedgpu.so would
+    bring in /opt/rocm's runtime and a later `import torch` would map PyTorch's copy NEXT to it: two runtimes, correct
+    results, and "double free or corruption" at interpreter exit.  So when no runtime is mapped yet and a PyTorch that ships
+    one is installed, that copy is loaded first (by path, nothing of torch is imported): whatever the application imports
+    afterwards, in whatever order, finds it.  EDGPU_HIP_RUNTIME=system keeps the ROCm installation's runtime (for processes
+    that never load PyTorch); the library itself refuses to touch the device while two copies are mapped."""
+    if mapped_hip_runtimes() or os.environ.get("EDGPU_HIP_RUNTIME", "auto") == "system":
+        return None
+    import importlib.util
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return None
+    path = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if not os.path.exists(path):
+        return None
+    return C.CDLL(path, mode=C.RTLD_GLOBAL)
+
+
+def assert_single_hip_runtime():
+    rt = mapped_hip_runtimes()
+    if len(rt) > 1:
+        raise ImportError("%d copies of the HIP runtime are mapped in this process (%s): import torch BEFORE edgpu, or leave "
+                          "EDGPU_HIP_RUNTIME unset so that edgpu binds to PyTorch's copy; continuing would corrupt the heap at exit"
+                          % (len(rt), ", ".join(rt)))
+
+
 def lib():
     """Load libedgpu.so; fails loudly when the HIP extension has not been built."""
-    global _lib
+    global _lib, _hip_keep
     if _lib is not None:
         return _lib
     if not os.path.exists(LIB_PATH):
         raise ImportError("libedgpu.so is missing (%s): build it with __graft_entry__.build(); there is no fallback path" % LIB_PATH)
+    _hip_keep = _preload_embedding_hip_runtime()
     L = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    assert_single_hip_runtime()
     vp, i32, i64, dbl = C.c_void_p, C.c_int32, C.c_int64, C.c_double
     P = C.POINTER
     sig = {

@@ -75,6 +75,30 @@ def test_bench_refuses_to_report_fewer_gpus_than_asked():
     assert "refusing to report a different GPU count" in err
 
 
+@pytest.mark.gpu
+def test_wrong_import_order_exits_cleanly():
+    """edgpu first (a whole ground-state search), THEN `import torch` and a CUDA call: the order that ended round 2's full run
+    in "double free or corruption" at interpreter exit.  One HIP runtime is mapped, results are right, exit code 0."""
+    code = (
+        "import sys; sys.path[:0] = [%r, %r]\n"
+        "import numpy as np, edgpu\n"
+        "from edgpu import model, capi\n"
+        "m, nu, nd = model.half_filled_c(5)\n"
+        "G = edgpu.HvSector(m, nu, nd); e0, x, n = G.sp_lanc_eigh(nitermax=200, threshold=1e-14); G.close()\n"
+        "import torch\n"
+        "t = torch.ones(1024, device='cuda').sum().item()\n"
+        "G = edgpu.HvSector(m, nu, nd, storage='csr'); e1, x, n = G.sp_lanc_eigh(nitermax=200, threshold=1e-14)\n"
+        "print('E0 %%.12f %%.12f SUM %%d RUNTIMES %%d' %% (e0, e1, t, len(capi.mapped_hip_runtimes())))\n"
+    ) % (ROOT, os.path.join(ROOT, "dmft-lanc-ed_amd"))
+    env = dict(os.environ); env.pop("EDGPU_HIP_RUNTIME", None)
+    r = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, env=env, timeout=600)
+    out = r.stdout.decode()
+    assert r.returncode == 0, out
+    assert "SUM 1024 RUNTIMES 1" in out, out
+    e0, e1 = [float(x) for x in out.split("E0")[1].split()[:2]]
+    assert abs(e0 - (-7.39968598202036)) < 1e-10 and abs(e1 - e0) < 1e-10       # SURVEY 8c known answer of config 1
+
+
 def test_bench_launcher_needs_no_gpu_to_refuse():
     """CPU: with no device visible the launcher path exits non-zero without a line (it never reports n_gpus < --gpus)."""
     err = _run(["--gpus", "2", "--no-extra"], expect_fail=True)

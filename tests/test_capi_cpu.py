@@ -70,3 +70,50 @@ def test_dw_partition_matches_reference_formula():
             assert q == mpiQdw and d0 == r * mpiQdw + mpiRdw
             tot += q
         assert tot == DimDw
+
+
+_ORDER_SNIPPET = """
+import sys, ctypes as C
+sys.path.insert(0, %(pkg)r)
+from edgpu import capi
+%(first)s
+%(second)s
+rt = capi.mapped_hip_runtimes()
+p = C.c_void_p()
+rc = capi.lib().edgpu_malloc(C.byref(p), 8)          # first entry that would touch the device
+print("RUNTIMES", len(rt)); print("RC", rc); print("MSG", capi.lib().edgpu_last_error().decode())
+%(tail)s
+"""
+
+
+def _run_order(first, second, env=None, tail=""):
+    import subprocess, sys
+    code = _ORDER_SNIPPET % dict(pkg=os.path.join(ROOT, "dmft-lanc-ed_amd"), first=first, second=second, tail=tail)
+    e = dict(os.environ); e.pop("EDGPU_HIP_RUNTIME", None); e.update(env or {})
+    r = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, env=e, timeout=600)
+    return r.returncode, r.stdout.decode()
+
+
+def test_one_hip_runtime_whatever_the_import_order():
+    """Round-2 abort ("double free or corruption" at interpreter exit) came from two HIP runtimes in one process: libedgpu.so
+    bound to /opt/rocm's libamdhip64, then `import torch` mapping PyTorch's own copy.  The binding now loads the embedding
+    framework's runtime first, so both orders end with ONE runtime and a clean exit."""
+    pytest.importorskip("torch")
+    for first, second in (("capi.lib()", "import torch"), ("import torch", "capi.lib()")):
+        rc, out = _run_order(first, second)
+        assert rc == 0, out
+        assert "RUNTIMES 1" in out, out
+        assert "copies of the HIP runtime" not in out, out
+
+
+def test_two_hip_runtimes_are_refused_with_a_clear_error():
+    """EDGPU_HIP_RUNTIME=system keeps the ROCm installation's runtime; a PyTorch imported afterwards brings a second one.
+    The library then refuses every entry that would touch the device (EDGPU_EHIP and the two paths) instead of running into
+    the exit-time heap corruption, and the Python binding raises the same complaint when it is asked to check."""
+    pytest.importorskip("torch")
+    tail = "\ntry:\n    capi.assert_single_hip_runtime()\nexcept ImportError as e:\n    print('PYERR', e)\n"
+    rc, out = _run_order("capi.lib()", "import torch", env={"EDGPU_HIP_RUNTIME": "system"}, tail=tail)
+    assert rc == 0, out
+    if "RUNTIMES 1" in out:
+        pytest.skip("this PyTorch shares the system HIP runtime")
+    assert "RC -3" in out and "copies of the HIP runtime are mapped" in out and "PYERR" in out, out
