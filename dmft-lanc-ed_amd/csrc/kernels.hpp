@@ -829,6 +829,7 @@ struct DwArgs {
     const double *v, *vfull; double *out;
     const double *scal; double *partial;
     int32_t w, wshift, ntiles, R, chunks;
+    int32_t xpt;               // XCDs that share one tile (1, 2, 4 or 8; 0 = 1): each walks 1/xpt of the row chunks, 8/xpt tiles are in flight at a time
     int32_t ld;                // row pitch of v / vfull / out / uprev2 in doubles (0: DimUp)
     const double *uprev2;      // fused Lanczos iteration (EPI only): out holds the UNSCALED local part; out = s_cur*(out + dw part) - beta*s_prev*uprev2
 };
@@ -843,6 +844,19 @@ __device__ __forceinline__ void xcd_tile_map(uint32_t b, uint32_t ntiles, uint32
     const uint32_t t8 = ntiles & ~7u, nmain = t8 * chunks;
     if (b < nmain) { const uint32_t xcd = b & 7u, sidx = b >> 3, tl = sidx / chunks; chunk = sidx - tl * chunks; tile = (int)(tl * 8u + xcd); }
     else { const uint32_t r = b - nmain, tl = r / chunks; chunk = r - tl * chunks; tile = (int)(t8 + tl); }
+}
+
+// The same dealing with `xpt` XCDs per tile: XCD x works on tile slot x / xpt and walks the row chunks [part*cp, (part+1)*cp),
+// part = x % xpt, cp = ceil(chunks / xpt).  Fewer slabs in flight (8/xpt x 25 MB at Ns=18 instead of 8 x 25 MB next to the
+// 256 MB Infinity Cache); the near dw hops stay inside an XCD's part, the hops on the top log2(xpt) bath levels cross parts.
+// Grid = ceil(ntiles / (8/xpt)) * cp * 8; blocks beyond the last tile or chunk return tile = ntiles.
+__device__ __forceinline__ void xcd_tile_map_shared(uint32_t b, uint32_t ntiles, uint32_t chunks, uint32_t xpt, int &tile, uint32_t &chunk)
+{
+    const uint32_t xcd = b & 7u, sidx = b >> 3, slots = 8u / xpt, cp = (chunks + xpt - 1) / xpt;
+    const uint32_t grp = sidx / cp, c = sidx - grp * cp, part = xcd % xpt, slot = xcd / xpt;
+    chunk = part * cp + c;
+    tile = (int)(grp * slots + slot);
+    if (chunk >= chunks) tile = (int)ntiles;
 }
 
 template <bool EPI>
@@ -892,7 +906,8 @@ __global__ void __launch_bounds__(256) k_dwpass2(DwArgs A)
     double *tv = dyn_lds;                                               // [row in block][k]
     int32_t *tc = reinterpret_cast<int32_t *>(dyn_lds + A.R * A.dww);
     int tile; uint32_t chunk;
-    xcd_tile_map(blockIdx.x, (uint32_t)A.ntiles, (uint32_t)A.chunks, tile, chunk);
+    if (A.xpt > 1) xcd_tile_map_shared(blockIdx.x, (uint32_t)A.ntiles, (uint32_t)A.chunks, (uint32_t)A.xpt, tile, chunk);
+    else xcd_tile_map(blockIdx.x, (uint32_t)A.ntiles, (uint32_t)A.chunks, tile, chunk);
     double asum = 0.0;
     if (tile < A.ntiles) {
         const int64_t nrows = A.Qdw * A.DimPh, row0 = (int64_t)chunk * A.R;

@@ -648,8 +648,31 @@ static int eigsh_pro(S *s, int nev, int ncv, int maxiter, double tol, double *ev
             normT = std::max(normT, std::fabs(alpha) + beta + (j > 0 ? std::fabs(Tm(j, j - 1)) : 0.0));
             const bool arrow = l > 0 && j == l;            // H v_l couples to every kept Ritz vector
             std::vector<int> idx;
-            if (arrow) idx = all_upto(j);
-            else {
+            if (arrow && beta > 0.0) {
+                // first step after a restart: H v_l = sum_i sigma_i y_i + alpha v_l + beta v_{l+1} with the KNOWN sigma_i = T(i,l):
+                // they are subtracted in one pass over the kept Ritz vectors (no dots); how orthogonal the result is to them is
+                // what the recurrence below estimates from the defects eta_i -- a pass with measured coefficients follows only
+                // if that estimate asks for it
+                double nrm2 = 0.0;
+                for (int i = 0; i < l; i++) coef[i] = Tm(i, l) * sc[i];
+                HIPCHK(hipMemcpyAsync(s->eig_h.p, coef.data(), (size_t)l * 8, hipMemcpyHostToDevice, s->stream));
+                HIPCHK(hipStreamSynchronize(s->stream));
+                const int ngroups = std::max(1, (int)cdiv(l, kMaxBasis));
+                for (int g = 0; g < ngroups; g++) {
+                    const int g0 = g * kMaxBasis, gc = std::min(kMaxBasis, l - g0);
+                    BasisArgs Bu{}; Bu.nv = gc; for (int i = 0; i < gc; i++) Bu.V[i] = B(g0 + i);
+                    if (g == ngroups - 1) launch_multiaxpy_norm(s->stream, nb, Bu, (const double *)(s->eig_h.p + g0), B(j + 1), vlen, s->eig_partial.p);
+                    else launch_multiaxpy(s->stream, nb, Bu, (const double *)(s->eig_h.p + g0), B(j + 1), vlen);
+                    HIPCHK(hipGetLastError());
+                }
+                hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(1024), 0, s->stream, (const double *)s->eig_partial.p, (int64_t)nb, s->scal.p + SC_TMP);
+                HIPCHK(hipGetLastError());
+                CHK(allreduce_tmp(s));
+                CHK(scalar_mode(6));
+                HIPCHK(hipMemcpyAsync(&nrm2, s->scal.p + SC_TMP, 8, hipMemcpyDeviceToHost, s->stream)); HIPCHK(hipStreamSynchronize(s->stream));
+                beta = std::sqrt(std::max(nrm2, 0.0)); nreads += l;
+            }
+            {
                 // omega recurrence: estimates w(j+1,k), k < j
                 const double psi = 2.0 * eps * normT;
                 bool any = false, beyond = false;
@@ -672,7 +695,7 @@ static int eigsh_pro(S *s, int nev, int ncv, int maxiter, double tol, double *ev
                 beta = std::sqrt(std::max(nrm2, 0.0));
                 for (size_t t = 0; t < idx.size(); t++) {
                     Wm(j + 1, idx[t]) = Wm(idx[t], j + 1) = eps;
-                    if (!arrow) Fm(idx[t], j) += removed[t];      // the arrow coefficients ARE in T (theoretical values)
+                    Fm(idx[t], j) += removed[t];                 // not part of T: feeds the defect of the Ritz vectors formed at the next restart
                 }
             }
             Tm(j + 1, j) = Tm(j, j + 1) = beta; beta_last = beta;

@@ -400,6 +400,8 @@ static int hxv(S *s, const double *v, double *out, bool epi, const double *uprev
                 D.R = vec2 ? std::min(64, s->dw_rows) : 256 / D.w;
                 D.chunks = (int32_t)cdiv(H.Qdw * H.DimPh, D.R);
                 nblocks = (int64_t)D.ntiles * D.chunks;
+                D.xpt = vec2 ? s->dw_xpt : 1;
+                if (D.xpt > 1) nblocks = cdiv(D.ntiles, 8 / D.xpt) * cdiv(D.chunks, D.xpt) * 8;
                 if (!vec2) {
                     if (wr) return fail(EDGPU_EINVAL, "edgpu: internal: write-only dw pass needs the vectorised kernel");
                     if (dw_epi) hipLaunchKernelGGL(k_dwpass<true>, dim3((unsigned)nblocks), dim3(256), 0, s->stream, D);

@@ -246,6 +246,7 @@ struct edgpu_sector_s {
     int64_t npartial = 0;
     // knobs read from the environment ONCE, at sector creation (never inside a product)
     int dbg = 0; bool tables_wave = true; int dw_lds_kb = 0; bool lz_fused_on = true;
+    int dw_xpt = 1;           // XCDs sharing one column tile of the dw pass (k_dwpass2: xcd_tile_map_shared)
     int dw_first = 2;         // rows beyond LDS, one rank: dw pass first as a write-only pass (1: plain stores, 2: write-through), local pass adds + epilogue; 0: local pass first
     int eig_ncv_used = 0;     // basis size the last edgpu_eigsh call actually ran with
     // Lanczos iteration fusion (single rank)

@@ -447,6 +447,7 @@ static int create(const edgpu_desc *desc, S **out)
         s->up_threads = dbg_int("EDGPU_UP_THREADS", 1024) == 512 ? 512 : 1024;
         s->dw_rows = std::max(1, std::min(64, dbg_int("EDGPU_DW_ROWS", 16)));
         s->dw_first = std::max(0, std::min(2, dbg_int("EDGPU_DW_FIRST", 2)));
+        { const int x = dbg_int("EDGPU_DW_XPT", 1); s->dw_xpt = (x == 2 || x == 4 || x == 8) ? x : 1; }
         if (s->dw_w != 8 && s->dw_w != 16 && s->dw_w != 32 && s->dw_w != 64 && s->dw_w != 128 && s->dw_w != 256) s->dw_w = 32;
     }
     // operator storage

@@ -45,7 +45,18 @@ for st, prefixes in PRODUCT.items():
         print("  %-50s FETCH_SIZE %.4g KiB  WRITE_SIZE %.4g KiB  -> %.3f GB per product (n=%d)" % (kn, fs, ws, b / 1e9, n))
         tot += b
     print("  total %.2f GB per product" % (tot / 1e9))
+    # kernel time per product under rocprofv3 (--kernel-trace --stats of the same command): mean duration of the same kernels
+    rp_ms = None
+    stats = os.path.join(root, "bench_c3_%s_kernel_stats.csv" % st)
+    if os.path.exists(stats):
+        rp_ms = 0.0
+        for r in csv.DictReader(open(stats)):
+            kn = r["Name"].split("(")[0].replace("void edgpu::", "").replace("edgpu::", "")
+            if kn in per["FETCH_SIZE"]:
+                rp_ms += float(r["AverageNs"]) * 1e-6 * (2 if "k_direct_tables" in kn else 1)
+        print("  kernel time per product under rocprofv3: %.3f ms" % rp_ms)
     out.append({"storage": st, "nbath": 15, "n_gpus": 1, "hbm_bytes_per_launch": tot, "source_stamp": STAMP, "kernels": sorted(per["FETCH_SIZE"]),
-                "file": "profiles/r02/pmc_traffic_summary.txt",
+                "rocprof_kernel_ms_per_product": rp_ms,
+                "file": "profiles/%s/pmc_traffic_summary.txt" % os.environ.get("EDGPU_PROFILE_ROUND", "r03"),
                 "source": "profiles: (2*FETCH_SIZE + WRITE_SIZE)*1024 per dispatch, summed over the kernels of one product (%s); FETCH_SIZE doubled per MI355X_MICROARCH.md (64 B tallied per 128-B request); fabric-side count, Infinity-Cache hits included" % ", ".join(sorted(per["FETCH_SIZE"]))})
 json.dump(out, open(os.path.join(root, "pmc_traffic.json"), "w"), indent=1)

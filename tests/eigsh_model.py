@@ -27,8 +27,10 @@ def eigsh_pro(matvec, n, nev, ncv, maxiter=300, tol=1e-12, tau=1.5e-8, seed=0, v
             normT=max(normT,abs(alpha)+beta+(abs(T[j,j-1]) if j>0 else 0))
             arrow = l>0 and j==l
             idx=[]
-            if arrow: idx=list(range(j+1))
-            else:
+            if arrow and beta>0:      # known coefficients sigma_i = T[i,l]: one pass, no dots
+                for i in range(l): w=w-T[i,l]*sc[i]*Bv[i]
+                reads+=l; beta=np.linalg.norm(w)
+            if True:
                 psi=2*eps*normT
                 for k in range(j):
                     num=0.0
@@ -49,8 +51,7 @@ def eigsh_pro(matvec, n, nev, ncv, maxiter=300, tol=1e-12, tau=1.5e-8, seed=0, v
                     d=np.array([Bv[i]@w for i in idx]); reads+=2*len(idx)
                     cv=d*sc[idx]          # coefficient wrt normalised v_i
                     for t,i in enumerate(idx): w=w-cv[t]*sc[i]*Bv[i]
-                    if not arrow:
-                        for t,i in enumerate(idx): F[i,j]+=cv[t]
+                    for t,i in enumerate(idx): F[i,j]+=cv[t]
                     if w@w>=0.5*before: break
                 beta=np.linalg.norm(w)
                 for k in idx: W[j+1,k]=W[k,j+1]=eps
