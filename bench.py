@@ -338,6 +338,13 @@ def main():
         dist.all_reduce(mat)
         out["exchange_bytes_per_product"] = {"mode": xmode, "send_matrix_MB": [[round(float(x) / 1e6, 2) for x in row] for row in mat.cpu().tolist()],
                                              "busiest_pair_MB": round(float(mat.max()) / 1e6, 2), "per_rank_received_MB": [round(float(x) / 1e6, 2) for x in mat.sum(0).cpu().tolist()]}
+        # what that exchange should cost on xGMI (point-to-point links, one message per peer and direction; 60-77 GB/s per
+        # direction and link measured elsewhere on this generation): the busiest pair bounds the product.
+        # A model to read the first real multi-GPU run against -- NOT a measurement.
+        bp = float(mat.max())
+        out["exchange_model_ms"] = {"busiest_pair_at_77GBps": bp / 77e9 * 1e3, "busiest_pair_at_60GBps": bp / 60e9 * 1e3,
+                                    "perfectly_balanced_over_%d_links_at_77GBps" % max(world - 1, 1): float(mat.sum(0).max()) / max(world - 1, 1) / 77e9 * 1e3,
+                                    "measured_exchange_ms_on_comm_stream": comm_ms, "note": "model, not a measurement; ranks sharing one GPU exchange through device copies"}
     # HBM traffic from the counter passes committed under profiles/: only while it was measured on THIS code
     pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(pmc):

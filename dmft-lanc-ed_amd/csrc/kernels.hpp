@@ -895,7 +895,11 @@ __device__ __forceinline__ void store_through(dbl2v *p, dbl2v v)
 }
 // WR = 0: out += dw hops (read-modify-write, optionally with the Lanczos epilogue).  WR = 1 / 2: out = dw hops, nothing of
 // `out` is read (the local pass that follows adds to it and carries the epilogue: hxv(), "dw first"); 2 stores write-through.
-template <bool EPI, bool NT, bool RAGGED, int WR = 0>   // RAGGED: rows have different hop counts (multi-orbital models): skip the ELL padding
+// UNR: every load of a row step is issued before the first one is consumed -- up to 16 gathers in groups of four, then the
+// result / v / u_prev operands.  The rolled form (4 gathers in flight, then a remainder one by one, then the operand loads)
+// is a chain of 4 dependent memory round trips per row step and 8 per workgroup: at Ns=18 (2.3 M workgroups, 2 048
+// resident) that chain alone is the 18 ms the pass took, whatever the traffic (profiles/r03/ns18_dw_pass_variants.txt).
+template <bool EPI, bool NT, bool RAGGED, int WR = 0, bool UNR = false>   // RAGGED: rows have different hop counts (multi-orbital models): skip the ELL padding
 __global__ void __launch_bounds__(256) k_dwpass2(DwArgs A)
 {
     // dynamic LDS sized by the launch to R*dww entries (was a fixed 64x64 image = 48 KB, i.e. 3 workgroups per CU whatever
@@ -936,16 +940,35 @@ __global__ void __launch_bounds__(256) k_dwpass2(DwArgs A)
                 dbl2v acc = {0.0, 0.0};
                 const double *tvr = tv + r * A.dww; const int32_t *tcr = tc + r * A.dww;
                 const int nk = RAGGED ? tn[r] : A.dww;   // hops of this row (ELL padding sits at the end: not gathered)
-                for (int k = 0; k < nk; k++) {
-                    const dbl2v x = *reinterpret_cast<const dbl2v *>(A.vfull + fbase + (int64_t)tcr[k] * ld);
-                    acc += tvr[k] * x;
-                }
                 dbl2v *po = reinterpret_cast<dbl2v *>(A.out + e);
+                dbl2v o = {0.0, 0.0}, vl = {0.0, 0.0}, up = {0.0, 0.0};
+                if (UNR) {
+                    dbl2v xg[16];
+#pragma unroll
+                    for (int g = 0; g < 4; g++)
+                        if (g * 4 < nk) {      // wave-uniform
+#pragma unroll
+                            for (int q = 0; q < 4; q++) { const int k = g * 4 + q < nk ? g * 4 + q : nk - 1; xg[g * 4 + q] = *reinterpret_cast<const dbl2v *>(A.vfull + fbase + (int64_t)tcr[k] * ld); }
+                        }
+                    if (!WR) o = NT ? __builtin_nontemporal_load(po) : *po;
+                    if (EPI) { vl = *reinterpret_cast<const dbl2v *>(A.v + e); if (A.uprev2) up = *reinterpret_cast<const dbl2v *>(A.uprev2 + e); }
+#pragma unroll
+                    for (int g = 0; g < 4; g++)
+                        if (g * 4 < nk) {
+#pragma unroll
+                            for (int q = 0; q < 4; q++) { const int k = g * 4 + q; const double t = k < nk ? tvr[k < nk ? k : 0] : 0.0; acc += t * xg[k]; }
+                        }
+                } else {
+                    for (int k = 0; k < nk; k++) {
+                        const dbl2v x = *reinterpret_cast<const dbl2v *>(A.vfull + fbase + (int64_t)tcr[k] * ld);
+                        acc += tvr[k] * x;
+                    }
+                    if (!WR) o = NT ? __builtin_nontemporal_load(po) : *po;
+                    if (EPI) { vl = *reinterpret_cast<const dbl2v *>(A.v + e); if (A.uprev2) up = *reinterpret_cast<const dbl2v *>(A.uprev2 + e); }
+                }
                 if (WR) { if (WR == 2) store_through(po, acc); else if (NT) __builtin_nontemporal_store(acc, po); else *po = acc; continue; }
-                dbl2v o = NT ? __builtin_nontemporal_load(po) : *po;
                 if (EPI) {
-                    const dbl2v vl = *reinterpret_cast<const dbl2v *>(A.v + e);
-                    if (A.uprev2) { const dbl2v up = *reinterpret_cast<const dbl2v *>(A.uprev2 + e); o = s_cur * (o + acc) - c_prev2 * up; }
+                    if (A.uprev2) o = s_cur * (o + acc) - c_prev2 * up;
                     else o += s_cur * acc;
                     asum += (s_cur * vl.x) * o.x + (s_cur * vl.y) * o.y;
                 } else o += acc;
@@ -1288,11 +1311,11 @@ __global__ void __launch_bounds__(1024) k_tdw(TdwArgs A)
 // the same pass reading and writing the all-to-all block layout directly (rows that fit LDS): row il of vt is the
 // concatenation of one contiguous segment per sender, staged into LDS in place of the k_tblocks pass; the result is
 // written straight into the block layout of the way back -- two passes over the shard less
-struct TdwFusedArgs { int32_t DimDw, dww, P; int64_t Qup; int64_t dw0[65]; const int32_t *ellc; const double *ellv; const double *blk_in; double *blk_out; };
+struct TdwFusedArgs { int32_t DimDw, dww, P; int64_t Qup; int64_t dw0[65]; const int32_t *ellc; const double *ellv; const double *blk_in; double *blk_out; int64_t il0; };   // il0: first row of this launch (chunked pipeline)
 __global__ void __launch_bounds__(1024) k_tdw_blocks(TdwFusedArgs A)
 {
     extern __shared__ double lds[];
-    const int64_t il = blockIdx.x;
+    const int64_t il = A.il0 + blockIdx.x;
     for (int i = threadIdx.x; i < A.DimDw; i += blockDim.x) {
         int sl = 0; while (sl + 1 < A.P && A.dw0[sl + 1] <= i) sl++;
         lds[i] = A.blk_in[A.Qup * A.dw0[sl] + il * (A.dw0[sl + 1] - A.dw0[sl]) + (i - A.dw0[sl])];
@@ -1962,7 +1985,23 @@ __global__ void __launch_bounds__(256) k_axpy_norm(double *__restrict__ w, const
     double s = 0.0;
     const int64_t n2 = n >> 1;
     dbl2v *w2 = reinterpret_cast<dbl2v *>(w); const dbl2v *u2 = reinterpret_cast<const dbl2v *>(u); dbl2v *a2 = reinterpret_cast<dbl2v *>(acc);
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += (int64_t)gridDim.x * blockDim.x) {
+    // four strided pairs per trip, all eight loads issued before the first use: one memory round trip per trip instead of
+    // one per pair (Ns=18: 9 000 trips per lane at 4.0 TB/s in the rolled form)
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i + 3 * stride < n2; i += 4 * stride) {
+        dbl2v uu[4], ww[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) { uu[q] = u2[i + q * stride]; ww[q] = w2[i + q * stride]; }
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const dbl2v vi = s_cur * uu[q];
+            const dbl2v wi = ww[q] - alpha * vi;
+            w2[i + q * stride] = wi; s += wi.x * wi.x + wi.y * wi.y;
+            if (acc) a2[i + q * stride] += zk * vi;
+        }
+    }
+    for (; i < n2; i += stride) {
         const dbl2v vi = s_cur * u2[i];
         const dbl2v wi = w2[i] - alpha * vi;
         w2[i] = wi; s += wi.x * wi.x + wi.y * wi.y;

@@ -255,7 +255,8 @@ static int lanczos_gs_impl(S *s, int nitermax, double threshold, int ncheck, dou
     }
     // small sectors: every vector of the search in ONE cached allocation (grown geometrically), so that a run over many
     // small sectors of growing size does not pay a hundred allocations each time
-    const int64_t want_all = (int64_t)std::min(nitermax + 2, store_max) * vlen;
+    const int64_t vstride = (vlen + 1) & ~(int64_t)1;      // even stride: every vector of the slab starts on a 16-byte boundary (the basis kernels use 16-B loads)
+    const int64_t want_all = (int64_t)std::min(nitermax + 2, store_max) * vstride;
     const bool slab_mode = store && want_all * 8 <= ((int64_t)512 << 20);
     if (slab_mode && g_kpool.slab_cap < (size_t)want_all) {
         if (g_kpool.slab) { (void)hipFree(g_kpool.slab); g_kpool.slab = nullptr; }
@@ -265,7 +266,7 @@ static int lanczos_gs_impl(S *s, int nitermax, double threshold, int ncheck, dou
     // buffer of u_k: cached from an earlier search when large enough, else (re)allocated within the budget
     auto ring_get = [&](int k) -> double * {
         if (k >= store_max) return nullptr;
-        if (slab_mode) return (g_kpool.slab && (size_t)(k + 1) * (size_t)vlen <= g_kpool.slab_cap) ? g_kpool.slab + (int64_t)k * vlen : nullptr;
+        if (slab_mode) return (g_kpool.slab && (size_t)(k + 1) * (size_t)vstride <= g_kpool.slab_cap) ? g_kpool.slab + (int64_t)k * vstride : nullptr;
         while ((int)g_kpool.buf.size() <= k) { g_kpool.buf.push_back(nullptr); g_kpool.cap.push_back(0); }
         if (g_kpool.cap[k] >= (size_t)vlen) return g_kpool.buf[k];
         const int64_t need = (int64_t)vlen * 8;

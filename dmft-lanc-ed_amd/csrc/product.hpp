@@ -111,20 +111,64 @@ static int transposed_dw_pass(S *s, const double *v, hipStream_t st)
     const unsigned tgrid = (unsigned)(cdiv(H.Qdw, 32) * cdiv(H.DimUp, 32));
     hipLaunchKernelGGL(k_transpose2d, dim3(tgrid), dim3(256), 0, st, v, s->tA.p, H.Qdw, H.DimUp);     // tA: DimUp x Qdw
     HIPCHK(hipGetLastError());
-    CHK(a2a(s->tA.p, sc, sd, s->tB.p, rc, rd));                                                       // tB: blocks by sender
+    {
+        // the chunked LDS pipeline below issues its own forward messages
+        int64_t qmin = s->Qup; for (int r = 0; r < P; r++) { int64_t q, u; split(H.DimUp, r, q, u); qmin = std::min(qmin, q); }
+        const bool chunked = s->tr_lds && std::min<int64_t>(s->tr_chunks, qmin) > 1;
+        if (!chunked) CHK(a2a(s->tA.p, sc, sd, s->tB.p, rc, rd));                                     // tB: blocks by sender
+    }
     if (s->tr_lds) {
-        // rows fit LDS: read the received blocks and write the blocks of the way back directly (tVT is the out buffer)
+        // rows fit LDS: read the received blocks and write the blocks of the way back directly (tVT is the out buffer).
+        // Pipelined over C chunks of the up-block rows (as the reference sends its transposes column by column,
+        // ED_HAMILTONIAN_COMMON.f90:96-113): chunk c of every rank's up-block is a contiguous piece of each message in both
+        // directions, so the all-to-all of chunk c+1 is in flight on the comm stream while chunk c runs its row pass on a
+        // stream of its own, and the way back of chunk c follows as soon as that pass has finished.  C = 1: the serial form.
         TdwFusedArgs F{}; F.DimDw = (int32_t)H.DimDw; F.dww = s->dwf->width; F.P = P; F.Qup = s->Qup;
         for (int r = 0; r <= P; r++) F.dw0[r] = Bk.dw0[r];
         F.ellc = s->dwf->ellc.p; F.ellv = s->dwf->ellv.p; F.blk_in = s->tB.p; F.blk_out = s->tVT.p;
         if (s->dbg & 2) F.dww = 0;
-        if (s->Qup > 0) {
-            static OncePerDevice once;
-            if (once.first(s->device)) { if (hipFuncSetAttribute((const void *)k_tdw_blocks, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024) != hipSuccess) (void)hipGetLastError(); }
-            hipLaunchKernelGGL(k_tdw_blocks, dim3((unsigned)s->Qup), dim3(H.DimDw >= 4096 ? 1024 : 256), (size_t)H.DimDw * 8, st, F);
+        static OncePerDevice once;
+        if (once.first(s->device)) { if (hipFuncSetAttribute((const void *)k_tdw_blocks, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024) != hipSuccess) (void)hipGetLastError(); }
+        std::vector<int64_t> qu(P), u0(P), qd(P), d0(P);
+        for (int r = 0; r < P; r++) { split(H.DimUp, r, qu[r], u0[r]); split(H.DimDw, r, qd[r], d0[r]); }
+        int64_t qmin = s->Qup; for (int r = 0; r < P; r++) qmin = std::min(qmin, qu[r]);
+        const int C = (int)std::max<int64_t>(1, std::min<int64_t>(s->tr_chunks, qmin));
+        if (C == 1) {
+            // forward exchange was issued above as one message per peer
+            if (s->Qup > 0) hipLaunchKernelGGL(k_tdw_blocks, dim3((unsigned)s->Qup), dim3(H.DimDw >= 4096 ? 1024 : 256), (size_t)H.DimDw * 8, st, F);
+            HIPCHK(hipGetLastError());
+            CHK(a2a(s->tVT.p, rc, rd, s->tA.p, sc, sd));                                              // tA: DimUp x Qdw again
+            return EDGPU_OK;
         }
-        HIPCHK(hipGetLastError());
-        CHK(a2a(s->tVT.p, rc, rd, s->tA.p, sc, sd));                                                  // tA: DimUp x Qdw again
+        if (!s->tstream) HIPCHK(hipStreamCreateWithFlags(&s->tstream, hipStreamNonBlocking));
+        while ((int)s->tr_ev.size() < 2 * C) { hipEvent_t e; HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming)); s->tr_ev.push_back(e); }
+        auto cut = [&](int64_t q, int c) { return q * c / C; };                                       // chunk c of a block of q rows: [cut(q,c), cut(q,c+1))
+        std::vector<int64_t> sc2(P), sd2(P), rc2(P), rd2(P);
+        auto counts = [&](int c) {
+            for (int r = 0; r < P; r++) {
+                const int64_t a = cut(qu[r], c), b = cut(qu[r], c + 1), ma = cut(s->Qup, c), mb = cut(s->Qup, c + 1);
+                sc2[r] = (b - a) * H.Qdw; sd2[r] = H.Qdw * (u0[r] + a);                              // rows u0_r+a .. of my transposed shard -> rank r
+                rc2[r] = (mb - ma) * qd[r]; rd2[r] = s->Qup * d0[r] + ma * qd[r];                      // my rows ma.. out of rank r's dw columns
+            }
+        };
+        // comm stream: F(0) F(1) B(0) F(2) B(1) ... ; compute stream: row pass of chunk c after F(c)
+        auto forward = [&](int c) -> int { counts(c); CHK(a2a(s->tA.p, sc2, sd2, s->tB.p, rc2, rd2)); HIPCHK(hipEventRecord(s->tr_ev[2 * c], st)); return EDGPU_OK; };
+        auto rowpass = [&](int c) -> int {
+            HIPCHK(hipStreamWaitEvent(s->tstream, s->tr_ev[2 * c], 0));
+            const int64_t ma = cut(s->Qup, c), mb = cut(s->Qup, c + 1);
+            TdwFusedArgs Fc = F; Fc.il0 = ma;
+            if (mb > ma) hipLaunchKernelGGL(k_tdw_blocks, dim3((unsigned)(mb - ma)), dim3(H.DimDw >= 4096 ? 1024 : 256), (size_t)H.DimDw * 8, s->tstream, Fc);
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipEventRecord(s->tr_ev[2 * c + 1], s->tstream));
+            return EDGPU_OK;
+        };
+        auto backward = [&](int c) -> int { HIPCHK(hipStreamWaitEvent(st, s->tr_ev[2 * c + 1], 0)); counts(c); CHK(a2a(s->tVT.p, rc2, rd2, s->tA.p, sc2, sd2)); return EDGPU_OK; };
+        for (int c = 0; c < C; c++) {
+            CHK(forward(c));
+            CHK(rowpass(c));
+            if (c > 0) CHK(backward(c - 1));
+        }
+        CHK(backward(C - 1));
         return EDGPU_OK;
     }
     const unsigned bgrid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(cdiv(s->Qup * H.DimDw, 256), 65536));
@@ -244,16 +288,18 @@ static int fused_dw(S *s, const double *u, double *t, const double *uprev)
     const int64_t nblocks = (int64_t)D.ntiles * D.chunks;
     const bool nt = s->dw_variant != 2, rag = s->dwf->ragged;
     const size_t dlds = std::max<size_t>((size_t)D.R * D.dww * 12 + 16, (size_t)s->dw_lds_kb * 1024);
-#define DW2_LAUNCH(N_, R_)                                                                                                      \
+#define DW2_LAUNCH_U(N_, R_, U_)                                                                                                \
     do {                                                                                                                            \
         static OncePerDevice once_;                                                                                                 \
         if (dlds > 60 * 1024 && once_.first(s->device)) {                                                                           \
-            if (hipFuncSetAttribute((const void *)k_dwpass2<true, N_, R_>, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024) != hipSuccess) (void)hipGetLastError(); \
+            if (hipFuncSetAttribute((const void *)k_dwpass2<true, N_, R_, 0, U_>, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024) != hipSuccess) (void)hipGetLastError(); \
         }                                                                                                                           \
-        hipLaunchKernelGGL((k_dwpass2<true, N_, R_>), dim3((unsigned)nblocks), dim3(256), dlds, s->stream, D);                      \
+        hipLaunchKernelGGL((k_dwpass2<true, N_, R_, 0, U_>), dim3((unsigned)nblocks), dim3(256), dlds, s->stream, D);               \
     } while (0)
+#define DW2_LAUNCH(N_, R_) do { if (s->dw_unr && D.dww <= 16) DW2_LAUNCH_U(N_, R_, true); else DW2_LAUNCH_U(N_, R_, false); } while (0)
     if (nt) { if (rag) DW2_LAUNCH(true, true); else DW2_LAUNCH(true, false); } else { if (rag) DW2_LAUNCH(false, true); else DW2_LAUNCH(false, false); }
 #undef DW2_LAUNCH
+#undef DW2_LAUNCH_U
     HIPCHK(hipGetLastError());
     s->fuse_mode = 5; s->fuse_zvec = nullptr;
     const int rc = reduce_partials(s, nblocks);
@@ -410,19 +456,22 @@ static int hxv(S *s, const double *v, double *out, bool epi, const double *uprev
                     const bool nt = dv != 2, rag = s->dwf->ragged;
                     // extra LDS (EDGPU_DW_LDS_KB) caps the workgroups per CU; with 16-row chunks full residency measured best (Ns=16 and Ns=18 sweeps, round 2)
                     const size_t dlds = std::max<size_t>((size_t)D.R * D.dww * 12 + 16, (size_t)s->dw_lds_kb * 1024);
-#define DW_LAUNCH(E_, N_, R_, W_)                                                                                               \
+#define DW_LAUNCH_U(E_, N_, R_, W_, U_)                                                                                         \
     do {                                                                                                                            \
         static OncePerDevice once_;                                                                                                 \
         if (dlds > 60 * 1024 && once_.first(s->device)) {      /* static LDS of the kernel comes on top: stay below the 160 KB of a CU */ \
-            if (hipFuncSetAttribute((const void *)k_dwpass2<E_, N_, R_, W_>, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024) != hipSuccess) (void)hipGetLastError(); \
+            if (hipFuncSetAttribute((const void *)k_dwpass2<E_, N_, R_, W_, U_>, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024) != hipSuccess) (void)hipGetLastError(); \
         }                                                                                                                           \
-        hipLaunchKernelGGL((k_dwpass2<E_, N_, R_, W_>), dim3((unsigned)nblocks), dim3(256), dlds, s->stream, D);                    \
+        hipLaunchKernelGGL((k_dwpass2<E_, N_, R_, W_, U_>), dim3((unsigned)nblocks), dim3(256), dlds, s->stream, D);                \
     } while (0)
+#define DW_LAUNCH(E_, N_, R_, W_) do { if (unr) DW_LAUNCH_U(E_, N_, R_, W_, true); else DW_LAUNCH_U(E_, N_, R_, W_, false); } while (0)
+                    const bool unr = s->dw_unr && D.dww <= 16;
                     if (wr == 2) { if (rag) DW_LAUNCH(false, false, true, 2); else DW_LAUNCH(false, false, false, 2); }
                     else if (wr == 1) { if (rag) DW_LAUNCH(false, false, true, 1); else DW_LAUNCH(false, false, false, 1); }
                     else if (dw_epi) { if (nt) { if (rag) DW_LAUNCH(true, true, true, 0); else DW_LAUNCH(true, true, false, 0); } else { if (rag) DW_LAUNCH(true, false, true, 0); else DW_LAUNCH(true, false, false, 0); } }
                     else { if (nt) { if (rag) DW_LAUNCH(false, true, true, 0); else DW_LAUNCH(false, true, false, 0); } else { if (rag) DW_LAUNCH(false, false, true, 0); else DW_LAUNCH(false, false, false, 0); } }
 #undef DW_LAUNCH
+#undef DW_LAUNCH_U
                 }
                 HIPCHK(hipGetLastError());
                 return EDGPU_OK;

@@ -241,13 +241,16 @@ struct edgpu_sector_s {
     std::vector<hipEvent_t> bench_ev; int bench_k = 0; bool bench_fused = false; double *bv[3] = {nullptr, nullptr, nullptr};
     // distributed-transpose form of the dw hops (opt-in, EDGPU_DW_TRANSPOSE=1)
     bool tr_on = false; int64_t Qup = 0, up0 = 0; DevBuf<double> tA, tB, tVT, tHVT; bool tr_lds = false;
+    // chunked pipeline of that exchange: the all-to-all of up-block chunk c+1 travels while chunk c runs its row pass (own stream)
+    int tr_chunks = 4; hipStream_t tstream = nullptr; std::vector<hipEvent_t> tr_ev;
     std::vector<hipEvent_t> comm_ev; int comm_slot = -1;     // timed bench steps: events around the exchange on the comm stream
     int64_t nnz_total = 0, bytes_stored = 0;
     int64_t npartial = 0;
     // knobs read from the environment ONCE, at sector creation (never inside a product)
     int dbg = 0; bool tables_wave = true; int dw_lds_kb = 0; bool lz_fused_on = true;
+    bool dw_unr = false;      // dw pass with every load of a row step issued up front (k_dwpass2<..., UNR>; <= 16 dw hops per row): measured slower (occupancy 4 instead of 8 waves per SIMD), kept as a knob
     int dw_xpt = 1;           // XCDs sharing one column tile of the dw pass (k_dwpass2: xcd_tile_map_shared)
-    int dw_first = 2;         // rows beyond LDS, one rank: dw pass first as a write-only pass (1: plain stores, 2: write-through), local pass adds + epilogue; 0: local pass first
+    int dw_first = 0;         // rows beyond LDS, one rank: dw pass first as a write-only pass (1: plain stores, 2: write-through), local pass adds + epilogue; 0 (default): local pass first -- the write-only form cuts the dw pass's reads by 30 % but the local pass pays them back (profiles/r03/ns18_dw_pass_variants.txt)
     int eig_ncv_used = 0;     // basis size the last edgpu_eigsh call actually ran with
     // Lanczos iteration fusion (single rank)
     int fuse_mode = -1; const double *fuse_zvec = nullptr;   // >= 0: the product's final reduction also performs this scalar step
@@ -277,6 +280,8 @@ inline edgpu_sector_s::~edgpu_sector_s()
     if (ev_b) (void)hipEventDestroy(ev_b);
     if (ev_gather) (void)hipEventDestroy(ev_gather);
     if (ev_ready) (void)hipEventDestroy(ev_ready);
+    for (auto e : tr_ev) (void)hipEventDestroy(e);
+    if (tstream) (void)hipStreamDestroy(tstream);
     if (stream) (void)hipStreamDestroy(stream);
     if (cstream) (void)hipStreamDestroy(cstream);
 }

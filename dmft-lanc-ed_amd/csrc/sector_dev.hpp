@@ -446,7 +446,8 @@ static int create(const edgpu_desc *desc, S **out)
         s->nd_split = dbg_int("EDGPU_ND_SPLIT", 1) != 0;
         s->up_threads = dbg_int("EDGPU_UP_THREADS", 1024) == 512 ? 512 : 1024;
         s->dw_rows = std::max(1, std::min(64, dbg_int("EDGPU_DW_ROWS", 16)));
-        s->dw_first = std::max(0, std::min(2, dbg_int("EDGPU_DW_FIRST", 2)));
+        s->dw_first = std::max(0, std::min(2, dbg_int("EDGPU_DW_FIRST", 0)));
+        s->dw_unr = dbg_int("EDGPU_DW_UNR", 0) != 0;
         { const int x = dbg_int("EDGPU_DW_XPT", 1); s->dw_xpt = (x == 2 || x == 4 || x == 8) ? x : 1; }
         if (s->dw_w != 8 && s->dw_w != 16 && s->dw_w != 32 && s->dw_w != 64 && s->dw_w != 128 && s->dw_w != 256) s->dw_w = 32;
     }
@@ -469,6 +470,7 @@ static int create(const edgpu_desc *desc, S **out)
         CHK(s->tA.alloc((size_t)s->nloc_el)); CHK(s->tB.alloc((size_t)(s->Qup * H.DimDw)));
         CHK(s->tVT.alloc((size_t)(s->Qup * H.DimDw))); CHK(s->tHVT.alloc((size_t)(s->Qup * H.DimDw)));
         s->tr_lds = (size_t)H.DimDw * 8 + 128 <= 150 * 1024 && !(dbg_flags() & 4);
+        s->tr_chunks = std::max(1, std::min(32, dbg_int("EDGPU_TR_CHUNKS", 4)));
     }
     if (desc->storage != EDGPU_STORE_DIRECT) { CHK(build_diag(s.get())); s->bytes_stored = s->nloc_el * 8; }
     if (desc->storage == EDGPU_STORE_CSR) {

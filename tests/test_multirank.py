@@ -113,10 +113,14 @@ def test_multirank_large_sector_forms(edgpu_mod, case, size):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("case,size,env", [("c_nb7_half", 3, {}), ("nb5_offhalf_2_4", 4, {}), ("nb6_even", 2, {"EDGPU_DEBUG": "4"}),
-                                           ("nspin2_random_bath", 3, {}), ("norb2_normal_offdiag_hloc", 2, {})])
+                                           ("nspin2_random_bath", 3, {}), ("norb2_normal_offdiag_hloc", 2, {}),
+                                           ("c_nb7_half", 3, {"EDGPU_TR_CHUNKS": "1"}), ("c_nb7_half", 4, {"EDGPU_TR_CHUNKS": "7"}),
+                                           ("nb5_offhalf_2_4", 3, {"EDGPU_TR_CHUNKS": "32"})])
 def test_multirank_distributed_transpose(edgpu_mod, case, size, env):
     """EDGPU_DW_TRANSPOSE=1: the dw hops through the reference's own scheme (transpose, all-to-all, local pass along
-    rows, transpose back) instead of the needed-rows exchange; uneven up/dw splits, rows with and without LDS staging."""
+    rows, transpose back) instead of the needed-rows exchange; uneven up/dw splits, rows with and without LDS staging.
+    The exchange is pipelined over chunks of the up-block rows (default 4; EDGPU_TR_CHUNKS=1 is the serial form, 7 and 32 give
+    uneven and single-row chunks): every form must reach the dense ground-state energy."""
     res = _launch("gpu", case, size, extra_env=dict({"EDGPU_DW_TRANSPOSE": "1"}, **env))
     name, m, nu, nd = [z for z in __import__("cases").zoo() if z[0] == case][0]
     from oracle import oracle
