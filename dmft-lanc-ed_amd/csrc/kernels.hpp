@@ -680,7 +680,8 @@ struct UpHaloArgs {
     const double *uprev, *scal; double *partial;
 };
 constexpr int kHaloSegMax = 6144, kHaloMax = 12288;     // up to 3 pairs and 12 halo values per lane of a 1024-thread workgroup
-template <bool DIRECT, int NQ, int MAXH, bool ADD = false, bool EPI = false>      // NQ: pairs per lane = steps per (row, segment) item; MAXH: halo values per lane
+// ABL (timing experiments only, results wrong): 1 = amplitudes not looked up in LDS (constant), 2 = gathers read the lane's own element
+template <bool DIRECT, int NQ, int MAXH, bool ADD = false, bool EPI = false, int ABL = 0>      // NQ: pairs per lane = steps per (row, segment) item; MAXH: halo values per lane
 __global__ void __launch_bounds__(1024) k_uppass_halo(UpHaloArgs A)
 {
     extern __shared__ double lds[];
@@ -747,9 +748,9 @@ __global__ void __launch_bounds__(1024) k_uppass_halo(UpHaloArgs A)
             for (int e = 0; e < 10; e++) {
                 const uint32_t code0 = (k0[e >> 2] >> (8 * (e & 3))) & 0xffu, col0 = (c0[e >> 1] >> (16 * (e & 1))) & 0xffffu;
                 const uint32_t code1 = (k1[e >> 2] >> (8 * (e & 3))) & 0xffu, col1 = (c1[e >> 1] >> (16 * (e & 1))) & 0xffffu;
-                double t0 = tv[code0 & 0x7fu], t1 = tv[code1 & 0x7fu];
+                double t0 = (ABL & 1) ? 0.25 : tv[code0 & 0x7fu], t1 = (ABL & 1) ? 0.25 : tv[code1 & 0x7fu];
                 t0 = (code0 & 0x80u) ? -t0 : t0; t1 = (code1 & 0x80u) ? -t1 : t1;
-                a0 += t0 * lds[col0]; a1 += t1 * lds[col1];
+                a0 += t0 * ((ABL & 2) ? xx.x + (double)col0 : lds[col0]); a1 += t1 * ((ABL & 2) ? xx.y + (double)col1 : lds[col1]);
             }
             if (ADD) { a0 += cur.od.x; a1 += cur.od.y; }
             if (EPI) {
@@ -1985,11 +1986,13 @@ __global__ void __launch_bounds__(256) k_axpy_norm(double *__restrict__ w, const
     double s = 0.0;
     const int64_t n2 = n >> 1;
     dbl2v *w2 = reinterpret_cast<dbl2v *>(w); const dbl2v *u2 = reinterpret_cast<const dbl2v *>(u); dbl2v *a2 = reinterpret_cast<dbl2v *>(acc);
-    // four strided pairs per trip, all eight loads issued before the first use: one memory round trip per trip instead of
-    // one per pair (Ns=18: 9 000 trips per lane at 4.0 TB/s in the rolled form)
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    for (; i + 3 * stride < n2; i += 4 * stride) {
+    // Every workgroup owns ONE contiguous piece of the vectors (a grid-stride walk puts consecutive accesses of a lane
+    // gridDim*4 KB apart: 2 MB at 512 workgroups, a new page each time on the 19 GB vectors of Ns=18, where the pass ran at
+    // 4.0 TB/s against 5.7 at Ns=16); four pairs per trip, all eight loads issued before the first use.
+    const int64_t per = (n2 + gridDim.x - 1) / gridDim.x, stride = blockDim.x;
+    const int64_t n2b = (int64_t)(blockIdx.x + 1) * per < n2 ? (int64_t)(blockIdx.x + 1) * per : n2;
+    int64_t i = (int64_t)blockIdx.x * per + threadIdx.x;
+    for (; i + 3 * stride < n2b; i += 4 * stride) {
         dbl2v uu[4], ww[4];
 #pragma unroll
         for (int q = 0; q < 4; q++) { uu[q] = u2[i + q * stride]; ww[q] = w2[i + q * stride]; }
@@ -2001,7 +2004,7 @@ __global__ void __launch_bounds__(256) k_axpy_norm(double *__restrict__ w, const
             if (acc) a2[i + q * stride] += zk * vi;
         }
     }
-    for (; i < n2; i += stride) {
+    for (; i < n2b; i += stride) {
         const dbl2v vi = s_cur * u2[i];
         const dbl2v wi = w2[i] - alpha * vi;
         w2[i] = wi; s += wi.x * wi.x + wi.y * wi.y;

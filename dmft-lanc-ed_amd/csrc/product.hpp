@@ -554,6 +554,18 @@ static int hxv(S *s, const double *v, double *out, bool epi, const double *uprev
 #define HALO_AE(D_, Q_, H_) do { if (!dw_first) HALO_LAUNCH(D_, Q_, H_, false, false); else if (epi) HALO_LAUNCH(D_, Q_, H_, true, true); else HALO_LAUNCH(D_, Q_, H_, true, false); } while (0)
 #define HALO_Q(D_, H_) do { if (nq == 1) HALO_AE(D_, 1, H_); else if (nq == 2) HALO_AE(D_, 2, H_); else HALO_AE(D_, 3, H_); } while (0)
                 const int nq = (int)cdiv(U.seglen / 2, 1024);
+                const int abl = (s->dbg >> 4) & 3;      // EDGPU_DEBUG bits 16 / 32: timing ablations of the hop loop (wrong results)
+                if (abl && direct && nq == 2 && U.halocap <= 8 * 1024 && !dw_first) {
+                    static OncePerDevice once_a;
+                    if (once_a.first(s->device)) {
+                        (void)hipFuncSetAttribute((const void *)k_uppass_halo<true, 2, 8, false, false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                        (void)hipFuncSetAttribute((const void *)k_uppass_halo<true, 2, 8, false, false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                        (void)hipFuncSetAttribute((const void *)k_uppass_halo<true, 2, 8, false, false, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                    }
+                    if (abl == 1) hipLaunchKernelGGL((k_uppass_halo<true, 2, 8, false, false, 1>), dim3(grid), dim3(1024), lds, s->stream, U);
+                    else if (abl == 2) hipLaunchKernelGGL((k_uppass_halo<true, 2, 8, false, false, 2>), dim3(grid), dim3(1024), lds, s->stream, U);
+                    else hipLaunchKernelGGL((k_uppass_halo<true, 2, 8, false, false, 3>), dim3(grid), dim3(1024), lds, s->stream, U);
+                } else
                 if (U.halocap <= 8 * 1024) { if (direct) HALO_Q(true, 8); else HALO_Q(false, 8); }
                 else { if (direct) HALO_Q(true, 12); else HALO_Q(false, 12); }
 #undef HALO_Q

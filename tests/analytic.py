@@ -261,3 +261,14 @@ def apply_c_fock(m, nups, ndws, iorb, ispin, dagger, state):
     if ispin == 2 and nu % 2:
         out = -out
     return out
+
+
+def free_imp_occupations(m, nups, ndws):
+    """<n_{a,up}>, <n_{a,dw}> of the quadratic model's sector ground state (ed_total_ud=T): sum over the filled one-body
+    levels of |<a|level>|^2.  Uncorrelated spins: <n_up n_dw> = <n_up><n_dw>."""
+    Norb = m["Norb"]
+    out = []
+    for spin, n in ((0, int(np.atleast_1d(nups)[0])), (1, int(np.atleast_1d(ndws)[0]))):
+        w, U = np.linalg.eigh(one_body(m, spin))
+        out.append(np.array([(U[a, :n] ** 2).sum() for a in range(Norb)]))
+    return out[0], out[1]

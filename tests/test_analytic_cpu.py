@@ -166,3 +166,17 @@ def test_oracle_c2_free_ground_state_by_lanczos():
     e0, vec, nl = oracle.sp_lanc_eigh(S.spmatvec, v0, 300, threshold=1e-13)
     ref, gap = analytic.free_e0(z, nu, nd)
     assert abs(e0 - ref) <= 1e-10, (e0, ref, nl)
+
+
+@pytest.mark.parametrize("nb,nu,nd", [(5, 4, 2), (5, 3, 3), (7, 5, 2)])
+def test_oracle_free_observables(nb, nu, nd):
+    """lanc_observables of the oracle on the non-interacting ground state against one-body occupations"""
+    from edgpu import model
+    m, _, _ = model.half_filled_c(nb)
+    z0 = analytic.non_interacting(m, xmu=-0.15)
+    S = oracle.Sector(z0, [nu], [nd])
+    w, U = np.linalg.eigh(S.hmat())
+    ob = oracle.lanc_observables(S, U[:, 0])
+    nup, ndw = analytic.free_imp_occupations(z0, [nu], [nd])
+    assert abs(ob["dens_up"][0] - nup[0]) <= 1e-12 and abs(ob["dens_dw"][0] - ndw[0]) <= 1e-12
+    assert abs(ob["docc"][0] - nup[0] * ndw[0]) <= 1e-12

@@ -213,3 +213,25 @@ def test_c3_gf_target_sectors_full_size(edgpu_mod):
             Gt.close()
         dout.free(); dh.free()
     dgs.free(); G0.close()
+
+
+@pytest.mark.parametrize("nb,nu,nd", [(5, 4, 2), (11, 7, 5), (15, 9, 7)])
+def test_free_observables(edgpu_mod, nb, nu, nd):
+    """Local observables of the non-interacting ground state from the device (edgpu_imp_histogram -> lanc_observables sums,
+    ED_OBSERVABLES.f90:150-215) against one-body occupations: <n_s> = sum over filled levels of |<d|level>|^2,
+    <n_up n_dw> = <n_up><n_dw>, at c1, c2 and c3 size (sector (9,7): N = 130,873,600, magnetised)."""
+    from edgpu import model
+    m, _, _ = model.half_filled_c(nb)
+    z0 = analytic.non_interacting(m, xmu=-0.15)
+    G0 = edgpu_mod.HvSector(z0, [nu], [nd], storage="direct")
+    ev, X, info = G0.sp_eigh(1, nblock=20, nitermax=300, tol=1e-12)
+    assert abs(ev[0] - analytic.free_e0(z0, [nu], [nd])[0]) <= E0_TOL
+    gs = edgpu_mod.DeviceVector(G0.vecDim).upload(X[:, 0]); del X
+    nup, ndw = analytic.free_imp_occupations(z0, [nu], [nd])
+    ob = G0.observables(gs)
+    assert abs(ob["dens_up"][0] - nup[0]) <= 1e-9 and abs(ob["dens_dw"][0] - ndw[0]) <= 1e-9
+    assert abs(ob["dens"][0] - (nup[0] + ndw[0])) <= 1e-9 and abs(ob["magz"][0] - (nup[0] - ndw[0])) <= 1e-9
+    assert abs(ob["docc"][0] - nup[0] * ndw[0]) <= 1e-9
+    le = G0.local_energy(gs)
+    assert abs(le["Epot"]) <= 1e-12 and abs(le["Dust"]) <= 1e-12          # no interaction, one orbital
+    gs.free(); G0.close()
