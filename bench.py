@@ -416,7 +416,7 @@ def main():
                 for _ in range(2):
                     t0 = time.perf_counter(); ev, _x, info = g.sp_eigh(2, nblock=20, nitermax=300, tol=1e-10, vectors=False); te = time.perf_counter() - t0
                 out["eigsh_c3_s"] = te
-                out["default_solver_path"] = {"call": "edgpu_eigsh(nev=2, ncv=20, tol=1e-10) = sp_eigh of ED_DIAG.f90:153-170", "storage": "kron", "seconds": te,
+                out["default_solver_path"] = {"call": "edgpu_eigsh(nev=2, ncv=20, tol=1e-10) = sp_eigh of ED_DIAG.f90:153-170 (the library may enlarge the basis when HBM is free: ncv_used)", "storage": "kron", "seconds": te,
                                               "E": [float(x) for x in ev], "products": info["matvecs"], "restarts": info["restarts"], "ncv_used": info["ncv_used"]}
             g.close()
         out["other_formats"] = extra

@@ -681,11 +681,12 @@ struct UpHaloArgs {
 };
 constexpr int kHaloSegMax = 6144, kHaloMax = 12288;     // up to 3 pairs and 12 halo values per lane of a 1024-thread workgroup
 // ABL (timing experiments only, results wrong): 1 = amplitudes not looked up in LDS (constant), 2 = gathers read the lane's own element
-template <bool DIRECT, int NQ, int MAXH, bool ADD = false, bool EPI = false, int ABL = 0>      // NQ: pairs per lane = steps per (row, segment) item; MAXH: halo values per lane
-__global__ void __launch_bounds__(1024) k_uppass_halo(UpHaloArgs A)
+// NT: threads per workgroup.  1024 = one workgroup per CU (the 16 waves of a CU share both barriers of every item); 512 with
+// segments half as long = two independent workgroups per CU whose barrier phases interleave (EDGPU_UP_SEGMAX=2048 EDGPU_UP_NT=512).
+template <bool DIRECT, int NQ, int MAXH, bool ADD = false, bool EPI = false, int ABL = 0, int NT = 1024>      // NQ: pairs per lane = steps per (row, segment) item; MAXH: halo values per lane
+__global__ void __launch_bounds__(NT, 4) k_uppass_halo(UpHaloArgs A)      // 4 waves per SIMD: one workgroup of 1024 or two of 512 per CU
 {
     extern __shared__ double lds[];
-    constexpr int NT = 1024;
     const int DimUp = A.DimUp, tid = threadIdx.x;
     const int64_t ld = A.ld ? A.ld : DimUp;
     const int x = blockIdx.x & 7, j = blockIdx.x >> 3, G = (int)(gridDim.x >> 3) / A.nseg;
@@ -899,7 +900,7 @@ __device__ __forceinline__ void store_through(dbl2v *p, dbl2v v)
 // UNR: every load of a row step is issued before the first one is consumed -- up to 16 gathers in groups of four, then the
 // result / v / u_prev operands.  The rolled form (4 gathers in flight, then a remainder one by one, then the operand loads)
 // is a chain of 4 dependent memory round trips per row step and 8 per workgroup: at Ns=18 (2.3 M workgroups, 2 048
-// resident) that chain alone is the 18 ms the pass took, whatever the traffic (profiles/r03/ns18_dw_pass_variants.txt).
+// resident) that chain alone is the 18 ms the pass took, whatever the traffic (profiles/r03/ns18_product_variants.txt).
 template <bool EPI, bool NT, bool RAGGED, int WR = 0, bool UNR = false>   // RAGGED: rows have different hop counts (multi-orbital models): skip the ELL padding
 __global__ void __launch_bounds__(256) k_dwpass2(DwArgs A)
 {

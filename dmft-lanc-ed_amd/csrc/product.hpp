@@ -553,8 +553,24 @@ static int hxv(S *s, const double *v, double *out, bool epi, const double *uprev
     } while (0)
 #define HALO_AE(D_, Q_, H_) do { if (!dw_first) HALO_LAUNCH(D_, Q_, H_, false, false); else if (epi) HALO_LAUNCH(D_, Q_, H_, true, true); else HALO_LAUNCH(D_, Q_, H_, true, false); } while (0)
 #define HALO_Q(D_, H_) do { if (nq == 1) HALO_AE(D_, 1, H_); else if (nq == 2) HALO_AE(D_, 2, H_); else HALO_AE(D_, 3, H_); } while (0)
-                const int nq = (int)cdiv(U.seglen / 2, 1024);
+                const int nt = s->up_halo_nt;
+                const int nq = (int)cdiv(U.seglen / 2, nt);
                 const int abl = (s->dbg >> 4) & 3;      // EDGPU_DEBUG bits 16 / 32: timing ablations of the hop loop (wrong results)
+                if (nt == 512 && !dw_first && nq <= 2 && U.halocap <= 12 * 512) {
+                    // two workgroups of 512 threads per CU (needs segments of <= 2048 elements and <= 6144 halo values)
+                    const unsigned grid5 = (unsigned)std::max(8 * U.nseg, (2 * s->up_grid) & ~7);
+#define HALO5(D_, Q_, H_)                                                                                                       \
+    do {                                                                                                                            \
+        static OncePerDevice once_;                                                                                                 \
+        if (once_.first(s->device)) (void)hipFuncSetAttribute((const void *)k_uppass_halo<D_, Q_, H_, false, false, 0, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+        hipLaunchKernelGGL((k_uppass_halo<D_, Q_, H_, false, false, 0, 512>), dim3(grid5), dim3(512), lds, s->stream, U);           \
+    } while (0)
+                    const bool h8 = U.halocap <= 8 * 512;
+                    if (direct) { if (nq == 1) { if (h8) HALO5(true, 1, 8); else HALO5(true, 1, 12); } else { if (h8) HALO5(true, 2, 8); else HALO5(true, 2, 12); } }
+                    else { if (nq == 1) { if (h8) HALO5(false, 1, 8); else HALO5(false, 1, 12); } else { if (h8) HALO5(false, 2, 8); else HALO5(false, 2, 12); } }
+#undef HALO5
+                    halo_epi = epi;
+                } else
                 if (abl && direct && nq == 2 && U.halocap <= 8 * 1024 && !dw_first) {
                     static OncePerDevice once_a;
                     if (once_a.first(s->device)) {

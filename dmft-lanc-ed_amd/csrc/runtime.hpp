@@ -248,9 +248,10 @@ struct edgpu_sector_s {
     int64_t npartial = 0;
     // knobs read from the environment ONCE, at sector creation (never inside a product)
     int dbg = 0; bool tables_wave = true; int dw_lds_kb = 0; bool lz_fused_on = true;
+    int up_halo_nt = 1024;    // threads per workgroup of k_uppass_halo (512: two workgroups per CU, with EDGPU_UP_SEGMAX=2048)
     bool dw_unr = false;      // dw pass with every load of a row step issued up front (k_dwpass2<..., UNR>; <= 16 dw hops per row): measured slower (occupancy 4 instead of 8 waves per SIMD), kept as a knob
     int dw_xpt = 1;           // XCDs sharing one column tile of the dw pass (k_dwpass2: xcd_tile_map_shared)
-    int dw_first = 0;         // rows beyond LDS, one rank: dw pass first as a write-only pass (1: plain stores, 2: write-through), local pass adds + epilogue; 0 (default): local pass first -- the write-only form cuts the dw pass's reads by 30 % but the local pass pays them back (profiles/r03/ns18_dw_pass_variants.txt)
+    int dw_first = 0;         // rows beyond LDS, one rank: dw pass first as a write-only pass (1: plain stores, 2: write-through), local pass adds + epilogue; 0 (default): local pass first -- the write-only form cuts the dw pass's reads by 30 % but the local pass pays them back (profiles/r03/ns18_product_variants.txt)
     int eig_ncv_used = 0;     // basis size the last edgpu_eigsh call actually ran with
     // Lanczos iteration fusion (single rank)
     int fuse_mode = -1; const double *fuse_zvec = nullptr;   // >= 0: the product's final reduction also performs this scalar step

@@ -115,7 +115,7 @@ static int build_up_segments(S *s)
     // first choice: two pairs and eight halo values per lane (the kernel variant that fits 128 registers without spilling)
     const int32_t lim[2][2] = {{std::min(dbg_int("EDGPU_UP_SEGMAX", 4096), kHaloSegMax), std::min(dbg_int("EDGPU_UP_HALOMAX", 8192), kHaloMax)}, {kHaloSegMax, kHaloMax}};
     for (int pass = 0; pass < 2; pass++)
-        for (int nseg = 2; nseg <= 32; nseg *= 2) {
+        for (int nseg = 2; nseg <= 64; nseg *= 2) {
             const int32_t seglen = (int32_t)((cdiv(f.dim, nseg) + 1) & ~(int64_t)1);
             if (seglen > lim[pass][0]) continue;
             std::vector<int32_t> ext, off(1, 0); int32_t maxh = 0; bool ok = true;
@@ -448,6 +448,7 @@ static int create(const edgpu_desc *desc, S **out)
         s->dw_rows = std::max(1, std::min(64, dbg_int("EDGPU_DW_ROWS", 16)));
         s->dw_first = std::max(0, std::min(2, dbg_int("EDGPU_DW_FIRST", 0)));
         s->dw_unr = dbg_int("EDGPU_DW_UNR", 0) != 0;
+        s->up_halo_nt = dbg_int("EDGPU_UP_NT", 1024) == 512 ? 512 : 1024;
         { const int x = dbg_int("EDGPU_DW_XPT", 1); s->dw_xpt = (x == 2 || x == 4 || x == 8) ? x : 1; }
         if (s->dw_w != 8 && s->dw_w != 16 && s->dw_w != 32 && s->dw_w != 64 && s->dw_w != 128 && s->dw_w != 256) s->dw_w = 32;
     }
