@@ -28,6 +28,27 @@ def test_lowest_eigenpairs_match_dense(edgpu_mod, name, m, nu, nd):
         G.close()
 
 
+@pytest.mark.parametrize("case", ["c_nb7_half", "norb3_nb1_JxJp", "replica_sz_sx_JxJp", "orbs_norb2_nb3"])
+def test_eigsh_survives_many_restarts(edgpu_mod, case):
+    """Tiny bases (8 vectors for 3 pairs, 14 for 6, 4 for 1): 30-300 thick restarts per search.  The partial re-orthogonalisation
+    must keep the basis semi-orthogonal through all of them (the relation-defect term of DESIGN.md section 5; the numpy model
+    tests/eigsh_model.py takes 854 products and 283 restarts on norb3_nb1_JxJp with 8 vectors): every returned value is an
+    eigenvalue of the dense matrix to 1e-10, the lowest one is E0, and the vectors are orthonormal eigenvectors."""
+    name, m, nu, nd = [z for z in cases.zoo() if z[0] == case][0]
+    S = oracle.Sector(m, nu, nd)
+    w = np.linalg.eigvalsh(S.hmat())
+    G = edgpu_mod.HvSector(m, nu, nd, storage="kron")
+    for neigen, nblock in ((3, 8), (6, 14), (1, 4)):
+        ev, X, info = G.sp_eigh(neigen, nblock=nblock, nitermax=3000, tol=1e-12)
+        assert info["nconv"] == neigen and info["ncv_used"] == nblock, info
+        assert abs(ev[0] - w[0]) <= 1e-10
+        for i in range(neigen):
+            assert np.abs(w - ev[i]).min() <= 1e-10, (neigen, i, ev[i])
+            assert np.linalg.norm(S.spmatvec(X[:, i]) - ev[i] * X[:, i]) < 1e-7
+        assert np.abs(X.T @ X - np.eye(neigen)).max() < 1e-10
+    G.close()
+
+
 def test_eigsh_agrees_with_plain_lanczos_on_c2(edgpu_mod):
     from edgpu import model
     m, nu, nd = model.half_filled_c(11)          # N = 853776
