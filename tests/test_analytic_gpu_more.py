@@ -1,0 +1,71 @@
+"""More oracle-free anchors of the HIP path (tests/analytic.py): the spin / charge susceptibility legs of the non-interacting
+model at every BASELINE size, and free-fermion ground states of ed_total_ud=F and hybrid-bath sectors beyond dense reach."""
+import numpy as np
+import pytest
+
+import analytic
+import cases
+
+pytestmark = pytest.mark.gpu
+
+
+def _cf(z, norm2, a, b, n, e0):
+    g = 0.0
+    for k in range(n - 1, -1, -1):
+        bk2 = b[k + 1] ** 2 if k + 1 < n else 0.0
+        g = 1.0 / (z - (a[k] - e0) - bk2 * g)
+    return norm2 * g
+
+
+def _free_chi(m, nu, nd, cu, cd, zs):
+    """<gs| O (z - (H - E0))^-1 O |gs> for O = cu n_d,up + cd n_d,dw on the Slater-determinant ground state:
+    O|gs> = <O>|gs> + sum_s c_s sum_{n filled, m empty} U_dm U_dn |ph_s(m,n)>, particle-hole states being eigenstates at e_m - e_n"""
+    tot = np.zeros(len(zs), complex); mean = 0.0
+    for spin, n, c in ((0, nu, cu), (1, nd, cd)):
+        w, U = np.linalg.eigh(analytic.one_body(m, spin))
+        mean += c * (U[0, :n] ** 2).sum()
+        for i in range(n):
+            for j in range(n, w.size):
+                tot += c * c * (U[0, i] * U[0, j]) ** 2 / (zs - (w[j] - w[i]))
+    return tot + mean * mean / zs
+
+
+@pytest.mark.parametrize("nb,nu,nd", [(5, 3, 3), (5, 4, 2), (11, 6, 6), (15, 8, 8), (15, 9, 7)])
+def test_free_susceptibility_legs(edgpu_mod, nb, nu, nd):
+    """edgpu_chi_lanczos (Sz and n start vectors of ED_GF_CHISPIN.f90:169-171 / ED_GF_CHIDENS.f90:166-168) on the U=0 ground
+    state against the particle-hole sum, to 1e-8, up to the c3 sectors (N = 165,636,900 and 130,873,600)."""
+    from edgpu import model
+    m, _, _ = model.half_filled_c(nb)
+    z0 = analytic.non_interacting(m, xmu=0.1)
+    G = edgpu_mod.HvSector(z0, [nu], [nd], storage="kron")
+    ev, X, info = G.sp_eigh(1, nblock=20, nitermax=300, tol=1e-12)
+    e0 = float(ev[0])
+    assert abs(e0 - analytic.free_e0(z0, [nu], [nd])[0]) <= 1e-10
+    gs = edgpu_mod.DeviceVector(G.vecDim).upload(X[:, 0]); del X
+    zs = 1j * np.array([0.2, 1.0, 3.0]) + np.array([0.0, 0.4, -0.7])
+    for cu, cd in ((0.5, -0.5), (1.0, 1.0)):
+        n2, a, b, used = G.chi_lanczos([cu], [cd], gs, 80, threshold=1e-9)
+        got = np.array([_cf(z, n2, a, b, used, e0) for z in zs])
+        np.testing.assert_allclose(got, _free_chi(z0, nu, nd, cu, cd, zs), rtol=0, atol=1e-8)
+    gs.free(); G.close()
+
+
+def test_free_fermion_e0_orbs_and_hybrid_large(edgpu_mod):
+    """ed_total_ud=F with two orbitals and 7 bath levels each (N = 24,010,000: composite two-factor blocks) and a hybrid bath
+    (Norb=2, Nbath=10, N = 853,776), interactions off: Lanczos E0 of every storage = sum of one-body levels."""
+    from edgpu import model
+    imp = np.diag([0.3, -0.3]).reshape(1, 1, 2, 2)
+    mo = model.make_model(Norb=2, Nbath=7, ed_total_ud=False, Uloc=(2.0, 2.0), Ust=1.5, Jh=0.25, impHloc=imp,
+                          bath_v=np.random.RandomState(8).uniform(0.2, 0.6, (1, 2, 7)), bath_e=np.random.RandomState(9).uniform(-1, 1, (1, 2, 7)))
+    mh = model.make_model(Norb=2, Nbath=10, bath_type="hybrid", Uloc=(2.0, 2.0), Ust=1.0, Jh=0.3, Jx=0.3, Jp=0.3,
+                          bath_v=np.random.RandomState(3).uniform(0.2, 0.6, (1, 2, 10)))
+    for mm, nu, nd in ((mo, [4, 4], [4, 3]), (mh, [6], [6])):
+        z = analytic.non_interacting(mm, xmu=0.15)
+        ref, gap = analytic.free_e0(z, nu, nd)
+        for st in ("kron", "direct", "csr"):
+            G = edgpu_mod.HvSector(z, nu, nd, storage=st)
+            dv = edgpu_mod.DeviceVector(G.vecDim).zero()
+            e0, nl = G.sp_lanc_eigh_device(dv, nitermax=800, threshold=1e-13)
+            assert abs(e0 - ref) <= 1e-10, (st, e0, ref, nl)
+            dv.free(); G.close()
+            edgpu_mod.cache_release()
