@@ -44,6 +44,11 @@ def test_bench_line(extra):
     if not extra:
         assert set(d["other_formats"]) == {"kron", "direct"}
         assert d["ground_state"]["nlanc"] > 10 and d["ground_state"]["seconds"] > 0
+        # the reference's default solver path (sp_eigh, two pairs) timed next to the plain ground state, same E0
+        assert d["eigsh_c3_s"] > 0 and abs(d["default_solver_path"]["E"][0] - d["ground_state"]["E0"]) < 1e-8
+        assert "bounded" in r["bound_note"]
+    if "--gpus" in extra or "--force-dist" in extra:
+        assert "exchange_model_ms" in d and d["exchange_model_ms"]["busiest_pair_at_77GBps"] >= 0.0
 
 
 @pytest.mark.gpu
