@@ -558,8 +558,11 @@ static int eigsh_pro(S *s, int nev, int ncv, int maxiter, double tol, double *ev
     const int m = ncv, M = m + 2;
     CHK(lz_prepare(s, m + 4));
     if (s->lz[3].n != (size_t)n) CHK(s->lz[3].alloc((size_t)n));
-    while ((int)s->eigV.size() < m + 1) s->eigV.push_back(std::make_unique<DevBuf<double>>());
-    for (int i = 0; i <= m; i++) {
+    // the fused iteration (stored factors / on the fly, one rank) forms the local part of H u_{j+1} one buffer ahead
+    const bool fused = fused_ok(s) && dbg_int("EDGPU_EIGSH_FUSED", 1) != 0;
+    const int nbuf = m + 1 + (fused ? 1 : 0);
+    while ((int)s->eigV.size() < nbuf) s->eigV.push_back(std::make_unique<DevBuf<double>>());
+    for (int i = 0; i < nbuf; i++) {
         if (s->eigV[i]->n < (size_t)vlen) CHK(s->eigV[i]->alloc((size_t)vlen));
         if (s->pad_on) HIPCHK(hipMemsetAsync(s->eigV[i]->p, 0, (size_t)vlen * 8, s->stream));      // padding columns must hold zeros
     }
@@ -577,7 +580,13 @@ static int eigsh_pro(S *s, int nev, int ncv, int maxiter, double tol, double *ev
     auto rotate = [&](int nv, int nout, const std::vector<double> &Yc) -> int {      // B_a <- sum_k B_k Yc(k,a), a < nout (in place)
         HIPCHK(hipMemcpyAsync(s->eig_y.p, Yc.data(), (size_t)nv * nout * 8, hipMemcpyHostToDevice, s->stream));
         HIPCHK(hipStreamSynchronize(s->stream));      // Yc may be a temporary of the caller
-        if (nv <= kMaxBasis) { RotArgs R{}; R.nv = nv; R.nout = nout; R.Y = s->eig_y.p; for (int i = 0; i < nv; i++) R.V[i] = B(i);
+        const int g2 = (int)std::max<int64_t>(1, std::min<int64_t>(cdiv(vlen, 256 * 2 * 16), 2048));
+        const int rot2 = dbg_int("EDGPU_ROT2", 1);
+        if (nv <= 20 && rot2) { RotArgs2<5> R{}; R.nv = nv; R.nout = nout; R.Y = s->eig_y.p; for (int i = 0; i < nv; i++) R.V[i] = B(i);
+            hipLaunchKernelGGL(k_basis_rotate2<5>, dim3(g2), dim3(256), (size_t)nv * nout * 8, s->stream, R, vlen); }
+        else if (nv <= 32 && rot2) { RotArgs2<8> R{}; R.nv = nv; R.nout = nout; R.Y = s->eig_y.p; for (int i = 0; i < nv; i++) R.V[i] = B(i);
+            hipLaunchKernelGGL(k_basis_rotate2<8>, dim3(g2), dim3(256), (size_t)nv * nout * 8, s->stream, R, vlen); }
+        else if (nv <= kMaxBasis) { RotArgs R{}; R.nv = nv; R.nout = nout; R.Y = s->eig_y.p; for (int i = 0; i < nv; i++) R.V[i] = B(i);
             hipLaunchKernelGGL(k_basis_rotate<kMaxBasis>, dim3(gs), dim3(256), (size_t)nv * nout * 8, s->stream, R, vlen); }
         else { RotArgsT<kMaxBasisBig> R{}; R.nv = nv; R.nout = nout; R.Y = s->eig_y.p; for (int i = 0; i < nv; i++) R.V[i] = B(i);
             static OncePerDevice once;
@@ -635,8 +644,19 @@ static int eigsh_pro(S *s, int nev, int ncv, int maxiter, double tol, double *ev
     HIPCHK(hipGetLastError());
     CHK(lzf_copy_in(s, B(0), dense));
     LzVecs V{s->lz[0].p, B(0), B(1)};
-    CHK(lz_start(s, V));                                  // zeroes the dummy previous vector, scale of u_0 -> scal[SCUR]
+    LzF Fz{B(0), s->lz[0].p, B(1)};                       // fused: u = u_j, uprev = u_{j-1}, t = local part of H u_j (unscaled), one buffer ahead
+    if (fused) { HIPCHK(hipMemsetAsync(Fz.uprev, 0, (size_t)vlen * 8, s->stream)); CHK(lzf_begin(s, Fz, nullptr)); }
+    else CHK(lz_start(s, V));                             // zeroes the dummy previous vector, scale of u_0 -> scal[SCUR]
     HIPCHK(hipMemcpyAsync(&sc[0], s->scal.p + SC_SCUR, 8, hipMemcpyDeviceToHost, s->stream)); HIPCHK(hipStreamSynchronize(s->stream));
+    // after u_{j+1} = B(j+1) was changed in place: its norm / scale / beta_j follow; the fused form also redoes the local half
+    auto renorm = [&](int j, double &beta) -> int {
+        if (fused) CHK(fused_local(s, B(j + 1), B(j), B(j + 2), nullptr, true));
+        else CHK(scalar_mode(6));
+        double b2 = 0.0;
+        HIPCHK(hipMemcpyAsync(&b2, s->scal.p + SC_TMP, 8, hipMemcpyDeviceToHost, s->stream)); HIPCHK(hipStreamSynchronize(s->stream));
+        beta = std::sqrt(std::max(b2, 0.0));
+        return EDGPU_OK;
+    };
     Wm(0, 0) = 1.0;
     int l = 0, j = 0, kloc = 0, nconv = 0, it = 0, nmv = 0, meff = m, n_full = 0, n_sel = 0; int64_t nreads = 0;
     bool exact = false; double normT = 0.0, beta_last = 0.0;
@@ -644,8 +664,9 @@ static int eigsh_pro(S *s, int nev, int ncv, int maxiter, double tol, double *ev
     for (it = 0; it < maxiter; it++) {
         meff = m; exact = false;
         for (; j < m; j++) {
-            V.ucur = B(j); V.w = B(j + 1);
-            CHK(lz_iter(s, V, kloc, nullptr)); nmv++;      // afterwards V.uprev = B(j), V.ucur = B(j+1)
+            if (fused) { Fz.u = B(j); Fz.t = B(j + 1); CHK(lzf_iter(s, Fz, B(j + 2), nullptr)); }      // afterwards Fz.u = B(j+1), Fz.uprev = B(j), Fz.t = B(j+2)
+            else { V.ucur = B(j); V.w = B(j + 1); CHK(lz_iter(s, V, kloc, nullptr)); }              // afterwards V.uprev = B(j), V.ucur = B(j+1)
+            nmv++;
             double ab[2];
             HIPCHK(hipMemcpyAsync(&ab[0], s->alphas.p + kloc, 8, hipMemcpyDeviceToHost, s->stream));
             HIPCHK(hipMemcpyAsync(&ab[1], s->betas.p + kloc + 1, 8, hipMemcpyDeviceToHost, s->stream));
@@ -676,9 +697,8 @@ static int eigsh_pro(S *s, int nev, int ncv, int maxiter, double tol, double *ev
                 hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(1024), 0, s->stream, (const double *)s->eig_partial.p, (int64_t)nb, s->scal.p + SC_TMP);
                 HIPCHK(hipGetLastError());
                 CHK(allreduce_tmp(s));
-                CHK(scalar_mode(6));
-                HIPCHK(hipMemcpyAsync(&nrm2, s->scal.p + SC_TMP, 8, hipMemcpyDeviceToHost, s->stream)); HIPCHK(hipStreamSynchronize(s->stream));
-                beta = std::sqrt(std::max(nrm2, 0.0)); nreads += l;
+                (void)nrm2;
+                CHK(renorm(j, beta)); nreads += l;
             }
             {
                 // omega recurrence: estimates w(j+1,k), k < j
@@ -699,8 +719,7 @@ static int eigsh_pro(S *s, int nev, int ncv, int maxiter, double tol, double *ev
                 double nrm2 = 0.0;
                 std::vector<double> scl(idx.size()); for (size_t t = 0; t < idx.size(); t++) scl[t] = sc[idx[t]];
                 CHK(project_out(idx, scl.data(), B(j + 1), nrm2)); nreads += 2 * (int64_t)idx.size();
-                CHK(scalar_mode(6));                       // beta_j and the scale of u_{j+1} follow the new norm
-                beta = std::sqrt(std::max(nrm2, 0.0));
+                CHK(renorm(j, beta));                      // beta_j and the scale of u_{j+1} follow the new norm
                 for (size_t t = 0; t < idx.size(); t++) {
                     Wm(j + 1, idx[t]) = Wm(idx[t], j + 1) = eps;
                     Fm(idx[t], j) += removed[t];                 // not part of T: feeds the defect of the Ritz vectors formed at the next restart
@@ -721,8 +740,9 @@ static int eigsh_pro(S *s, int nev, int ncv, int maxiter, double tol, double *ev
                 CHK(project_out(all, scl.data(), B(j + 1), nrm2));
                 CHK(project_out(all, scl.data(), B(j + 1), nrm2));
                 if (!(nrm2 > 0.0)) { meff = j + 1; exact = true; break; }
-                CHK(scalar_mode(6)); CHK(scalar_mode(7));
-                sc[j + 1] = 1.0 / std::sqrt(nrm2); kloc = 0; V.uprev = B(j);
+                { double bb = 0.0; CHK(renorm(j, bb)); }
+                CHK(scalar_mode(7));
+                sc[j + 1] = 1.0 / std::sqrt(nrm2); kloc = 0; V.uprev = B(j); Fz.uprev = B(j);
                 for (int k = 0; k <= j; k++) Wm(j + 1, k) = Wm(k, j + 1) = eps;
                 Wm(j + 1, j + 1) = 1.0;
             }
@@ -743,6 +763,7 @@ static int eigsh_pro(S *s, int nev, int ncv, int maxiter, double tol, double *ev
         for (int a = 0; a < lnew; a++) for (int k = 0; k < m; k++) Yc[k + (size_t)m * a] = sc[k] * Y[k + (size_t)m * a];
         CHK(rotate(m, lnew, Yc)); nreads += m + lnew;
         std::swap(s->eigV[lnew], s->eigV[m]);            // B(lnew) <- u_m, no copy
+        if (fused) std::swap(s->eigV[lnew + 1], s->eigV[m + 1]);      // ... and the local part of H u_m that is already there
         std::vector<double> Wn((size_t)M * M, 0.0), etan((size_t)M, 0.0);
         for (int a = 0; a < lnew; a++) {
             for (int b = 0; b <= a; b++) {
@@ -767,7 +788,7 @@ static int eigsh_pro(S *s, int nev, int ncv, int maxiter, double tol, double *ev
         sc[lnew] = scm;
         CHK(scalar_mode(7));                              // scal[SCUR] already is the scale of u_m
         l = lnew; j = l; kloc = 0;
-        V.uprev = B(l - 1);                               // any finite vector: its coefficient is zero
+        V.uprev = B(l - 1); Fz.uprev = B(l - 1);           // any finite vector: its coefficient is zero
     }
     const int nout = std::min(nev, meff);
     {

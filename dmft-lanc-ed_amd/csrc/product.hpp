@@ -228,8 +228,11 @@ static bool fused_ok(const S *s)
            (H.DimUp % 2 == 0) && s->dw_variant >= 2 && s->dw_w >= 4 && s->dwf->width <= 64;
 }
 // local half: r <- u_k = r - alpha s u_prev (in place), TMP = |u_k|^2 and the norm step, t <- local part of H u_k (unscaled)
-static int fused_local(S *s, double *r, const double *uprev, double *t, double *acc)
+// redo: r already IS u_k (it was changed in place after the pass that formed it): alpha is zeroed so that r stays as it is,
+// and the scalar step that follows the norm does not rotate the scales again (k_scalar_step modes 9 / 8)
+static int fused_local(S *s, double *r, const double *uprev, double *t, double *acc, bool redo = false)
 {
+    if (redo) { hipLaunchKernelGGL(k_scalar_step, dim3(1), dim3(1), 0, s->stream, s->scal.p, s->alphas.p, s->betas.p, (const double *)nullptr, -1, 9); HIPCHK(hipGetLastError()); }
     const SectorHost &H = s->H; const edgpu_desc &d = H.desc;
     const bool direct = d.storage == EDGPU_STORE_DIRECT;
     if (direct) CHK(direct_tables(s));
@@ -258,7 +261,7 @@ static int fused_local(S *s, double *r, const double *uprev, double *t, double *
     }
 #undef AX_LAUNCH
     HIPCHK(hipGetLastError());
-    s->fuse_mode = 4; s->fuse_zvec = nullptr;
+    s->fuse_mode = redo ? 8 : 4; s->fuse_zvec = nullptr;
     const int rc = reduce_partials(s, grid);
     s->fuse_mode = -1;
     if (rc != EDGPU_OK) return rc;
