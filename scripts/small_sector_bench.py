@@ -26,3 +26,18 @@ for nbath in (7, 9, 11, 13):
         assert nl_a == nl_b and abs(e_a - e_b) < 1e-12 and np.array_equal(aa, ab), (nl_a, nl_b, e_a, e_b)
         print("Ns=%d N=%d %s: lanc_eigh nlanc=%d  check-every-step %.2f ms (%.1f us/it)  chunked %.2f ms (%.1f us/it) | tridiag200 %.2f / %.2f ms"
               % (nbath + 1, G.Dim, st, nl_a, t1a * 1e3, t1a / (2 * nl_a) * 1e6, t1b * 1e3, t1b / (2 * nl_b) * 1e6, t2a * 1e3, t2b * 1e3), flush=True)
+
+# the reference's default solver path on the same sectors: sp_eigh(Neigen=2, Nblock=20) -> edgpu_eigsh, both forms
+for nbath in (7, 9, 11, 13):
+    m, nu, nd = model.half_filled_c(nbath)
+    out = []
+    for pro in ("1", "0"):
+        os.environ["EDGPU_EIGSH_PRO"] = pro
+        G = edgpu.HvSector(m, nu, nd, storage="kron")
+        G.sp_eigh(2, nblock=20, nitermax=300, tol=1e-10, vectors=False)
+        t0 = time.perf_counter(); ev, _, info = G.sp_eigh(2, nblock=20, nitermax=300, tol=1e-10, vectors=False); t1 = time.perf_counter() - t0
+        out.append((t1, info["matvecs"], ev))
+        G.close()
+    assert np.abs(out[0][2] - out[1][2]).max() < 1e-9
+    print("Ns=%d N=%d kron: sp_eigh(2 pairs, 20 vectors) partial re-orthogonalisation %.2f ms (%d products) | whole-basis form %.2f ms (%d products)"
+          % (nbath + 1, G.Dim, out[0][0] * 1e3, out[0][1], out[1][0] * 1e3, out[1][1]), flush=True)
