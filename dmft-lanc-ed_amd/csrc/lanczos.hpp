@@ -547,7 +547,8 @@ static int eigsh_pro(S *s, int nev, int ncv, int maxiter, double tol, double *ev
     // Nblock is a workspace size, not part of the result: with HBM to spare a basis of 32 vectors needs fewer restarts and fewer
     // products than the reference's default of 20 (Ns=16, two pairs: 167 products / 0.81 s against 182 / 0.94 s); taken only
     // when the extra vectors fit comfortably (a quarter of the free memory), reported through edgpu_eigsh_ncv_used
-    if (ncv < 32 && Dim >= (1 << 20) && dbg_int("EDGPU_EIGSH_GROW", 1)) {
+    // (one rank only: the free memory differs from rank to rank, and every rank must run the same basis)
+    if (ncv < 32 && Dim >= (1 << 20) && !s->multi && dbg_int("EDGPU_EIGSH_GROW", 1)) {
         size_t fr = 0, tot = 0;
         if (hipMemGetInfo(&fr, &tot) == hipSuccess && (size_t)(32 + 5) * (size_t)vlen * 8 < fr / 4) ncv = 32; else (void)hipGetLastError();
     }
