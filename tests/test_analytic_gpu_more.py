@@ -69,3 +69,34 @@ def test_free_fermion_e0_orbs_and_hybrid_large(edgpu_mod):
             assert abs(e0 - ref) <= 1e-10, (st, e0, ref, nl)
             dv.free(); G.close()
             edgpu_mod.cache_release()
+
+
+@pytest.mark.parametrize("nb,nu,nd", [(5, 3, 3), (5, 4, 2), (11, 6, 6), (15, 8, 8), (15, 9, 7)])
+def test_spectral_sum_rules_of_the_interacting_model(edgpu_mod, nb, nu, nd):
+    """Exact identities of the INTERACTING impurity model (U=2, away from particle-hole symmetry) that need no reference
+    solution: for an eigenstate, the zeroth and first moments of the impurity spectral function built from the two
+    Green's-function legs are  M0 = <{c,c^+}> = 1  and  M1 = <{[c,H],c^+}> = eps_d - mu + U(<n_-s> - 1/2)  (the hybridisation
+    drops out of the anticommutator).  M0 = norm2(c^+ leg) + norm2(c leg); M1 = norm2_p (a_1p - E) - norm2_h (a_1h - E) from
+    the first Lanczos coefficient of each leg; <n_-s> from edgpu_imp_histogram.  Up to the c3 sectors."""
+    from edgpu import model
+    m, _, _ = model.half_filled_c(nb)
+    m = dict(m, xmu=0.25)
+    G0 = edgpu_mod.HvSector(m, [nu], [nd], storage="kron")
+    ev, X, info = G0.sp_eigh(1, nblock=20, nitermax=400, tol=1e-12)
+    e0 = float(ev[0])
+    gs = edgpu_mod.DeviceVector(G0.vecDim).upload(X[:, 0]); del X
+    ob = G0.observables(gs)
+    U = m["Uloc"][0]
+    for ispin, nother in ((1, ob["dens_dw"][0]), (2, ob["dens_up"][0])):
+        m0 = 0.0; m1 = 0.0
+        for dagger in (True, False):
+            nu2, nd2 = [nu], [nd]
+            (nu2 if ispin == 1 else nd2)[0] += 1 if dagger else -1
+            Gt = edgpu_mod.HvSector(m, nu2, nd2, storage="direct")
+            n2, a, b, used = edgpu_mod.gf_lanczos(G0, Gt, 1, ispin, dagger, gs, 3)
+            m0 += n2
+            m1 += (1.0 if dagger else -1.0) * n2 * (a[0] - e0)
+            Gt.close()
+        assert abs(m0 - 1.0) <= 1e-9, (ispin, m0)
+        assert abs(m1 - (-m["xmu"] + U * (nother - 0.5))) <= 1e-7, (ispin, m1, -m["xmu"] + U * (nother - 0.5))
+    gs.free(); G0.close()
