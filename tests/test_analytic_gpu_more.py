@@ -100,3 +100,40 @@ def test_spectral_sum_rules_of_the_interacting_model(edgpu_mod, nb, nu, nd):
         assert abs(m0 - 1.0) <= 1e-9, (ispin, m0)
         assert abs(m1 - (-m["xmu"] + U * (nother - 0.5))) <= 1e-7, (ispin, m1, -m["xmu"] + U * (nother - 0.5))
     gs.free(); G0.close()
+
+
+@pytest.mark.parametrize("nb", [5, 11, 15])
+def test_symmetries_and_hellmann_feynman(edgpu_mod, nb):
+    """More reference-free identities of the interacting model, up to c3 size.  (i) spin symmetry: E0(Nup,Ndw) = E0(Ndw,Nup) for
+    sectors off half filling, whose up configurations have different numbers of hops (9 / 7 at c3).  (ii) particle-hole symmetry
+    of the half-filled sector (symmetric bath, mu = 0, Hartree-shifted U): the particle and the hole leg of the Green's function have
+    the same weight and the same Lanczos coefficients relative to E0.  (iii) Hellmann-Feynman: dE0/dU = <(n_up-1/2)(n_dw-1/2)>,
+    central difference of three ground-state searches against the impurity histogram."""
+    from edgpu import model
+    m, nu, nd = model.half_filled_c(nb)
+    h = nu[0]
+
+    def e0_of(mm, a, b, vec=False):
+        G = edgpu_mod.HvSector(mm, [a], [b], storage="kron")
+        ev, X, info = G.sp_eigh(1, nblock=20, nitermax=400, tol=1e-12, vectors=vec)
+        return float(ev[0]), X, G
+    ea, _, Ga = e0_of(m, h + 1, h - 1); Ga.close()
+    eb, _, Gb = e0_of(m, h - 1, h + 1); Gb.close()
+    assert abs(ea - eb) <= 1e-9, (ea, eb)
+    e0, X, G0 = e0_of(m, h, h, vec=True)
+    gs = edgpu_mod.DeviceVector(G0.vecDim).upload(X[:, 0]); del X
+    legs = []
+    for dagger in (True, False):
+        Gt = edgpu_mod.HvSector(m, [h + (1 if dagger else -1)], [h], storage="kron")
+        n2, a, b, used = edgpu_mod.gf_lanczos(G0, Gt, 1, 1, dagger, gs, 12)
+        legs.append((n2, a - e0, b)); Gt.close()
+    assert abs(legs[0][0] - 0.5) <= 1e-7 and abs(legs[0][0] - legs[1][0]) <= 1e-8
+    np.testing.assert_allclose(legs[0][1][:10], legs[1][1][:10], rtol=0, atol=1e-6)
+    np.testing.assert_allclose(legs[0][2][1:10], legs[1][2][1:10], rtol=0, atol=1e-6)
+    ob = G0.observables(gs)
+    rhs = ob["docc"][0] - 0.5 * ob["dens"][0] + 0.25
+    gs.free(); G0.close()
+    dU = 2e-3
+    ep, _, Gp = e0_of(dict(m, Uloc=(m["Uloc"][0] + dU, 0, 0, 0, 0)), h, h); Gp.close()
+    em, _, Gm = e0_of(dict(m, Uloc=(m["Uloc"][0] - dU, 0, 0, 0, 0)), h, h); Gm.close()
+    assert abs((ep - em) / (2 * dU) - rhs) <= 2e-6, ((ep - em) / (2 * dU), rhs)
