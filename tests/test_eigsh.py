@@ -49,6 +49,27 @@ def test_eigsh_survives_many_restarts(edgpu_mod, case):
     G.close()
 
 
+@pytest.mark.parametrize("env", [{"EDGPU_EIGSH_PRO": "0"}, {"EDGPU_EIGSH_FUSED": "0"}, {"EDGPU_ROT2": "0", "EDGPU_EIGSH_OMEGA_PCT": "1"}])
+def test_eigsh_alternative_forms(edgpu_mod, monkeypatch, env):
+    """The forms behind knobs stay correct: every vector orthogonalised against the whole basis (round-2 solver), the
+    three-pass iteration inside the partial-reorthogonalisation solver, the one-element rotation kernel with a trigger level
+    of 1 % of sqrt(eps) (many more passes over the basis, same answer)."""
+    from edgpu import model
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    m, nu, nd = model.half_filled_c(9)          # N = 63504, split two-pass product with the fused iteration available
+    monkeypatch.setenv("EDGPU_KRON_SPLIT", "1")
+    S = oracle.Sector(m, nu, nd)
+    G = edgpu_mod.HvSector(m, nu, nd, storage="kron")
+    e0, x, nl = G.sp_lanc_eigh(nitermax=300, threshold=1e-13)
+    ev, X, info = G.sp_eigh(3, nblock=12, nitermax=500, tol=1e-12)
+    assert info["nconv"] == 3 and abs(ev[0] - e0) <= 1e-10 and np.all(np.diff(ev) > -1e-10)
+    for i in range(3):
+        assert np.linalg.norm(S.spmatvec(X[:, i]) - ev[i] * X[:, i]) < 1e-7
+    assert np.abs(X.T @ X - np.eye(3)).max() < 1e-10
+    G.close()
+
+
 def test_eigsh_agrees_with_plain_lanczos_on_c2(edgpu_mod):
     from edgpu import model
     m, nu, nd = model.half_filled_c(11)          # N = 853776
