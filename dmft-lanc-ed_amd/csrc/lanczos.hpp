@@ -534,6 +534,7 @@ static void jacobi_eig(std::vector<double> &A, int m, std::vector<double> &w, st
 // orthonormalised among themselves at the end.  Basis vectors stay unnormalised (v_i = sc_i * B_i), the scales are folded
 // into the rotation and projection coefficients.
 // ---------------------------------------------------------------------------------------
+static int eigsh_full(S *s, int nev, int ncv, int maxiter, double tol, double *evals, double *evecs_host, int *nconv_out, int *nrestart_out, int *nmatvec_out);
 static int eigsh_pro(S *s, int nev, int ncv, int maxiter, double tol, double *evals, double *evecs_host, int *nconv_out, int *nrestart_out, int *nmatvec_out)
 {
     const int64_t Dim = s->H.Dim, n = s->nloc, vlen = s->vlen;
@@ -806,6 +807,31 @@ static int eigsh_pro(S *s, int nev, int ncv, int maxiter, double tol, double *ev
         else { CHK(reduce_dot(s, B(0), B(0), vlen)); HIPCHK(hipMemcpyAsync(&nrm2, s->scal.p + SC_TMP, 8, hipMemcpyDeviceToHost, s->stream)); HIPCHK(hipStreamSynchronize(s->stream)); }
         hipLaunchKernelGGL(k_scale_copy, dim3(gs), dim3(256), 0, s->stream, B(i), (const double *)B(i), nrm2 > 0.0 ? 1.0 / std::sqrt(nrm2) : 0.0, vlen);
         HIPCHK(hipGetLastError());
+    }
+    // Safety net: the TRUE residual |H x - theta x| of every returned pair (one product and one pass each).  The Lanczos estimate
+    // beta |s_m| that declared them converged assumes a basis orthogonal to sqrt(eps); should that assumption ever fail the
+    // residual shows it, and the call is answered by the whole-basis form instead (EDGPU_EIGSH_VERIFY=0 skips the check).
+    if (nconv >= nev && nout < m && dbg_int("EDGPU_EIGSH_VERIFY", 1)) {
+        double worst = 0.0;
+        for (int i = 0; i < nout; i++) {
+            double *w = B(m);                              // stale basis vector: free after the final rotation
+            CHK(hxv(s, B(i), w, false, nullptr, s->vld));
+            coef[0] = theta[i];
+            HIPCHK(hipMemcpyAsync(s->eig_h.p, coef.data(), 8, hipMemcpyHostToDevice, s->stream)); HIPCHK(hipStreamSynchronize(s->stream));
+            BasisArgs Bu{}; Bu.nv = 1; Bu.V[0] = B(i);
+            launch_multiaxpy_norm(s->stream, nb, Bu, (const double *)s->eig_h.p, w, vlen, s->eig_partial.p);
+            hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(1024), 0, s->stream, (const double *)s->eig_partial.p, (int64_t)nb, s->scal.p + SC_TMP);
+            HIPCHK(hipGetLastError());
+            CHK(allreduce_tmp(s));
+            double r2 = 0.0;
+            HIPCHK(hipMemcpyAsync(&r2, s->scal.p + SC_TMP, 8, hipMemcpyDeviceToHost, s->stream)); HIPCHK(hipStreamSynchronize(s->stream));
+            worst = std::max(worst, std::sqrt(std::max(r2, 0.0)) / std::max(1.0, std::fabs(theta[i])));
+        }
+        if (s->dbg & 8) fprintf(stderr, "edgpu_eigsh: largest true residual / max(1,|theta|) of the returned pairs: %.3e\n", worst);
+        if (!(worst <= 1e-6)) {
+            if (s->dbg & 8) fprintf(stderr, "edgpu_eigsh: residual check failed, repeating with whole-basis re-orthogonalisation\n");
+            return eigsh_full(s, nev, ncv, maxiter, tol, evals, evecs_host, nconv_out, nrestart_out, nmatvec_out);
+        }
     }
     for (int i = 0; i < nev; i++) evals[i] = i < nout ? theta[i] : 0.0;
     if (evecs_host)
