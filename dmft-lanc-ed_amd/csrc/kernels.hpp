@@ -656,6 +656,16 @@ __global__ void __launch_bounds__(NT) k_uppass_ax(UpAxArgs A)
     if (tid == 0) A.partial[blockIdx.x] = rr;
 }
 
+// DIRECT storage: per dw configuration the part of the diagonal that does not depend on the up bath levels, one value per up
+// impurity word: Edw + econst + cross(up word, dw word).  n*nI doubles, rebuilt per product like the other on-the-fly tables.
+__global__ void k_crow_table(const double *Edw, const int32_t *mapdw, const double *cross, double econst, int32_t impmask, int32_t nI, int64_t n, double *out)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n * nI) return;
+    const int64_t idw = t / nI; const int i = (int)(t - idw * nI);
+    out[t] = Edw[idw] + econst + cross[i * nI + ((uint32_t)mapdw[idw] & impmask)];
+}
+
 // Local pass for rows too long for LDS, segment + halo form (Ns=17/18).  The up configurations are sorted by value, so a
 // contiguous 1/16 of a row is (nearly) "the configurations with given top bath bits": three quarters of the up hops of an
 // element stay inside its own segment, only the hops on the top levels leave it.  A persistent 1024-thread workgroup owns
@@ -678,9 +688,11 @@ struct UpHaloArgs {
     // ADD: `out` already holds the dw part (k_dwpass2<..., WR>): this pass adds to it.  EPI: Lanczos epilogue on top,
     // out = s_cur*(local + dw) - beta*s_prev*uprev and the alpha partial sums (s_cur*v).out per workgroup
     const double *uprev, *scal; double *partial;
+    const double *crowtab;   // DIRECT: [idw][nI] Edw + econst + cross(up impurity word, dw impurity word), rebuilt with the other on-the-fly tables
 };
 constexpr int kHaloSegMax = 6144, kHaloMax = 12288;     // up to 3 pairs and 12 halo values per lane of a 1024-thread workgroup
-// ABL (timing experiments only, results wrong): 1 = amplitudes not looked up in LDS (constant), 2 = gathers read the lane's own element
+// ABL (timing experiments only, results wrong): 1 = amplitudes not looked up in LDS (constant), 2 = gathers read the lane's own element,
+// 4 = halo values not loaded, 8 = hop words loaded for the first two rows only, 16 = no stores (EDGPU_ABL)
 // NT: threads per workgroup.  1024 = one workgroup per CU (the 16 waves of a CU share both barriers of every item); 512 with
 // segments half as long = two independent workgroups per CU whose barrier phases interleave (EDGPU_UP_SEGMAX=2048 EDGPU_UP_NT=512).
 template <bool DIRECT, int NQ, int MAXH, bool ADD = false, bool EPI = false, int ABL = 0, int NT = 1024>      // NQ: pairs per lane = steps per (row, segment) item; MAXH: halo values per lane
@@ -708,14 +720,22 @@ __global__ void __launch_bounds__(NT, 4) k_uppass_halo(UpHaloArgs A)      // 4 w
         const int t0 = tid + h * NT, t1 = t0 + NT;
         hc[h >> 1] = (t0 < nh ? (uint32_t)A.ext[eoff + t0] : 0u) | ((t1 < nh ? (uint32_t)A.ext[eoff + t1] : 0u) << 16);
     }
-    dbl2v xr[NQ]; double xh[MAXH];
-    const int64_t rstep = (int64_t)G * 8;
+    dbl2v xr[NQ]; double xh[MAXH]; double crn = 0.0;
+    const int64_t rstep = (int64_t)G * 8, lastrow = A.nrows - 1;
+    const int pmax = npair > 0 ? npair - 1 : 0;
+    // No branch around a prefetch load, neither per lane nor uniform: lanes and rows out of range load a clamped address and
+    // discard the value.  A wait for an older load is `s_waitcnt vmcnt(N)` with N = the memory operations issued since, and the
+    // compiler has to take the SMALLEST N over all paths: one path that skips the prefetch turns every such wait into
+    // vmcnt(0), i.e. the operands requested a moment ago are waited for at once (the first form of this kernel did exactly
+    // that: scripts/isa_waits.py; 17.3 ms at Ns=18).
     auto fetch_row = [&](int64_t rw) {
+        rw = rw < lastrow ? rw : lastrow;
         const double *vr = A.v + rw * ld;
 #pragma unroll
-        for (int q = 0; q < NQ; q++) { const int p = tid + q * NT; if (p < npair) xr[q] = *reinterpret_cast<const dbl2v *>(vr + lo + 2 * p); }
+        for (int q = 0; q < NQ; q++) { int p = tid + q * NT; p = p < npair ? p : pmax; xr[q] = *reinterpret_cast<const dbl2v *>(vr + lo + 2 * p); }
 #pragma unroll
-        for (int h = 0; h < MAXH; h++) if (tid + h * NT < nh) xh[h] = vr[(hc[h >> 1] >> (16 * (h & 1))) & 0xffffu];
+        for (int h = 0; h < MAXH; h++) xh[h] = (ABL & 4) ? 1.0 : vr[(hc[h >> 1] >> (16 * (h & 1))) & 0xffffu];      // entries beyond the list hold column 0
+        if (DIRECT) crn = A.crowtab[(A.dw0 + rw % A.Qdw) * A.nI + (tid < A.nI ? tid : 0)];      // Edw + const + cross term of that row (k_crow_table)
     };
     // Operand ring of two slots, continuous across items: the image slice of a workgroup is the same for every row, so the
     // operands of linear step L+2 (possibly of the next row) are requested as soon as step L has used its slot.  Loads return
@@ -723,15 +743,14 @@ __global__ void __launch_bounds__(NT, 4) k_uppass_halo(UpHaloArgs A)      // 4 w
     struct Ops { dbl2v d; uint4 w0, w1, w2, w3; dbl2v od, up; };       // d: stored diagonal (KRON) or Eup (DIRECT); od: dw part already in out (ADD); up: u_prev (EPI)
     Ops o[2];
     auto load_ops = [&](int64_t rw, int q, Ops &t) {
-        const int p = tid + q * NT;
-        if (rw < A.nrows && p < npair) {
-            const int i = lo + 2 * p;
-            if (!DIRECT) t.d = *reinterpret_cast<const dbl2v *>(A.diag + (rw % A.Qdw) * DimUp + i);
-            else t.d = *reinterpret_cast<const dbl2v *>(A.Eup + i);
-            t.w0 = A.pseg8[2 * i]; t.w1 = A.pseg8[2 * i + 1]; t.w2 = A.pseg8[2 * i + 2]; t.w3 = A.pseg8[2 * i + 3];
-            if (ADD) t.od = *reinterpret_cast<const dbl2v *>(A.out + rw * ld + i);      // this lane alone writes that position, two steps from now
-            if (EPI && A.uprev) t.up = *reinterpret_cast<const dbl2v *>(A.uprev + rw * ld + i);
-        }
+        int p = tid + q * NT; p = p < npair ? p : pmax;
+        rw = rw < lastrow ? rw : lastrow;
+        const int i = lo + 2 * p;
+        if (!DIRECT) t.d = *reinterpret_cast<const dbl2v *>(A.diag + (rw % A.Qdw) * DimUp + i);
+        else t.d = *reinterpret_cast<const dbl2v *>(A.Eup + i);
+        if (!(ABL & 8) || rw < rstep * 2) { t.w0 = A.pseg8[2 * i]; t.w1 = A.pseg8[2 * i + 1]; t.w2 = A.pseg8[2 * i + 2]; t.w3 = A.pseg8[2 * i + 3]; }
+        if (ADD) t.od = *reinterpret_cast<const dbl2v *>(A.out + rw * ld + i);      // lanes in range: this lane alone writes that position, two steps from now
+        if (EPI && A.uprev) t.up = *reinterpret_cast<const dbl2v *>(A.uprev + rw * ld + i);
     };
     auto step = [&](int64_t rw, int q, const Ops &cur) {
         const int p = tid + q * NT;
@@ -760,29 +779,28 @@ __global__ void __launch_bounds__(NT, 4) k_uppass_halo(UpHaloArgs A)      // 4 w
                 asum += (s_cur * xx.x) * a0 + (s_cur * xx.y) * a1;
             }
             dbl2v r; r.x = a0; r.y = a1;
-            *reinterpret_cast<dbl2v *>(A.out + rw * ld + lo + 2 * p) = r;
+            if (!(ABL & 16) || a0 == 12345.678) *reinterpret_cast<dbl2v *>(A.out + rw * ld + lo + 2 * p) = r;
         }
     };
     auto item = [&](auto par, int64_t rw) {              // par: slot of this item's step 0
         constexpr int P = decltype(par)::value;
-        const int64_t idw = A.dw0 + rw % A.Qdw;
 #pragma unroll
         for (int q = 0; q < NQ; q++) { const int p = tid + q * NT; if (p < npair) *reinterpret_cast<dbl2v *>(lds + 2 * p) = xr[q]; }
 #pragma unroll
         for (int h = 0; h < MAXH; h++) if (tid + h * NT < nh) halo[tid + h * NT] = xh[h];
-        if (DIRECT && tid < A.nI) crow[tid] = A.Edw[idw] + A.econst + A.cross[tid * A.nI + ((uint32_t)A.mapdw[idw] & A.impmask)];
+        if (DIRECT && tid < A.nI) crow[tid] = crn;
         __syncthreads();
 #pragma unroll
         for (int q = 0; q < NQ; q++) {
             Ops &slot = o[(P + q) & 1];
             step(rw, q, slot);
             load_ops(rw + (int64_t)((q + 2) / NQ) * rstep, (q + 2) % NQ, slot);
-            if (q == 0 && rw + rstep < A.nrows) fetch_row(rw + rstep);
+            if (q == 0) fetch_row(rw + rstep);
         }
         __syncthreads();
     };
     int64_t row = (int64_t)g * 8 + x;
-    if (row < A.nrows) fetch_row(row);
+    fetch_row(row);
     load_ops(row, 0, o[0]);
     load_ops(row + (int64_t)(1 / NQ) * rstep, 1 % NQ, o[1]);
     while (row < A.nrows) {

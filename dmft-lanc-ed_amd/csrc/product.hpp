@@ -544,6 +544,12 @@ static int hxv(S *s, const double *v, double *out, bool epi, const double *uprev
                 U.diag = A.diag; U.Eup = A.Eup; U.Edw = A.Edw; U.cross = A.cross; U.mapup = A.mapup; U.mapdw = A.mapdw; U.impmask = A.impmask; U.nI = A.nI; U.econst = A.econst;
                 U.v = v; U.out = out; U.ld = (int32_t)ld;
                 U.uprev = uprev; U.scal = s->scal.p; U.partial = s->partial.p;
+                if (direct) {
+                    const int64_t nct = H.DimDw * U.nI;
+                    if (s->crow_tab.n != (size_t)nct) CHK(s->crow_tab.alloc((size_t)nct));
+                    hipLaunchKernelGGL(k_crow_table, dim3((unsigned)cdiv(nct, 256)), dim3(256), 0, s->stream, U.Edw, U.mapdw, U.cross, U.econst, U.impmask, U.nI, H.DimDw, s->crow_tab.p);
+                    U.crowtab = s->crow_tab.p;
+                }
                 const size_t lds = ((size_t)U.seglen + U.halocap + 128 + 32 + 16) * 8;
                 const unsigned grid = (unsigned)std::max(8 * U.nseg, s->up_grid & ~7);
                 if (dw_first) { CHK(run_dw(s->dw_first, false, nullptr)); dw_done = true; nblocks = grid; }
@@ -558,7 +564,7 @@ static int hxv(S *s, const double *v, double *out, bool epi, const double *uprev
 #define HALO_Q(D_, H_) do { if (nq == 1) HALO_AE(D_, 1, H_); else if (nq == 2) HALO_AE(D_, 2, H_); else HALO_AE(D_, 3, H_); } while (0)
                 const int nt = s->up_halo_nt;
                 const int nq = (int)cdiv(U.seglen / 2, nt);
-                const int abl = (s->dbg >> 4) & 3;      // EDGPU_DEBUG bits 16 / 32: timing ablations of the hop loop (wrong results)
+                const int abl = ((s->dbg >> 4) & 3) | dbg_int("EDGPU_ABL", 0);      // EDGPU_DEBUG bits 16 / 32, EDGPU_ABL: timing ablations (wrong results)
                 if (nt == 512 && !dw_first && nq <= 2 && U.halocap <= 12 * 512) {
                     // two workgroups of 512 threads per CU (needs segments of <= 2048 elements and <= 6144 halo values)
                     const unsigned grid5 = (unsigned)std::max(8 * U.nseg, (2 * s->up_grid) & ~7);
@@ -575,15 +581,17 @@ static int hxv(S *s, const double *v, double *out, bool epi, const double *uprev
                     halo_epi = epi;
                 } else
                 if (abl && direct && nq == 2 && U.halocap <= 8 * 1024 && !dw_first) {
-                    static OncePerDevice once_a;
-                    if (once_a.first(s->device)) {
-                        (void)hipFuncSetAttribute((const void *)k_uppass_halo<true, 2, 8, false, false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-                        (void)hipFuncSetAttribute((const void *)k_uppass_halo<true, 2, 8, false, false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-                        (void)hipFuncSetAttribute((const void *)k_uppass_halo<true, 2, 8, false, false, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+#define HALO_ABL(V_)                                                                                                            \
+    case V_: {                                                                                                                      \
+        static OncePerDevice once_;                                                                                                 \
+        if (once_.first(s->device)) (void)hipFuncSetAttribute((const void *)k_uppass_halo<true, 2, 8, false, false, V_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+        hipLaunchKernelGGL((k_uppass_halo<true, 2, 8, false, false, V_>), dim3(grid), dim3(1024), lds, s->stream, U);               \
+    } break
+                    switch (abl) {
+                    HALO_ABL(1); HALO_ABL(2); HALO_ABL(3); HALO_ABL(4); HALO_ABL(8); HALO_ABL(12); HALO_ABL(16); HALO_ABL(28); HALO_ABL(31);
+                    default: return fail(EDGPU_EINVAL, "edgpu: EDGPU_ABL takes 1,2,3,4,8,12,16,28,31");
                     }
-                    if (abl == 1) hipLaunchKernelGGL((k_uppass_halo<true, 2, 8, false, false, 1>), dim3(grid), dim3(1024), lds, s->stream, U);
-                    else if (abl == 2) hipLaunchKernelGGL((k_uppass_halo<true, 2, 8, false, false, 2>), dim3(grid), dim3(1024), lds, s->stream, U);
-                    else hipLaunchKernelGGL((k_uppass_halo<true, 2, 8, false, false, 3>), dim3(grid), dim3(1024), lds, s->stream, U);
+#undef HALO_ABL
                 } else
                 if (U.halocap <= 8 * 1024) { if (direct) HALO_Q(true, 8); else HALO_Q(false, 8); }
                 else { if (direct) HALO_Q(true, 12); else HALO_Q(false, 12); }

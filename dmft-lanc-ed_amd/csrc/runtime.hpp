@@ -215,6 +215,7 @@ struct edgpu_sector_s {
     // when off); the Lanczos loops then run on pitched vectors, a caller's dense vectors go through csr_xs / csr_ys
     int axpy_nb = 512;      // workgroups of the axpy+norm pass of the three-pass iteration
     int64_t csr_ld = 0; DevBuf<double> csr_xs, csr_ys;
+    DevBuf<double> crow_tab;      // DIRECT, rows beyond LDS: k_crow_table
     bool csr_tm = false; DevBuf<int64_t> csrD_cpre, csrO_cpre; std::vector<int32_t> h_cntD, h_cntO;      // tile-major order of the dw-type blocks
     // needed-rows exchange: the dw block is stored as two blocks, hops into the rank's own rows (runs while the exchange
     // is in flight) and hops into received rows (csrD_*: runs after it)
