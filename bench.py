@@ -345,6 +345,12 @@ def main():
         out["exchange_model_ms"] = {"busiest_pair_at_77GBps": bp / 77e9 * 1e3, "busiest_pair_at_60GBps": bp / 60e9 * 1e3,
                                     "perfectly_balanced_over_%d_links_at_77GBps" % max(world - 1, 1): float(mat.sum(0).max()) / max(world - 1, 1) / 77e9 * 1e3,
                                     "measured_exchange_ms_on_comm_stream": comm_ms, "note": "model, not a measurement; ranks sharing one GPU exchange through device copies"}
+        if xmode == "needed-rows":      # what the opt-in relay routing (EDGPU_RELAY=1, two phases through idle peers) does or would do to the busiest link
+            ri = G.relay_info()
+            rowb = float(G.DimUp) * 8.0
+            out["exchange_model_ms"]["relay_routing"] = {"enabled": ri["enabled"], "relayed_chunks": ri["chunks"],
+                                                         "busiest_link_MB": round(ri["busiest_after"] * rowb / 1e6, 2),
+                                                         "busiest_link_at_77GBps": ri["busiest_after"] * rowb / 77e9 * 1e3}
     # HBM traffic from the counter passes committed under profiles/: only while it was measured on THIS code
     pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(pmc):

@@ -1180,6 +1180,19 @@ int edgpu_sector_exchange_info(edgpu_handle h, int32_t *mode, int64_t *send_byte
     }
     return EDGPU_OK;
 }
+int edgpu_sector_relay_info(edgpu_handle h, int32_t *enabled, int32_t *nchunks, int64_t *busiest_before, int64_t *busiest_after, int64_t *rows_direct, int64_t *rows_routed)
+{
+    if (!h) return fail(EDGPU_EINVAL, "edgpu_sector_relay_info: null handle");
+    const size_t PP = (size_t)h->comm.size * h->comm.size;
+    if (enabled) *enabled = h->relay_on ? 1 : 0;
+    if (nchunks) *nchunks = h->relay_on ? h->relay_chunks : 0;
+    int64_t mx = 0; for (int64_t v : h->xch_rows) mx = std::max(mx, v);
+    if (busiest_before) *busiest_before = mx;
+    if (busiest_after) *busiest_after = h->relay_on ? h->relay_after : mx;
+    if (rows_direct) for (size_t i = 0; i < PP; i++) rows_direct[i] = i < h->xch_rows.size() ? h->xch_rows[i] : 0;
+    if (rows_routed) for (size_t i = 0; i < PP; i++) rows_routed[i] = h->relay_on ? h->relay_link_rows[i] : (i < h->xch_rows.size() ? h->xch_rows[i] : 0);
+    return EDGPU_OK;
+}
 int edgpu_comm_init_callbacks(edgpu_handle h, edgpu_allgatherv_fn ag, edgpu_exchange_fn xch, edgpu_allreduce_fn ar, void *ctx)
 {
     if (!h || !ag || !xch || !ar) return fail(EDGPU_EINVAL, "edgpu_comm_init_callbacks: null argument");

@@ -60,6 +60,49 @@ static int halo_exchange(S *s, const double *v_local, hipStream_t st)
         hipLaunchKernelGGL(k_pack_rows, dim3((unsigned)std::min<int64_t>(cdiv(tot, 256), 65536)), dim3(256), 0, st, K);
         HIPCHK(hipGetLastError());
     }
+    if (s->relay_on) {      // two-phase relay routing (relay_plan, sector_dev.hpp); DimPh == 1
+        double *x = s->vfull.p, *xr = x + H.Qdw * rowlen, *stg = s->relay_stage.p; const double *sb = s->sendbuf.p;
+        if (!s->csr_three) HIPCHK(hipMemcpyAsync(x, v_local, (size_t)s->nloc_el * 8, hipMemcpyDeviceToDevice, st));
+        for (int phase = 1; phase <= 2; phase++) {
+            // per peer: the direct piece and the relayed piece of this phase, each with the buffer it leaves from / lands in
+            auto pieces = [&](int b, const S::RelayPiece *&sd, const S::RelayPiece *&sr, const S::RelayPiece *&rd, const S::RelayPiece *&rr) {
+                const S::RelayPeer &Q = s->relay[b];
+                if (phase == 1) { sd = &Q.s1d; sr = &Q.s1r; rd = &Q.r1d; rr = &Q.r1r; } else { sd = &Q.s2d; sr = &Q.s2f; rd = &Q.r2d; rr = &Q.r2f; }
+            };
+            const double *srsrc = phase == 1 ? sb : stg;      // relayed rows leave from my send buffer (phase 1) or from what I hold (phase 2)
+            double *rrdst = phase == 1 ? stg : xr;            // and land in the holding buffer (phase 1) or in the x-space (phase 2)
+            if (c.kind == Comm::RCCL) {
+                int rc = g_rccl.GroupStart();
+                for (int b = 0; b < P && rc == 0; b++) {
+                    if (b == c.rank) continue;
+                    const S::RelayPiece *sd, *sr, *rd, *rr; pieces(b, sd, sr, rd, rr);
+                    // same order on both sides of a link: direct piece first, relayed piece second
+                    if (sd->cnt) rc = g_rccl.Send(sb + sd->off * rowlen, (size_t)(sd->cnt * rowlen), kNcclDouble, b, c.nccl, st);
+                    if (rc == 0 && sr->cnt) rc = g_rccl.Send(srsrc + sr->off * rowlen, (size_t)(sr->cnt * rowlen), kNcclDouble, b, c.nccl, st);
+                    if (rc == 0 && rd->cnt) rc = g_rccl.Recv(xr + rd->off * rowlen, (size_t)(rd->cnt * rowlen), kNcclDouble, b, c.nccl, st);
+                    if (rc == 0 && rr->cnt) rc = g_rccl.Recv(rrdst + rr->off * rowlen, (size_t)(rr->cnt * rowlen), kNcclDouble, b, c.nccl, st);
+                }
+                int rc2 = g_rccl.GroupEnd();
+                if (rc || rc2) return fail(EDGPU_ECOMM, std::string("edgpu: RCCL send/recv failed: ") + g_rccl.GetErrorString(rc ? rc : rc2));
+            } else if (c.kind == Comm::CALLBACK) {
+                if (!c.xch) return fail(EDGPU_ECOMM, "edgpu: the callback exchange needs an all-to-all-v callback");
+                std::vector<int64_t> sc(P, 0), sd_(P, 0), rcv(P, 0), rd_(P, 0);
+                HIPCHK(hipStreamSynchronize(st));
+                for (int kind = 0; kind < 2; kind++) {      // one all-to-all-v per kind of piece (a callback moves one piece per peer)
+                    for (int b = 0; b < P; b++) {
+                        sc[b] = sd_[b] = rcv[b] = rd_[b] = 0;
+                        if (b == c.rank) continue;
+                        const S::RelayPiece *sd, *sr, *rd, *rr; pieces(b, sd, sr, rd, rr);
+                        const S::RelayPiece *ps = kind ? sr : sd, *pr = kind ? rr : rd;
+                        sc[b] = ps->cnt * rowlen; sd_[b] = ps->off * rowlen; rcv[b] = pr->cnt * rowlen; rd_[b] = pr->off * rowlen;
+                    }
+                    if (c.xch(c.ctx, kind ? srsrc : sb, sc.data(), sd_.data(), kind ? rrdst : xr, rcv.data(), rd_.data(), P)) return fail(EDGPU_ECOMM, "edgpu: exchange callback failed");
+                }
+            } else
+                return fail(EDGPU_ECOMM, "edgpu: mpi_size>1 but no communicator attached (edgpu_comm_init_*)");
+        }
+        return EDGPU_OK;
+    }
     for (int iph = 0; iph < H.DimPh; iph++) {
         double *x = s->vfull.p + (int64_t)iph * s->nhalo * rowlen;
         // own rows of the x-space: not needed by the three-block CSR (its received-row block never reads them)

@@ -233,6 +233,12 @@ struct edgpu_sector_s {
     std::vector<int64_t> send_rows_cnt, recv_rows_cnt, send_rows_off, recv_rows_off;
     DevBuf<int32_t> send_list, dw_ellc_x, dw_cols_x, xmap_dev; DevBuf<double> sendbuf;
     hipEvent_t ev_pack = nullptr;
+    // Relay routing of that exchange (opt-in, EDGPU_RELAY=1, >= 3 ranks): the rows of a heavy pair travel partly through a third
+    // rank in two phases (relay_plan, exchange.hpp).  xch_rows[s*P+d]: rows rank s sends to rank d per product, on every rank.
+    struct RelayPiece { int64_t off = 0, cnt = 0; };       // rows: offset in the buffer it is read from / written to, and count
+    struct RelayPeer { RelayPiece s1d, s1r, r1d, r1r, s2d, s2f, r2d, r2f; };   // s/r: send/receive, 1/2: phase, d: direct rows, r: rows handed to a relay, f: forwarded rows
+    std::vector<int64_t> xch_rows, relay_link_rows;        // relay_link_rows[a*P+b]: rows on link a->b, both phases, under the plan
+    std::vector<RelayPeer> relay; bool relay_on = false; int relay_chunks = 0; int64_t relay_before = 0, relay_after = 0; DevBuf<double> relay_stage;
     std::vector<std::unique_ptr<DevBuf<double>>> eigV; DevBuf<double> eig_h, eig_y, eig_partial;
     DevBuf<double> vfull, tmp_in, tmp_out, lz[5], scal, alphas, betas, zvec, partial, partial2;
     int64_t nloc = 0, nloc_el = 0, vecdim = 0;

@@ -145,6 +145,77 @@ static int build_up_segments(S *s)
 // word moved to another orbital, stored/H_non_local.f90:21-83).  H_dw is small and known to every rank, so the lists are
 // computed locally on both sides (no set-up communication).  At Ns=16 this is 53 % / 36 % / 24 %
 // of the all-gather volume at 2 / 4 / 8 ranks.
+// Relay routing of the needed-rows exchange (opt-in).  The partner blocks of a dw block are its hypercube neighbours, so a few
+// of a rank's links carry most of what it receives while the others idle (Ns=18 on 8 ranks: 3 548 of 10 181 rows from one peer).
+// Two phases: in phase 1 every pair sends half of its direct rows, and the heavy pairs hand a chunk of theirs to a third rank;
+// in phase 2 the other half travels and the relays forward what they hold.  At most one relayed chunk per directed link and
+// phase; greedy: take the pair with the largest load, give it the relay that lowers it most, until nothing improves.  Every rank
+// runs the same integer plan on the same matrix.  Row order of pair (s -> d) in s's send buffer and in d's x-space:
+// [phase-1 direct | phase-2 direct | chunk 1 | chunk 2 ...].  Model: scripts/relay_model.py (busiest link 3 548 -> 2 622 rows
+// at Ns=18 x 8, 954 -> 662 at Ns=16 x 8).  Unmeasured on xGMI, like the rest of the multi-rank code.
+static int relay_plan(S *s)
+{
+    const int P = s->comm.size, me = s->comm.rank;
+    const std::vector<int64_t> &M = s->xch_rows;
+    auto at = [P](std::vector<int64_t> &v, int a, int b) -> int64_t & { return v[(size_t)a * P + b]; };
+    std::vector<int64_t> dirn = M, rel1((size_t)P * P, 0), rel2((size_t)P * P, 0);
+    std::vector<char> used1((size_t)P * P, 0), used2((size_t)P * P, 0);
+    struct Chunk { int s, d, r; int64_t cnt; };
+    std::vector<Chunk> chunks;
+    auto d1 = [&](int a, int b) { return (dirn[(size_t)a * P + b] + 1) / 2; };
+    auto d2 = [&](int a, int b) { return dirn[(size_t)a * P + b] - d1(a, b); };
+    auto L1 = [&](int a, int b) { return d1(a, b) + rel1[(size_t)a * P + b]; };
+    auto L2 = [&](int a, int b) { return d2(a, b) + rel2[(size_t)a * P + b]; };
+    auto total = [&]() { int64_t m1 = 0, m2 = 0; for (int a = 0; a < P; a++) for (int b = 0; b < P; b++) { m1 = std::max(m1, L1(a, b)); m2 = std::max(m2, L2(a, b)); } return m1 + m2; };
+    s->relay_before = 0; for (int64_t v : M) s->relay_before = std::max(s->relay_before, v);
+    for (int it = 0; it < 4 * P * P; it++) {
+        int bs = -1, bd = -1; int64_t Ld = 0;
+        for (int a = 0; a < P; a++) for (int b = 0; b < P; b++) { const int64_t l = std::max(L1(a, b), L2(a, b)); if (at(dirn, a, b) > 0 && l > Ld) { Ld = l; bs = a; bd = b; } }
+        if (bs < 0) break;
+        int br = -1; int64_t bdelta = 0;
+        for (int r = 0; r < P; r++) {
+            if (r == bs || r == bd || used1[(size_t)bs * P + r] || used2[(size_t)r * P + bd]) continue;
+            const int64_t base = std::max(L1(bs, r), L2(r, bd));
+            int64_t delta = (Ld - base) * 2 / 3;
+            delta = std::min(delta, at(dirn, bs, bd));
+            if (delta >= 1 && delta > bdelta) { bdelta = delta; br = r; }
+        }
+        if (br < 0) break;
+        const int64_t before = total();
+        at(dirn, bs, bd) -= bdelta; at(rel1, bs, br) += bdelta; at(rel2, br, bd) += bdelta;
+        if (total() > before) { at(dirn, bs, bd) += bdelta; at(rel1, bs, br) -= bdelta; at(rel2, br, bd) -= bdelta; break; }      // no longer an improvement
+        used1[(size_t)bs * P + br] = 1; used2[(size_t)br * P + bd] = 1;
+        chunks.push_back({bs, bd, br, bdelta});
+    }
+    s->relay_after = total(); s->relay_chunks = (int)chunks.size();
+    s->relay_link_rows.assign((size_t)P * P, 0);
+    for (int a = 0; a < P; a++) for (int b = 0; b < P; b++) s->relay_link_rows[(size_t)a * P + b] = L1(a, b) + L2(a, b);
+    // this rank's pieces
+    s->relay.assign((size_t)P, S::RelayPeer{});
+    for (int b = 0; b < P; b++) {
+        if (b == me) continue;
+        S::RelayPeer &Q = s->relay[b];
+        Q.s1d = {s->send_rows_off[b], d1(me, b)}; Q.s2d = {s->send_rows_off[b] + d1(me, b), d2(me, b)};
+        Q.r1d = {s->recv_rows_off[b], d1(b, me)}; Q.r2d = {s->recv_rows_off[b] + d1(b, me), d2(b, me)};
+    }
+    std::vector<int64_t> coff((size_t)P * P, 0);      // rows of pair (s,d) placed so far behind its direct rows
+    int64_t stage = 0;
+    for (const Chunk &c : chunks) {
+        const int64_t off = at(dirn, c.s, c.d) + at(coff, c.s, c.d);
+        at(coff, c.s, c.d) += c.cnt;
+        if (c.s == me) s->relay[c.r].s1r = {s->send_rows_off[c.d] + off, c.cnt};               // hand to the relay, from my send block for d
+        if (c.r == me) { s->relay[c.s].r1r = {stage, c.cnt}; s->relay[c.d].s2f = {stage, c.cnt}; stage += c.cnt; }      // hold, then forward
+        if (c.d == me) s->relay[c.r].r2f = {s->recv_rows_off[c.s] + off, c.cnt};               // lands behind the direct rows of s
+    }
+    CHK(s->relay_stage.alloc((size_t)std::max<int64_t>(stage, 1) * s->H.DimUp));
+    s->relay_on = true;
+    if ((s->dbg & 8) && me == 0) {
+        fprintf(stderr, "edgpu: relay routing on %d ranks: busiest link %lld rows -> %lld (two phases), %d relayed chunks\n", P, (long long)s->relay_before, (long long)s->relay_after, s->relay_chunks);
+        for (int a = 0; a < P; a++) { fprintf(stderr, "  rows %d ->:", a); for (int b = 0; b < P; b++) fprintf(stderr, " %lld/%lld", (long long)M[(size_t)a * P + b], (long long)s->relay_link_rows[(size_t)a * P + b]); fprintf(stderr, "\n"); }
+    }
+    return EDGPU_OK;
+}
+
 static int setup_halo(S *s)
 {
     const SectorHost &H = s->H; const Factor &dw = *s->hdw;
@@ -169,12 +240,15 @@ static int setup_halo(S *s)
         };
         for (int64_t i = H.dw0; i < H.dw0 + H.Qdw; i++) mark_row(i);
         for (int64_t j = 0; j < H.DimDw; j++) if (mark[j] && owner[j] != me) recv_rows[owner[j]].push_back((int32_t)j);
-        // what rank r needs from me: rows j of mine that some row i of r couples to
+        // what rank r needs from me: rows j of mine that some row i of r couples to; and, for the routing of the exchange, how
+        // many rows every rank needs from every other one (xch_rows[s*P+d], the same on all ranks)
+        s->xch_rows.assign((size_t)P * P, 0);
         for (int r = 0; r < P; r++) {
-            if (r == me) continue;
             int64_t d0, qd; range_of(r, d0, qd);
             std::fill(mark.begin(), mark.end(), 0);
             for (int64_t i = d0; i < d0 + qd; i++) mark_row(i);
+            for (int64_t j = 0; j < H.DimDw; j++) if (mark[j] && owner[j] != r) s->xch_rows[(size_t)owner[j] * P + r]++;
+            if (r == me) continue;
             for (int64_t j = H.dw0; j < H.dw0 + H.Qdw; j++) if (mark[j]) send_rows[r].push_back((int32_t)(j - H.dw0));
         }
     }
@@ -204,6 +278,7 @@ static int setup_halo(S *s)
     if (H.Jhflag) CHK(s->xmap_dev.upload(xmap));      // the non-local pass finds its partner rows through this
     HIPCHK(hipEventCreateWithFlags(&s->ev_pack, hipEventDisableTiming));
     s->halo = true;
+    if (P >= 3 && H.DimPh == 1 && dbg_int("EDGPU_RELAY", 0) != 0) CHK(relay_plan(s));
     return EDGPU_OK;
 }
 

@@ -25,7 +25,7 @@ SYMBOLS = [
     "edgpu_sp_init_matrix", "edgpu_sp_init_matrix_mpi", "edgpu_sp_load_matrix", "edgpu_sp_insert_element", "edgpu_sp_delete_matrix", "edgpu_sp_dump_matrix", "edgpu_sp_row", "edgpu_sp_matvec", "edgpu_sp_matvec_device",
     "edgpu_comm_unique_id", "edgpu_comm_init_rccl", "edgpu_comm_init_callbacks",
     "edgpu_comm_create_rccl", "edgpu_comm_create_callbacks", "edgpu_comm_sub", "edgpu_comm_destroy", "edgpu_sector_attach_comm",
-    "edgpu_comm_count", "edgpu_comm_allreduce_sum", "edgpu_sector_exchange_info",
+    "edgpu_comm_count", "edgpu_comm_allreduce_sum", "edgpu_sector_exchange_info", "edgpu_sector_relay_info",
     "edgpu_device_count", "edgpu_malloc", "edgpu_free", "edgpu_memcpy_h2d", "edgpu_memcpy_d2h", "edgpu_memset",
     "edgpu_device_synchronize", "edgpu_last_error", "edgpu_abi_version",
 ]
@@ -183,6 +183,7 @@ def lib():
         "edgpu_comm_count": (C.c_int, [P(i32)]),
         "edgpu_comm_allreduce_sum": (C.c_int, [vp, vp, i32]),
         "edgpu_sector_exchange_info": (C.c_int, [vp, P(i32), vp, vp]),
+        "edgpu_sector_relay_info": (C.c_int, [vp, P(i32), P(i32), P(i64), P(i64), vp, vp]),
         "edgpu_device_count": (C.c_int, [P(i32)]),
         "edgpu_malloc": (C.c_int, [P(vp), C.c_size_t]),
         "edgpu_free": (C.c_int, [vp]),

@@ -362,6 +362,14 @@ class HvSector:
         check(capi.lib().edgpu_sector_exchange_info(self._h, C.byref(mode), sb.ctypes.data, rb.ctypes.data))
         return ("none", "needed-rows", "all-gather", "transpose")[mode.value], sb, rb
 
+    def relay_info(self):
+        """Routing of the needed-rows exchange: dict(enabled, chunks, busiest_before, busiest_after, rows_direct[P,P], rows_routed[P,P])."""
+        P = int(self._desc.mpi_size)
+        en = C.c_int32(); nc = C.c_int32(); b0 = C.c_int64(); b1 = C.c_int64()
+        rd = np.zeros((P, P), np.int64); rr = np.zeros((P, P), np.int64)
+        check(capi.lib().edgpu_sector_relay_info(self._h, C.byref(en), C.byref(nc), C.byref(b0), C.byref(b1), rd.ctypes.data, rr.ctypes.data))
+        return dict(enabled=bool(en.value), chunks=nc.value, busiest_before=b0.value, busiest_after=b1.value, rows_direct=rd, rows_routed=rr)
+
     def comm_init_rccl(self, uid_bytes):
         buf = C.create_string_buffer(bytes(uid_bytes), 128)
         check(capi.lib().edgpu_comm_init_rccl(self._h, buf))

@@ -272,6 +272,12 @@ int edgpu_comm_allreduce_sum(edgpu_comm c, double *buf_host, int32_t n);
 /* what one product of this sector exchanges: mode 0 none, 1 needed dw rows (send/recv pairs), 2 all-gather, 3 distributed
  * transpose; send_bytes/recv_bytes (mpi_size entries each, may be NULL): bytes to / from every peer per product */
 int edgpu_sector_exchange_info(edgpu_handle h, int32_t *mode, int64_t *send_bytes, int64_t *recv_bytes);
+/* Routing of the needed-rows exchange (mode 1).  rows_direct[s*P+d]: dw rows rank s sends to rank d per product (the same
+   matrix on every rank, derived from H_dw).  With EDGPU_RELAY=1 at sector creation (>= 3 ranks) the heavy pairs hand part of
+   their rows to a third rank in a two-phase schedule: enabled, number of relayed chunks, rows on the busiest directed link
+   before (one phase) and after (phase 1 + phase 2), rows_routed[a*P+b] = rows on link a->b under the plan.  Any output pointer
+   may be NULL.  Replaces nothing in the reference (its exchange is MPI_AllGatherV, ED_SETUP.f90:689-733). */
+int edgpu_sector_relay_info(edgpu_handle h, int32_t *enabled, int32_t *nchunks, int64_t *busiest_before, int64_t *busiest_after, int64_t *rows_direct, int64_t *rows_routed);
 
 /* ---- sparse-matrix container (ED_SPARSE_MATRIX.f90): same semantics, product on the GPU ------------------
  * sp_init_matrix (127-172), sp_insert_element = duplicate-summing append in storage order (255-323),

@@ -255,6 +255,10 @@ def main():
             res["e0_" + st] = e0
             a, b, used = G.sp_lanc_tridiag(v0, 20)
             res["a_" + st] = a.tolist(); res["b_" + st] = b.tolist()
+            if os.environ.get("EDGPU_RELAY"):
+                ri = G.relay_info()
+                res["relay_" + st] = dict(enabled=ri["enabled"], chunks=ri["chunks"], before=ri["busiest_before"], after=ri["busiest_after"],
+                                          direct=ri["rows_direct"].tolist(), routed=ri["rows_routed"].tolist(), mode=G.exchange_info()[0])
             if 8 < S.Dim <= 500 and st == "kron":      # the multi-eigenpair solvers on the sharded operator (small cases: the staged host exchange is slow)
                 wd = np.linalg.eigvalsh(S.hmat())[:2]
                 evd, _, info = G.sp_dvdson_eigh(2, nitermax=400, tol=1e-11)

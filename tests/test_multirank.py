@@ -132,6 +132,43 @@ def test_multirank_distributed_transpose(edgpu_mod, case, size, env):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("case,size,env", [("c_nb7_half", 3, {}), ("c_nb7_half", 4, {}), ("nb5_offhalf_2_4", 4, {"EDGPU_KRON_SPLIT": "1", "EDGPU_CSR_SPLIT": "1"}),
+                                           ("norb2_normal_JxJp", 3, {}), ("nb6_even", 5, {})])
+def test_multirank_relay_routing(edgpu_mod, case, size, env):
+    """EDGPU_RELAY=1: the needed-rows exchange in two phases with the heavy pairs handing part of their rows to a third rank
+    (relay_plan).  The x-space a rank ends up with is the same, so everything downstream is: dense ground-state energy, the
+    single-rank Lanczos coefficients; the plan is the same on every rank, moves every row (those that are relayed over two
+    links) and never loads the busiest link more than the plain exchange does."""
+    import cases
+    from oracle import oracle
+    res = _launch("gpu", case, size, extra_env=dict({"EDGPU_RELAY": "1"}, **env))
+    name, m, nu, nd = [z for z in cases.zoo() if z[0] == case][0]
+    S = oracle.Sector(m, nu, nd)
+    e_dense = np.linalg.eigvalsh(S.hmat())[0]
+    G = edgpu_mod.HvSector(m, nu, nd)
+    a1, b1, _ = G.sp_lanc_tridiag(np.random.RandomState(5).uniform(0, 1, S.Dim), 20)
+    G.close()
+    for r in res:
+        for k, v in r.items():
+            if k.startswith("e0_"):
+                assert abs(v - e_dense) < 1e-10, (k, v, e_dense)
+            if k.startswith("a_"):
+                np.testing.assert_allclose(v, a1, rtol=1e-9, atol=1e-9)
+            if k.startswith("b_"):
+                np.testing.assert_allclose(v, b1, rtol=1e-9, atol=1e-9)
+    for st in ("kron", "direct", "csr"):
+        infos = [r["relay_" + st] for r in res]
+        assert all(i == infos[0] for i in infos)                       # one plan, derived independently on every rank
+        i0 = infos[0]
+        assert i0["mode"] == "needed-rows" and i0["enabled"]
+        D, R = np.array(i0["direct"]), np.array(i0["routed"])
+        assert i0["before"] == D.max() and i0["after"] <= i0["before"]
+        assert R.sum() >= D.sum() and (R.sum() > D.sum()) == (i0["chunks"] > 0)
+        assert (np.diag(R) == 0).all()
+        print(case, size, st, "busiest link", i0["before"], "->", i0["after"], "rows,", i0["chunks"], "chunks")
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("case,size", [("c_nb5_half", 2), ("norb2_normal_JxJp", 3), ("orbs_norb2_nb3", 2), ("phonons_nb3_nph3", 2), ("phonons_orbs", 2)])
 def test_multirank_legs_observables_twin(edgpu_mod, case, size):
     """GF / chi / phonon legs, impurity histogram + density matrix and the twin-sector hand-off with the
