@@ -458,6 +458,7 @@ __global__ void __launch_bounds__(NT) k_uppass2_ax(UpAxArgs A)
         return u;
     };
     dbl2v xu[MAXQ];                                      // u of the row that enters LDS next
+    const int pmax = npair > 0 ? npair - 1 : 0;
     int64_t row = blockIdx.x;
     if (row < A.nrows) {
 #pragma unroll
@@ -474,23 +475,29 @@ __global__ void __launch_bounds__(NT) k_uppass2_ax(UpAxArgs A)
     while (row < A.nrows) {
         const int64_t idwl = row % A.Qdw, idw = A.dw0 + idwl;
         const int64_t next = row + gridDim.x; const bool more = next < A.nrows;
+        // No branch around an operand load (lanes beyond the row load a clamped pair, the last row loads itself again): a wait for
+        // an older load can only carry the smallest count over all paths, and one path that skips the prefetch makes every such
+        // wait vmcnt(0) (see k_uppass_halo).
+        const int64_t nrow = more ? next : row;
         auto load_ops = [&](int p, Ops &o) {
+            p = p < npair ? p : pmax;
             if (!DIRECT) o.d = *reinterpret_cast<const dbl2v *>(A.diag + idwl * DimUp + 2 * p);
             else o.d = *reinterpret_cast<const dbl2v *>(A.Eup + 2 * p);
             o.w0 = A.packed[3 * p]; o.w1 = A.packed[3 * p + 1]; o.w2 = A.packed[3 * p + 2];
-            if (more) { o.nr = *reinterpret_cast<const dbl2v *>(A.r + next * ld + 2 * p); o.nv = *reinterpret_cast<const dbl2v *>(A.vprev + next * ld + 2 * p); }
+            o.nr = *reinterpret_cast<const dbl2v *>(A.r + nrow * ld + 2 * p); o.nv = *reinterpret_cast<const dbl2v *>(A.vprev + nrow * ld + 2 * p);
         };
         Ops cur, nxt;
-        if (tid < npair) load_ops(tid, cur);
+        load_ops(tid, cur);
 #pragma unroll
         for (int q = 0; q < MAXQ; q++) { const int p = tid + q * NT; if (q < nq && p < npair) *reinterpret_cast<dbl2v *>(lds + 2 * p) = xu[q]; }
         if (DIRECT && tid < A.nI) crow[tid] = A.Edw[idw] + A.econst + A.cross[tid * A.nI + ((uint32_t)A.mapdw[idw] & A.impmask)];
         __syncthreads();
 #pragma unroll
         for (int q = 0; q < MAXQ; q++) {
+            if (q >= nq) break;
             const int p = tid + q * NT;
-            if (q < nq && p < npair) {
-                if (p + NT < npair) load_ops(p + NT, nxt);
+            load_ops(p + NT, nxt);
+            if (p < npair) {
                 if (more) xu[q] = combine(next, p, cur.nr, cur.nv);      // xu[q] of THIS row is in LDS already
                 const dbl2v x = *reinterpret_cast<const dbl2v *>(lds + 2 * p);
                 dbl2v dval;
@@ -512,8 +519,8 @@ __global__ void __launch_bounds__(NT) k_uppass2_ax(UpAxArgs A)
                 }
                 dbl2v o; o.x = a0; o.y = a1;
                 *reinterpret_cast<dbl2v *>(A.t_out + row * ld + 2 * p) = o;
-                cur = nxt;
             }
+            cur = nxt;
         }
         __syncthreads();
         row = next;
