@@ -2463,6 +2463,63 @@ __global__ void __launch_bounds__(256) k_basis_rotate(RotArgsT<MAXB> R, int64_t 
         }
     }
 }
+// Rotation of a large basis on the matrix cores: V_j <- sum_i V_i Y[i + nv*j] is a tall-skinny GEMM (n x nv times nv x nout,
+// n ~ 1e8), in place.  v_mfma_f64_16x16x4_f64 with rows = 16 outputs, columns = 16 consecutive elements, k = 4 inputs:
+//   A lane l = Y(input 4ks + (l>>4), output 16ot + (l&15))   -- staged in LDS once per workgroup, fragment-major (64 consecutive
+//                                                                doubles per (ot, ks): conflict-free 512-byte reads)
+//   B lane l = V[4ks + (l>>4)][e0 + (l&15)]                   -- one 8-byte load per lane and k-step, 128-byte segments
+//   D lane l, register r = output 16ot + (l>>4) + 4r, element e0 + (l&15)
+// A wave owns a 16-element tile: it reads all nv inputs of the tile (KU k-steps of loads in flight), keeps the OT output tiles
+// in 8*OT accumulator registers and only then writes, so the rotation can overwrite its own inputs.  The one-element kernels
+// above hold the whole basis of an element in registers (200 VGPRs at 96 vectors: 212 ms per rotation of 80 -> 40 vectors at
+// Ns=16, 7x the time the 160 GB take); this one needs 8*OT + 2*KU registers whatever the basis size.  No branch around a load:
+// k-steps and pointers are padded (zero coefficients, a valid address), elements beyond n load the last one.
+typedef double dbl4_t __attribute__((ext_vector_type(4)));
+struct RotMfmaArgs { double *V[kMaxBasisBig + 8]; int32_t nv, nout, nks; const double *Y; };      // nks: k-steps, padded to a multiple of KU
+template <int OT, int KU>
+__global__ void __launch_bounds__(256) k_basis_rotate_mfma(RotMfmaArgs R, int64_t n)
+{
+    extern __shared__ double ysh[];     // [OT][nks][64] coefficient fragments, then the pointer table (4*nks entries)
+    const int nks = R.nks, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    double **vp = reinterpret_cast<double **>(ysh + (size_t)OT * nks * 64);
+    for (int t = threadIdx.x; t < OT * nks * 64; t += blockDim.x) {
+        const int l = t & 63, ks = (t >> 6) % nks, ot = (t >> 6) / nks;
+        const int i = 4 * ks + (l >> 4), j = 16 * ot + (l & 15);
+        ysh[t] = (i < R.nv && j < R.nout) ? R.Y[i + R.nv * j] : 0.0;
+    }
+    for (int t = threadIdx.x; t < 4 * nks; t += blockDim.x) vp[t] = R.V[t < R.nv ? t : 0];
+    __syncthreads();
+    const int64_t ntiles = (n + 15) >> 4, nw = (int64_t)gridDim.x * 4;
+    const int64_t per = (ntiles + nw - 1) / nw, w = (int64_t)blockIdx.x * 4 + wave;      // each wave walks one contiguous piece
+    const int64_t t1 = (w + 1) * per < ntiles ? (w + 1) * per : ntiles;
+    for (int64_t tile = w * per; tile < t1; tile++) {
+        const int64_t e = tile * 16 + (lane & 15), ec = e < n ? e : n - 1;
+        dbl4_t acc[OT];
+#pragma unroll
+        for (int ot = 0; ot < OT; ot++) acc[ot] = dbl4_t{0.0, 0.0, 0.0, 0.0};
+        for (int ks0 = 0; ks0 < nks; ks0 += KU) {
+            double x[KU];
+#pragma unroll
+            for (int u = 0; u < KU; u++) x[u] = vp[4 * (ks0 + u) + (lane >> 4)][ec];
+#pragma unroll
+            for (int u = 0; u < KU; u++) {
+#pragma unroll
+                for (int ot = 0; ot < OT; ot++)
+                    acc[ot] = __builtin_amdgcn_mfma_f64_16x16x4f64(ysh[((size_t)ot * nks + ks0 + u) * 64 + lane], x[u], acc[ot], 0, 0, 0);
+            }
+        }
+        if (e < n) {
+#pragma unroll
+            for (int ot = 0; ot < OT; ot++) {
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const int j = 16 * ot + (lane >> 4) + 4 * r;
+                    if (j < R.nout) vp[j][e] = acc[ot][r];      // nout <= nv: the table holds that pointer
+                }
+            }
+        }
+    }
+}
 // y = a*x
 // Davidson step (dvdson() in lanczos.hpp): residual of the Ritz pair (theta, V y) and the diagonally preconditioned
 // correction in one pass over the two bases:

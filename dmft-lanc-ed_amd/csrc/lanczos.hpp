@@ -425,6 +425,26 @@ static int lanczos_tridiag(S *s, const double *vin_dev, int nlanc, double thresh
     return EDGPU_OK;
 }
 
+// in-place rotation of a basis of up to 96 vectors on the matrix cores (k_basis_rotate_mfma)
+static inline int launch_basis_rotate_mfma(hipStream_t st, int device, double *const *V, int nv, int nout, const double *Ydev, int64_t n)
+{
+    constexpr int KU = 8;
+    RotMfmaArgs R{}; R.nv = nv; R.nout = nout; R.Y = Ydev; R.nks = (int)(cdiv(cdiv(nv, 4), KU) * KU);
+    for (int i = 0; i < kMaxBasisBig + 8; i++) R.V[i] = V[i < nv ? i : 0];
+    const int ot = (int)cdiv(nout, 16);
+    const size_t lds = (size_t)ot * R.nks * 64 * 8 + (size_t)4 * R.nks * 8;
+    const int64_t ntiles = cdiv(n, 16);
+    const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(cdiv(ntiles, 4 * 8), 1024));
+#define ROT_(O_)                                                                                                                \
+    case O_: {                                                                                                                      \
+        static OncePerDevice once_;                                                                                                 \
+        if (once_.first(device)) (void)hipFuncSetAttribute((const void *)k_basis_rotate_mfma<O_, KU>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024); \
+        hipLaunchKernelGGL((k_basis_rotate_mfma<O_, KU>), dim3(grid), dim3(256), lds, st, R, n);                                    \
+    } break
+    switch (ot) { ROT_(1); ROT_(2); ROT_(3); ROT_(4); ROT_(5); ROT_(6); default: return EDGPU_EINVAL; }
+#undef ROT_
+    return EDGPU_OK;
+}
 // Orthogonalise w against the first nv vectors of a basis by classical Gram-Schmidt in at most two passes.
 // A single pass against a basis that is orthonormal to delta leaves w orthogonal only to about delta*|w|/|w'|, so the
 // error is multiplied by |w|/|w'| at every step: harmless when that ratio is ~1, exponentially unstable when it is
@@ -584,7 +604,11 @@ static int eigsh_pro(S *s, int nev, int ncv, int maxiter, double tol, double *ev
         HIPCHK(hipStreamSynchronize(s->stream));      // Yc may be a temporary of the caller
         const int g2 = (int)std::max<int64_t>(1, std::min<int64_t>(cdiv(vlen, 256 * 2 * 16), 2048));
         const int rot2 = dbg_int("EDGPU_ROT2", 1);
-        if (nv <= 20 && rot2) { RotArgs2<5> R{}; R.nv = nv; R.nout = nout; R.Y = s->eig_y.p; for (int i = 0; i < nv; i++) R.V[i] = B(i);
+        const bool rot_mfma = dbg_int("EDGPU_ROT_MFMA", 1) != 0;      // 0: the one- and two-element kernels that hold the basis of an element in registers
+        if (rot_mfma) {      // tall-skinny GEMM on the matrix cores, any basis size (Ns=16: 80 -> 40 vectors 212 ms -> ~35 ms, 20 -> 2 slightly faster as well)
+            std::vector<double *> vb((size_t)nv); for (int i = 0; i < nv; i++) vb[i] = B(i);
+            CHK(launch_basis_rotate_mfma(s->stream, s->device, vb.data(), nv, nout, s->eig_y.p, vlen)); }
+        else if (nv <= 20 && rot2) { RotArgs2<5> R{}; R.nv = nv; R.nout = nout; R.Y = s->eig_y.p; for (int i = 0; i < nv; i++) R.V[i] = B(i);
             hipLaunchKernelGGL(k_basis_rotate2<5>, dim3(g2), dim3(256), (size_t)nv * nout * 8, s->stream, R, vlen); }
         else if (nv <= 32 && rot2) { RotArgs2<8> R{}; R.nv = nv; R.nout = nout; R.Y = s->eig_y.p; for (int i = 0; i < nv; i++) R.V[i] = B(i);
             hipLaunchKernelGGL(k_basis_rotate2<8>, dim3(g2), dim3(256), (size_t)nv * nout * 8, s->stream, R, vlen); }
@@ -882,7 +906,10 @@ static int eigsh_full(S *s, int nev, int ncv, int maxiter, double tol, double *e
     const int gsr = (int)std::max<int64_t>(1, std::min<int64_t>(cdiv(n, 256 * 4), 4096));
     // V_j <- sum_i V_i Y_ij in place; bases above 48 vectors take the 96-capacity instantiation
     auto rotate = [&](int nv, int nout) -> int {
-        if (nv <= kMaxBasis) { RotArgs R{}; R.nv = nv; R.nout = nout; R.Y = s->eig_y.p; for (int i = 0; i < nv; i++) R.V[i] = Vp(i);
+        if (dbg_int("EDGPU_ROT_MFMA", 1) != 0) {
+            std::vector<double *> vb((size_t)nv); for (int i = 0; i < nv; i++) vb[i] = Vp(i);
+            CHK(launch_basis_rotate_mfma(s->stream, s->device, vb.data(), nv, nout, s->eig_y.p, n)); }
+        else if (nv <= kMaxBasis) { RotArgs R{}; R.nv = nv; R.nout = nout; R.Y = s->eig_y.p; for (int i = 0; i < nv; i++) R.V[i] = Vp(i);
             hipLaunchKernelGGL(k_basis_rotate<kMaxBasis>, dim3(gsr), dim3(256), (size_t)nv * nout * 8, s->stream, R, n); }
         else { RotArgsT<kMaxBasisBig> R{}; R.nv = nv; R.nout = nout; R.Y = s->eig_y.p; for (int i = 0; i < nv; i++) R.V[i] = Vp(i);
             static OncePerDevice once;
@@ -983,6 +1010,7 @@ static int dvdson(S *s, int nev, int maxiter, double tol, double *evals, double 
     if (s->eig_partial.n < (size_t)nb * (mmax + 2)) CHK(s->eig_partial.alloc((size_t)nb * (mmax + 2)));
     if (s->eig_y.n < (size_t)mmax * mmax) CHK(s->eig_y.alloc((size_t)mmax * mmax));
     const SectorHost &H = s->H;
+    const bool rot_mfma = dbg_int("EDGPU_ROT_MFMA", 1) != 0;
     auto norm_of = [&](const double *x, double &out) -> int {
         CHK(reduce_dot(s, x, x));
         HIPCHK(hipMemcpyAsync(&out, s->scal.p + SC_TMP, 8, hipMemcpyDeviceToHost, s->stream)); HIPCHK(hipStreamSynchronize(s->stream));
@@ -1038,6 +1066,8 @@ static int dvdson(S *s, int nev, int maxiter, double tol, double *evals, double 
             const int keep = std::min(mmax - 1, nev + 4);
             HIPCHK(hipMemcpyAsync(s->eig_y.p, Y.data(), (size_t)m * keep * 8, hipMemcpyHostToDevice, s->stream));
             for (int half = 0; half < 2; half++) {
+                if (rot_mfma) { std::vector<double *> vb((size_t)m); for (int i = 0; i < m; i++) vb[i] = half ? Wp(i) : Vp(i);
+                    CHK(launch_basis_rotate_mfma(s->stream, s->device, vb.data(), m, keep, s->eig_y.p, n)); continue; }
                 RotArgs Rt{}; Rt.nv = m; Rt.nout = keep; Rt.Y = s->eig_y.p; for (int i = 0; i < m; i++) Rt.V[i] = half ? Wp(i) : Vp(i);
                 hipLaunchKernelGGL(k_basis_rotate<kMaxBasis>, dim3(gs), dim3(256), (size_t)m * keep * 8, s->stream, Rt, n);
             }
@@ -1064,8 +1094,10 @@ static int dvdson(S *s, int nev, int maxiter, double tol, double *evals, double 
     }
     const int nout = std::min(nev, m);
     HIPCHK(hipMemcpyAsync(s->eig_y.p, Y.data(), (size_t)m * nout * 8, hipMemcpyHostToDevice, s->stream));
-    RotArgs Rt{}; Rt.nv = m; Rt.nout = nout; Rt.Y = s->eig_y.p; for (int i = 0; i < m; i++) Rt.V[i] = Vp(i);
-    hipLaunchKernelGGL(k_basis_rotate<kMaxBasis>, dim3(gs), dim3(256), (size_t)m * nout * 8, s->stream, Rt, n);
+    if (rot_mfma) { std::vector<double *> vb((size_t)m); for (int i = 0; i < m; i++) vb[i] = Vp(i);
+        CHK(launch_basis_rotate_mfma(s->stream, s->device, vb.data(), m, nout, s->eig_y.p, n)); }
+    else { RotArgs Rt{}; Rt.nv = m; Rt.nout = nout; Rt.Y = s->eig_y.p; for (int i = 0; i < m; i++) Rt.V[i] = Vp(i);
+        hipLaunchKernelGGL(k_basis_rotate<kMaxBasis>, dim3(gs), dim3(256), (size_t)m * nout * 8, s->stream, Rt, n); }
     HIPCHK(hipGetLastError());
     for (int i = 0; i < nev; i++) evals[i] = i < nout ? theta[i] : 0.0;
     if (evecs_host)

@@ -49,12 +49,13 @@ def test_eigsh_survives_many_restarts(edgpu_mod, case):
     G.close()
 
 
-@pytest.mark.parametrize("env", [{"EDGPU_EIGSH_PRO": "0"}, {"EDGPU_EIGSH_FUSED": "0"}, {"EDGPU_ROT2": "0", "EDGPU_EIGSH_OMEGA_PCT": "1"},
-                                 {"EDGPU_EIGSH_OMEGA_PCT": "2000000000"}])      # never re-orthogonalise: the true-residual check must catch what comes out
+@pytest.mark.parametrize("env", [{"EDGPU_EIGSH_PRO": "0"}, {"EDGPU_EIGSH_FUSED": "0"}, {"EDGPU_ROT2": "0", "EDGPU_ROT_MFMA": "0", "EDGPU_EIGSH_OMEGA_PCT": "1"},
+                                 {"EDGPU_ROT_MFMA": "0"}, {"EDGPU_ROT_MFMA": "0", "EDGPU_EIGSH_PRO": "0"}, {"EDGPU_EIGSH_OMEGA_PCT": "2000000000"}])      # never re-orthogonalise: the true-residual check must catch what comes out
 def test_eigsh_alternative_forms(edgpu_mod, monkeypatch, env):
     """The forms behind knobs stay correct: every vector orthogonalised against the whole basis (round-2 solver), the
     three-pass iteration inside the partial-reorthogonalisation solver, the one-element rotation kernel with a trigger level
-    of 1 % of sqrt(eps) (many more passes over the basis, same answer).  Last case: a trigger level that never fires lets the
+    of 1 % of sqrt(eps) (many more passes over the basis, same answer), the register-resident rotation kernels instead of the
+    matrix-core one.  Last case: a trigger level that never fires lets the
     basis lose its orthogonality; the solver's safety net (true residuals of the returned pairs, then the whole-basis form)
     must still hand back correct pairs."""
     from edgpu import model
