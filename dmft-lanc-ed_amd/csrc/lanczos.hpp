@@ -577,6 +577,7 @@ static int eigsh_pro(S *s, int nev, int ncv, int maxiter, double tol, double *ev
     if (maxiter < 1) maxiter = 1;
     const double eps = 2.220446049250313e-16, tol_eff = std::max(tol, 1e-12), eps23 = std::pow(eps, 2.0 / 3.0);
     const double tau = std::sqrt(eps) * (double)std::max(1, dbg_int("EDGPU_EIGSH_OMEGA_PCT", 100)) / 100.0;
+    const double sel = (double)std::max(0, dbg_int("EDGPU_EIGSH_SEL_PPM", 100000)) * 1e-6;      // a pass over kept Ritz vectors takes those whose estimate exceeds sel*tau
     const int m = ncv, M = m + 2;
     CHK(lz_prepare(s, m + 4));
     if (s->lz[3].n != (size_t)n) CHK(s->lz[3].alloc((size_t)n));
@@ -739,7 +740,7 @@ static int eigsh_pro(S *s, int nev, int ncv, int maxiter, double tol, double *ev
                 }
                 Wm(j + 1, j) = Wm(j, j + 1) = eps * normT / std::max(beta, 1e-300); Wm(j + 1, j + 1) = 1.0;
                 if (any && beyond) { idx = all_upto(j); n_full++; }
-                else if (any) { for (int k = 0; k < l; k++) if (!(std::fabs(Wm(j + 1, k)) <= 0.1 * tau)) idx.push_back(k); n_sel++; }
+                else if (any) { for (int k = 0; k < l; k++) if (!(std::fabs(Wm(j + 1, k)) <= sel * tau)) idx.push_back(k); n_sel++; }
             }
             if (!idx.empty() && beta > 0.0) {
                 double nrm2 = 0.0;
