@@ -2,6 +2,8 @@
 !  initial bath (ED_BATH/dmft_aux.f90:110-133).  Binds the GPU operator to a procedure pointer
 !  with the reference's abstract interface and prints the SURVEY 8c known-answer quantities.
 program demo_c1
+  use, intrinsic :: iso_c_binding
+  use EDGPU_C_API
   use ED_HAMILTONIAN_GPU
   use ED_SPARSE_MATRIX
   implicit none
@@ -26,6 +28,13 @@ program demo_c1
   real(8), allocatable :: gs(:), tw(:)
   integer :: nused
   real(8) :: dense(3,3), xv(3), yv(3)
+  ! device-resident flow through the C ABI (vectors as type(c_ptr) device addresses)
+  type(sector_gpu) :: Sdst
+  type(c_ptr) :: gs_dev
+  real(8), pointer, contiguous :: gs_f(:)
+  real(c_double) :: e_dev, n2_dev, agd(20), bgd(20)
+  integer(c_int32_t) :: nl_dev, nu_dev
+  integer(c_int) :: rc
   impHloc = 0d0
   bath_diag(1,1,:) = [-2d0, -1d0, 0d0, 1d0, 2d0]
   diag_hybr = 1d0/sqrt(dble(Nbath))
@@ -82,6 +91,20 @@ program demo_c1
   write(*,"(A,2ES24.16)") "gf_alanc_1_2=", agf(1:2)
   write(*,"(A,ES24.16)") "gf_blanc_2=", bgf(2)
   call delete_Hv_sector_gpu()
+  ! the same leg with the state resident in HBM: zero start vector (the library generates its own, ED_DIAG.f90:147), ground
+  ! state searched in place, handed to the leg as a device address -- nothing crosses PCIe but the coefficients
+  call create_sector_gpu(Sdst, Norb, Nspin, Nbath, 0, "normal", .true., .true., .true., [4], [3], &
+       Uloc, 0d0, 0d0, 0d0, 0d0, 0d0, 0d0, g_ph, impHloc, diag_hybr, bath_diag)
+  rc = edgpu_malloc(gs_dev, int(N, c_size_t) * 8_c_size_t)
+  if (rc == 0) rc = edgpu_memset(gs_dev, 0_c_int32_t, int(N, c_size_t) * 8_c_size_t)
+  if (rc == 0) rc = edgpu_lanczos_gs_device(Ssrc%h, 400_c_int32_t, 1d-14, 10_c_int32_t, e_dev, gs_dev, nl_dev)
+  write(*,"(A,F20.14,A,I3)") "E0_device=", e_dev, " rc=", rc
+  call c_f_pointer(gs_dev, gs_f, [N])          ! a Fortran name for the device address; never dereferenced on the host
+  rc = edgpu_gf_lanczos(Ssrc%h, Sdst%h, 1_c_int32_t, 1_c_int32_t, 1_c_int32_t, gs_f, 20_c_int32_t, 1d-12, n2_dev, agd, bgd, nu_dev)
+  write(*,"(A,ES24.16,A,I3)") "gf_norm2_device=", n2_dev, " rc=", rc
+  write(*,"(A,2ES24.16)") "gf_alanc_1_2_device=", agd(1:2)
+  rc = edgpu_free(gs_dev)
+  call delete_sector_gpu(Sdst)
   call delete_sector_gpu(Ssrc)
   ! sparse container: duplicate-summing insert, dense dump, product on the device
   call sp_init_matrix(spA, 3)

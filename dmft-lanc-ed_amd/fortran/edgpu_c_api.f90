@@ -324,6 +324,122 @@ module EDGPU_C_API
        integer(c_int32_t) :: n
        integer(c_int)     :: rc
      end function edgpu_device_count
+     ! ---- device-resident flow: vectors stay in HBM between calls (type(c_ptr) = device address) ----------------------
+     function edgpu_malloc(dev, bytes) bind(C, name="edgpu_malloc") result(rc)
+       import :: c_int, c_size_t, c_ptr
+       type(c_ptr)              :: dev
+       integer(c_size_t), value :: bytes
+       integer(c_int)           :: rc
+     end function edgpu_malloc
+     function edgpu_free(dev) bind(C, name="edgpu_free") result(rc)
+       import :: c_int, c_ptr
+       type(c_ptr), value :: dev
+       integer(c_int)     :: rc
+     end function edgpu_free
+     function edgpu_memcpy_h2d(dev, host, bytes) bind(C, name="edgpu_memcpy_h2d") result(rc)
+       import :: c_int, c_size_t, c_ptr, c_double
+       type(c_ptr), value         :: dev
+       real(c_double), intent(in) :: host(*)
+       integer(c_size_t), value   :: bytes
+       integer(c_int)             :: rc
+     end function edgpu_memcpy_h2d
+     function edgpu_memcpy_d2h(host, dev, bytes) bind(C, name="edgpu_memcpy_d2h") result(rc)
+       import :: c_int, c_size_t, c_ptr, c_double
+       real(c_double)           :: host(*)
+       type(c_ptr), value       :: dev
+       integer(c_size_t), value :: bytes
+       integer(c_int)           :: rc
+     end function edgpu_memcpy_d2h
+     function edgpu_memset(dev, byte_value, bytes) bind(C, name="edgpu_memset") result(rc)
+       import :: c_int, c_int32_t, c_size_t, c_ptr
+       type(c_ptr), value        :: dev
+       integer(c_int32_t), value :: byte_value
+       integer(c_size_t), value  :: bytes
+       integer(c_int)            :: rc
+     end function edgpu_memset
+     function edgpu_device_synchronize() bind(C, name="edgpu_device_synchronize") result(rc)
+       import :: c_int
+       integer(c_int) :: rc
+     end function edgpu_device_synchronize
+     function edgpu_hxv_device(handle, v_dev, hv_dev) bind(C, name="edgpu_hxv_device") result(rc)
+       import :: c_int, c_ptr
+       type(c_ptr), value :: handle, v_dev, hv_dev
+       integer(c_int)     :: rc
+     end function edgpu_hxv_device
+     function edgpu_lanczos_gs_device(handle, nitermax, threshold, ncheck, egs, vect_dev, nlanc) &
+          bind(C, name="edgpu_lanczos_gs_device") result(rc)
+       import :: c_int, c_int32_t, c_double, c_ptr
+       type(c_ptr), value        :: handle, vect_dev
+       integer(c_int32_t), value :: nitermax, ncheck
+       real(c_double), value     :: threshold
+       real(c_double)            :: egs
+       integer(c_int32_t)        :: nlanc
+       integer(c_int)            :: rc
+     end function edgpu_lanczos_gs_device
+     function edgpu_lanczos_tridiag_device(handle, vin_dev, nlanc, threshold, alanc, blanc, nused) &
+          bind(C, name="edgpu_lanczos_tridiag_device") result(rc)
+       import :: c_int, c_int32_t, c_double, c_ptr
+       type(c_ptr), value        :: handle, vin_dev
+       integer(c_int32_t), value :: nlanc
+       real(c_double), value     :: threshold
+       real(c_double)            :: alanc(*), blanc(*)
+       integer(c_int32_t)        :: nused
+       integer(c_int)            :: rc
+     end function edgpu_lanczos_tridiag_device
+     function edgpu_apply_op(hfrom, hto, iorb, ispin, dagger, vin_dev, vout_dev, norm2) bind(C, name="edgpu_apply_op") result(rc)
+       import :: c_int, c_int32_t, c_double, c_ptr
+       type(c_ptr), value        :: hfrom, hto, vin_dev, vout_dev
+       integer(c_int32_t), value :: iorb, ispin, dagger
+       real(c_double)            :: norm2
+       integer(c_int)            :: rc
+     end function edgpu_apply_op
+     ! ---- introspection --------------------------------------------------------------------------------------------
+     function edgpu_abi_version_of_library() bind(C, name="edgpu_abi_version") result(v)      ! compare with the parameter EDGPU_ABI_VERSION
+       import :: c_int32_t
+       integer(c_int32_t) :: v
+     end function edgpu_abi_version_of_library
+     function edgpu_eigsh_ncv_cap() bind(C, name="edgpu_eigsh_ncv_cap") result(n)
+       import :: c_int32_t
+       integer(c_int32_t) :: n
+     end function edgpu_eigsh_ncv_cap
+     function edgpu_eigsh_ncv_used(handle) bind(C, name="edgpu_eigsh_ncv_used") result(n)
+       import :: c_int32_t, c_ptr
+       type(c_ptr), value :: handle
+       integer(c_int32_t) :: n
+     end function edgpu_eigsh_ncv_used
+     function edgpu_lanczos_is_fused(handle) bind(C, name="edgpu_lanczos_is_fused") result(n)
+       import :: c_int32_t, c_ptr
+       type(c_ptr), value :: handle
+       integer(c_int32_t) :: n
+     end function edgpu_lanczos_is_fused
+     function edgpu_sector_describe(handle, buf, cap) bind(C, name="edgpu_sector_describe") result(rc)
+       import :: c_int, c_int32_t, c_char, c_ptr
+       type(c_ptr), value        :: handle
+       character(kind=c_char)    :: buf(*)
+       integer(c_int32_t), value :: cap
+       integer(c_int)            :: rc
+     end function edgpu_sector_describe
+     function edgpu_comm_count(n) bind(C, name="edgpu_comm_count") result(rc)
+       import :: c_int, c_int32_t
+       integer(c_int32_t) :: n
+       integer(c_int)     :: rc
+     end function edgpu_comm_count
+     function edgpu_sector_exchange_info(handle, mode, send_bytes, recv_bytes) bind(C, name="edgpu_sector_exchange_info") result(rc)
+       import :: c_int, c_int32_t, c_int64_t, c_ptr
+       type(c_ptr), value :: handle
+       integer(c_int32_t) :: mode
+       integer(c_int64_t) :: send_bytes(*), recv_bytes(*)      ! one entry per rank
+       integer(c_int)     :: rc
+     end function edgpu_sector_exchange_info
+     function edgpu_sector_relay_info(handle, enabled, nchunks, busiest_before, busiest_after, rows_direct, rows_routed) &
+          bind(C, name="edgpu_sector_relay_info") result(rc)
+       import :: c_int, c_int32_t, c_int64_t, c_ptr
+       type(c_ptr), value :: handle
+       integer(c_int32_t) :: enabled, nchunks
+       integer(c_int64_t) :: busiest_before, busiest_after
+       integer(c_int64_t) :: rows_direct(*), rows_routed(*)    ! MpiSize*MpiSize entries, [from][to] row-major
+       integer(c_int)     :: rc
+     end function edgpu_sector_relay_info
   end interface
 
 contains

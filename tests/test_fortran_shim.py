@@ -61,6 +61,12 @@ def test_fortran_driver_legs_and_observables():
     obs = oracle.lanc_observables(S, gs)
     assert abs(f("docc")[0] - float(np.ravel(obs["docc"])[0])) < 1e-7
     assert abs(f("hist_sum")[0] - 1.0) < 1e-10
+    # device-resident flow (edgpu_malloc / memset / lanczos_gs_device, then the leg on the device address): same numbers
+    assert " rc=  0" in re.search(r"E0_device=.*", out).group(0) and abs(f("E0_device")[0] - w[0]) < 1e-10
+    assert " rc=  0" in re.search(r"gf_norm2_device=.*", out).group(0)
+    assert abs(f("gf_norm2_device")[0] - f("gf_norm2")[0]) < 1e-9
+    for x, y in zip(f("gf_alanc_1_2_device"), f("gf_alanc_1_2")):
+        assert abs(x - y) < 1e-8
     assert abs(f("twin_overlap")[0] - 1.0) < 1e-7          # (3,3) is its own twin; the ground state is non-degenerate
     # Sz leg: vv = (n_up - n_dw)/2 |gs>
     nup = np.zeros(S.Dim); ndw = np.zeros(S.Dim)
