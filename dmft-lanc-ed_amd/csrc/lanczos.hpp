@@ -73,9 +73,9 @@ static bool tridiag_lowest(const double *al, const double *be, int k, double *e0
 // 1/beta scale carried in a device scalar, so one iteration is: fused product+alpha, one
 // axpy+norm pass, two single-workgroup reductions -- and no host synchronisation.
 // ---------------------------------------------------------------------------------------
-static int lz_prepare(S *s, int nmax)
+static int lz_prepare(S *s, int nmax, int nvec = 3)
 {
-    for (int i = 0; i < 3; i++) if (s->lz[i].n != (size_t)s->vlen) CHK(s->lz[i].alloc((size_t)s->vlen));      // vlen: padded length when the fused loops pad the row pitch
+    for (int i = 0; i < nvec; i++) if (s->lz[i].n != (size_t)s->vlen) CHK(s->lz[i].alloc((size_t)s->vlen));      // vlen: padded length when the fused loops pad the row pitch
     if (s->nmax < nmax) {
         CHK(s->alphas.alloc((size_t)nmax + 2)); CHK(s->betas.alloc((size_t)nmax + 2)); CHK(s->zvec.alloc((size_t)nmax + 2));
         s->nmax = nmax;
@@ -573,20 +573,61 @@ static int eigsh_pro(S *s, int nev, int ncv, int maxiter, double tol, double *ev
         size_t fr = 0, tot = 0;
         if (hipMemGetInfo(&fr, &tot) == hipSuccess && (size_t)(32 + 5) * (size_t)vlen * 8 < fr / 4) ncv = 32; else (void)hipGetLastError();
     }
+    // Memory: the basis, one buffer ahead for the fused iteration, a zero/previous vector and a dense scratch vector.  When the
+    // requested basis does not fit (Ns=18 on one GPU: 18.9 GB per vector, 14 fit) the search runs with the vectors that do --
+    // more restarts, same pairs -- and says so through edgpu_eigsh_ncv_used; below nev + 2 vectors it refuses.  Several ranks
+    // must run the same basis: there the request either fits everywhere or every rank returns EDGPU_ENOMEM.
+    {
+        const bool fused0 = fused_ok(s) && dbg_int("EDGPU_EIGSH_FUSED", 1) != 0;
+        const int extra = 3 + (fused0 ? 1 : 0);      // B(m), the buffer ahead, lz[0], lz[3]
+        const int memcap_mb = dbg_int("EDGPU_EIGSH_MEM_MB", 0);
+        auto fit = [&]() -> int64_t {
+            size_t fr = 0, tot = 0;
+            if (hipMemGetInfo(&fr, &tot) != hipSuccess) { (void)hipGetLastError(); return 1 << 20; }
+            int64_t held = 0;
+            for (auto &b : s->eigV) if (b && b->n >= (size_t)vlen) held++;
+            if (s->lz[0].n == (size_t)vlen) held++;
+            if (s->lz[3].n == (size_t)n) held++;
+            int64_t avail = (int64_t)fr - ((int64_t)2 << 30) - (int64_t)((double)tot * 0.02);
+            if (memcap_mb > 0) avail = std::min<int64_t>(avail, (int64_t)memcap_mb << 20);      // tests: pretend the device is this full
+            return avail / (vlen * 8) + held - extra;
+        };
+        int64_t mfit = fit();
+        if (mfit < ncv) {      // give back what other loops cached: Krylov vectors of earlier ground-state searches, the two rotating vectors this routine does not use
+            kpool_release(); s->lz[1].release(); s->lz[2].release();
+            for (auto &b : s->eigV) if (b && b->n && b->n < (size_t)vlen) b->release();
+            mfit = fit();
+        }
+        int fits = mfit >= ncv ? 1 : 0;
+        if (s->multi) {
+            DevBuf<double> f; std::vector<double> one(1, (double)fits);
+            CHK(f.upload(one)); CHK(allreduce_dev(s, f.p, 1));
+            HIPCHK(hipMemcpyAsync(one.data(), f.p, 8, hipMemcpyDeviceToHost, s->stream)); HIPCHK(hipStreamSynchronize(s->stream));
+            if (one[0] < (double)s->comm.size - 0.5)
+                return fail(EDGPU_ENOMEM, "edgpu_eigsh: a basis of " + std::to_string(ncv) + " vectors of " + std::to_string(vlen * 8 >> 20) + " MiB does not fit on every rank (" + std::to_string(mfit) + " fit here)");
+        } else if (!fits) {
+            if (mfit < nev + 2)
+                return fail(EDGPU_ENOMEM, "edgpu_eigsh: only " + std::to_string(std::max<int64_t>(mfit, 0)) + " basis vectors of " + std::to_string(vlen * 8 >> 20) + " MiB fit in the free device memory; " + std::to_string(nev + 2) + " are the minimum for " + std::to_string(nev) + " pairs (use more ranks)");
+            ncv = (int)mfit;
+        }
+    }
     s->eig_ncv_used = ncv;
     if (maxiter < 1) maxiter = 1;
     const double eps = 2.220446049250313e-16, tol_eff = std::max(tol, 1e-12), eps23 = std::pow(eps, 2.0 / 3.0);
     const double tau = std::sqrt(eps) * (double)std::max(1, dbg_int("EDGPU_EIGSH_OMEGA_PCT", 100)) / 100.0;
     const double sel = (double)std::max(0, dbg_int("EDGPU_EIGSH_SEL_PPM", 100000)) * 1e-6;      // a pass over kept Ritz vectors takes those whose estimate exceeds sel*tau
     const int m = ncv, M = m + 2;
-    CHK(lz_prepare(s, m + 4));
+    CHK(lz_prepare(s, m + 4, 1));      // of the three rotating vectors of the plain loops only the first is used here
     if (s->lz[3].n != (size_t)n) CHK(s->lz[3].alloc((size_t)n));
     // the fused iteration (stored factors / on the fly, one rank) forms the local part of H u_{j+1} one buffer ahead
     const bool fused = fused_ok(s) && dbg_int("EDGPU_EIGSH_FUSED", 1) != 0;
     const int nbuf = m + 1 + (fused ? 1 : 0);
     while ((int)s->eigV.size() < nbuf) s->eigV.push_back(std::make_unique<DevBuf<double>>());
     for (int i = 0; i < nbuf; i++) {
-        if (s->eigV[i]->n < (size_t)vlen) CHK(s->eigV[i]->alloc((size_t)vlen));
+        if (s->eigV[i]->n < (size_t)vlen && s->eigV[i]->alloc((size_t)vlen) != EDGPU_OK) {
+            for (auto &b : s->eigV) if (b) b->release();      // leave nothing behind that would starve the next call
+            return fail(EDGPU_ENOMEM, "edgpu_eigsh: out of device memory for basis vector " + std::to_string(i) + " of " + std::to_string(nbuf));
+        }
         if (s->pad_on) HIPCHK(hipMemsetAsync(s->eigV[i]->p, 0, (size_t)vlen * 8, s->stream));      // padding columns must hold zeros
     }
     const int nb = (int)std::max<int64_t>(1, std::min<int64_t>(cdiv(vlen, 256 * 8), 1024));

@@ -12,6 +12,7 @@ STORAGE = {"kron": STORE_KRON, "csr": STORE_CSR, "direct": STORE_DIRECT}
 BATH = {"normal": 0, "hybrid": 1, "replica": 2}
 SP_ND, SP_UP, SP_DW = 1, 2, 3
 ENODEVICE = -2
+ENOMEM = -4
 ENOTCONVERGED = -7
 
 # every symbol include/edgpu.h declares

@@ -114,6 +114,33 @@ def test_eigsh_large_basis_and_unconverged_is_an_error(edgpu_mod):
     G.close()
 
 
+def test_eigsh_runs_with_the_basis_that_fits(edgpu_mod, monkeypatch):
+    """Nblock is a workspace size: when the requested basis does not fit the free device memory (Ns=18 on one GPU: 14 vectors of
+    18.9 GB) the search runs with the vectors that do and reports it; below nev + 2 vectors it returns EDGPU_ENOMEM and leaves
+    no basis buffers behind.  EDGPU_EIGSH_MEM_MB pretends the device is that full."""
+    from edgpu import model, capi
+    m, nu, nd = model.half_filled_c(9)           # N = 63504: 0.5 MB per vector
+    S = oracle.Sector(m, nu, nd)
+    G = edgpu_mod.HvSector(m, nu, nd)
+    e0, x, nl = G.sp_lanc_eigh(nitermax=300, threshold=1e-13)
+    monkeypatch.setenv("EDGPU_EIGSH_MEM_MB", "5")
+    ev, X, info = G.sp_eigh(2, nblock=20, nitermax=2000, tol=1e-11)
+    assert info["nconv"] == 2 and 4 <= info["ncv_used"] <= 10, info      # 10 vectors fit in 5 MB, two are held already, three go to the work buffers
+    assert abs(ev[0] - e0) < 1e-9 and ev[1] > ev[0]
+    for i in range(2):
+        assert np.linalg.norm(S.spmatvec(X[:, i]) - ev[i] * X[:, i]) < 1e-7
+    G.close()
+    G = edgpu_mod.HvSector(m, nu, nd)
+    monkeypatch.setenv("EDGPU_EIGSH_MEM_MB", "1")
+    with pytest.raises(capi.EdgpuError) as e:
+        G.sp_eigh(2, nblock=20, nitermax=300, tol=1e-11)
+    assert e.value.code == capi.ENOMEM and "fit" in str(e.value)
+    monkeypatch.delenv("EDGPU_EIGSH_MEM_MB")
+    ev2, _, info = G.sp_eigh(2, nblock=20, nitermax=300, tol=1e-11)      # and the sector is still usable
+    assert info["ncv_used"] == 20 and abs(ev2[0] - e0) < 1e-9
+    G.close()
+
+
 def test_eigsh_argument_errors(edgpu_mod):
     from edgpu import model, capi
     m, nu, nd = model.half_filled_c(1)           # N = 4
