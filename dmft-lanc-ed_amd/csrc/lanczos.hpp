@@ -938,7 +938,11 @@ static int eigsh_full(S *s, int nev, int ncv, int maxiter, double tol, double *e
     const double tol_eff = std::max(tol, 1e-12), eps23 = std::pow(2.220446049250313e-16, 2.0 / 3.0);
     const int m = ncv;
     while ((int)s->eigV.size() < m + 1) s->eigV.push_back(std::make_unique<DevBuf<double>>());
-    for (int i = 0; i <= m; i++) if (s->eigV[i]->n < (size_t)n) CHK(s->eigV[i]->alloc((size_t)n));
+    for (int i = 0; i <= m; i++)
+        if (s->eigV[i]->n < (size_t)n && s->eigV[i]->alloc((size_t)n) != EDGPU_OK) {
+            for (auto &b : s->eigV) if (b) b->release();      // leave nothing behind that would starve the next call
+            return fail(EDGPU_ENOMEM, "edgpu_eigsh: out of device memory for basis vector " + std::to_string(i) + " of " + std::to_string(m + 1) + " (" + std::to_string(n * 8 >> 20) + " MiB each)");
+        }
     const int nb = (int)std::max<int64_t>(1, std::min<int64_t>(cdiv(n, 256 * 8), 1024));
     if (s->eig_h.n < (size_t)(m + 3)) CHK(s->eig_h.alloc((size_t)m + 3));
     if (s->eig_partial.n < (size_t)nb * (kMaxBasis + 2)) CHK(s->eig_partial.alloc((size_t)nb * (kMaxBasis + 2)));
@@ -1042,7 +1046,11 @@ static int dvdson(S *s, int nev, int maxiter, double tol, double *evals, double 
     // the diagonal of H: stored formats hold it, the on-the-fly format derives it once here
     if (s->diag.n != (size_t)s->nloc_el) CHK(build_diag(s));
     while ((int)s->eigV.size() < 2 * mmax + 1) s->eigV.push_back(std::make_unique<DevBuf<double>>());
-    for (int i = 0; i <= 2 * mmax; i++) if (s->eigV[i]->n < (size_t)n) CHK(s->eigV[i]->alloc((size_t)n));
+    for (int i = 0; i <= 2 * mmax; i++)
+        if (s->eigV[i]->n < (size_t)n && s->eigV[i]->alloc((size_t)n) != EDGPU_OK) {
+            for (auto &b : s->eigV) if (b) b->release();
+            return fail(EDGPU_ENOMEM, "edgpu_dvdson: out of device memory for vector " + std::to_string(i) + " of " + std::to_string(2 * mmax + 1) + " (search space and its image, " + std::to_string(n * 8 >> 20) + " MiB each)");
+        }
     auto Vp = [&](int i) { return s->eigV[i]->p; };
     auto Wp = [&](int i) { return s->eigV[mmax + i]->p; };
     double *t = s->eigV[2 * mmax]->p;
