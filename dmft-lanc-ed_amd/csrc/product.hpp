@@ -564,7 +564,7 @@ static int hxv(S *s, const double *v, double *out, bool epi, const double *uprev
 #define HALO_Q(D_, H_) do { if (nq == 1) HALO_AE(D_, 1, H_); else if (nq == 2) HALO_AE(D_, 2, H_); else HALO_AE(D_, 3, H_); } while (0)
                 const int nt = s->up_halo_nt;
                 const int nq = (int)cdiv(U.seglen / 2, nt);
-                const int abl = ((s->dbg >> 4) & 3) | dbg_int("EDGPU_ABL", 0);      // EDGPU_DEBUG bits 16 / 32, EDGPU_ABL: timing ablations (wrong results)
+                const int abl = ((s->dbg >> 4) & 3) | s->abl;      // EDGPU_DEBUG bits 16 / 32, EDGPU_ABL: timing ablations (wrong results)
                 if (nt == 512 && !dw_first && nq <= 2 && U.halocap <= 12 * 512) {
                     // two workgroups of 512 threads per CU (needs segments of <= 2048 elements and <= 6144 halo values)
                     const unsigned grid5 = (unsigned)std::max(8 * U.nseg, (2 * s->up_grid) & ~7);

@@ -254,6 +254,7 @@ struct edgpu_sector_s {
     int64_t nnz_total = 0, bytes_stored = 0;
     int64_t npartial = 0;
     // knobs read from the environment ONCE, at sector creation (never inside a product)
+    int abl = 0;              // EDGPU_ABL: timing ablations of k_uppass_halo (wrong results; scripts/prof_halo2.sh)
     int dbg = 0; bool tables_wave = true; int dw_lds_kb = 0; bool lz_fused_on = true;
     int up_halo_nt = 1024;    // threads per workgroup of k_uppass_halo (512: two workgroups per CU, with EDGPU_UP_SEGMAX=2048)
     bool dw_unr = false;      // dw pass with every load of a row step issued up front (k_dwpass2<..., UNR>; <= 16 dw hops per row): measured slower (occupancy 4 instead of 8 waves per SIMD), kept as a knob
