@@ -1173,7 +1173,7 @@ int edgpu_sector_exchange_info(edgpu_handle h, int32_t *mode, int64_t *send_byte
         int64_t sb = 0, rb = 0;
         if (r != me && h->multi) {
             if (h->tr_on) { int64_t qu, qd; split(H.DimUp, r, qu); split(H.DimDw, r, qd); sb = 2 * qu * H.Qdw * 8; rb = 2 * h->Qup * qd * 8; }
-            else if (h->halo) { sb = h->send_rows_cnt[r] * H.DimUp * H.DimPh * 8; rb = h->recv_rows_cnt[r] * H.DimUp * H.DimPh * 8; }
+            else if (h->halo) { sb = h->send_rows_cnt[r] * xspace_ld(h) * H.DimPh * 8; rb = h->recv_rows_cnt[r] * xspace_ld(h) * H.DimPh * 8; }
             else { int64_t qd; split(H.DimDw, r, qd); sb = h->nloc * 8; rb = qd * H.DimUp * H.DimPh * 8; }
         }
         send_bytes[r] = sb; recv_bytes[r] = rb;

@@ -1593,14 +1593,14 @@ __global__ void __launch_bounds__(256) k_direct_tables_wave(TabArgs A)
 // Explicit CSR (storage=CSR): expansion of the Kronecker sum, then a row-block streaming SpMV.
 // ---------------------------------------------------------------------------------------------
 // rows a peer needs, copied out of the shard into one contiguous message per peer
-struct PackArgs { int32_t DimUp, DimPh; int64_t Qdw, nrows; const int32_t *list; const double *v; double *out; };
+struct PackArgs { int32_t DimUp, DimPh; int64_t Qdw, nrows; const int32_t *list; const double *v; double *out; int64_t ld; };      // ld: row pitch of v and of the packed rows (DimUp, or the padded pitch of the explicit CSR)
 __global__ void __launch_bounds__(256) k_pack_rows(PackArgs A)
 {
     const int64_t total = A.nrows * A.DimPh * (int64_t)A.DimUp;
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
         const int64_t r = e / A.DimUp; const int i = (int)(e - r * A.DimUp);
         const int64_t iph = r / A.nrows, q = r - iph * A.nrows;
-        A.out[e] = A.v[(iph * A.Qdw + A.list[q]) * A.DimUp + i];
+        A.out[r * A.ld + i] = A.v[(iph * A.Qdw + A.list[q]) * A.ld + i];      // padding columns of the message rows stay zero (buffer cleared once)
     }
 }
 

@@ -319,6 +319,17 @@ static int hxv(S *s, const double *v, double *out, bool epi, const double *uprev
     const bool multi = s->multi;
     const bool direct = d.storage == EDGPU_STORE_DIRECT;
     if (direct) CHK(direct_tables(s));
+    // explicit CSR with columns stored in the pitched space: a caller's dense vectors (plain products only) go through pitched
+    // scratch copies -- made before the exchange starts, which reads the pitched copy
+    const bool via_scratch = d.storage == EDGPU_STORE_CSR && s->csr_ld > H.DimUp && ld == 0;
+    double *dense_out = out;
+    if (via_scratch) {
+        if (epi) return fail(EDGPU_EINVAL, "edgpu: internal: Lanczos epilogue on dense vectors with pitched CSR columns");
+        const size_t rows = (size_t)(s->nloc / H.DimUp), vl = rows * (size_t)s->csr_ld;
+        if (!s->csr_xs.p) { CHK(s->csr_xs.alloc(vl)); CHK(s->csr_ys.alloc(vl)); HIPCHK(hipMemsetAsync(s->csr_xs.p, 0, vl * 8, s->stream)); HIPCHK(hipMemsetAsync(s->csr_ys.p, 0, vl * 8, s->stream)); }
+        HIPCHK(hipMemcpy2DAsync(s->csr_xs.p, (size_t)s->csr_ld * 8, v, (size_t)H.DimUp * 8, (size_t)H.DimUp * 8, rows, hipMemcpyDeviceToDevice, s->stream));
+        v = s->csr_xs.p; out = s->csr_ys.p;
+    }
     if (multi) {  // start the exchange on the comm stream; local work overlaps it
         HIPCHK(hipEventRecord(s->ev_ready, s->stream));
         HIPCHK(hipStreamWaitEvent(s->cstream, s->ev_ready, 0));
@@ -335,16 +346,6 @@ static int hxv(S *s, const double *v, double *out, bool epi, const double *uprev
         // shard itself (pointer shifted to global column numbering) while the exchange is in flight
         const bool overlap = multi && s->csr_split && H.DimPh == 1;
         if (multi && !overlap) HIPCHK(hipStreamWaitEvent(s->stream, s->ev_gather, 0));
-        // columns stored in the pitched space: a caller's dense vectors (plain products only) go through pitched scratch copies
-        const bool via_scratch = s->csr_ld > H.DimUp && ld == 0;
-        double *dense_out = out;
-        if (via_scratch) {
-            if (epi) return fail(EDGPU_EINVAL, "edgpu: internal: Lanczos epilogue on dense vectors with pitched CSR columns");
-            const size_t rows = (size_t)(s->nloc / H.DimUp), vl = rows * (size_t)s->csr_ld;
-            if (!s->csr_xs.p) { CHK(s->csr_xs.alloc(vl)); CHK(s->csr_ys.alloc(vl)); HIPCHK(hipMemsetAsync(s->csr_xs.p, 0, vl * 8, s->stream)); HIPCHK(hipMemsetAsync(s->csr_ys.p, 0, vl * 8, s->stream)); }
-            HIPCHK(hipMemcpy2DAsync(s->csr_xs.p, (size_t)s->csr_ld * 8, v, (size_t)H.DimUp * 8, (size_t)H.DimUp * 8, rows, hipMemcpyDeviceToDevice, s->stream));
-            v = s->csr_xs.p; out = s->csr_ys.p;
-        }
         CsrArgs A{};
         A.ld = s->csr_ld;
         A.nrows = s->nloc_el; A.rows_per_block = s->csr_rpb; A.DimUp = (int32_t)H.DimUp; A.blocks_per_row = s->csr_bpr; A.Qdw = H.Qdw; A.tile = s->csr_tile;

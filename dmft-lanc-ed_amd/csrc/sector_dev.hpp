@@ -207,7 +207,7 @@ static int relay_plan(S *s)
         if (c.r == me) { s->relay[c.s].r1r = {stage, c.cnt}; s->relay[c.d].s2f = {stage, c.cnt}; stage += c.cnt; }      // hold, then forward
         if (c.d == me) s->relay[c.r].r2f = {s->recv_rows_off[c.s] + off, c.cnt};               // lands behind the direct rows of s
     }
-    CHK(s->relay_stage.alloc((size_t)std::max<int64_t>(stage, 1) * s->H.DimUp));
+    CHK(s->relay_stage.alloc((size_t)std::max<int64_t>(stage, 1) * (size_t)((s->H.DimUp + 15) & ~(int64_t)15)));
     s->relay_on = true;
     if ((s->dbg & 8) && me == 0) {
         fprintf(stderr, "edgpu: relay routing on %d ranks: busiest link %lld rows -> %lld (two phases), %d relayed chunks\n", P, (long long)s->relay_before, (long long)s->relay_after, s->relay_chunks);
@@ -266,7 +266,10 @@ static int setup_halo(S *s)
     s->nhalo = H.Qdw + ro;
     if (send_list.empty()) send_list.push_back(0);
     CHK(s->send_list.upload(send_list));
-    CHK(s->sendbuf.alloc((size_t)std::max<int64_t>(so, 1) * H.DimUp * H.DimPh));
+    {   // message rows may carry the line-aligned pitch of the explicit CSR (decided later, in build_csr): room for it, zeros in the padding
+        const size_t nsb = (size_t)std::max<int64_t>(so, 1) * (size_t)((H.DimUp + 15) & ~(int64_t)15) * H.DimPh;
+        CHK(s->sendbuf.alloc(nsb)); HIPCHK(hipMemsetAsync(s->sendbuf.p, 0, nsb * 8, s->stream));
+    }
     // H_dw column indices translated to x-space for the local rows (ELL image and CSR image)
     const int W = s->dwf->width;
     std::vector<int32_t> ec((size_t)W * dw.dim, 0), cc(dw.cols.size(), 0);
@@ -299,6 +302,9 @@ static int build_diag(S *s)
     return EDGPU_OK;
 }
 
+// row pitch of the x-space [own rows | received rows] and of the vectors the exchange reads: padded only for the explicit CSR whose
+// columns were built in the pitched space (build_csr)
+static inline int64_t xspace_ld(const S *s) { return (s->H.desc.storage == EDGPU_STORE_CSR && s->halo && s->csr_ld > s->H.DimUp) ? s->csr_ld : s->H.DimUp; }
 static bool fused_ok(const S *s);      // product.hpp
 static bool pitch_ok(const S *s);
 
@@ -356,7 +362,8 @@ static int build_csr(S *s)
     s->csr_split = dbg_int("EDGPU_CSR_SPLIT", (H.DimUp * H.DimDw * 8 > ((int64_t)48 << 20)) ? 1 : 0) != 0 || H.Jhflag || H.DimPh > 1;      // the non-local / phonon passes go between the local and the dw block
     s->csrL_nnz = H.Qdw * uppre[up.dim]; s->csrD_nnz = s->csr_nnz - s->csrL_nnz;
     s->csr_ld = H.DimUp;
-    if (!s->multi && s->csr_split && !H.Jhflag && H.DimPh == 1 && (H.DimUp % 16) != 0 && dbg_int("EDGPU_PAD", 1) != 0 && dbg_int("EDGPU_CSR_PITCH", 1) != 0) {
+    // several ranks: only with the needed-rows exchange, whose messages carry the pitch (EDGPU_CSR_PITCH_MULTI=0: dense rows as in round 2)
+    if ((!s->multi || (s->halo && dbg_int("EDGPU_CSR_PITCH_MULTI", 1) != 0)) && s->csr_split && !H.Jhflag && H.DimPh == 1 && (H.DimUp % 16) != 0 && dbg_int("EDGPU_PAD", 1) != 0 && dbg_int("EDGPU_CSR_PITCH", 1) != 0) {
         const int64_t ld = (H.DimUp + 15) & ~(int64_t)15;
         if (ld * s->nhalo < ((int64_t)1 << 31)) s->csr_ld = ld;
     }
@@ -554,7 +561,11 @@ static int create(const edgpu_desc *desc, S **out)
         s->bytes_stored = s->csr_nnz * 12 + (s->nloc_el + 1) * 8 * (s->csr_three ? 3 : (s->csr_split ? 2 : 1)) + s->nd_nnz * 13 + (s->nd_nr + 1) * 16;
         s->nnz_total += s->nd_nnz;
     }
-    if (s->multi && !s->tr_on) CHK(s->vfull.alloc((size_t)(H.DimUp * s->nhalo * H.DimPh)));
+    if (s->multi && !s->tr_on) {
+        const size_t nx = (size_t)(xspace_ld(s.get()) * s->nhalo * H.DimPh);
+        CHK(s->vfull.alloc(nx));
+        if (xspace_ld(s.get()) > H.DimUp) HIPCHK(hipMemsetAsync(s->vfull.p, 0, nx * 8, s->stream));
+    }
     s->axpy_nb = std::max(1, dbg_int("EDGPU_AXPY_NB", 512));
     s->vld = H.DimUp; s->vlen = s->nloc;
     s->pad_on = (fused_ok(s.get()) || pitch_ok(s.get())) && (H.DimUp % 16) != 0 && dbg_int("EDGPU_PAD", 1) != 0;
