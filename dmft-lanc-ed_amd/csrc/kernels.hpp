@@ -339,6 +339,7 @@ struct UpArgs2 {
     const double *diag, *Eup, *Edw, *cross; const int32_t *mapup, *mapdw; int32_t impmask, nI; double econst;
     const double *v; double *out; const double *uprev; const double *scal;
     int32_t ld;              // row pitch of v / out / uprev in doubles (0: DimUp)
+    const double *crowtab;   // DIRECT: [idw][nI] row constants (k_crow_table)
 };
 
 template <bool DIRECT, bool EPI, int NT>
@@ -349,10 +350,19 @@ __global__ void __launch_bounds__(NT) k_uppass2(UpArgs2 A)
     const int DimUp = A.DimUp, npair = DimUp >> 1, tid = threadIdx.x;
     const int64_t ld = A.ld ? A.ld : DimUp;
     double *tv = lds + DimUp;
+    // DIRECT: the diagonal is Eup(iup) [an operand like the stored diagonal] + crow(up impurity word), with crow = Edw + econst +
+    // cross(., dw impurity word) of the row taken from the per-product table a row ahead (k_crow_table) and the impurity word of
+    // every up configuration staged in LDS once per launch -- the first form loaded mapup, Eup and cross one after the other
+    // inside every step (2.37 ms per product at Ns=16 against 2.17 with the stored diagonal)
+    double *crow = tv + 128;
+    uint8_t *imp8 = reinterpret_cast<uint8_t *>(crow + 32);
     for (int t = tid; t < A.nterms; t += NT) tv[t] = A.tval[t];
+    if (DIRECT) for (int t = tid; t < DimUp; t += NT) imp8[t] = (uint8_t)((uint32_t)A.mapup[t] & A.impmask);
     const int nq = (npair + NT - 1) / NT;
     dbl2v xr[MAXQ];
     int64_t row = blockIdx.x;
+    double crn = 0.0;
+    if (DIRECT) crn = A.crowtab[(A.dw0 + (row < A.nrows ? row : 0) % A.Qdw) * A.nI + (tid < A.nI ? tid : 0)];
     if (row < A.nrows) {
 #pragma unroll
         for (int q = 0; q < MAXQ; q++) { const int p = tid + q * NT; if (q < nq && p < npair) xr[q] = *reinterpret_cast<const dbl2v *>(A.v + row * ld + 2 * p); }
@@ -361,9 +371,10 @@ __global__ void __launch_bounds__(NT) k_uppass2(UpArgs2 A)
     if (EPI) { s_cur = A.scal[SC_SCUR]; c_prev = A.scal[SC_BETA] * A.scal[SC_SPREV]; }
     struct Ops { dbl2v d, u; uint4 w0, w1, w2; };
     while (row < A.nrows) {
-        const int64_t idwl = row % A.Qdw, idw = A.dw0 + idwl;
+        const int64_t idwl = row % A.Qdw;
         auto load_ops = [&](int p, Ops &o) {
             if (!DIRECT) o.d = *reinterpret_cast<const dbl2v *>(A.diag + idwl * DimUp + 2 * p);
+            else o.d = *reinterpret_cast<const dbl2v *>(A.Eup + 2 * p);
             if (EPI) o.u = *reinterpret_cast<const dbl2v *>(A.uprev + row * ld + 2 * p);
             o.w0 = A.packed[3 * p]; o.w1 = A.packed[3 * p + 1]; o.w2 = A.packed[3 * p + 2];
         };
@@ -371,23 +382,22 @@ __global__ void __launch_bounds__(NT) k_uppass2(UpArgs2 A)
         if (tid < npair) load_ops(tid, cur);
 #pragma unroll
         for (int q = 0; q < MAXQ; q++) { const int p = tid + q * NT; if (q < nq && p < npair) *reinterpret_cast<dbl2v *>(lds + 2 * p) = xr[q]; }
+        if (DIRECT && tid < A.nI) crow[tid] = crn;
         __syncthreads();
         const int64_t next = row + gridDim.x;
+        if (DIRECT) crn = A.crowtab[(A.dw0 + (next < A.nrows ? next : row) % A.Qdw) * A.nI + (tid < A.nI ? tid : 0)];
         if (next < A.nrows) {
 #pragma unroll
             for (int q = 0; q < MAXQ; q++) { const int p = tid + q * NT; if (q < nq && p < npair) xr[q] = *reinterpret_cast<const dbl2v *>(A.v + next * ld + 2 * p); }
         }
-        uint32_t mdw = 0; double edw = 0.0;
-        if (DIRECT) { mdw = (uint32_t)A.mapdw[idw] & A.impmask; edw = A.Edw[idw] + A.econst; }
         for (int p = tid; p < npair; p += NT) {
             if (p + NT < npair) load_ops(p + NT, nxt);
             const dbl2v x = *reinterpret_cast<const dbl2v *>(lds + 2 * p);
             dbl2v dval;
             if (DIRECT) {
-                const int2 mm = *reinterpret_cast<const int2 *>(A.mapup + 2 * p);
-                const dbl2v e2 = *reinterpret_cast<const dbl2v *>(A.Eup + 2 * p);
-                dval.x = edw + e2.x + A.cross[((uint32_t)mm.x & A.impmask) * A.nI + mdw];
-                dval.y = edw + e2.y + A.cross[((uint32_t)mm.y & A.impmask) * A.nI + mdw];
+                const uint32_t im = *reinterpret_cast<const uint16_t *>(imp8 + 2 * p);
+                dval.x = cur.d.x + crow[im & 0xffu];
+                dval.y = cur.d.y + crow[im >> 8];
             } else dval = cur.d;
             // element 0 of the pair: dwords w0.x w0.y w0.z w0.w (cols) w1.x w1.y (codes); element 1: w1.z w1.w w2.x w2.y, w2.z w2.w
             const uint32_t c0[4] = {cur.w0.x, cur.w0.y, cur.w0.z, cur.w0.w}, k0[2] = {cur.w1.x, cur.w1.y};
@@ -432,6 +442,7 @@ struct UpAxArgs {
     double *acc; const double *zvec;   // optional eigenvector accumulation acc += zvec[K] * u_k (K = iteration counter in scal)
     int32_t ld;              // row pitch of r / vprev / t_out / acc in doubles (0: DimUp); the stored diagonal keeps pitch DimUp
     const uint32_t *pcols, *pcodes; int32_t upw;      // k_uppass_ax (one configuration per lane, up to 16 hops): packed ELL image as k_uppass
+    const double *crowtab;   // DIRECT: [idw][nI] row constants (k_crow_table)
 };
 
 template <bool DIRECT, bool ACC, int NT>
@@ -444,7 +455,9 @@ __global__ void __launch_bounds__(NT) k_uppass2_ax(UpAxArgs A)
     double *tv = lds + DimUp;
     double *red = tv + 128;
     double *crow = red + 32;                             // DIRECT: Edw + const + cross term of this row, per up impurity word
+    uint8_t *imp8 = reinterpret_cast<uint8_t *>(crow + 32);      // DIRECT: impurity word of every up configuration (the index into crow), staged once per launch
     for (int t = tid; t < A.nterms; t += NT) tv[t] = A.tval[t];
+    if (DIRECT) for (int t = tid; t < DimUp; t += NT) imp8[t] = (uint8_t)((uint32_t)A.mapup[t] & A.impmask);
     const int nq = (npair + NT - 1) / NT;
     const double c_ax = A.scal[SC_ALPHA] * A.scal[SC_SCUR];          // alpha_{k-1} * s_{k-1}  (0 at k = 0)
     const double zk = ACC ? A.zvec[(int)A.scal[SC_K]] : 0.0;
@@ -458,6 +471,8 @@ __global__ void __launch_bounds__(NT) k_uppass2_ax(UpAxArgs A)
         return u;
     };
     dbl2v xu[MAXQ];                                      // u of the row that enters LDS next
+    double crn = 0.0;
+    if (DIRECT) crn = A.crowtab[(A.dw0 + (blockIdx.x < A.nrows ? blockIdx.x : 0) % A.Qdw) * A.nI + (tid < A.nI ? tid : 0)];
     const int pmax = npair > 0 ? npair - 1 : 0;
     int64_t row = blockIdx.x;
     if (row < A.nrows) {
@@ -478,33 +493,38 @@ __global__ void __launch_bounds__(NT) k_uppass2_ax(UpAxArgs A)
         // No branch around an operand load (lanes beyond the row load a clamped pair, the last row loads itself again): a wait for
         // an older load can only carry the smallest count over all paths, and one path that skips the prefetch makes every such
         // wait vmcnt(0) (see k_uppass_halo).
-        const int64_t nrow = more ? next : row;
+        // (The on-the-fly form keeps the guarded loads: its extra operands push the straight-line form from 16 to 26 spilled
+        // registers and the pass from 1.27 to 1.35-1.43 ms at Ns=16; the stored form gains nothing either way, 1.21-1.24 ms.)
+        constexpr bool STRAIGHT = !DIRECT;
+        const int64_t nrow = (STRAIGHT && !more) ? row : next;
         auto load_ops = [&](int p, Ops &o) {
-            p = p < npair ? p : pmax;
+            if (STRAIGHT) p = p < npair ? p : pmax;
             if (!DIRECT) o.d = *reinterpret_cast<const dbl2v *>(A.diag + idwl * DimUp + 2 * p);
             else o.d = *reinterpret_cast<const dbl2v *>(A.Eup + 2 * p);
             o.w0 = A.packed[3 * p]; o.w1 = A.packed[3 * p + 1]; o.w2 = A.packed[3 * p + 2];
-            o.nr = *reinterpret_cast<const dbl2v *>(A.r + nrow * ld + 2 * p); o.nv = *reinterpret_cast<const dbl2v *>(A.vprev + nrow * ld + 2 * p);
+            if (STRAIGHT || more) { o.nr = *reinterpret_cast<const dbl2v *>(A.r + nrow * ld + 2 * p); o.nv = *reinterpret_cast<const dbl2v *>(A.vprev + nrow * ld + 2 * p); }
         };
         Ops cur, nxt;
-        load_ops(tid, cur);
+        if (STRAIGHT || tid < npair) load_ops(tid, cur);
 #pragma unroll
         for (int q = 0; q < MAXQ; q++) { const int p = tid + q * NT; if (q < nq && p < npair) *reinterpret_cast<dbl2v *>(lds + 2 * p) = xu[q]; }
-        if (DIRECT && tid < A.nI) crow[tid] = A.Edw[idw] + A.econst + A.cross[tid * A.nI + ((uint32_t)A.mapdw[idw] & A.impmask)];
+        if (DIRECT && tid < A.nI) crow[tid] = crn;
         __syncthreads();
+        if (DIRECT) crn = A.crowtab[(A.dw0 + (more ? next : row) % A.Qdw) * A.nI + (tid < A.nI ? tid : 0)];      // row constant of the next row (k_crow_table), a row ahead
 #pragma unroll
         for (int q = 0; q < MAXQ; q++) {
             if (q >= nq) break;
             const int p = tid + q * NT;
-            load_ops(p + NT, nxt);
+            if (STRAIGHT) load_ops(p + NT, nxt);
             if (p < npair) {
+                if (!STRAIGHT && p + NT < npair) load_ops(p + NT, nxt);
                 if (more) xu[q] = combine(next, p, cur.nr, cur.nv);      // xu[q] of THIS row is in LDS already
                 const dbl2v x = *reinterpret_cast<const dbl2v *>(lds + 2 * p);
                 dbl2v dval;
                 if (DIRECT) {
-                    const int2 mm = *reinterpret_cast<const int2 *>(A.mapup + 2 * p);
-                    dval.x = cur.d.x + crow[(uint32_t)mm.x & A.impmask];
-                    dval.y = cur.d.y + crow[(uint32_t)mm.y & A.impmask];
+                    const uint32_t im = *reinterpret_cast<const uint16_t *>(imp8 + 2 * p);
+                    dval.x = cur.d.x + crow[im & 0xffu];
+                    dval.y = cur.d.y + crow[im >> 8];
                 } else dval = cur.d;
                 const uint32_t c0[4] = {cur.w0.x, cur.w0.y, cur.w0.z, cur.w0.w}, k0[2] = {cur.w1.x, cur.w1.y};
                 const uint32_t c1[4] = {cur.w1.z, cur.w1.w, cur.w2.x, cur.w2.y}, k1[2] = {cur.w2.z, cur.w2.w};

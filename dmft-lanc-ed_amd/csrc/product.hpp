@@ -51,6 +51,14 @@ static int dispatch_kron2(S *s, int flags, const Kron2Args &A, int64_t rows)
 static int direct_tables(S *s)
 {
     const SectorHost &H = s->H; const edgpu_desc &d = H.desc;
+    if (s->kron2 && s->dwf && s->dwf->E.p && s->dwf->map.p && s->cross.p) {
+        // row constants of the on-the-fly diagonal, Edw + econst + cross(up impurity word, dw impurity word), per dw configuration
+        // (two-factor and composite sectors alike: the local-pass kernels read them a row ahead instead of chasing mapdw -> cross)
+        const int32_t nI = 1 << d.Norb; const int64_t nct = H.DimDw * nI;
+        if (s->crow_tab.n != (size_t)nct) CHK(s->crow_tab.alloc((size_t)nct));
+        hipLaunchKernelGGL(k_crow_table, dim3((unsigned)cdiv(nct, 256)), dim3(256), 0, s->stream, (const double *)s->dwf->E.p, (const int32_t *)s->dwf->map.p, (const double *)s->cross.p, H.econst, (int32_t)(nI - 1), nI, H.DimDw, s->crow_tab.p);
+        HIPCHK(hipGetLastError());
+    }
     if (s->composite) return EDGPU_OK;      // composite blocks (ed_total_ud=F) keep their tables; only the diagonal is formed on the fly
     for (int k = 0; k < 2 * H.Ns_Ud; k++) {
         DevFactor &f = *s->fac[k];
@@ -242,9 +250,10 @@ static int fused_local(S *s, double *r, const double *uprev, double *t, double *
     U.diag = s->diag.p; U.Eup = s->upf->E.p; U.Edw = s->dwf->E.p; U.cross = s->cross.p; U.mapup = s->upf->map.p; U.mapdw = s->dwf->map.p;
     U.impmask = (1 << d.Norb) - 1; U.nI = 1 << d.Norb; U.econst = H.econst;
     U.r = r; U.vprev = uprev; U.t_out = t; U.scal = s->scal.p; U.partial = s->partial.p; U.acc = acc; U.zvec = s->zvec.p; U.ld = (int32_t)s->vld;
-    const size_t lds = (((size_t)H.DimUp + 1) & ~(size_t)1) * 8 + 128 * 8 + 32 * 8 + 32 * 8;
+    const size_t lds = (((size_t)H.DimUp + 1) & ~(size_t)1) * 8 + 128 * 8 + 32 * 8 + 32 * 8 + (direct ? (((size_t)H.DimUp + 15) & ~(size_t)15) : 0);      // + the impurity-word bytes of the on-the-fly form
     const int grid = (int)std::min<int64_t>(U.nrows, s->up_grid);
-    U.pcols = s->upf->pcols.p; U.pcodes = s->upf->pcodes.p; U.upw = s->upf->width;
+    U.pcols = s->upf->pcols.p; U.pcodes = s->upf->pcodes.p; U.upw = s->upf->width; U.crowtab = direct ? s->crow_tab.p : nullptr;
+    if (direct && !U.crowtab) return fail(EDGPU_EINVAL, "edgpu: internal: row-constant table of the on-the-fly form missing");
     const dim3 g(grid), b(LZAX_NT);
 #define AX_LAUNCH(K_, D_, A_)                                                                                                   \
     do {                                                                                                                            \
@@ -491,7 +500,9 @@ static int hxv(S *s, const double *v, double *out, bool epi, const double *uprev
                 U.packed = reinterpret_cast<const uint4 *>(s->upf->pelem.p); U.tval = s->upf->ptval.p; U.nterms = s->upf->pterms;
                 U.diag = A.diag; U.Eup = A.Eup; U.Edw = A.Edw; U.cross = A.cross; U.mapup = A.mapup; U.mapdw = A.mapdw; U.impmask = A.impmask; U.nI = A.nI; U.econst = A.econst;
                 U.v = v; U.out = out; U.uprev = uprev; U.scal = s->scal.p; U.ld = (int32_t)ld;
-                const size_t lds = (size_t)H.DimUp * 8 + 128 * 8;
+                U.crowtab = direct ? s->crow_tab.p : nullptr;
+                if (direct && !U.crowtab) return fail(EDGPU_EINVAL, "edgpu: internal: row-constant table of the on-the-fly form missing");
+                const size_t lds = (size_t)H.DimUp * 8 + 128 * 8 + (direct ? 32 * 8 + (((size_t)H.DimUp + 15) & ~(size_t)15) : 0);
                 const int grid = (int)std::min<int64_t>(U.nrows, s->up_grid);
                 static OncePerDevice once2;
                 if (once2.first(s->device)) {
@@ -545,12 +556,7 @@ static int hxv(S *s, const double *v, double *out, bool epi, const double *uprev
                 U.diag = A.diag; U.Eup = A.Eup; U.Edw = A.Edw; U.cross = A.cross; U.mapup = A.mapup; U.mapdw = A.mapdw; U.impmask = A.impmask; U.nI = A.nI; U.econst = A.econst;
                 U.v = v; U.out = out; U.ld = (int32_t)ld;
                 U.uprev = uprev; U.scal = s->scal.p; U.partial = s->partial.p;
-                if (direct) {
-                    const int64_t nct = H.DimDw * U.nI;
-                    if (s->crow_tab.n != (size_t)nct) CHK(s->crow_tab.alloc((size_t)nct));
-                    hipLaunchKernelGGL(k_crow_table, dim3((unsigned)cdiv(nct, 256)), dim3(256), 0, s->stream, U.Edw, U.mapdw, U.cross, U.econst, U.impmask, U.nI, H.DimDw, s->crow_tab.p);
-                    U.crowtab = s->crow_tab.p;
-                }
+                if (direct) { U.crowtab = s->crow_tab.p; if (!U.crowtab) return fail(EDGPU_EINVAL, "edgpu: internal: row-constant table of the on-the-fly form missing"); }      // built with the other on-the-fly tables (direct_tables)
                 const size_t lds = ((size_t)U.seglen + U.halocap + 128 + 32 + 16) * 8;
                 const unsigned grid = (unsigned)std::max(8 * U.nseg, s->up_grid & ~7);
                 if (dw_first) { CHK(run_dw(s->dw_first, false, nullptr)); dw_done = true; nblocks = grid; }
