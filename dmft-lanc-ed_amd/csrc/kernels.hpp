@@ -252,6 +252,7 @@ struct UpArgs {
     const double *diag, *Eup, *Edw, *cross; const int32_t *mapup, *mapdw; int32_t impmask, nI; double econst;
     const double *v; double *out; const double *uprev; const double *scal;
     int32_t ld;              // row pitch of v / out / uprev in doubles (0: DimUp); the stored diagonal keeps pitch DimUp
+    const double *crowtab;   // DIRECT: [idw][nI] row constants (k_crow_table)
 };
 
 template <bool DIRECT, bool EPI, int NT>
@@ -263,7 +264,10 @@ __global__ void __launch_bounds__(NT) k_uppass(UpArgs A)
     const int DimUp = A.DimUp, tid = threadIdx.x;
     const int64_t ld = A.ld ? A.ld : DimUp;
     double *tv = lds + ((DimUp + 1) & ~1);
+    double *crow = tv + 128;                                      // DIRECT: see k_uppass2
+    uint8_t *imp8 = reinterpret_cast<uint8_t *>(crow + 32);
     for (int t = tid; t < A.nterms; t += NT) tv[t] = A.tval[t];
+    if (DIRECT) for (int t = tid; t < DimUp; t += NT) imp8[t] = (uint8_t)((uint32_t)A.mapup[t] & A.impmask);
     const int nq = (DimUp + NT - 1) / NT;
     const int ncw = (A.upw + 1) >> 1, ndw = (A.upw + 3) >> 2;
     // Two software pipelines.  Over rows: the NEXT row of v is requested into registers while
@@ -271,6 +275,8 @@ __global__ void __launch_bounds__(NT) k_uppass(UpArgs A)
     // diagonal, u_prev, packed hops) are requested before element q is computed.
     double xr[MAXQ];
     int64_t row = blockIdx.x;
+    double crn = 0.0;
+    if (DIRECT) crn = A.crowtab[(A.dw0 + (row < A.nrows ? row : 0) % A.Qdw) * A.nI + (tid < A.nI ? tid : 0)];
     if (row < A.nrows) {
 #pragma unroll
         for (int q = 0; q < MAXQ; q++) { const int i = tid + q * NT; xr[q] = (q < nq && i < DimUp) ? A.v[row * ld + i] : 0.0; }
@@ -279,9 +285,9 @@ __global__ void __launch_bounds__(NT) k_uppass(UpArgs A)
     if (EPI) { s_cur = A.scal[SC_SCUR]; c_prev = A.scal[SC_BETA] * A.scal[SC_SPREV]; }
     struct Ops { double d, u; uint32_t codes[MAXC], cols[2 * MAXC]; };
     while (row < A.nrows) {
-        const int64_t idwl = row % A.Qdw, idw = A.dw0 + idwl;
+        const int64_t idwl = row % A.Qdw;
         auto load_ops = [&](int i, Ops &o) {
-            if (!DIRECT) o.d = A.diag[idwl * DimUp + i];
+            o.d = DIRECT ? A.Eup[i] : A.diag[idwl * DimUp + i];
             if (EPI) o.u = A.uprev[row * ld + i];
 #pragma unroll
             for (int c = 0; c < MAXC; c++) if (c < ndw) o.codes[c] = A.pcodes[(int64_t)c * DimUp + i];
@@ -292,20 +298,18 @@ __global__ void __launch_bounds__(NT) k_uppass(UpArgs A)
         if (tid < DimUp) load_ops(tid, cur);
 #pragma unroll
         for (int q = 0; q < MAXQ; q++) { const int i = tid + q * NT; if (q < nq && i < DimUp) lds[i] = xr[q]; }
+        if (DIRECT && tid < A.nI) crow[tid] = crn;
         __syncthreads();
         const int64_t next = row + gridDim.x;
+        if (DIRECT) crn = A.crowtab[(A.dw0 + (next < A.nrows ? next : row) % A.Qdw) * A.nI + (tid < A.nI ? tid : 0)];
         if (next < A.nrows) {
 #pragma unroll
             for (int q = 0; q < MAXQ; q++) { const int i = tid + q * NT; if (q < nq && i < DimUp) xr[q] = A.v[next * ld + i]; }
         }
-        uint32_t mdw = 0; double edw = 0.0;
-        if (DIRECT) { mdw = (uint32_t)A.mapdw[idw] & A.impmask; edw = A.Edw[idw] + A.econst; }
         for (int i = tid; i < DimUp; i += NT) {
             if (i + NT < DimUp) load_ops(i + NT, nxt);
             const double x = lds[i];
-            double dval;
-            if (DIRECT) dval = edw + A.Eup[i] + A.cross[((uint32_t)A.mapup[i] & A.impmask) * A.nI + mdw];
-            else dval = cur.d;
+            const double dval = DIRECT ? cur.d + crow[imp8[i]] : cur.d;
             double acc = dval * x;
 #pragma unroll
             for (int c = 0; c < MAXC; c++)
@@ -615,7 +619,9 @@ __global__ void __launch_bounds__(NT) k_uppass_ax(UpAxArgs A)
     double *tv = lds + ((DimUp + 1) & ~1);
     double *red = tv + 128;
     double *crow = red + 32;
+    uint8_t *imp8 = reinterpret_cast<uint8_t *>(crow + 32);      // DIRECT: impurity word of every up configuration, staged once per launch
     for (int t = tid; t < A.nterms; t += NT) tv[t] = A.tval[t];
+    if (DIRECT) for (int t = tid; t < DimUp; t += NT) imp8[t] = (uint8_t)((uint32_t)A.mapup[t] & A.impmask);
     const int nq = (DimUp + NT - 1) / NT;
     const int ncw = (A.upw + 1) >> 1, ndw = (A.upw + 3) >> 2;
     const double c_ax = A.scal[SC_ALPHA] * A.scal[SC_SCUR];
@@ -623,13 +629,15 @@ __global__ void __launch_bounds__(NT) k_uppass_ax(UpAxArgs A)
     double bsum = 0.0;
     double xr[MAXQ];
     int64_t row = blockIdx.x;
+    double crn = 0.0;      // DIRECT: row constant of the row about to enter LDS (k_crow_table), requested a row ahead
+    if (DIRECT) crn = A.crowtab[(A.dw0 + (row < A.nrows ? row : 0) % A.Qdw) * A.nI + (tid < A.nI ? tid : 0)];
     if (row < A.nrows) {
 #pragma unroll
         for (int q = 0; q < MAXQ; q++) { const int i = tid + q * NT; xr[q] = (q < nq && i < DimUp) ? A.r[row * ld + i] : 0.0; }
     }
     struct Ops { double d; uint32_t codes[MAXC], cols[2 * MAXC]; };
     while (row < A.nrows) {
-        const int64_t idwl = row % A.Qdw, idw = A.dw0 + idwl;
+        const int64_t idwl = row % A.Qdw;
         auto load_ops = [&](int i, Ops &o) {
             o.d = DIRECT ? A.Eup[i] : A.diag[idwl * DimUp + i];
 #pragma unroll
@@ -649,9 +657,10 @@ __global__ void __launch_bounds__(NT) k_uppass_ax(UpAxArgs A)
                 if (ACC) A.acc[row * ld + i] += zk * u;
             }
         }
-        if (DIRECT && tid < A.nI) crow[tid] = A.Edw[idw] + A.econst + A.cross[tid * A.nI + ((uint32_t)A.mapdw[idw] & A.impmask)];
+        if (DIRECT && tid < A.nI) crow[tid] = crn;
         __syncthreads();
         const int64_t next = row + gridDim.x;
+        if (DIRECT) crn = A.crowtab[(A.dw0 + (next < A.nrows ? next : row) % A.Qdw) * A.nI + (tid < A.nI ? tid : 0)];
         if (next < A.nrows) {
 #pragma unroll
             for (int q = 0; q < MAXQ; q++) { const int i = tid + q * NT; if (q < nq && i < DimUp) xr[q] = A.r[next * ld + i]; }
@@ -659,7 +668,7 @@ __global__ void __launch_bounds__(NT) k_uppass_ax(UpAxArgs A)
         for (int i = tid; i < DimUp; i += NT) {
             if (i + NT < DimUp) load_ops(i + NT, nxt);
             const double x = lds[i];
-            const double dval = DIRECT ? cur.d + crow[(uint32_t)A.mapup[i] & A.impmask] : cur.d;
+            const double dval = DIRECT ? cur.d + crow[imp8[i]] : cur.d;
             double acc = dval * x;
 #pragma unroll
             for (int c = 0; c < MAXC; c++)

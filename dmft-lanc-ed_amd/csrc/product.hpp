@@ -526,7 +526,9 @@ static int hxv(S *s, const double *v, double *out, bool epi, const double *uprev
                 U.pcols = s->upf->pcols.p; U.pcodes = s->upf->pcodes.p; U.upw = s->upf->width; U.tval = s->upf->ptval.p; U.nterms = s->upf->pterms;
                 U.diag = A.diag; U.Eup = A.Eup; U.Edw = A.Edw; U.cross = A.cross; U.mapup = A.mapup; U.mapdw = A.mapdw; U.impmask = A.impmask; U.nI = A.nI; U.econst = A.econst;
                 U.v = v; U.out = out; U.uprev = uprev; U.scal = s->scal.p; U.ld = (int32_t)ld;
-                const size_t lds = (((size_t)H.DimUp + 1) & ~(size_t)1) * 8 + 128 * 8;
+                U.crowtab = direct ? s->crow_tab.p : nullptr;
+                if (direct && !U.crowtab) return fail(EDGPU_EINVAL, "edgpu: internal: row-constant table of the on-the-fly form missing");
+                const size_t lds = (((size_t)H.DimUp + 1) & ~(size_t)1) * 8 + 128 * 8 + (direct ? 32 * 8 + (((size_t)H.DimUp + 15) & ~(size_t)15) : 0);
                 const int grid = (int)std::min<int64_t>(U.nrows, s->up_grid);
 #define UP_LAUNCH(D_, E_, T_)                                                                                                   \
     do {                                                                                                                            \
