@@ -2574,8 +2574,9 @@ __global__ void __launch_bounds__(256) k_dvd_resid(DvdArgs A, double *__restrict
     const int64_t n2 = n >> 1;
     for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < n2; p += (int64_t)gridDim.x * blockDim.x) {
         dbl2_t r; r.x = 0.0; r.y = 0.0;
-#pragma unroll
+#pragma unroll 1      // unrolled over all 13 groups the compiler hoists every load of the element: 359 registers, one wave per SIMD
         for (int g = 0; g < kBasisGroups; g++) {
+            if (g * 4 >= nv) break;
             const int lim = (kMaxBasis + 1 - g * 4) < 4 ? (kMaxBasis + 1 - g * 4) : 4;
             if (lim == 4 && (g + 1) * 4 <= nv) {
                 dbl2_t wv[4], vv[4];
