@@ -16,7 +16,8 @@ namespace edgpu {
 constexpr int kMaxTerms = 256;
 
 // scalars of the Lanczos recurrence, resident in HBM so the loop needs no host round trip
-enum { SC_SCUR = 0, SC_SPREV = 1, SC_BETA = 2, SC_ALPHA = 3, SC_TMP = 4, SC_ZK = 5, SC_K = 6, SC_COUNT = 8 };   // SC_K: iteration counter kept on the device (fused reduce+step kernels)
+enum { SC_SCUR = 0, SC_SPREV = 1, SC_BETA = 2, SC_ALPHA = 3, SC_TMP = 4, SC_ZK = 5, SC_K = 6,
+       SC_NPEND = 7, SC_SV_SCUR = 8, SC_SV_BETA = 9, SC_PAIR = 10 /* and 11 */, SC_COUNT = 16 };      // 7-11: deferred-norm form of the loop for several ranks (one all-reduce per iteration)   // SC_K: iteration counter kept on the device (fused reduce+step kernels)
 
 struct DiagArgs {  // bit-exact diagonal (stored/H_local.f90:13-71, stored/Orbs/H_local.f90:1-80)
     int32_t Norb, Nspin, Nbath, Nfoo, hfmode, total_ud, Ns_Ud;
@@ -2074,6 +2075,45 @@ __global__ void __launch_bounds__(256) k_axpy_norm(double *__restrict__ w, const
     if (threadIdx.x == 0) partial[blockIdx.x] = r;
 }
 
+// Deferred-norm form (several ranks, one all-reduce per iteration): w holds H u_k of the UNNORMALISED u_k, the scales are known
+// only now:  r_k = s_cur*w - alpha*s_cur*u - beta*s_prev*u_prev  (in place over w), partial |r_k|^2, optionally acc += zk*s_cur*u.
+__global__ void __launch_bounds__(256) k_axpy3_norm(double *__restrict__ w, const double *__restrict__ u, const double *__restrict__ up, double *__restrict__ acc,
+                                                    const double *__restrict__ scal, int64_t n, double *__restrict__ partial)
+{
+    __shared__ double red[4];
+    const double s_cur = scal[SC_SCUR], as = scal[SC_ALPHA] * scal[SC_SCUR], cp = scal[SC_BETA] * scal[SC_SPREV], zk = scal[SC_ZK];
+    double s = 0.0;
+    const int64_t n2 = n >> 1;
+    dbl2v *w2 = reinterpret_cast<dbl2v *>(w); const dbl2v *u2 = reinterpret_cast<const dbl2v *>(u), *p2 = reinterpret_cast<const dbl2v *>(up); dbl2v *a2 = reinterpret_cast<dbl2v *>(acc);
+    const int64_t per = (n2 + gridDim.x - 1) / gridDim.x, stride = blockDim.x;      // one contiguous piece per workgroup, as k_axpy_norm
+    const int64_t n2b = (int64_t)(blockIdx.x + 1) * per < n2 ? (int64_t)(blockIdx.x + 1) * per : n2;
+    int64_t i = (int64_t)blockIdx.x * per + threadIdx.x;
+    for (; i + stride < n2b; i += 2 * stride) {
+        dbl2v uu[2], ww[2], pp[2];
+#pragma unroll
+        for (int q = 0; q < 2; q++) { uu[q] = u2[i + q * stride]; ww[q] = w2[i + q * stride]; pp[q] = p2[i + q * stride]; }
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            const dbl2v wi = s_cur * ww[q] - as * uu[q] - cp * pp[q];
+            w2[i + q * stride] = wi; s += wi.x * wi.x + wi.y * wi.y;
+            if (acc) a2[i + q * stride] += (zk * s_cur) * uu[q];
+        }
+    }
+    for (; i < n2b; i += stride) {
+        const dbl2v uu = u2[i];
+        const dbl2v wi = s_cur * w2[i] - as * uu - cp * p2[i];
+        w2[i] = wi; s += wi.x * wi.x + wi.y * wi.y;
+        if (acc) a2[i] += (zk * s_cur) * uu;
+    }
+    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+        const double uu = u[n - 1], wi = s_cur * w[n - 1] - as * uu - cp * up[n - 1];
+        w[n - 1] = wi; s += wi * wi;
+        if (acc) acc[n - 1] += zk * s_cur * uu;
+    }
+    double r = block_sum(s, red);
+    if (threadIdx.x == 0) partial[blockIdx.x] = r;
+}
+
 // scalar bookkeeping, one thread.  mode 0: alpha = TMP ; store alphas[k].
 // mode 1: beta = sqrt(TMP) ; store betas[k+1] ; rotate scales (s_prev=s_cur, s_cur=1/beta).
 // mode 2: start: s_cur = 1/sqrt(TMP), s_prev = 0, beta = 0.   mode 3: ZK = zvec[k].
@@ -2101,6 +2141,21 @@ __device__ __forceinline__ void scalar_step(double *scal, double *alphas, double
     // TMP = its new |.|^2; beta and the scale follow, the previous scale stays (mode 4 would rotate it a second time)
     else if (mode == 8) { const double b = sqrt(scal[SC_TMP]); if (k > 0) betas[k] = b; scal[SC_BETA] = k > 0 ? b : 0.0; scal[SC_SCUR] = b > 0.0 ? 1.0 / b : 0.0; }
     else if (mode == 9) { scal[SC_ALPHA] = 0.0; }      // before such a redo: u = r - alpha*s*u_prev must leave r as it is
+    // Several ranks, ONE all-reduce per iteration (lz_iter_deferred): the norm of the newest vector u_k = r_{k-1} stays a per-rank
+    // partial sum (NPEND) and travels together with the next product's u_k.H u_k.
+    // 10: before that product -- it runs on the unnormalised u_k with neutral scales (w = H u_k, TMP = u_k.H u_k)
+    else if (mode == 10) { scal[SC_SV_SCUR] = scal[SC_SCUR]; scal[SC_SV_BETA] = scal[SC_BETA]; scal[SC_SCUR] = 1.0; scal[SC_BETA] = 0.0; }
+    // 13: the two partial sums side by side for the 16-byte all-reduce
+    else if (mode == 13) { scal[SC_PAIR] = scal[SC_TMP]; scal[SC_PAIR + 1] = scal[SC_NPEND]; }
+    // 11: after it -- beta_k = |u_k|, the scales rotate, alpha_k = (u_k.H u_k) / |u_k|^2
+    else if (mode == 11) {
+        const double b = sqrt(scal[SC_PAIR + 1]), sn = b > 0.0 ? 1.0 / b : 0.0;
+        betas[k] = b; scal[SC_SPREV] = scal[SC_SV_SCUR]; scal[SC_SCUR] = sn; scal[SC_BETA] = b;
+        scal[SC_ALPHA] = scal[SC_PAIR] * sn * sn; alphas[k] = scal[SC_ALPHA];
+        scal[SC_ZK] = zvec ? zvec[k] : 0.0;
+    }
+    // 12: flush -- NPEND (summed over ranks) is the norm of the vector iteration k left behind: what mode 1 does with TMP
+    else if (mode == 12) { const double b = sqrt(scal[SC_NPEND]); betas[k + 1] = b; scal[SC_BETA] = b; scal[SC_SPREV] = scal[SC_SCUR]; scal[SC_SCUR] = b > 0.0 ? 1.0 / b : 0.0; scal[SC_K] = (double)(k + 1); }
 }
 __global__ void k_scalar_step(double *scal, double *alphas, double *betas, const double *zvec, int k, int mode)
 {

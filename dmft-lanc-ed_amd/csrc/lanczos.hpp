@@ -101,6 +101,7 @@ struct LzVecs { double *uprev, *ucur, *w; };
 // start: ucur holds the (unnormalised) start vector
 static int lz_start(S *s, LzVecs &V)
 {
+    s->npend = false;
     HIPCHK(hipMemsetAsync(V.uprev, 0, (size_t)s->vlen * 8, s->stream));
     CHK(reduce_dot(s, V.ucur, V.ucur, s->vlen));
     hipLaunchKernelGGL(k_scalar_step, dim3(1), dim3(1), 0, s->stream, s->scal.p, s->alphas.p, s->betas.p, (const double *)nullptr, 0, 2);
@@ -130,8 +131,59 @@ static int lz_iter_tail(S *s, LzVecs &V, int k, double *acc, bool alpha_done = f
     double *t = V.uprev; V.uprev = V.ucur; V.ucur = V.w; V.w = t;
     return EDGPU_OK;
 }
+// Several ranks, one all-reduce per iteration (EDGPU_ONE_ALLREDUCE=1; the plain loops switch it on around their iterations).
+// alpha_k needs the finished product and beta_k the vector after the alpha update, so the two sums cannot be taken together as
+// they stand.  Here the norm of the newest vector stays a per-rank partial sum: the next product runs on the unnormalised vector
+// with neutral scales, its dot u_k.H u_k and the pending |u_k|^2 are summed in ONE 16-byte all-reduce, the scales follow, and a
+// three-vector pass forms r_k = s w - alpha s u_k - beta s_prev u_{k-1} (and the next pending norm).  Same traffic as the
+// two-all-reduce form (the u_prev stream moves from the product's epilogue to the update pass), alpha in the v.Hv form
+// (without the -beta v.v_prev term, which is rounding noise), beta_k known one product later: callers that look at beta on the host
+// either test it one iteration late (lanczos_gs) or flush the pending norm first (lz_flush).
+static int lz_iter_deferred(S *s, LzVecs &V, int k, double *acc)
+{
+    const int nb = (int)std::max<int64_t>(1, std::min<int64_t>(cdiv(s->vlen, 256 * 4), (int64_t)s->axpy_nb));
+    if (!s->npend) {      // scales known (first iteration, or after a flush): product with its epilogue, alpha summed by itself
+        CHK(hxv(s, V.ucur, V.w, true, V.uprev, s->vld));
+        hipLaunchKernelGGL(k_scalar_step, dim3(1), dim3(1), 0, s->stream, s->scal.p, s->alphas.p, s->betas.p, (const double *)nullptr, k, 0);
+        if (acc) hipLaunchKernelGGL(k_scalar_step, dim3(1), dim3(1), 0, s->stream, s->scal.p, s->alphas.p, s->betas.p, (const double *)s->zvec.p, k, 3);
+        hipLaunchKernelGGL(k_axpy_norm, dim3(nb), dim3(256), 0, s->stream, V.w, V.ucur, acc, s->scal.p, s->vlen, s->partial.p);
+    } else {
+        hipLaunchKernelGGL(k_scalar_step, dim3(1), dim3(1), 0, s->stream, s->scal.p, s->alphas.p, s->betas.p, (const double *)nullptr, k, 10);
+        HIPCHK(hipGetLastError());
+        s->defer_ar = true;
+        const int rc = hxv(s, V.ucur, V.w, true, V.uprev, s->vld);
+        s->defer_ar = false;
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_scalar_step, dim3(1), dim3(1), 0, s->stream, s->scal.p, s->alphas.p, s->betas.p, (const double *)nullptr, k, 13);
+        HIPCHK(hipGetLastError());
+        CHK(allreduce_dev(s, s->scal.p + SC_PAIR, 2));
+        hipLaunchKernelGGL(k_scalar_step, dim3(1), dim3(1), 0, s->stream, s->scal.p, s->alphas.p, s->betas.p, (const double *)(acc ? s->zvec.p : nullptr), k, 11);
+        hipLaunchKernelGGL(k_axpy3_norm, dim3(nb), dim3(256), 0, s->stream, V.w, V.ucur, V.uprev, acc, s->scal.p, s->vlen, s->partial.p);
+    }
+    hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(1024), 0, s->stream, s->partial.p, (int64_t)nb, s->scal.p + SC_NPEND);
+    HIPCHK(hipGetLastError());
+    s->npend = true; s->npend_k = k;
+    double *t = V.uprev; V.uprev = V.ucur; V.ucur = V.w; V.w = t;
+    return EDGPU_OK;
+}
+// the pending norm becomes beta (and the scales rotate) now: one 8-byte all-reduce
+static int lz_flush(S *s)
+{
+    if (!s->npend) return EDGPU_OK;
+    CHK(allreduce_dev(s, s->scal.p + SC_NPEND, 1));
+    hipLaunchKernelGGL(k_scalar_step, dim3(1), dim3(1), 0, s->stream, s->scal.p, s->alphas.p, s->betas.p, (const double *)nullptr, s->npend_k, 12);
+    HIPCHK(hipGetLastError());
+    s->npend = false;
+    return EDGPU_OK;
+}
+struct OneArScope {      // the deferred form is on between construction and destruction of this object (every return path of the loops)
+    S *s; bool was;
+    explicit OneArScope(S *s_) : s(s_), was(s_->one_ar_on) { s->one_ar_on = s->multi && s->one_ar; s->npend = false; }
+    ~OneArScope() { s->one_ar_on = was; s->npend = false; }
+};
 static int lz_iter(S *s, LzVecs &V, int k, double *acc)
 {
+    if (s->multi && s->one_ar_on) return lz_iter_deferred(s, V, k, acc);
     if (!s->multi) {   // alpha step rides on the product's final reduction (device counter == k by construction)
         s->fuse_mode = 0; s->fuse_zvec = acc ? s->zvec.p : nullptr;
         int rc = hxv(s, V.ucur, V.w, true, V.uprev, s->vld);
@@ -222,6 +274,7 @@ static int lanczos_gs_impl(S *s, int nitermax, double threshold, int ncheck, dou
     if (ncheck < 1) ncheck = 10;
     if ((int64_t)nitermax > s->H.Dim) nitermax = (int)s->H.Dim;   // ED_DIAG.f90:100 Nitermax=min(dim,lanc_niter)
     CHK(lz_prepare(s, nitermax));
+    OneArScope one_ar_scope(s);
     const bool fused = fused_ok(s);
     const int64_t vlen = s->vlen;      // length of a work vector (row pitch padded to the 128-B line where the product kernels take one)
     if (s->lz[3].n != (size_t)s->nloc) CHK(s->lz[3].alloc((size_t)s->nloc));
@@ -327,6 +380,9 @@ static int lanczos_gs_impl(S *s, int nitermax, double threshold, int ncheck, dou
         CHK(fetch_coeffs(s, kend - 1, al, be));
         for (; k < kend; k++) {
             nlanc = k + 1;
+            if (s->one_ar_on) {       // beta_{k+1} is still a pending partial sum: the invariant-subspace test looks at beta_k, one product late
+                if (k > 0 && std::fabs(be[k]) < threshold) { nlanc = k; done = true; break; }
+            } else
             if (std::fabs(be[k + 1]) < threshold) { done = true; break; }       // invariant subspace reached
             if (!tridiag_lowest(al.data(), be.data(), nlanc, &e0, nullptr)) return fail(EDGPU_ENOTCONVERGED, "edgpu: tridiagonal QL did not converge");
             if (nlanc >= ncheck && std::fabs(e0 - esave) <= threshold) { done = true; break; }
@@ -391,6 +447,7 @@ static int lanczos_tridiag(S *s, const double *vin_dev, int nlanc, double thresh
 {
     if (nlanc < 1) return fail(EDGPU_EINVAL, "edgpu_lanczos_tridiag: nlanc < 1");
     CHK(lz_prepare(s, nlanc));
+    OneArScope one_ar_scope(s);
     const bool fused = fused_ok(s);
     LzVecs V{s->lz[0].p, s->lz[1].p, s->lz[2].p};
     LzF F{s->lz[0].p, s->lz[2].p, s->lz[1].p};
@@ -412,6 +469,7 @@ static int lanczos_tridiag(S *s, const double *vin_dev, int nlanc, double thresh
         if (fused) { for (int j = k; j < kend; j++) CHK(lzf_iter(s, F, F.uprev, nullptr)); }
         else CHK(lz_iters(s, V, k, kend - k, nullptr));
         k = kend;
+        CHK(lz_flush(s));      // deferred-norm form: the last beta of the chunk
         CHK(fetch_coeffs(s, k - 1, al, be));
         bool stop = false;
         for (int i = used; i < k; i++) {

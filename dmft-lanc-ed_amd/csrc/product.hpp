@@ -665,7 +665,7 @@ static int hxv(S *s, const double *v, double *out, bool epi, const double *uprev
     }
     if (epi) {
         CHK(reduce_partials(s, nblocks));
-        CHK(allreduce_tmp(s));
+        if (!s->defer_ar) CHK(allreduce_tmp(s));      // deferred-norm loop: the caller sums this together with the pending norm
     }
     return EDGPU_OK;
 }

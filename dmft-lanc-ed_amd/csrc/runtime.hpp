@@ -262,6 +262,8 @@ struct edgpu_sector_s {
     int dw_first = 0;         // rows beyond LDS, one rank: dw pass first as a write-only pass (1: plain stores, 2: write-through), local pass adds + epilogue; 0 (default): local pass first -- the write-only form cuts the dw pass's reads by 30 % but the local pass pays them back (profiles/r03/ns18_product_variants.txt)
     int eig_ncv_used = 0;     // basis size the last edgpu_eigsh call actually ran with
     // Lanczos iteration fusion (single rank)
+    // several ranks: one 16-byte all-reduce per Lanczos iteration instead of two of 8 bytes (EDGPU_ONE_ALLREDUCE=1; lz_iter_deferred)
+    bool one_ar = false, one_ar_on = false, npend = false, defer_ar = false; int npend_k = 0;
     int fuse_mode = -1; const double *fuse_zvec = nullptr;   // >= 0: the product's final reduction also performs this scalar step
     edgpu_sector_s() = default;
     edgpu_sector_s(const edgpu_sector_s &) = delete;

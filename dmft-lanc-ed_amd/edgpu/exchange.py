@@ -25,6 +25,7 @@ class StagedExchange:
 
     def __init__(self, dist, d2h=_host_copy, h2d=_host_copy, group=None):
         self.dist, self.d2h, self.h2d, self.group = dist, d2h, h2d, group
+        self.n_allreduce = 0; self.n_allreduce_doubles = 0      # call counters (tests: collectives per Lanczos iteration)
 
     def allgatherv(self, send_ptr, nsend, recv_ptr, counts, displs):
         import torch
@@ -67,6 +68,7 @@ class StagedExchange:
 
     def allreduce(self, arr):
         import torch
+        self.n_allreduce += 1; self.n_allreduce_doubles += len(arr)
         t = torch.from_numpy(np.array(arr, np.float64))
         self.dist.all_reduce(t, group=self.group)
         arr[:] = t.numpy()

@@ -253,8 +253,10 @@ def main():
             v0 = local_slice(np.random.RandomState(5).uniform(0, 1, S.Dim))
             e0, x, nl = G.sp_lanc_eigh(v0, nitermax=min(300, S.Dim), threshold=1e-14)
             res["e0_" + st] = e0
+            n0 = ex.n_allreduce
             a, b, used = G.sp_lanc_tridiag(v0, 20)
             res["a_" + st] = a.tolist(); res["b_" + st] = b.tolist()
+            res["allreduce_calls_tridiag20_" + st] = ex.n_allreduce - n0
             if os.environ.get("EDGPU_RELAY"):
                 ri = G.relay_info()
                 res["relay_" + st] = dict(enabled=ri["enabled"], chunks=ri["chunks"], before=ri["busiest_before"], after=ri["busiest_after"],

@@ -132,6 +132,38 @@ def test_multirank_distributed_transpose(edgpu_mod, case, size, env):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("case,size,env", [("c_nb7_half", 2, {}), ("nb5_offhalf_2_4", 3, {"EDGPU_KRON_SPLIT": "1", "EDGPU_CSR_SPLIT": "1"}),
+                                           ("norb2_normal_JxJp", 2, {}), ("phonons_nb3_nph3", 2, {}), ("orbs_norb2_nb3", 2, {})])
+def test_multirank_one_allreduce_per_iteration(edgpu_mod, case, size, env):
+    """EDGPU_ONE_ALLREDUCE=1: the plain Lanczos loops of several ranks carry the norm of the newest vector as a per-rank partial
+    sum and add it to the next product's dot in one 16-byte all-reduce (lz_iter_deferred).  Same ground-state energy as the dense
+    matrix (the invariant-subspace test looks one product late), same tridiagonal coefficients as a single rank, and about half
+    the all-reduce calls of the two-call form for a 20-step tridiagonalisation."""
+    import cases
+    from oracle import oracle
+    res1 = _launch("gpu", case, size, extra_env=dict({"EDGPU_ONE_ALLREDUCE": "1"}, **env))
+    res0 = _launch("gpu", case, size, extra_env=dict(env))
+    name, m, nu, nd = [z for z in cases.zoo() if z[0] == case][0]
+    S = oracle.Sector(m, nu, nd)
+    e_dense = np.linalg.eigvalsh(S.hmat())[0]
+    G = edgpu_mod.HvSector(m, nu, nd)
+    a1, b1, _ = G.sp_lanc_tridiag(np.random.RandomState(5).uniform(0, 1, S.Dim), 20)
+    G.close()
+    for r1, r0 in zip(res1, res0):
+        for k, v in r1.items():
+            if k.startswith("e0_"):
+                assert abs(v - e_dense) < 1e-10, (k, v, e_dense)
+            if k.startswith("a_"):
+                np.testing.assert_allclose(v, a1, rtol=1e-9, atol=1e-9)
+            if k.startswith("b_"):
+                np.testing.assert_allclose(v, b1, rtol=1e-9, atol=1e-9)
+            if k.startswith("allreduce_calls_tridiag20_"):
+                n20 = min(20, S.Dim)
+                assert r0[k] >= 2 * n20 and v <= r0[k] - n20 // 2 - 2, (k, v, r0[k])      # 1 start + 20 x 2 against 1 start + (7 merged + 1 + 1 flush) per chunk of 8
+                print(case, size, k, "all-reduce calls", r0[k], "->", v)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("case,size,env", [("c_nb7_half", 3, {}), ("c_nb7_half", 4, {}), ("nb5_offhalf_2_4", 4, {"EDGPU_KRON_SPLIT": "1", "EDGPU_CSR_SPLIT": "1"}),
                                            ("norb2_normal_JxJp", 3, {}), ("nb6_even", 5, {})])
 def test_multirank_relay_routing(edgpu_mod, case, size, env):
