@@ -165,7 +165,8 @@ def test_multirank_one_allreduce_per_iteration(edgpu_mod, case, size, env):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("case,size,env", [("c_nb7_half", 3, {}), ("c_nb7_half", 4, {}), ("nb5_offhalf_2_4", 4, {"EDGPU_KRON_SPLIT": "1", "EDGPU_CSR_SPLIT": "1"}),
-                                           ("norb2_normal_JxJp", 3, {}), ("nb6_even", 5, {})])
+                                           ("norb2_normal_JxJp", 3, {}), ("nb6_even", 5, {}),
+                                           ("c_nb7_half", 4, {"EDGPU_ONE_ALLREDUCE": "1", "EDGPU_KRON_SPLIT": "1", "EDGPU_CSR_SPLIT": "1"})])      # all opt-in forms together, pitched CSR rows
 def test_multirank_relay_routing(edgpu_mod, case, size, env):
     """EDGPU_RELAY=1: the needed-rows exchange in two phases with the heavy pairs handing part of their rows to a third rank
     (relay_plan).  The x-space a rank ends up with is the same, so everything downstream is: dense ground-state energy, the
