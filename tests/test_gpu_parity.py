@@ -254,7 +254,7 @@ def test_device_pointer_path_and_errors(edgpu_mod):
     G.close()
 
 
-FORCED = [z for z in ZOO if z[0] in ("orbs_norb2_nb3", "orbs_norb2_nb4", "phonons_orbs", "c_nb7_half", "nb5_offhalf_2_4", "nb6_even", "nspin2_random_bath", "norb2_normal_offdiag_hloc", "c_nb5_half",
+FORCED = [z for z in ZOO if z[0] in ("orbs_norb2_nb3", "phonons_orbs", "c_nb7_half", "nb5_offhalf_2_4", "nb6_even", "nspin2_random_bath", "norb2_normal_offdiag_hloc", "c_nb5_half",
                                     "norb2_normal_JxJp", "norb2_hybrid_JxJp", "replica_sz_sx_JxJp", "norb3_nb1_JxJp")]   # Jx/Jp: the non-local pass
 
 

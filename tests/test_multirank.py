@@ -133,7 +133,7 @@ def test_multirank_distributed_transpose(edgpu_mod, case, size, env):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("case,size,env", [("c_nb7_half", 2, {}), ("nb5_offhalf_2_4", 3, {"EDGPU_KRON_SPLIT": "1", "EDGPU_CSR_SPLIT": "1"}),
-                                           ("norb2_normal_JxJp", 2, {}), ("phonons_nb3_nph3", 2, {}), ("orbs_norb2_nb3", 2, {})])
+                                           ("norb2_normal_JxJp", 2, {}), ("phonons_orbs", 2, {})])
 def test_multirank_one_allreduce_per_iteration(edgpu_mod, case, size, env):
     """EDGPU_ONE_ALLREDUCE=1: the plain Lanczos loops of several ranks carry the norm of the newest vector as a per-rank partial
     sum and add it to the next product's dot in one 16-byte all-reduce (lz_iter_deferred).  Same ground-state energy as the dense
