@@ -347,7 +347,10 @@ struct UpArgs2 {
     const double *crowtab;   // DIRECT: [idw][nI] row constants (k_crow_table)
 };
 
-template <bool DIRECT, bool EPI, int NT>
+// NH: hop slots per up configuration.  8: the 6-dword element image (3 x 16 bytes per pair); 10: the 8-dword image pelem8 (4 x 16 bytes
+// per pair) -- sectors one or two electrons off half filling (9-10 up hops: the Green's-function target sectors), which otherwise
+// fall to the one-configuration-per-lane kernel with its 12-dword image.
+template <bool DIRECT, bool EPI, int NT, int NH = 8>
 __global__ void __launch_bounds__(NT) k_uppass2(UpArgs2 A)
 {
     extern __shared__ double lds[];
@@ -374,14 +377,15 @@ __global__ void __launch_bounds__(NT) k_uppass2(UpArgs2 A)
     }
     double s_cur = 1.0, c_prev = 0.0;
     if (EPI) { s_cur = A.scal[SC_SCUR]; c_prev = A.scal[SC_BETA] * A.scal[SC_SPREV]; }
-    struct Ops { dbl2v d, u; uint4 w0, w1, w2; };
+    struct Ops { dbl2v d, u; uint4 w0, w1, w2, w3; };
     while (row < A.nrows) {
         const int64_t idwl = row % A.Qdw;
         auto load_ops = [&](int p, Ops &o) {
             if (!DIRECT) o.d = *reinterpret_cast<const dbl2v *>(A.diag + idwl * DimUp + 2 * p);
             else o.d = *reinterpret_cast<const dbl2v *>(A.Eup + 2 * p);
             if (EPI) o.u = *reinterpret_cast<const dbl2v *>(A.uprev + row * ld + 2 * p);
-            o.w0 = A.packed[3 * p]; o.w1 = A.packed[3 * p + 1]; o.w2 = A.packed[3 * p + 2];
+            if (NH == 8) { o.w0 = A.packed[3 * p]; o.w1 = A.packed[3 * p + 1]; o.w2 = A.packed[3 * p + 2]; }
+            else { o.w0 = A.packed[4 * p]; o.w1 = A.packed[4 * p + 1]; o.w2 = A.packed[4 * p + 2]; o.w3 = A.packed[4 * p + 3]; }
         };
         Ops cur, nxt;
         if (tid < npair) load_ops(tid, cur);
@@ -404,12 +408,14 @@ __global__ void __launch_bounds__(NT) k_uppass2(UpArgs2 A)
                 dval.x = cur.d.x + crow[im & 0xffu];
                 dval.y = cur.d.y + crow[im >> 8];
             } else dval = cur.d;
-            // element 0 of the pair: dwords w0.x w0.y w0.z w0.w (cols) w1.x w1.y (codes); element 1: w1.z w1.w w2.x w2.y, w2.z w2.w
-            const uint32_t c0[4] = {cur.w0.x, cur.w0.y, cur.w0.z, cur.w0.w}, k0[2] = {cur.w1.x, cur.w1.y};
-            const uint32_t c1[4] = {cur.w1.z, cur.w1.w, cur.w2.x, cur.w2.y}, k1[2] = {cur.w2.z, cur.w2.w};
+            // NH = 8: element 0 of the pair: dwords w0.x w0.y w0.z w0.w (cols) w1.x w1.y (codes); element 1: w1.z w1.w w2.x w2.y, w2.z w2.w
+            // NH = 10: element 0 = (w0, w1), element 1 = (w2, w3): five dwords of columns, three of codes each
+            const uint32_t c0[5] = {cur.w0.x, cur.w0.y, cur.w0.z, cur.w0.w, NH == 8 ? 0u : cur.w1.x}, k0[3] = {NH == 8 ? cur.w1.x : cur.w1.y, NH == 8 ? cur.w1.y : cur.w1.z, NH == 8 ? 0u : cur.w1.w};
+            const uint32_t c1[5] = {NH == 8 ? cur.w1.z : cur.w2.x, NH == 8 ? cur.w1.w : cur.w2.y, NH == 8 ? cur.w2.x : cur.w2.z, NH == 8 ? cur.w2.y : cur.w2.w, NH == 8 ? 0u : cur.w3.x},
+                           k1[3] = {NH == 8 ? cur.w2.z : cur.w3.y, NH == 8 ? cur.w2.w : cur.w3.z, NH == 8 ? 0u : cur.w3.w};
             double a0 = dval.x * x.x, a1 = dval.y * x.y;
 #pragma unroll
-            for (int e = 0; e < 8; e++) {
+            for (int e = 0; e < NH; e++) {
                 const uint32_t code0 = (k0[e >> 2] >> (8 * (e & 3))) & 0xffu, col0 = (c0[e >> 1] >> (16 * (e & 1))) & 0xffffu;
                 const uint32_t code1 = (k1[e >> 2] >> (8 * (e & 3))) & 0xffu, col1 = (c1[e >> 1] >> (16 * (e & 1))) & 0xffffu;
                 double t0 = tv[code0 & 0x7fu], t1 = tv[code1 & 0x7fu];
@@ -450,7 +456,7 @@ struct UpAxArgs {
     const double *crowtab;   // DIRECT: [idw][nI] row constants (k_crow_table)
 };
 
-template <bool DIRECT, bool ACC, int NT>
+template <bool DIRECT, bool ACC, int NT, int NH = 8>      // NH: hop slots per up configuration, as k_uppass2
 __global__ void __launch_bounds__(NT) k_uppass2_ax(UpAxArgs A)
 {
     extern __shared__ double lds[];
@@ -491,7 +497,7 @@ __global__ void __launch_bounds__(NT) k_uppass2_ax(UpAxArgs A)
     // The operands of step q+1 of the hop loop are loaded during step q: the H_up image and diagonal of pair q+1 of this row
     // AND pair q+1 of the NEXT row's r and vprev, which step q+1 turns into u (registers, one pair per step) -- the next row
     // is complete when this one is, with 8 staging registers instead of a second row-sized register array.
-    struct Ops { dbl2v d, nr, nv; uint4 w0, w1, w2; };      // d: stored diagonal (KRON) or Eup (DIRECT)
+    struct Ops { dbl2v d, nr, nv; uint4 w0, w1, w2, w3; };      // d: stored diagonal (KRON) or Eup (DIRECT); w3: NH = 10 only
     while (row < A.nrows) {
         const int64_t idwl = row % A.Qdw, idw = A.dw0 + idwl;
         const int64_t next = row + gridDim.x; const bool more = next < A.nrows;
@@ -506,7 +512,8 @@ __global__ void __launch_bounds__(NT) k_uppass2_ax(UpAxArgs A)
             if (STRAIGHT) p = p < npair ? p : pmax;
             if (!DIRECT) o.d = *reinterpret_cast<const dbl2v *>(A.diag + idwl * DimUp + 2 * p);
             else o.d = *reinterpret_cast<const dbl2v *>(A.Eup + 2 * p);
-            o.w0 = A.packed[3 * p]; o.w1 = A.packed[3 * p + 1]; o.w2 = A.packed[3 * p + 2];
+            if (NH == 8) { o.w0 = A.packed[3 * p]; o.w1 = A.packed[3 * p + 1]; o.w2 = A.packed[3 * p + 2]; }
+            else { o.w0 = A.packed[4 * p]; o.w1 = A.packed[4 * p + 1]; o.w2 = A.packed[4 * p + 2]; o.w3 = A.packed[4 * p + 3]; }
             if (STRAIGHT || more) { o.nr = *reinterpret_cast<const dbl2v *>(A.r + nrow * ld + 2 * p); o.nv = *reinterpret_cast<const dbl2v *>(A.vprev + nrow * ld + 2 * p); }
         };
         Ops cur, nxt;
@@ -531,11 +538,12 @@ __global__ void __launch_bounds__(NT) k_uppass2_ax(UpAxArgs A)
                     dval.x = cur.d.x + crow[im & 0xffu];
                     dval.y = cur.d.y + crow[im >> 8];
                 } else dval = cur.d;
-                const uint32_t c0[4] = {cur.w0.x, cur.w0.y, cur.w0.z, cur.w0.w}, k0[2] = {cur.w1.x, cur.w1.y};
-                const uint32_t c1[4] = {cur.w1.z, cur.w1.w, cur.w2.x, cur.w2.y}, k1[2] = {cur.w2.z, cur.w2.w};
+                const uint32_t c0[5] = {cur.w0.x, cur.w0.y, cur.w0.z, cur.w0.w, NH == 8 ? 0u : cur.w1.x}, k0[3] = {NH == 8 ? cur.w1.x : cur.w1.y, NH == 8 ? cur.w1.y : cur.w1.z, NH == 8 ? 0u : cur.w1.w};
+                const uint32_t c1[5] = {NH == 8 ? cur.w1.z : cur.w2.x, NH == 8 ? cur.w1.w : cur.w2.y, NH == 8 ? cur.w2.x : cur.w2.z, NH == 8 ? cur.w2.y : cur.w2.w, NH == 8 ? 0u : cur.w3.x},
+                               k1[3] = {NH == 8 ? cur.w2.z : cur.w3.y, NH == 8 ? cur.w2.w : cur.w3.z, NH == 8 ? 0u : cur.w3.w};
                 double a0 = dval.x * x.x, a1 = dval.y * x.y;
 #pragma unroll
-                for (int e = 0; e < 8; e++) {
+                for (int e = 0; e < NH; e++) {
                     const uint32_t code0 = (k0[e >> 2] >> (8 * (e & 3))) & 0xffu, col0 = (c0[e >> 1] >> (16 * (e & 1))) & 0xffffu;
                     const uint32_t code1 = (k1[e >> 2] >> (8 * (e & 3))) & 0xffu, col1 = (c1[e >> 1] >> (16 * (e & 1))) & 0xffffu;
                     double t0 = tv[code0 & 0x7fu], t1 = tv[code1 & 0x7fu];

@@ -219,12 +219,14 @@ static bool pitch_ok(const S *s)
     const bool halo = !s->use_lds && s->upf->seg_ok && s->up_halo && !s->extra;
     return persistent || halo;
 }
-// which local-half kernel the fused iteration uses: 2 = pair form (<= 8 hops per up configuration), 1 = one configuration per
-// lane (<= 16 hops), 0 = none (rows beyond LDS, wider factors)
+// which local-half kernel the fused iteration uses: 2 = pair form (<= 8 hops per up configuration), 3 = pair form with 10 hop
+// slots (9-10 hops: one or two electrons off half filling), 1 = one configuration per lane (<= 16 hops), 0 = none (rows beyond
+// LDS, wider factors)
 static int fused_form(const S *s)
 {
     if (!s->upf || !s->up_persistent || !s->use_lds || s->H.DimUp > 13312) return 0;
     if (s->up_pairs && s->upf->packed_elem && s->upf->width <= 8) return 2;
+    if (s->up_pairs && s->up_pairs10 && s->upf->packed_elem8 && s->upf->width <= 10 && s->H.DimUp % 2 == 0) return 3;      // pair form with 10 hop slots (8-dword element image)
     return (s->upf->packed && s->upf->width <= 16) ? 1 : 0;
 }
 static bool fused_ok(const S *s)
@@ -246,7 +248,7 @@ static int fused_local(S *s, double *r, const double *uprev, double *t, double *
     if (direct) CHK(direct_tables(s));
     UpAxArgs U{};
     U.DimUp = (int32_t)H.DimUp; U.DimPh = H.DimPh; U.Qdw = H.Qdw; U.dw0 = H.dw0; U.nrows = H.Qdw * H.DimPh;
-    U.packed = reinterpret_cast<const uint4 *>(s->upf->pelem.p); U.tval = s->upf->ptval.p; U.nterms = s->upf->pterms;
+    U.packed = reinterpret_cast<const uint4 *>(fused_form(s) == 3 ? s->upf->pelem8.p : s->upf->pelem.p); U.tval = s->upf->ptval.p; U.nterms = s->upf->pterms;
     U.diag = s->diag.p; U.Eup = s->upf->E.p; U.Edw = s->dwf->E.p; U.cross = s->cross.p; U.mapup = s->upf->map.p; U.mapdw = s->dwf->map.p;
     U.impmask = (1 << d.Norb) - 1; U.nI = 1 << d.Norb; U.econst = H.econst;
     U.r = r; U.vprev = uprev; U.t_out = t; U.scal = s->scal.p; U.partial = s->partial.p; U.acc = acc; U.zvec = s->zvec.p; U.ld = (int32_t)s->vld;
@@ -261,6 +263,16 @@ static int fused_local(S *s, double *r, const double *uprev, double *t, double *
         if (once_.first(s->device)) (void)hipFuncSetAttribute((const void *)K_<D_, A_, LZAX_NT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
         hipLaunchKernelGGL((K_<D_, A_, LZAX_NT>), g, b, lds, s->stream, U);                                                         \
     } while (0)
+#define AX10_LAUNCH(D_, A_)                                                                                                     \
+    do {                                                                                                                            \
+        static OncePerDevice once_;                                                                                                 \
+        if (once_.first(s->device)) (void)hipFuncSetAttribute((const void *)k_uppass2_ax<D_, A_, LZAX_NT, 10>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+        hipLaunchKernelGGL((k_uppass2_ax<D_, A_, LZAX_NT, 10>), g, b, lds, s->stream, U);                                           \
+    } while (0)
+    if (fused_form(s) == 3) {
+        if (direct) { if (acc) AX10_LAUNCH(true, true); else AX10_LAUNCH(true, false); }
+        else { if (acc) AX10_LAUNCH(false, true); else AX10_LAUNCH(false, false); }
+    } else
     if (fused_form(s) == 2) {
         if (direct) { if (acc) AX_LAUNCH(k_uppass2_ax, true, true); else AX_LAUNCH(k_uppass2_ax, true, false); }
         else { if (acc) AX_LAUNCH(k_uppass2_ax, false, true); else AX_LAUNCH(k_uppass2_ax, false, false); }
@@ -269,6 +281,7 @@ static int fused_local(S *s, double *r, const double *uprev, double *t, double *
         else { if (acc) AX_LAUNCH(k_uppass_ax, false, true); else AX_LAUNCH(k_uppass_ax, false, false); }
     }
 #undef AX_LAUNCH
+#undef AX10_LAUNCH
     HIPCHK(hipGetLastError());
     s->fuse_mode = redo ? 8 : 4; s->fuse_zvec = nullptr;
     const int rc = reduce_partials(s, grid);
@@ -494,6 +507,28 @@ static int hxv(S *s, const double *v, double *out, bool epi, const double *uprev
             // streams whole rows through LDS and has bandwidth to spare, adds its part on top and carries the Lanczos epilogue.
             const bool dw_first = halo_can && !persistent && !multi && !nd_pass && dw_vec2 && !s->tr_on && s->dw_first > 0 && !(s->dbg & 2);
             bool dw_done = false;
+            const bool pairs10 = persistent && s->up_pairs && s->up_pairs10 && !s->upf->packed_elem && s->upf->packed_elem8 && s->upf->width <= 10 && H.DimUp % 2 == 0;
+            if (pairs10) {      // pair form with 10 hop slots: the 8-dword element image (sectors one or two electrons off half filling)
+                UpArgs2 U{};
+                U.DimUp = A.DimUp; U.DimPh = A.DimPh; U.Qdw = A.Qdw; U.dw0 = A.dw0; U.nrows = H.Qdw * H.DimPh;
+                U.packed = reinterpret_cast<const uint4 *>(s->upf->pelem8.p); U.tval = s->upf->ptval.p; U.nterms = s->upf->pterms;
+                U.diag = A.diag; U.Eup = A.Eup; U.Edw = A.Edw; U.cross = A.cross; U.mapup = A.mapup; U.mapdw = A.mapdw; U.impmask = A.impmask; U.nI = A.nI; U.econst = A.econst;
+                U.v = v; U.out = out; U.uprev = uprev; U.scal = s->scal.p; U.ld = (int32_t)ld;
+                U.crowtab = direct ? s->crow_tab.p : nullptr;
+                if (direct && !U.crowtab) return fail(EDGPU_EINVAL, "edgpu: internal: row-constant table of the on-the-fly form missing");
+                const size_t lds = (size_t)H.DimUp * 8 + 128 * 8 + (direct ? 32 * 8 + (((size_t)H.DimUp + 15) & ~(size_t)15) : 0);
+                const int grid = (int)std::min<int64_t>(U.nrows, s->up_grid);
+#define UP10_LAUNCH(D_, E_)                                                                                                     \
+    do {                                                                                                                            \
+        static OncePerDevice once_;                                                                                                 \
+        if (once_.first(s->device)) (void)hipFuncSetAttribute((const void *)k_uppass2<D_, E_, 1024, 10>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+        hipLaunchKernelGGL((k_uppass2<D_, E_, 1024, 10>), dim3(grid), dim3(1024), lds, s->stream, U);                               \
+    } while (0)
+                if (direct) { if (epi) UP10_LAUNCH(true, true); else UP10_LAUNCH(true, false); }
+                else { if (epi) UP10_LAUNCH(false, true); else UP10_LAUNCH(false, false); }
+#undef UP10_LAUNCH
+                HIPCHK(hipGetLastError());
+            } else
             if (persistent && s->up_pairs && s->upf->packed_elem) {
                 UpArgs2 U{};
                 U.DimUp = A.DimUp; U.DimPh = A.DimPh; U.Qdw = A.Qdw; U.dw0 = A.dw0; U.nrows = H.Qdw * H.DimPh;

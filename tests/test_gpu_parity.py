@@ -511,6 +511,43 @@ def test_fused_iteration_equals_three_pass_iteration(edgpu_mod, monkeypatch):
             assert min(np.abs(x - res["plain"][4]).max(), np.abs(x + res["plain"][4]).max()) < 1e-8, tag
 
 
+@pytest.mark.parametrize("nup,ndw", [(3, 6), (10, 6), (9, 5), (2, 7)])
+def test_pair_form_with_ten_hop_slots(edgpu_mod, monkeypatch, nup, ndw):
+    """Sectors one or two electrons off half filling have 9-10 up hops per configuration (max(Nup, Ns-Nup)): the Green's-function
+    target sectors of a half-filled ground state.  Their LDS-row local passes run the pair form on the 8-dword element image
+    (k_uppass2 / k_uppass2_ax with 10 hop slots) instead of the one-configuration-per-lane kernels (EDGPU_UP_PAIRS10=0): product
+    against the oracle, fused iteration against the three-pass one and against the old form, stored and on the fly."""
+    from edgpu import model
+    m, _, _ = model.half_filled_c(11)            # Ns = 12
+    nu, nd = [nup], [ndw]
+    S = oracle.Sector(m, nu, nd)
+    assert max(nup, 12 - nup) in (9, 10) and S.DimUp % 2 == 0
+    v = np.random.RandomState(3).uniform(-0.5, 0.5, S.Dim)
+    ref = S.spmatvec(v)
+    v0 = np.random.RandomState(11).uniform(0, 1, S.Dim)
+    monkeypatch.setenv("EDGPU_KRON_SPLIT", "1")
+    out = {}
+    for st in ("kron", "direct"):
+        for tag, env in (("pairs10", {}), ("pairs10_plain", {"EDGPU_LZ_FUSED": "0"}), ("lane", {"EDGPU_UP_PAIRS10": "0"})):
+            for k, val in env.items():
+                monkeypatch.setenv(k, val)
+            G = edgpu_mod.HvSector(m, nu, nd, storage=st)
+            hv = G.spHtimesV(v)
+            assert np.abs(hv - ref).max() <= HXV_RTOL * np.abs(ref).max(), (st, tag)
+            a, b, used = G.sp_lanc_tridiag(v0, 30)
+            e0, x, nl = G.sp_lanc_eigh(v0, nitermax=300, threshold=1e-13)
+            assert np.linalg.norm(S.spmatvec(x) - e0 * x) < 1e-6, (st, tag)
+            out[(st, tag)] = (a, b, e0)
+            G.close()
+            for k in env:
+                monkeypatch.delenv(k)
+    a_ref, b_ref, used_ref = oracle.sp_lanc_tridiag(S.spmatvec, v0, 30)
+    for key, (a, b, e0) in out.items():
+        np.testing.assert_allclose(a[:used_ref], a_ref[:used_ref], rtol=1e-9, atol=1e-9, err_msg=str(key))
+        np.testing.assert_allclose(b[1:used_ref], b_ref[1:used_ref], rtol=1e-9, atol=1e-9, err_msg=str(key))
+        assert abs(e0 - out[("kron", "lane")][2]) <= 1e-10, key
+
+
 def test_sweep_over_all_sectors_of_a_small_model(edgpu_mod):
     """What a DMFT iteration does: every (Nup,Ndw) sector of the Ns=6 model in turn (dimensions 1 ... 400), ground state of
     each against dense diagonalisation.  Exercises the work-vector cache across sectors of changing size."""
