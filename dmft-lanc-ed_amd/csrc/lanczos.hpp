@@ -238,6 +238,7 @@ static int lzf_zero_pads(S *s, double *x)      // a buffer that joins the elemen
 static int lzf_begin(S *s, LzF &F, double *acc)      // F.u holds the (unnormalised) start vector, F.uprev any finite buffer
 {
     HIPCHK(hipMemsetAsync(s->scal.p, 0, SC_COUNT * sizeof(double), s->stream));       // alpha_{-1} = 0, iteration counter 0
+    CHK(lzf_zero_pads(s, F.t));      // odd DimUp: the dw half runs over DimUp + 1 columns and reads the padding column of t
     return fused_local(s, F.u, F.uprev, F.t, acc);                                     // u_0 unchanged, s_0 = 1/|u_0|
 }
 static int lzf_iter(S *s, LzF &F, double *tnew, double *acc)
@@ -367,7 +368,7 @@ static int lanczos_gs_impl(S *s, int nitermax, double threshold, int ncheck, dou
                 double *tnew = store ? ring_get(j + 2) : nullptr;
                 if (store && !tnew) store = false;    // out of memory: from here on the oldest of the three live vectors is recycled
                 if (tnew) CHK(lzf_zero_pads(s, tnew));
-                else tnew = (j == 0 && F.uprev == F.u) ? s->lz[2].p : F.uprev;
+                else { tnew = (j == 0 && F.uprev == F.u) ? s->lz[2].p : F.uprev; if (tnew != F.uprev) CHK(lzf_zero_pads(s, tnew)); }
                 CHK(lzf_iter(s, F, tnew, nullptr));
                 continue;
             }

@@ -208,13 +208,18 @@ static int transposed_dw_pass(S *s, const double *v, hipStream_t st)
 #endif
 // Can hxv() of this sector take vectors with a padded row pitch?  Only the two-pass product of a single rank whose local
 // pass is one of the LDS-staged kernels and whose dw pass is the vectorised column-tiled one (Jx/Jp through k_ndpass).
+// Odd DimUp: the vectorised dw pass and the fused iteration work on column PAIRS.  With the padded row pitch every row ends in at
+// least one zero column, so the pass simply runs over DimUp + 1 columns (the padding column stays zero: its hops read zeros, its
+// local part is never written).  All sectors of Ns = 7 (the reference's default Nbath = 6) and Ns = 15 have odd DimUp.
+static inline bool odd_cols_ok(const S *s) { return (s->H.DimUp % 2 == 0) || s->pad_allowed; }
+static inline int32_t dw_cols(const S *s, int64_t ld) { return (int32_t)((s->H.DimUp % 2 != 0 && ld > s->H.DimUp) ? s->H.DimUp + 1 : s->H.DimUp); }
 static bool pitch_ok(const S *s)
 {
     const SectorHost &H = s->H;
     if (H.desc.storage == EDGPU_STORE_CSR) return s->csr_ld > H.DimUp;      // explicit CSR whose columns index the pitched space (single rank)
     if (s->multi || !s->kron2 || !s->kron_split || H.DimPh != 1 || s->tr_on) return false;
     if (s->extra && !(s->has_nd && !s->has_ph && s->nd_split)) return false;
-    if (!(s->dw_variant >= 2 && (H.DimUp % 2 == 0) && s->dw_w >= 4 && s->dwf->width <= 64)) return false;
+    if (!(s->dw_variant >= 2 && odd_cols_ok(s) && s->dw_w >= 4 && s->dwf->width <= 64)) return false;
     const bool persistent = s->up_persistent && s->upf->packed && s->upf->width <= 16 && s->use_lds && H.DimUp <= 13312;
     const bool halo = !s->use_lds && s->upf->seg_ok && s->up_halo && !s->extra;
     return persistent || halo;
@@ -235,7 +240,7 @@ static bool fused_ok(const S *s)
     // Jx/Jp sectors run their non-local pass between the two halves; phonon terms live in the row-wise kernel only
     const bool terms_ok = !s->extra || (s->has_nd && !s->has_ph && s->nd_split);
     return s->lz_fused_on && !s->multi && s->kron2 && terms_ok && s->kron_split && H.desc.storage != EDGPU_STORE_CSR && fused_form(s) != 0 &&
-           (H.DimUp % 2 == 0) && s->dw_variant >= 2 && s->dw_w >= 4 && s->dwf->width <= 64;
+           (H.DimUp % 2 == 0 || (fused_form(s) == 1 && odd_cols_ok(s))) && s->dw_variant >= 2 && s->dw_w >= 4 && s->dwf->width <= 64;
 }
 // local half: r <- u_k = r - alpha s u_prev (in place), TMP = |u_k|^2 and the norm step, t <- local part of H u_k (unscaled)
 // redo: r already IS u_k (it was changed in place after the pass that formed it): alpha is zeroed so that r stays as it is,
@@ -302,12 +307,12 @@ static int fused_dw(S *s, const double *u, double *t, const double *uprev)
 {
     const SectorHost &H = s->H;
     DwArgs D{};
-    D.DimUp = (int32_t)H.DimUp; D.DimDw = (int32_t)H.DimDw; D.DimPh = H.DimPh; D.Qdw = H.Qdw; D.dw0 = H.dw0;
+    D.DimUp = dw_cols(s, s->vld); D.DimDw = (int32_t)H.DimDw; D.DimPh = H.DimPh; D.Qdw = H.Qdw; D.dw0 = H.dw0;
     D.dwc = s->dwf->ellc.p; D.dwv = s->dwf->ellv.p; D.dww = s->dwf->width; D.v = u; D.vfull = u; D.out = t; D.scal = s->scal.p; D.partial = s->partial.p;
     D.uprev2 = uprev;
     D.ld = (int32_t)s->vld;
     D.w = s->dw_w; D.wshift = 0; while ((1 << D.wshift) < D.w) D.wshift++;
-    D.ntiles = (int32_t)cdiv(H.DimUp, D.w);
+    D.ntiles = (int32_t)cdiv(D.DimUp, D.w);
     D.R = std::min(64, s->dw_rows);
     D.chunks = (int32_t)cdiv(H.Qdw * H.DimPh, D.R);
     const int64_t nblocks = (int64_t)D.ntiles * D.chunks;
@@ -455,7 +460,7 @@ static int hxv(S *s, const double *v, double *out, bool epi, const double *uprev
         else {
             const bool plain = !s->extra || nd_pass;      // local pass = stored/on-the-fly diagonal + up hops only
             // k_uppass_halo writes the unscaled local part; under the Lanczos epilogue the vectorised dw pass finishes it (uprev2)
-            const bool dw_vec2 = s->dw_variant >= 2 && (H.DimUp % 2 == 0) && s->dw_w >= 4 && s->dwf->width <= 64;
+            const bool dw_vec2 = s->dw_variant >= 2 && (H.DimUp % 2 == 0 || ld > H.DimUp) && s->dw_w >= 4 && s->dwf->width <= 64;      // odd DimUp: pitched vectors only (dw_cols)
             const bool halo_can = !s->use_lds && plain && s->upf->seg_ok && s->up_halo && (!epi || (dw_vec2 && !s->extra && !s->tr_on));
             bool halo_epi = false;
             const bool persistent = s->up_persistent && plain && s->upf->packed && s->upf->width <= 16 && s->use_lds && H.DimUp <= 13312;
@@ -467,8 +472,9 @@ static int hxv(S *s, const double *v, double *out, bool epi, const double *uprev
                 D.uprev2 = uprev2; D.ld = (int32_t)ld;
                 D.w = s->dw_w; D.wshift = 0; while ((1 << D.wshift) < D.w) D.wshift++;
                 const int dv = s->dw_variant;
-                const bool vec2 = dv >= 2 && (H.DimUp % 2 == 0) && D.w >= 4 && D.dww <= 64;
-                D.ntiles = (int32_t)cdiv(H.DimUp, D.w);
+                const bool vec2 = dv >= 2 && (H.DimUp % 2 == 0 || ld > H.DimUp) && D.w >= 4 && D.dww <= 64;
+                if (vec2) D.DimUp = dw_cols(s, ld);
+                D.ntiles = (int32_t)cdiv(D.DimUp, D.w);
                 D.R = vec2 ? std::min(64, s->dw_rows) : 256 / D.w;
                 D.chunks = (int32_t)cdiv(H.Qdw * H.DimPh, D.R);
                 nblocks = (int64_t)D.ntiles * D.chunks;

@@ -548,6 +548,53 @@ def test_pair_form_with_ten_hop_slots(edgpu_mod, monkeypatch, nup, ndw):
         assert abs(e0 - out[("kron", "lane")][2]) <= 1e-10, key
 
 
+@pytest.mark.parametrize("nbath,nup,ndw", [(6, 3, 4), (10, 3, 5), (10, 8, 6), (14, 7, 8)])
+def test_odd_row_length_uses_the_pair_kernels_on_pitched_vectors(edgpu_mod, monkeypatch, nbath, nup, ndw):
+    """Every sector of Ns = 7 (the reference's default Nbath = 6) and Ns = 15 has an odd DimUp.  The vectorised dw pass and the fused
+    iteration work on column pairs; on the padded row pitch of the Lanczos loops they run over DimUp + 1 columns (the padding
+    column holds zeros and keeps them).  Against the oracle (small sectors) and against the form without it (EDGPU_ODD_PAIRS=0:
+    scalar dw pass, three-pass iteration), incl. the BASELINE-sized Ns = 15 sector."""
+    from edgpu import model
+    m, _, _ = model.half_filled_c(nbath)
+    nu, nd = [nup], [ndw]
+    import math
+    DimUp, DimDw = math.comb(nbath + 1, nup), math.comb(nbath + 1, ndw)
+    assert DimUp % 2 == 1
+    small = DimUp * DimDw < 10 ** 6
+    monkeypatch.setenv("EDGPU_KRON_SPLIT", "1")
+    if small:
+        S = oracle.Sector(m, nu, nd)
+        v0 = np.random.RandomState(11).uniform(0, 1, S.Dim)
+        a_ref, b_ref, used_ref = oracle.sp_lanc_tridiag(S.spmatvec, v0, 30)
+    else:
+        v0 = np.random.RandomState(11).uniform(0, 1, DimUp * DimDw)
+    out = {}
+    for st in ("kron", "direct"):
+        for tag, env in (("pairs", {}), ("pairs_plain", {"EDGPU_LZ_FUSED": "0"}), ("scalar", {"EDGPU_ODD_PAIRS": "0"})):
+            for k, val in env.items():
+                monkeypatch.setenv(k, val)
+            G = edgpu_mod.HvSector(m, nu, nd, storage=st)
+            assert G.lanczos_fused == (tag == "pairs"), (st, tag, G.describe())
+            assert ("pitch=dense" in G.describe()) == (tag == "scalar"), (tag, G.describe())
+            a, b, used = G.sp_lanc_tridiag(v0, 30)
+            e0, x, nl = G.sp_lanc_eigh(v0, nitermax=300, threshold=1e-13)
+            r = np.linalg.norm(G.spHtimesV(x) - e0 * x)
+            if small:
+                assert np.linalg.norm(S.spmatvec(x) - e0 * x) < 1e-6, (st, tag)
+            out[(st, tag)] = (a, b, e0, r)
+            G.close()
+            for k in env:
+                monkeypatch.delenv(k)
+    ref = out[("kron", "scalar")]
+    for key, (a, b, e0, r) in out.items():
+        if small:
+            np.testing.assert_allclose(a[:used_ref], a_ref[:used_ref], rtol=1e-9, atol=1e-9, err_msg=str(key))
+            np.testing.assert_allclose(b[1:used_ref], b_ref[1:used_ref], rtol=1e-9, atol=1e-9, err_msg=str(key))
+        np.testing.assert_allclose(a, ref[0], rtol=1e-9, atol=1e-9, err_msg=str(key))
+        np.testing.assert_allclose(b, ref[1], rtol=1e-9, atol=1e-9, err_msg=str(key))
+        assert abs(e0 - ref[2]) <= 1e-10 and r < 1e-6, key
+
+
 def test_sweep_over_all_sectors_of_a_small_model(edgpu_mod):
     """What a DMFT iteration does: every (Nup,Ndw) sector of the Ns=6 model in turn (dimensions 1 ... 400), ground state of
     each against dense diagonalisation.  Exercises the work-vector cache across sectors of changing size."""
