@@ -345,6 +345,7 @@ struct UpArgs2 {
     const double *v; double *out; const double *uprev; const double *scal;
     int32_t ld;              // row pitch of v / out / uprev in doubles (0: DimUp)
     const double *crowtab;   // DIRECT: [idw][nI] row constants (k_crow_table)
+    int32_t dtrue;           // true DimUp when DimUp above is the row length rounded up to even (odd rows on pitched vectors: the last pair ends in the zero padding column); 0: same
 };
 
 // NH: hop slots per up configuration.  8: the 6-dword element image (3 x 16 bytes per pair); 10: the 8-dword image pelem8 (4 x 16 bytes
@@ -357,6 +358,7 @@ __global__ void __launch_bounds__(NT) k_uppass2(UpArgs2 A)
     constexpr int MAXQ = (13312 / 2 + NT - 1) / NT;      // pairs per lane
     const int DimUp = A.DimUp, npair = DimUp >> 1, tid = threadIdx.x;
     const int64_t ld = A.ld ? A.ld : DimUp;
+    const int dtrue = A.dtrue ? A.dtrue : DimUp;      // pitch of the stored diagonal, length of mapup
     double *tv = lds + DimUp;
     // DIRECT: the diagonal is Eup(iup) [an operand like the stored diagonal] + crow(up impurity word), with crow = Edw + econst +
     // cross(., dw impurity word) of the row taken from the per-product table a row ahead (k_crow_table) and the impurity word of
@@ -365,7 +367,7 @@ __global__ void __launch_bounds__(NT) k_uppass2(UpArgs2 A)
     double *crow = tv + 128;
     uint8_t *imp8 = reinterpret_cast<uint8_t *>(crow + 32);
     for (int t = tid; t < A.nterms; t += NT) tv[t] = A.tval[t];
-    if (DIRECT) for (int t = tid; t < DimUp; t += NT) imp8[t] = (uint8_t)((uint32_t)A.mapup[t] & A.impmask);
+    if (DIRECT) for (int t = tid; t < DimUp; t += NT) imp8[t] = t < dtrue ? (uint8_t)((uint32_t)A.mapup[t] & A.impmask) : (uint8_t)0;
     const int nq = (npair + NT - 1) / NT;
     dbl2v xr[MAXQ];
     int64_t row = blockIdx.x;
@@ -381,7 +383,8 @@ __global__ void __launch_bounds__(NT) k_uppass2(UpArgs2 A)
     while (row < A.nrows) {
         const int64_t idwl = row % A.Qdw;
         auto load_ops = [&](int p, Ops &o) {
-            if (!DIRECT) o.d = *reinterpret_cast<const dbl2v *>(A.diag + idwl * DimUp + 2 * p);
+            if (!DIRECT) { if (A.dtrue) { const double *dp = A.diag + idwl * dtrue + 2 * p; o.d.x = dp[0]; o.d.y = dp[1]; }      // odd rows: the dense diagonal is not 16-byte aligned row by row
+                           else o.d = *reinterpret_cast<const dbl2v *>(A.diag + idwl * dtrue + 2 * p); }
             else o.d = *reinterpret_cast<const dbl2v *>(A.Eup + 2 * p);
             if (EPI) o.u = *reinterpret_cast<const dbl2v *>(A.uprev + row * ld + 2 * p);
             if (NH == 8) { o.w0 = A.packed[3 * p]; o.w1 = A.packed[3 * p + 1]; o.w2 = A.packed[3 * p + 2]; }
@@ -454,6 +457,7 @@ struct UpAxArgs {
     int32_t ld;              // row pitch of r / vprev / t_out / acc in doubles (0: DimUp); the stored diagonal keeps pitch DimUp
     const uint32_t *pcols, *pcodes; int32_t upw;      // k_uppass_ax (one configuration per lane, up to 16 hops): packed ELL image as k_uppass
     const double *crowtab;   // DIRECT: [idw][nI] row constants (k_crow_table)
+    int32_t dtrue;           // pair forms: true DimUp when DimUp is the odd row length rounded up to even (see UpArgs2); 0: same
 };
 
 template <bool DIRECT, bool ACC, int NT, int NH = 8>      // NH: hop slots per up configuration, as k_uppass2
@@ -463,12 +467,13 @@ __global__ void __launch_bounds__(NT) k_uppass2_ax(UpAxArgs A)
     constexpr int MAXQ = (13312 / 2 + NT - 1) / NT;      // pairs per lane
     const int DimUp = A.DimUp, npair = DimUp >> 1, tid = threadIdx.x;
     const int64_t ld = A.ld ? A.ld : DimUp;
+    const int dtrue = A.dtrue ? A.dtrue : DimUp;      // pitch of the stored diagonal, length of mapup
     double *tv = lds + DimUp;
     double *red = tv + 128;
     double *crow = red + 32;                             // DIRECT: Edw + const + cross term of this row, per up impurity word
     uint8_t *imp8 = reinterpret_cast<uint8_t *>(crow + 32);      // DIRECT: impurity word of every up configuration (the index into crow), staged once per launch
     for (int t = tid; t < A.nterms; t += NT) tv[t] = A.tval[t];
-    if (DIRECT) for (int t = tid; t < DimUp; t += NT) imp8[t] = (uint8_t)((uint32_t)A.mapup[t] & A.impmask);
+    if (DIRECT) for (int t = tid; t < DimUp; t += NT) imp8[t] = t < dtrue ? (uint8_t)((uint32_t)A.mapup[t] & A.impmask) : (uint8_t)0;
     const int nq = (npair + NT - 1) / NT;
     const double c_ax = A.scal[SC_ALPHA] * A.scal[SC_SCUR];          // alpha_{k-1} * s_{k-1}  (0 at k = 0)
     const double zk = ACC ? A.zvec[(int)A.scal[SC_K]] : 0.0;
@@ -510,7 +515,8 @@ __global__ void __launch_bounds__(NT) k_uppass2_ax(UpAxArgs A)
         const int64_t nrow = (STRAIGHT && !more) ? row : next;
         auto load_ops = [&](int p, Ops &o) {
             if (STRAIGHT) p = p < npair ? p : pmax;
-            if (!DIRECT) o.d = *reinterpret_cast<const dbl2v *>(A.diag + idwl * DimUp + 2 * p);
+            if (!DIRECT) { if (A.dtrue) { const double *dp = A.diag + idwl * dtrue + 2 * p; o.d.x = dp[0]; o.d.y = dp[1]; }      // odd rows: the dense diagonal is not 16-byte aligned row by row
+                           else o.d = *reinterpret_cast<const dbl2v *>(A.diag + idwl * dtrue + 2 * p); }
             else o.d = *reinterpret_cast<const dbl2v *>(A.Eup + 2 * p);
             if (NH == 8) { o.w0 = A.packed[3 * p]; o.w1 = A.packed[3 * p + 1]; o.w2 = A.packed[3 * p + 2]; }
             else { o.w0 = A.packed[4 * p]; o.w1 = A.packed[4 * p + 1]; o.w2 = A.packed[4 * p + 2]; o.w3 = A.packed[4 * p + 3]; }

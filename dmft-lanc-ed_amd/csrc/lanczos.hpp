@@ -1103,7 +1103,7 @@ static int dvdson(S *s, int nev, int maxiter, double tol, double *evals, double 
     if (maxiter < 1) maxiter = 1;
     const double tol_eff = std::max(tol, 1e-11);
     // the diagonal of H: stored formats hold it, the on-the-fly format derives it once here
-    if (s->diag.n != (size_t)s->nloc_el) CHK(build_diag(s));
+    if (s->diag.n < (size_t)s->nloc_el) CHK(build_diag(s));
     while ((int)s->eigV.size() < 2 * mmax + 1) s->eigV.push_back(std::make_unique<DevBuf<double>>());
     for (int i = 0; i <= 2 * mmax; i++)
         if (s->eigV[i]->n < (size_t)n && s->eigV[i]->alloc((size_t)n) != EDGPU_OK) {

@@ -230,8 +230,8 @@ static bool pitch_ok(const S *s)
 static int fused_form(const S *s)
 {
     if (!s->upf || !s->up_persistent || !s->use_lds || s->H.DimUp > 13312) return 0;
-    if (s->up_pairs && s->upf->packed_elem && s->upf->width <= 8) return 2;
-    if (s->up_pairs && s->up_pairs10 && s->upf->packed_elem8 && s->upf->width <= 10 && s->H.DimUp % 2 == 0) return 3;      // pair form with 10 hop slots (8-dword element image)
+    if (s->up_pairs && s->upf->packed_elem && s->upf->width <= 8 && odd_cols_ok(s)) return 2;
+    if (s->up_pairs && s->up_pairs10 && s->upf->packed_elem8 && s->upf->width <= 10 && odd_cols_ok(s)) return 3;      // pair form with 10 hop slots (8-dword element image)
     return (s->upf->packed && s->upf->width <= 16) ? 1 : 0;
 }
 static bool fused_ok(const S *s)
@@ -240,7 +240,7 @@ static bool fused_ok(const S *s)
     // Jx/Jp sectors run their non-local pass between the two halves; phonon terms live in the row-wise kernel only
     const bool terms_ok = !s->extra || (s->has_nd && !s->has_ph && s->nd_split);
     return s->lz_fused_on && !s->multi && s->kron2 && terms_ok && s->kron_split && H.desc.storage != EDGPU_STORE_CSR && fused_form(s) != 0 &&
-           (H.DimUp % 2 == 0 || (fused_form(s) == 1 && odd_cols_ok(s))) && s->dw_variant >= 2 && s->dw_w >= 4 && s->dwf->width <= 64;
+           odd_cols_ok(s) && s->dw_variant >= 2 && s->dw_w >= 4 && s->dwf->width <= 64;
 }
 // local half: r <- u_k = r - alpha s u_prev (in place), TMP = |u_k|^2 and the norm step, t <- local part of H u_k (unscaled)
 // redo: r already IS u_k (it was changed in place after the pass that formed it): alpha is zeroed so that r stays as it is,
@@ -253,11 +253,12 @@ static int fused_local(S *s, double *r, const double *uprev, double *t, double *
     if (direct) CHK(direct_tables(s));
     UpAxArgs U{};
     U.DimUp = (int32_t)H.DimUp; U.DimPh = H.DimPh; U.Qdw = H.Qdw; U.dw0 = H.dw0; U.nrows = H.Qdw * H.DimPh;
+    if (fused_form(s) >= 2 && (H.DimUp & 1)) { U.DimUp = (int32_t)H.DimUp + 1; U.dtrue = (int32_t)H.DimUp; }      // odd rows, pair forms: the last pair ends in the padding column of the pitched vectors
     U.packed = reinterpret_cast<const uint4 *>(fused_form(s) == 3 ? s->upf->pelem8.p : s->upf->pelem.p); U.tval = s->upf->ptval.p; U.nterms = s->upf->pterms;
     U.diag = s->diag.p; U.Eup = s->upf->E.p; U.Edw = s->dwf->E.p; U.cross = s->cross.p; U.mapup = s->upf->map.p; U.mapdw = s->dwf->map.p;
     U.impmask = (1 << d.Norb) - 1; U.nI = 1 << d.Norb; U.econst = H.econst;
     U.r = r; U.vprev = uprev; U.t_out = t; U.scal = s->scal.p; U.partial = s->partial.p; U.acc = acc; U.zvec = s->zvec.p; U.ld = (int32_t)s->vld;
-    const size_t lds = (((size_t)H.DimUp + 1) & ~(size_t)1) * 8 + 128 * 8 + 32 * 8 + 32 * 8 + (direct ? (((size_t)H.DimUp + 15) & ~(size_t)15) : 0);      // + the impurity-word bytes of the on-the-fly form
+    const size_t lds = (((size_t)H.DimUp + 1) & ~(size_t)1) * 8 + 128 * 8 + 32 * 8 + 32 * 8 + (direct ? (((size_t)H.DimUp + 16) & ~(size_t)15) : 0);      // + the impurity-word bytes of the on-the-fly form
     const int grid = (int)std::min<int64_t>(U.nrows, s->up_grid);
     U.pcols = s->upf->pcols.p; U.pcodes = s->upf->pcodes.p; U.upw = s->upf->width; U.crowtab = direct ? s->crow_tab.p : nullptr;
     if (direct && !U.crowtab) return fail(EDGPU_EINVAL, "edgpu: internal: row-constant table of the on-the-fly form missing");
@@ -513,16 +514,18 @@ static int hxv(S *s, const double *v, double *out, bool epi, const double *uprev
             // streams whole rows through LDS and has bandwidth to spare, adds its part on top and carries the Lanczos epilogue.
             const bool dw_first = halo_can && !persistent && !multi && !nd_pass && dw_vec2 && !s->tr_on && s->dw_first > 0 && !(s->dbg & 2);
             bool dw_done = false;
-            const bool pairs10 = persistent && s->up_pairs && s->up_pairs10 && !s->upf->packed_elem && s->upf->packed_elem8 && s->upf->width <= 10 && H.DimUp % 2 == 0;
+            const bool rows_pair = (H.DimUp % 2 == 0) || (ld > H.DimUp && s->pad_allowed);      // odd rows: pair kernels on pitched vectors only (the last pair ends in the padding column)
+            const int32_t up_cols = (int32_t)(H.DimUp + (H.DimUp & 1)), up_dtrue = (H.DimUp & 1) ? (int32_t)H.DimUp : 0;
+            const bool pairs10 = persistent && rows_pair && s->up_pairs && s->up_pairs10 && !(s->upf->packed_elem && s->upf->width <= 8) && s->upf->packed_elem8 && s->upf->width <= 10;
             if (pairs10) {      // pair form with 10 hop slots: the 8-dword element image (sectors one or two electrons off half filling)
                 UpArgs2 U{};
-                U.DimUp = A.DimUp; U.DimPh = A.DimPh; U.Qdw = A.Qdw; U.dw0 = A.dw0; U.nrows = H.Qdw * H.DimPh;
+                U.DimUp = up_cols; U.dtrue = up_dtrue; U.DimPh = A.DimPh; U.Qdw = A.Qdw; U.dw0 = A.dw0; U.nrows = H.Qdw * H.DimPh;
                 U.packed = reinterpret_cast<const uint4 *>(s->upf->pelem8.p); U.tval = s->upf->ptval.p; U.nterms = s->upf->pterms;
                 U.diag = A.diag; U.Eup = A.Eup; U.Edw = A.Edw; U.cross = A.cross; U.mapup = A.mapup; U.mapdw = A.mapdw; U.impmask = A.impmask; U.nI = A.nI; U.econst = A.econst;
                 U.v = v; U.out = out; U.uprev = uprev; U.scal = s->scal.p; U.ld = (int32_t)ld;
                 U.crowtab = direct ? s->crow_tab.p : nullptr;
                 if (direct && !U.crowtab) return fail(EDGPU_EINVAL, "edgpu: internal: row-constant table of the on-the-fly form missing");
-                const size_t lds = (size_t)H.DimUp * 8 + 128 * 8 + (direct ? 32 * 8 + (((size_t)H.DimUp + 15) & ~(size_t)15) : 0);
+                const size_t lds = (size_t)up_cols * 8 + 128 * 8 + (direct ? 32 * 8 + (((size_t)up_cols + 15) & ~(size_t)15) : 0);
                 const int grid = (int)std::min<int64_t>(U.nrows, s->up_grid);
 #define UP10_LAUNCH(D_, E_)                                                                                                     \
     do {                                                                                                                            \
@@ -535,15 +538,15 @@ static int hxv(S *s, const double *v, double *out, bool epi, const double *uprev
 #undef UP10_LAUNCH
                 HIPCHK(hipGetLastError());
             } else
-            if (persistent && s->up_pairs && s->upf->packed_elem) {
+            if (persistent && rows_pair && s->up_pairs && s->upf->packed_elem && s->upf->width <= 8) {
                 UpArgs2 U{};
-                U.DimUp = A.DimUp; U.DimPh = A.DimPh; U.Qdw = A.Qdw; U.dw0 = A.dw0; U.nrows = H.Qdw * H.DimPh;
+                U.DimUp = up_cols; U.dtrue = up_dtrue; U.DimPh = A.DimPh; U.Qdw = A.Qdw; U.dw0 = A.dw0; U.nrows = H.Qdw * H.DimPh;
                 U.packed = reinterpret_cast<const uint4 *>(s->upf->pelem.p); U.tval = s->upf->ptval.p; U.nterms = s->upf->pterms;
                 U.diag = A.diag; U.Eup = A.Eup; U.Edw = A.Edw; U.cross = A.cross; U.mapup = A.mapup; U.mapdw = A.mapdw; U.impmask = A.impmask; U.nI = A.nI; U.econst = A.econst;
                 U.v = v; U.out = out; U.uprev = uprev; U.scal = s->scal.p; U.ld = (int32_t)ld;
                 U.crowtab = direct ? s->crow_tab.p : nullptr;
                 if (direct && !U.crowtab) return fail(EDGPU_EINVAL, "edgpu: internal: row-constant table of the on-the-fly form missing");
-                const size_t lds = (size_t)H.DimUp * 8 + 128 * 8 + (direct ? 32 * 8 + (((size_t)H.DimUp + 15) & ~(size_t)15) : 0);
+                const size_t lds = (size_t)up_cols * 8 + 128 * 8 + (direct ? 32 * 8 + (((size_t)up_cols + 15) & ~(size_t)15) : 0);
                 const int grid = (int)std::min<int64_t>(U.nrows, s->up_grid);
                 static OncePerDevice once2;
                 if (once2.first(s->device)) {

@@ -17,7 +17,7 @@ static int upload_factor(S *s, int k)
     CHK(df->map.upload(f.map)); CHK(df->rank.upload(f.rank));
     std::vector<int32_t> rp32(f.rowptr.begin(), f.rowptr.end());
     CHK(df->rowptr.upload(rp32)); CHK(df->cols.upload(f.cols)); CHK(df->vals.upload(f.vals));
-    CHK(df->E.upload(f.E));
+    { std::vector<double> e1(f.E); e1.push_back(0.0); CHK(df->E.upload(e1)); }      // one zero behind the end: the last pair of an odd row (pair kernels on pitched vectors)
     df->width = std::max(f.width, 1);
     for (int32_t i = 0; i < f.dim; i++) if (f.rowptr[i + 1] - f.rowptr[i] < df->width) { df->ragged = true; break; }
     if (df->width > 64) return fail(EDGPU_EUNSUPPORTED, "edgpu: more than 64 hops per spin configuration");
@@ -54,8 +54,12 @@ static int upload_factor(S *s, int k)
                 pd[(size_t)(q / 4) * f.dim + i] |= code << (8 * (q & 3));
             }
         if (ok) { CHK(df->pcols.upload(pc)); CHK(df->pcodes.upload(pd)); CHK(df->ptval.upload(tvl)); df->packed = true; df->pterms = 128; }
+        // odd dim: one more element in the element-major images, a padding configuration without hops (columns = its own index,
+        // codes 127): the pair kernels then run odd rows on pitched vectors, whose padding column it stands for
+        const int32_t dimp = f.dim + (f.dim & 1);
         if (ok && W <= 10) {                        // element-major image of 8 dwords for rows that do not fit LDS
-            std::vector<uint32_t> pe((size_t)8 * f.dim, 0u);
+            std::vector<uint32_t> pe((size_t)8 * dimp, 0u);
+            if (dimp > f.dim) { for (int c = 0; c < 5; c++) pe[(size_t)8 * f.dim + c] = (uint32_t)f.dim | ((uint32_t)f.dim << 16); for (int c = 5; c < 8; c++) pe[(size_t)8 * f.dim + c] = 0x7f7f7f7fu; }
             for (int32_t i = 0; i < f.dim; i++) {
                 for (int q = 0; q < 10; q++) {
                     int64_t p = f.rowptr[i] + q; bool has = q < W && p < f.rowptr[i + 1];
@@ -71,8 +75,9 @@ static int upload_factor(S *s, int k)
             }
             CHK(df->pelem8.upload(pe)); df->packed_elem8 = true;
         }
-        if (ok && W <= 8 && f.dim % 2 == 0) {       // element-major image for the pair kernel: 6 dwords per up configuration
-            std::vector<uint32_t> pe((size_t)6 * f.dim, 0u);
+        if (ok && W <= 8) {                         // element-major image for the pair kernel: 6 dwords per up configuration
+            std::vector<uint32_t> pe((size_t)6 * dimp, 0u);
+            if (dimp > f.dim) { for (int c = 0; c < 4; c++) pe[(size_t)6 * f.dim + c] = (uint32_t)f.dim | ((uint32_t)f.dim << 16); for (int c = 4; c < 6; c++) pe[(size_t)6 * f.dim + c] = 0x7f7f7f7fu; }
             for (int32_t i = 0; i < f.dim; i++) {
                 for (int c = 0; c < 4; c++) pe[(size_t)6 * i + c] = c < ncw ? pc[(size_t)c * f.dim + i] : ((uint32_t)i | ((uint32_t)i << 16));
                 for (int c = 0; c < 2; c++) pe[(size_t)6 * i + 4 + c] = c < ndw ? pd[(size_t)c * f.dim + i] : 0x7f7f7f7fu;
@@ -296,7 +301,7 @@ static int build_diag(S *s)
     for (int a = 1; a <= d.Norb; a++) { A.imp_up[a - 1] = H.imp(1, 1, a, a); A.imp_dw[a - 1] = H.imp(d.Nspin, d.Nspin, a, a); }
     A.Ust = d.Ust; A.Jh = d.Jh; A.xmu = d.xmu;
     A.bd_up = s->bd_up.p; A.bd_dw = s->bd_dw.p; A.stride = s->stride.p;
-    CHK(s->diag.alloc((size_t)s->nloc_el));
+    CHK(s->diag.alloc((size_t)s->nloc_el + 2)); HIPCHK(hipMemsetAsync(s->diag.p + s->nloc_el, 0, 16, s->stream));      // + 2: the last pair of an odd last row reads one element behind the end
     hipLaunchKernelGGL(k_build_diag, dim3((unsigned)cdiv(s->nloc_el, 256)), dim3(256), 0, s->stream, A, s->diag.p);
     HIPCHK(hipGetLastError());
     return EDGPU_OK;
