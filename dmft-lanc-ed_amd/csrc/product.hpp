@@ -48,8 +48,13 @@ static int dispatch_kron2(S *s, int flags, const Kron2Args &A, int64_t rows)
     return EDGPU_OK;
 }
 
+// The tables of the on-the-fly form (hop images of the factors from the bit patterns, row constants of the diagonal) depend on
+// the sector descriptor only, which never changes: derived by the first product and kept (EDGPU_DIRECT_CACHE=0: derived again by
+// every product, as the reference's directMatVec re-derives every element; three short launches, 45 us -- 2 % of a product at Ns=16,
+// a fifth of a Lanczos iteration at Ns=12).  What the form does not hold is the O(N) diagonal.
 static int direct_tables(S *s)
 {
+    if (s->direct_built && s->direct_cache) return EDGPU_OK;
     const SectorHost &H = s->H; const edgpu_desc &d = H.desc;
     if (s->kron2 && s->dwf && s->dwf->E.p && s->dwf->map.p && s->cross.p) {
         // row constants of the on-the-fly diagonal, Edw + econst + cross(up impurity word, dw impurity word), per dw configuration
@@ -59,7 +64,7 @@ static int direct_tables(S *s)
         hipLaunchKernelGGL(k_crow_table, dim3((unsigned)cdiv(nct, 256)), dim3(256), 0, s->stream, (const double *)s->dwf->E.p, (const int32_t *)s->dwf->map.p, (const double *)s->cross.p, H.econst, (int32_t)(nI - 1), nI, H.DimDw, s->crow_tab.p);
         HIPCHK(hipGetLastError());
     }
-    if (s->composite) return EDGPU_OK;      // composite blocks (ed_total_ud=F) keep their tables; only the diagonal is formed on the fly
+    if (s->composite) { s->direct_built = true; return EDGPU_OK; }      // composite blocks (ed_total_ud=F) keep their tables; only the diagonal is formed on the fly
     for (int k = 0; k < 2 * H.Ns_Ud; k++) {
         DevFactor &f = *s->fac[k];
         TabArgs T{};
@@ -77,6 +82,7 @@ static int direct_tables(S *s)
         else hipLaunchKernelGGL(k_direct_tables<64>, dim3((unsigned)cdiv(T.dim, 64)), dim3(64), 0, s->stream, T);
     }
     HIPCHK(hipGetLastError());
+    s->direct_built = true;
     return EDGPU_OK;
 }
 
@@ -592,7 +598,8 @@ static int hxv(S *s, const double *v, double *out, bool epi, const double *uprev
             } else if (halo_can) {
                 // rows beyond LDS: a workgroup per row segment, out-of-segment sources prefetched into an LDS halo (k_uppass_halo)
                 DevFactor &f0 = *s->upf;
-                if (direct) {       // the on-the-fly tables were just rebuilt with columns: positions again
+                if (direct && !(s->direct_cache && s->seg_remapped)) {       // the on-the-fly tables were (re)built with columns: positions again
+                    s->seg_remapped = true;
                     hipLaunchKernelGGL(k_seg_remap, dim3((unsigned)cdiv(H.DimUp, 256)), dim3(256), 0, s->stream, f0.pelem8.p, f0.pseg8.p, f0.seg_ext.p, f0.seg_ext_off.p, (int32_t)H.DimUp, f0.seglen, f0.seglen, f0.map.p, (int32_t)A.impmask);
                 }
                 UpHaloArgs U{};

@@ -254,6 +254,7 @@ struct edgpu_sector_s {
     int64_t nnz_total = 0, bytes_stored = 0;
     int64_t npartial = 0;
     // knobs read from the environment ONCE, at sector creation (never inside a product)
+    bool direct_built = false, direct_cache = true, seg_remapped = false;      // on-the-fly tables derived once per sector (direct_tables)
     bool pad_allowed = true;  // EDGPU_PAD != 0: work vectors of the Lanczos loops may carry a padded row pitch
     bool up_pairs10 = true;   // pair form of the LDS-row local passes for 9-10 up hops (EDGPU_UP_PAIRS10=0: one configuration per lane, as before round 3)
     int abl = 0;              // EDGPU_ABL: timing ablations of k_uppass_halo (wrong results; scripts/prof_halo2.sh)

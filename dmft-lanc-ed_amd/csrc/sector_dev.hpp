@@ -491,7 +491,7 @@ static int create(const edgpu_desc *desc, S **out)
     s->nloc_el = H.DimUp * H.Qdw; s->nloc = s->nloc_el * H.DimPh; s->vecdim = s->nloc;
     s->multi = desc->mpi_size > 1 || (desc->reserved & 1);   // reserved bit 0: run the exchange path even on one rank (tests)
     s->lz_fused_on = dbg_int("EDGPU_LZ_FUSED", 1) != 0;
-    s->dbg = dbg_flags(); s->abl = dbg_int("EDGPU_ABL", 0); s->one_ar = dbg_int("EDGPU_ONE_ALLREDUCE", 0) != 0; s->up_pairs10 = dbg_int("EDGPU_UP_PAIRS10", 1) != 0; s->pad_allowed = dbg_int("EDGPU_PAD", 1) != 0 && dbg_int("EDGPU_ODD_PAIRS", 1) != 0; s->tables_wave = dbg_int("EDGPU_TABLES_WAVE", 1) != 0; s->dw_lds_kb = std::min(dbg_int("EDGPU_DW_LDS_KB", 0), 150);
+    s->dbg = dbg_flags(); s->abl = dbg_int("EDGPU_ABL", 0); s->one_ar = dbg_int("EDGPU_ONE_ALLREDUCE", 0) != 0; s->up_pairs10 = dbg_int("EDGPU_UP_PAIRS10", 1) != 0; s->direct_cache = dbg_int("EDGPU_DIRECT_CACHE", 1) != 0; s->pad_allowed = dbg_int("EDGPU_PAD", 1) != 0 && dbg_int("EDGPU_ODD_PAIRS", 1) != 0; s->tables_wave = dbg_int("EDGPU_TABLES_WAVE", 1) != 0; s->dw_lds_kb = std::min(dbg_int("EDGPU_DW_LDS_KB", 0), 150);
     // distributed-transpose dw pass: opt-in (EDGPU_DW_TRANSPOSE=1) until an 8-GPU run has shown it correct and faster than the
     // needed-rows exchange; at most 64 ranks (larger jobs use the needed-rows exchange)
     s->tr_on = s->multi && s->two_factor && !s->extra && desc->storage != EDGPU_STORE_CSR && dbg_int("EDGPU_DW_TRANSPOSE", 0) != 0 && H.DimUp >= desc->mpi_size && desc->mpi_size <= 64;
