@@ -41,8 +41,9 @@ enum { EDGPU_BATH_NORMAL = 0, EDGPU_BATH_HYBRID = 1, EDGPU_BATH_REPLICA = 2 };
  *  CSR    : the same operator expanded to explicit CSR (int64 row_ptr, int32 col, fp64 val): for large sectors as a local
  *           block + a dw block; Jx/Jp sectors add the stored non-local block (spH0nd) as compressed rows, phonon sectors
  *           the stored electronic factor of the e-ph coupling (spH0e_eph); ed_total_ud=F through composite up/dw blocks.
- *  DIRECT : nothing stored (ed_sparse_H=F): diagonal and hop tables are recomputed from the
- *           bit patterns at every product; ED_HAMILTONIAN_DIRECT_HxV.f90:21-95. */
+ *  DIRECT : no stored operator (ed_sparse_H=F): the O(N) diagonal is recomputed from the bit patterns inside every product; the
+ *           O(DimUp + DimDw) hop tables of the spin factors are derived from the bit patterns by the first product of a sector
+ *           (EDGPU_DIRECT_CACHE=0 in the environment: by every product); ED_HAMILTONIAN_DIRECT_HxV.f90:21-95. */
 enum { EDGPU_STORE_KRON = 0, EDGPU_STORE_CSR = 1, EDGPU_STORE_DIRECT = 2 };
 
 /* Resolved inputs of build_Hv_sector (ED_HAMILTONIAN.f90:43-168) -- the values the
