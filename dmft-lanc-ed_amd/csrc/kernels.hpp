@@ -254,6 +254,7 @@ struct UpArgs {
     const double *v; double *out; const double *uprev; const double *scal;
     int32_t ld;              // row pitch of v / out / uprev in doubles (0: DimUp); the stored diagonal keeps pitch DimUp
     const double *crowtab;   // DIRECT: [idw][nI] row constants (k_crow_table)
+    const uint4 *pelem16;    // element-major image, 12 dwords per configuration (8 of 16-bit columns, 4 of 8-bit codes); nullptr: the slot-major image above
 };
 
 template <bool DIRECT, bool EPI, int NT>
@@ -290,10 +291,17 @@ __global__ void __launch_bounds__(NT) k_uppass(UpArgs A)
         auto load_ops = [&](int i, Ops &o) {
             o.d = DIRECT ? A.Eup[i] : A.diag[idwl * DimUp + i];
             if (EPI) o.u = A.uprev[row * ld + i];
+            if (A.pelem16) {      // three 16-byte loads: columns 0-7, 8-15, codes (padding slots: the row's own position, code 127)
+                const uint4 *pe = A.pelem16 + 3 * (int64_t)i;
+                const uint4 a = pe[0], b = pe[1], c4 = pe[2];
+                o.cols[0] = a.x; o.cols[1] = a.y; o.cols[2] = a.z; o.cols[3] = a.w; o.cols[4] = b.x; o.cols[5] = b.y; o.cols[6] = b.z; o.cols[7] = b.w;
+                o.codes[0] = c4.x; o.codes[1] = c4.y; o.codes[2] = c4.z; o.codes[3] = c4.w;
+            } else {
 #pragma unroll
             for (int c = 0; c < MAXC; c++) if (c < ndw) o.codes[c] = A.pcodes[(int64_t)c * DimUp + i];
 #pragma unroll
             for (int c = 0; c < 2 * MAXC; c++) o.cols[c] = c < ncw ? A.pcols[(int64_t)c * DimUp + i] : ((uint32_t)i | ((uint32_t)i << 16));      // slots beyond the image (odd widths): the row's own position, like any padding slot -- never an uninitialised LDS index
+            }
         };
         Ops cur, nxt;
         if (tid < DimUp) load_ops(tid, cur);
@@ -458,6 +466,7 @@ struct UpAxArgs {
     const uint32_t *pcols, *pcodes; int32_t upw;      // k_uppass_ax (one configuration per lane, up to 16 hops): packed ELL image as k_uppass
     const double *crowtab;   // DIRECT: [idw][nI] row constants (k_crow_table)
     int32_t dtrue;           // pair forms: true DimUp when DimUp is the odd row length rounded up to even (see UpArgs2); 0: same
+    const uint4 *pelem16;    // k_uppass_ax: element-major image of 12 dwords per configuration; nullptr: the slot-major image (pcols / pcodes)
 };
 
 template <bool DIRECT, bool ACC, int NT, int NH = 8>      // NH: hop slots per up configuration, as k_uppass2
@@ -655,10 +664,17 @@ __global__ void __launch_bounds__(NT) k_uppass_ax(UpAxArgs A)
         const int64_t idwl = row % A.Qdw;
         auto load_ops = [&](int i, Ops &o) {
             o.d = DIRECT ? A.Eup[i] : A.diag[idwl * DimUp + i];
+            if (A.pelem16) {      // three 16-byte loads: columns 0-7, 8-15, codes (padding slots: the row's own position, code 127)
+                const uint4 *pe = A.pelem16 + 3 * (int64_t)i;
+                const uint4 a = pe[0], b = pe[1], c4 = pe[2];
+                o.cols[0] = a.x; o.cols[1] = a.y; o.cols[2] = a.z; o.cols[3] = a.w; o.cols[4] = b.x; o.cols[5] = b.y; o.cols[6] = b.z; o.cols[7] = b.w;
+                o.codes[0] = c4.x; o.codes[1] = c4.y; o.codes[2] = c4.z; o.codes[3] = c4.w;
+            } else {
 #pragma unroll
             for (int c = 0; c < MAXC; c++) if (c < ndw) o.codes[c] = A.pcodes[(int64_t)c * DimUp + i];
 #pragma unroll
             for (int c = 0; c < 2 * MAXC; c++) o.cols[c] = c < ncw ? A.pcols[(int64_t)c * DimUp + i] : ((uint32_t)i | ((uint32_t)i << 16));      // slots beyond the image (odd widths): the row's own position, like any padding slot -- never an uninitialised LDS index
+            }
         };
         Ops cur, nxt;
         if (tid < DimUp) load_ops(tid, cur);

@@ -267,6 +267,7 @@ static int fused_local(S *s, double *r, const double *uprev, double *t, double *
     const size_t lds = (((size_t)H.DimUp + 1) & ~(size_t)1) * 8 + 128 * 8 + 32 * 8 + 32 * 8 + (direct ? (((size_t)H.DimUp + 16) & ~(size_t)15) : 0);      // + the impurity-word bytes of the on-the-fly form
     const int grid = (int)std::min<int64_t>(U.nrows, s->up_grid);
     U.pcols = s->upf->pcols.p; U.pcodes = s->upf->pcodes.p; U.upw = s->upf->width; U.crowtab = direct ? s->crow_tab.p : nullptr;
+    U.pelem16 = (s->upf->packed_elem16 && s->up_elem16) ? reinterpret_cast<const uint4 *>(s->upf->pelem16.p) : nullptr;
     if (direct && !U.crowtab) return fail(EDGPU_EINVAL, "edgpu: internal: row-constant table of the on-the-fly form missing");
     const dim3 g(grid), b(LZAX_NT);
 #define AX_LAUNCH(K_, D_, A_)                                                                                                   \
@@ -574,6 +575,7 @@ static int hxv(S *s, const double *v, double *out, bool epi, const double *uprev
                 UpArgs U{};
                 U.DimUp = A.DimUp; U.DimPh = A.DimPh; U.Qdw = A.Qdw; U.dw0 = A.dw0; U.nrows = H.Qdw * H.DimPh;
                 U.pcols = s->upf->pcols.p; U.pcodes = s->upf->pcodes.p; U.upw = s->upf->width; U.tval = s->upf->ptval.p; U.nterms = s->upf->pterms;
+                U.pelem16 = (s->upf->packed_elem16 && s->up_elem16) ? reinterpret_cast<const uint4 *>(s->upf->pelem16.p) : nullptr;
                 U.diag = A.diag; U.Eup = A.Eup; U.Edw = A.Edw; U.cross = A.cross; U.mapup = A.mapup; U.mapdw = A.mapdw; U.impmask = A.impmask; U.nI = A.nI; U.econst = A.econst;
                 U.v = v; U.out = out; U.uprev = uprev; U.scal = s->scal.p; U.ld = (int32_t)ld;
                 U.crowtab = direct ? s->crow_tab.p : nullptr;

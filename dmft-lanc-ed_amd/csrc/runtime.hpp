@@ -172,7 +172,7 @@ static void kpool_release()
 
 struct DevFactor {
     DevBuf<int32_t> map, rank, rowptr, cols, ellc, talpha, tbeta;
-    DevBuf<uint32_t> pcols, pcodes, pelem, pelem8; DevBuf<double> ptval; bool packed = false, packed_elem = false, packed_elem8 = false; int32_t pterms = 0;
+    DevBuf<uint32_t> pcols, pcodes, pelem, pelem8, pelem16; DevBuf<double> ptval; bool packed = false, packed_elem = false, packed_elem8 = false, packed_elem16 = false; int32_t pterms = 0;      // pelem16: element-major image of 12 dwords (16 hop slots) for the one-configuration-per-lane kernels
     // segment + halo form of the local pass for rows beyond LDS (k_uppass_halo): the row is cut into nseg segments; seg_ext
     // lists, per segment and ascending, the columns outside it that its hops reach; pseg8 is pelem8 with every column
     // replaced by its position in the workgroup's LDS image [segment | halo]
@@ -255,6 +255,7 @@ struct edgpu_sector_s {
     int64_t npartial = 0;
     // knobs read from the environment ONCE, at sector creation (never inside a product)
     bool direct_built = false, direct_cache = true, seg_remapped = false;      // on-the-fly tables derived once per sector (direct_tables)
+    bool up_elem16 = true;    // one-configuration-per-lane local passes read the element-major 12-dword image (EDGPU_UP_ELEM16=0: the slot-major one)
     bool pad_allowed = true;  // EDGPU_PAD != 0: work vectors of the Lanczos loops may carry a padded row pitch
     bool up_pairs10 = true;   // pair form of the LDS-row local passes for 9-10 up hops (EDGPU_UP_PAIRS10=0: one configuration per lane, as before round 3)
     int abl = 0;              // EDGPU_ABL: timing ablations of k_uppass_halo (wrong results; scripts/prof_halo2.sh)

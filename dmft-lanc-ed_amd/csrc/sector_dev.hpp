@@ -75,6 +75,14 @@ static int upload_factor(S *s, int k)
             }
             CHK(df->pelem8.upload(pe)); df->packed_elem8 = true;
         }
+        if (ok && W <= 16) {                        // element-major image of 12 dwords (8 of columns, 4 of codes: 16 hop slots) for the one-configuration-per-lane kernels:
+            std::vector<uint32_t> pe((size_t)12 * f.dim, 0u);      // three 16-byte loads per configuration instead of up to eleven 4-byte ones from the slot-major image
+            for (int32_t i = 0; i < f.dim; i++) {
+                for (int c = 0; c < 8; c++) pe[(size_t)12 * i + c] = c < ncw ? pc[(size_t)c * f.dim + i] : ((uint32_t)i | ((uint32_t)i << 16));
+                for (int c = 0; c < 4; c++) pe[(size_t)12 * i + 8 + c] = c < ndw ? pd[(size_t)c * f.dim + i] : 0x7f7f7f7fu;
+            }
+            CHK(df->pelem16.upload(pe)); df->packed_elem16 = true;
+        }
         if (ok && W <= 8) {                         // element-major image for the pair kernel: 6 dwords per up configuration
             std::vector<uint32_t> pe((size_t)6 * dimp, 0u);
             if (dimp > f.dim) { for (int c = 0; c < 4; c++) pe[(size_t)6 * f.dim + c] = (uint32_t)f.dim | ((uint32_t)f.dim << 16); for (int c = 4; c < 6; c++) pe[(size_t)6 * f.dim + c] = 0x7f7f7f7fu; }
@@ -491,7 +499,7 @@ static int create(const edgpu_desc *desc, S **out)
     s->nloc_el = H.DimUp * H.Qdw; s->nloc = s->nloc_el * H.DimPh; s->vecdim = s->nloc;
     s->multi = desc->mpi_size > 1 || (desc->reserved & 1);   // reserved bit 0: run the exchange path even on one rank (tests)
     s->lz_fused_on = dbg_int("EDGPU_LZ_FUSED", 1) != 0;
-    s->dbg = dbg_flags(); s->abl = dbg_int("EDGPU_ABL", 0); s->one_ar = dbg_int("EDGPU_ONE_ALLREDUCE", 0) != 0; s->up_pairs10 = dbg_int("EDGPU_UP_PAIRS10", 1) != 0; s->direct_cache = dbg_int("EDGPU_DIRECT_CACHE", 1) != 0; s->pad_allowed = dbg_int("EDGPU_PAD", 1) != 0 && dbg_int("EDGPU_ODD_PAIRS", 1) != 0; s->tables_wave = dbg_int("EDGPU_TABLES_WAVE", 1) != 0; s->dw_lds_kb = std::min(dbg_int("EDGPU_DW_LDS_KB", 0), 150);
+    s->dbg = dbg_flags(); s->abl = dbg_int("EDGPU_ABL", 0); s->one_ar = dbg_int("EDGPU_ONE_ALLREDUCE", 0) != 0; s->up_pairs10 = dbg_int("EDGPU_UP_PAIRS10", 1) != 0; s->direct_cache = dbg_int("EDGPU_DIRECT_CACHE", 1) != 0; s->up_elem16 = dbg_int("EDGPU_UP_ELEM16", 1) != 0; s->pad_allowed = dbg_int("EDGPU_PAD", 1) != 0 && dbg_int("EDGPU_ODD_PAIRS", 1) != 0; s->tables_wave = dbg_int("EDGPU_TABLES_WAVE", 1) != 0; s->dw_lds_kb = std::min(dbg_int("EDGPU_DW_LDS_KB", 0), 150);
     // distributed-transpose dw pass: opt-in (EDGPU_DW_TRANSPOSE=1) until an 8-GPU run has shown it correct and faster than the
     // needed-rows exchange; at most 64 ranks (larger jobs use the needed-rows exchange)
     s->tr_on = s->multi && s->two_factor && !s->extra && desc->storage != EDGPU_STORE_CSR && dbg_int("EDGPU_DW_TRANSPOSE", 0) != 0 && H.DimUp >= desc->mpi_size && desc->mpi_size <= 64;
