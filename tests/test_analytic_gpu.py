@@ -125,6 +125,20 @@ def test_free_fermion_e0_c3_full_size(edgpu_mod):
     assert abs(ref - (-17.223146712820377)) < 1e-12
 
 
+def test_free_fermion_e0_odd_rows_and_off_half_filling_full_size(edgpu_mod):
+    """Analytic anchors for the kernel forms of round 3 at full size, interactions off: Ns=15 (every sector has an odd DimUp: the
+    column-pair kernels on pitched vectors), sector (7,8), N=41,409,225; and the Green's-function target sectors of config 3,
+    (9,8) and (7,8) at Ns=16 (9 up hops per configuration: the pair form with 10 hop slots), N=147,232,800."""
+    from edgpu import model
+    m, nu, nd = model.half_filled_c(14)
+    assert (nu, nd) == ([7], [8])
+    _free_e0_check(edgpu_mod, analytic.non_interacting(m), nu, nd, ("kron", "direct"))
+    _free_e0_check(edgpu_mod, analytic.non_interacting(m, xmu=0.2), [6], [8], ("direct",))
+    m, _, _ = model.half_filled_c(15)
+    _free_e0_check(edgpu_mod, analytic.non_interacting(m), [9], [8], ("kron", "direct"))
+    _free_e0_check(edgpu_mod, analytic.non_interacting(m, xmu=-0.1), [7], [8], ("kron",))
+
+
 def test_free_fermion_e0_c4_full_size(edgpu_mod):
     """BASELINE config 4 (Ns=18, N=2,363,904,400) on one GPU: on-the-fly and stored-factor storage, E0 = -19.218415152809"""
     from edgpu import model
