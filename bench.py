@@ -201,6 +201,51 @@ def timed_steps(G, K, W, torch, dist):
     return dt
 
 
+def emulate_rank(a):
+    """One rank of `--of` P, alone on one GPU (ED_HAMILTONIAN.f90:96-110 partition, same row lists, x-space, pack kernel, streams as
+    the P-rank job; Communicator.emulated).  Prints one JSON line: per-step and per-product times of THAT rank's share, the exchange
+    volume it would receive, and the emulated exchange (device copies) timed on the comm stream.  `value` is the rank's share of the
+    equivalent-CSR bytes per step time -- a per-rank figure for the model of DESIGN section 6, not a job throughput."""
+    import torch
+    import numpy as np
+    import edgpu
+    from edgpu import model
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (libedgpu.so has no CPU path)")
+    r, P = a.emulate_rank, a.of
+    m, nu, nd = model.half_filled_c(a.nbath)
+    t0 = time.perf_counter()
+    G = edgpu.HvSector(m, nu, nd, storage=a.storage, rank=r, size=P, device=0)
+    comm = edgpu.Communicator.emulated(r, P)
+    G.attach_comm(comm)
+    torch.cuda.synchronize()
+    t_build = time.perf_counter() - t0
+    K, W = a.steps, a.warmup
+    dt = timed_steps(G, K, W, torch, None)
+    hxv_ms, _, _ = G.bench_result(K)
+    comm_ms = G.bench_comm_ms(K)
+    xmode, sendb, recvb = G.exchange_info()
+    N = int(G.Dim); Ns = m["Ns"]; Nloc = int(G.vecDim); nnz_loc = int(G.info.nnz_total)
+    bytes_fmt = {"csr": b_csr(Nloc, nnz_loc), "kron": 24 * Nloc, "direct": 16 * Nloc}[a.storage]
+    out = {"metric": "EMULATED rank %d of %d on ONE GPU: Lanczos-iteration time of that rank's share, Ns=%d half-filled sector (not a job throughput)" % (r, P, Ns),
+           "value": b_csr(Nloc, Nloc * (1 + Ns)) / (dt / K) / 1e9, "unit": "GB/s (equivalent-CSR bytes of the rank's rows / step time)",
+           "emulated": {"rank": r, "of": P, "exchange": "device-to-device copies of the received byte count on the comm stream"},
+           "n_gpus": 1, "steps": K, "warmup": W, "ms_per_step": dt / K * 1e3, "dtype": "f64", "data": "synthetic",
+           "config": {"workload": "1-orbital Anderson impurity, Nbath=%d (Ns=%d), N=%d, rank %d of %d owns %d dw columns = %d rows, storage=%s" % (a.nbath, Ns, N, r, P, int(G.info.mpiQdw), Nloc, a.storage),
+                      "storage": a.storage, "N": N, "rows_of_rank": Nloc, "forms": G.describe()},
+           "time_split_ms": {"hxv_product_of_rank": hxv_ms, "axpy_norm_reductions_scalars": dt / K * 1e3 - hxv_ms, "emulated_exchange_on_comm_stream": comm_ms},
+           "roofline_of_rank": {"algorithmic_bytes": bytes_fmt, "achieved_GBps": bytes_fmt / (hxv_ms * 1e-3) / 1e9 if hxv_ms > 0 else None, "frac": bytes_fmt / (hxv_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS if hxv_ms > 0 else None},
+           "exchange": {"mode": xmode, "received_MB_per_product": round(float(recvb.sum()) / 1e6, 2), "sent_MB_per_product": round(float(sendb.sum()) / 1e6, 2),
+                        "busiest_peer_received_MB": round(float(recvb.max()) / 1e6, 2), "received_by_peer_MB": [round(float(x) / 1e6, 2) for x in recvb]},
+           "model_on_xgmi_ms": {"busiest_peer_at_77GBps": float(recvb.max()) / 77e9 * 1e3, "busiest_peer_at_60GBps": float(recvb.max()) / 60e9 * 1e3,
+                                "balanced_over_%d_links_at_77GBps" % max(P - 1, 1): float(recvb.sum()) / max(P - 1, 1) / 77e9 * 1e3,
+                                "note": "link times are a model; kernel times above are measured"},
+           "build_s": t_build}
+    print(json.dumps(out))
+    G.close(); comm.close()
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -215,7 +260,11 @@ def main():
     ap.add_argument("--force-dist", action="store_true", help="run the N>1 code path (process group, communicator, exchange) even with one rank (self-test)")
     ap.add_argument("--share-gpus", action="store_true", help="allow more ranks than devices (ranks share devices; implies --comm gloo)")
     ap.add_argument("--launch-timeout", type=int, default=1500)
+    ap.add_argument("--emulate-rank", type=int, default=None, help="with --of P: time ONE rank of a P-rank job alone on this GPU (emulated communicator: exchanges become device copies of the same byte count); a measurement aid, not a job throughput")
+    ap.add_argument("--of", type=int, default=8, help="rank count of the emulated job")
     a = ap.parse_args()
+    if a.emulate_rank is not None:
+        raise SystemExit(emulate_rank(a))
     if a.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
     if a.share_gpus:

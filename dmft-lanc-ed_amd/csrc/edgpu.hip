@@ -52,6 +52,17 @@ extern "C" {
 
 int edgpu_abi_version(void) { return EDGPU_ABI_VERSION; }
 const char *edgpu_last_error(void) { return g_err.c_str(); }
+int edgpu_knob_count(void) { return kNumKnobs; }
+int edgpu_knob_info(int32_t i, const char **name, int32_t *default_value, const char **kind, const char **doc, const char **covered_by)
+{
+    if (i < 0 || i >= kNumKnobs) return fail(EDGPU_EINVAL, "edgpu_knob_info: index out of range");
+    if (name) *name = kKnobs[i].name;
+    if (default_value) *default_value = kKnobs[i].dflt;
+    if (kind) *kind = kKnobs[i].kind;
+    if (doc) *doc = kKnobs[i].doc;
+    if (covered_by) *covered_by = kKnobs[i].test;
+    return EDGPU_OK;
+}
 
 int edgpu_sector_create(const edgpu_desc *desc, edgpu_handle *out)
 {
@@ -1103,6 +1114,15 @@ int edgpu_comm_create_callbacks(int32_t rank, int32_t size, edgpu_allgatherv_fn 
     *out = c;
     return EDGPU_OK;
 }
+int edgpu_comm_create_emulated(int32_t rank, int32_t size, edgpu_comm *out)
+{
+    if (!out || size < 1 || rank < 0 || rank >= size) return fail(EDGPU_EINVAL, "edgpu_comm_create_emulated: bad argument");
+    auto *c = new edgpu_comm_s();
+    c->c.kind = Comm::EMULATED; c->c.rank = rank; c->c.size = size;
+    (void)hipGetDevice(&c->device); (void)hipGetLastError();
+    *out = c;
+    return EDGPU_OK;
+}
 // Sub-communicator of the first `nranks` ranks (ED_HAMILTONIAN.f90:65-93: sectors with DimDw < MpiSize run on the first
 // DimDw ranks).  COLLECTIVE over the parent: every rank calls it; *is_member = 0 and *out = NULL on the ranks left out.
 // The result is cached in the parent: one split per distinct size, however many sectors use it.
@@ -1150,6 +1170,7 @@ int edgpu_comm_allreduce_sum(edgpu_comm c, double *buf_host, int32_t n)
 {
     if (!c || !buf_host || n < 1) return fail(EDGPU_EINVAL, "edgpu_comm_allreduce_sum: bad argument");
     if (c->c.kind == Comm::CALLBACK) { if (c->c.ar(c->c.ctx, buf_host, n)) return fail(EDGPU_ECOMM, "edgpu: allreduce callback failed"); return EDGPU_OK; }
+    if (c->c.kind == Comm::EMULATED) return EDGPU_OK;      // the rank's own values stand for the sum
     if (c->c.kind != Comm::RCCL) return fail(EDGPU_ECOMM, "edgpu_comm_allreduce_sum: no communicator");
     HIPCHK(hipSetDevice(c->device));
     DevBuf<double> d; CHK(d.alloc((size_t)n));

@@ -8,6 +8,18 @@ namespace edgpu {
 // exchange step: gather the input vector of every rank (phonon block by phonon block)
 // ---------------------------------------------------------------------------------------
 static int halo_exchange(S *s, const double *v_local, hipStream_t st);
+// Emulated communicator (edgpu_comm_create_emulated): ONE rank of P runs alone on its GPU with the partition, row lists, x-space,
+// packing and stream structure of the P-rank job; what the peers would deliver is replaced by device-to-device copies of the same
+// byte count out of the rank's own data, issued on the comm stream where the receives would be (the write side of a receive is
+// HBM traffic of this rank; the read side of the copy is not, and stands in for the sends this rank serves).  The numbers that
+// arrive are not the peers' -- finite, of the right size -- so such a run measures time and traffic, never a result.
+static int emu_fill(double *dst, int64_t count, const double *src, int64_t srccap, hipStream_t st)
+{
+    if (srccap < 1) return EDGPU_OK;
+    for (int64_t o = 0; o < count; o += srccap)
+        HIPCHK(hipMemcpyAsync(dst + o, src, (size_t)std::min(srccap, count - o) * 8, hipMemcpyDeviceToDevice, st));
+    return EDGPU_OK;
+}
 // all-gather into the global layout [iph][idw][iup] at dst (allgather_vector_MPI, ED_SETUP.f90:689-733)
 static int gather_full(S *s, const double *v_local, double *dst, hipStream_t st)
 {
@@ -36,6 +48,8 @@ static int gather_full(S *s, const double *v_local, double *dst, hipStream_t st)
         } else if (c.kind == Comm::CALLBACK) {
             HIPCHK(hipStreamSynchronize(st));
             if (c.ag(c.ctx, send, nel_loc, recv, counts.data(), displs.data(), P)) return fail(EDGPU_ECOMM, "edgpu: allgatherv callback failed");
+        } else if (c.kind == Comm::EMULATED) {
+            for (int r = 0; r < P; r++) CHK(emu_fill(recv + displs[r], counts[r], send, nel_loc, st));
         } else
             return fail(EDGPU_ECOMM, "edgpu: mpi_size>1 but no communicator attached (edgpu_comm_init_*)");
     }
@@ -99,6 +113,13 @@ static int halo_exchange(S *s, const double *v_local, hipStream_t st)
                     }
                     if (c.xch(c.ctx, kind ? srsrc : sb, sc.data(), sd_.data(), kind ? rrdst : xr, rcv.data(), rd_.data(), P)) return fail(EDGPU_ECOMM, "edgpu: exchange callback failed");
                 }
+            } else if (c.kind == Comm::EMULATED) {
+                for (int b = 0; b < P; b++) {
+                    if (b == c.rank) continue;
+                    const S::RelayPiece *sd, *sr, *rd, *rr; pieces(b, sd, sr, rd, rr);
+                    CHK(emu_fill(xr + rd->off * rowlen, rd->cnt * rowlen, v_local, H.Qdw * rowlen, st));
+                    CHK(emu_fill(rrdst + rr->off * rowlen, rr->cnt * rowlen, v_local, H.Qdw * rowlen, st));
+                }
             } else
                 return fail(EDGPU_ECOMM, "edgpu: mpi_size>1 but no communicator attached (edgpu_comm_init_*)");
         }
@@ -125,6 +146,9 @@ static int halo_exchange(S *s, const double *v_local, hipStream_t st)
             for (int r = 0; r < P; r++) { sc[r] = s->send_rows_cnt[r] * rowlen; sd[r] = s->send_rows_off[r] * rowlen; rcv[r] = s->recv_rows_cnt[r] * rowlen; rd[r] = (H.Qdw + s->recv_rows_off[r]) * rowlen; }
             HIPCHK(hipStreamSynchronize(st));
             if (c.xch(c.ctx, sb, sc.data(), sd.data(), x, rcv.data(), rd.data(), P)) return fail(EDGPU_ECOMM, "edgpu: exchange callback failed");
+        } else if (c.kind == Comm::EMULATED) {
+            for (int r = 0; r < P; r++)
+                if (r != c.rank) CHK(emu_fill(x + (H.Qdw + s->recv_rows_off[r]) * rowlen, s->recv_rows_cnt[r] * rowlen, v_local + (int64_t)iph * s->nloc_el, H.Qdw * rowlen, st));
         } else
             return fail(EDGPU_ECOMM, "edgpu: mpi_size>1 but no communicator attached (edgpu_comm_init_*)");
     }
@@ -144,6 +168,8 @@ static int allreduce_dev(S *s, double *p, int n)
         HIPCHK(hipMemcpyAsync(h.data(), p, (size_t)n * 8, hipMemcpyDeviceToHost, s->stream)); HIPCHK(hipStreamSynchronize(s->stream));
         if (c.ar(c.ctx, h.data(), n)) return fail(EDGPU_ECOMM, "edgpu: allreduce callback failed");
         HIPCHK(hipMemcpyAsync(p, h.data(), (size_t)n * 8, hipMemcpyHostToDevice, s->stream)); HIPCHK(hipStreamSynchronize(s->stream));
+    } else if (c.kind == Comm::EMULATED) {
+        // the rank's own partial sums stand for the global ones
     } else
         return fail(EDGPU_ECOMM, "edgpu: mpi_size>1 but no communicator attached");
     return EDGPU_OK;

@@ -749,23 +749,30 @@ struct UpHaloArgs {
     int32_t DimUp, DimPh, nseg, seglen, halocap; int64_t Qdw, dw0, nrows;
     const uint4 *pseg8; const int32_t *ext, *ext_off;
     const double *tval; int32_t nterms;
-    const double *diag, *Eup, *Edw, *cross; const int32_t *mapup, *mapdw; int32_t impmask, nI; double econst;
+    const double *diag, *Eup; int32_t nI;
     const double *v; double *out;
     int32_t ld;              // row pitch of v / out in doubles (0: DimUp)
-    // ADD: `out` already holds the dw part (k_dwpass2<..., WR>): this pass adds to it.  EPI: Lanczos epilogue on top,
-    // out = s_cur*(local + dw) - beta*s_prev*uprev and the alpha partial sums (s_cur*v).out per workgroup
-    const double *uprev, *scal; double *partial;
     const double *crowtab;   // DIRECT: [idw][nI] Edw + econst + cross(up impurity word, dw impurity word), rebuilt with the other on-the-fly tables
 };
 constexpr int kHaloSegMax = 6144, kHaloMax = 12288;     // up to 3 pairs and 12 halo values per lane of a 1024-thread workgroup
-// ABL (timing experiments only, results wrong): 1 = amplitudes not looked up in LDS (constant), 2 = gathers read the lane's own element,
-// 4 = halo values not loaded, 8 = hop words loaded for the first two rows only, 16 = no stores (EDGPU_ABL)
-// NT: threads per workgroup.  1024 = one workgroup per CU (the 16 waves of a CU share both barriers of every item); 512 with
-// segments half as long = two independent workgroups per CU whose barrier phases interleave (EDGPU_UP_SEGMAX=2048 EDGPU_UP_NT=512).
-template <bool DIRECT, int NQ, int MAXH, bool ADD = false, bool EPI = false, int ABL = 0, int NT = 1024>      // NQ: pairs per lane = steps per (row, segment) item; MAXH: halo values per lane
-__global__ void __launch_bounds__(NT, 4) k_uppass_halo(UpHaloArgs A)      // 4 waves per SIMD: one workgroup of 1024 or two of 512 per CU
+// NQ: pairs per lane = steps per (row, segment) item; MAXH: halo values per lane; NH: hop slots walked per element (9 at half
+// filling of Ns=18: the tenth slot of the image is padding there).
+// Round 4 (profiles/r04/ns18_local_pass.txt):
+//  * the hop words of a lane (pseg8: LDS positions + term codes of its NQ element pairs, and Eup for the on-the-fly diagonal)
+//    do not depend on the row -- the segment of a workgroup is fixed for the launch -- so they are loaded ONCE and stay in
+//    registers (the first form re-read 64 bytes per pair and row from L2);
+//  * amplitudes come from a 256-entry SIGNED table (index = the code byte itself, sign bit included) at LDS address 0: a hop
+//    is 2 address instructions per LDS read + 1 FMA = 5 vector instructions, where the mask / compare / xor / select of the
+//    sign made it 10 -- the pass was bound by vector issue (4.15e9 wave instructions per launch, 6.8 ms of 17.4);
+//  * every global load of the next row (segment pairs, halo values, stored diagonal, row constant) is issued right after the
+//    first barrier, BEFORE this row's stores: on gfx9 loads and stores retire through one in-order counter (vmcnt), so a load
+//    issued behind a store cannot be consumed before that store has been acknowledged; now nothing the next LDS fill waits
+//    for sits behind a store of the same item.
+template <bool DIRECT, int NQ, int MAXH, int NH>
+__global__ void __launch_bounds__(1024, 4) k_uppass_halo(UpHaloArgs A)      // 4 waves per SIMD: one workgroup of 1024 per CU
 {
     extern __shared__ double lds[];
+    constexpr int NT = 1024;
     const int DimUp = A.DimUp, tid = threadIdx.x;
     const int64_t ld = A.ld ? A.ld : DimUp;
     const int x = blockIdx.x & 7, j = blockIdx.x >> 3, G = (int)(gridDim.x >> 3) / A.nseg;
@@ -773,108 +780,94 @@ __global__ void __launch_bounds__(NT, 4) k_uppass_halo(UpHaloArgs A)      // 4 w
     const int lo = sg * A.seglen, hi = lo + A.seglen < DimUp ? lo + A.seglen : DimUp;
     const int npair = (hi - lo) >> 1;
     const int eoff = A.ext_off[sg], nh = A.ext_off[sg + 1] - eoff;
-    double *halo = lds + A.seglen;
-    double *tv = halo + A.halocap;
-    double *crow = tv + 128;
-    double *red = crow + 32;
-    for (int t = tid; t < A.nterms && t < 128; t += NT) tv[t] = A.tval[t];
-    if (g >= G) { if (EPI && tid == 0) A.partial[blockIdx.x] = 0.0; return; }
-    const double s_cur = EPI ? A.scal[SC_SCUR] : 1.0, c_prev = (EPI && A.uprev) ? A.scal[SC_BETA] * A.scal[SC_SPREV] : 0.0;
-    double asum = 0.0;
+    double *tv = lds;                                    // signed amplitude table: tv[code], code = sign << 7 | term (127: padding slot, 0)
+    double *seg = lds + 256;                             // [segment | halo]: the positions stored in pseg8 index this
+    double *halo = seg + A.seglen;
+    double *crow = halo + A.halocap;
+    for (int t = tid; t < 256; t += NT) { const int k = t & 127; const double a = k < A.nterms ? A.tval[k] : 0.0; tv[t] = (t & 128) ? -a : a; }
+    if (g >= G) return;
     uint32_t hc[MAXH / 2];                               // this lane's halo columns, two 16-bit values per register: the same for every row
 #pragma unroll
     for (int h = 0; h < MAXH; h += 2) {
         const int t0 = tid + h * NT, t1 = t0 + NT;
         hc[h >> 1] = (t0 < nh ? (uint32_t)A.ext[eoff + t0] : 0u) | ((t1 < nh ? (uint32_t)A.ext[eoff + t1] : 0u) << 16);
     }
-    dbl2v xr[NQ]; double xh[MAXH]; double crn = 0.0;
-    const int64_t rstep = (int64_t)G * 8, lastrow = A.nrows - 1;
     const int pmax = npair > 0 ? npair - 1 : 0;
+    uint4 w[NQ][4]; dbl2v eup[NQ];                       // resident: hop words of the lane's pairs; Eup of their elements (DIRECT)
+#pragma unroll
+    for (int q = 0; q < NQ; q++) {
+        int p = tid + q * NT; p = p < npair ? p : pmax;
+        const int i = lo + 2 * p;
+        w[q][0] = A.pseg8[2 * i]; w[q][1] = A.pseg8[2 * i + 1]; w[q][2] = A.pseg8[2 * i + 2]; w[q][3] = A.pseg8[2 * i + 3];
+        if (DIRECT) eup[q] = *reinterpret_cast<const dbl2v *>(A.Eup + i);
+    }
+    dbl2v xr[NQ], dg[NQ]; double xh[MAXH]; double crn = 0.0;
+    const int64_t rstep = (int64_t)G * 8, lastrow = A.nrows - 1;
     // No branch around a prefetch load, neither per lane nor uniform: lanes and rows out of range load a clamped address and
-    // discard the value.  A wait for an older load is `s_waitcnt vmcnt(N)` with N = the memory operations issued since, and the
-    // compiler has to take the SMALLEST N over all paths: one path that skips the prefetch turns every such wait into
-    // vmcnt(0), i.e. the operands requested a moment ago are waited for at once (the first form of this kernel did exactly
-    // that: scripts/isa_waits.py; 17.3 ms at Ns=18).
-    auto fetch_row = [&](int64_t rw) {
+    // discard the value (a wait for an older load is `s_waitcnt vmcnt(N)` with the SMALLEST N over all paths: one path that
+    // skips the prefetch would turn every such wait into vmcnt(0), scripts/isa_waits.py).
+    auto fetch_row = [&](int64_t rw) {                   // rows = dw columns of this rank (DimPh == 1 here: phonon sectors use k_kron2)
         rw = rw < lastrow ? rw : lastrow;
         const double *vr = A.v + rw * ld;
 #pragma unroll
-        for (int q = 0; q < NQ; q++) { int p = tid + q * NT; p = p < npair ? p : pmax; xr[q] = *reinterpret_cast<const dbl2v *>(vr + lo + 2 * p); }
-#pragma unroll
-        for (int h = 0; h < MAXH; h++) xh[h] = (ABL & 4) ? 1.0 : vr[(hc[h >> 1] >> (16 * (h & 1))) & 0xffffu];      // entries beyond the list hold column 0
-        if (DIRECT) crn = A.crowtab[(A.dw0 + rw % A.Qdw) * A.nI + (tid < A.nI ? tid : 0)];      // Edw + const + cross term of that row (k_crow_table)
-    };
-    // Operand ring of two slots, continuous across items: the image slice of a workgroup is the same for every row, so the
-    // operands of linear step L+2 (possibly of the next row) are requested as soon as step L has used its slot.  Loads return
-    // in order: requests a step waits for are issued BEFORE the next row's prefetch, never behind it.
-    struct Ops { dbl2v d; uint4 w0, w1, w2, w3; dbl2v od, up; };       // d: stored diagonal (KRON) or Eup (DIRECT); od: dw part already in out (ADD); up: u_prev (EPI)
-    Ops o[2];
-    auto load_ops = [&](int64_t rw, int q, Ops &t) {
-        int p = tid + q * NT; p = p < npair ? p : pmax;
-        rw = rw < lastrow ? rw : lastrow;
-        const int i = lo + 2 * p;
-        if (!DIRECT) t.d = *reinterpret_cast<const dbl2v *>(A.diag + (rw % A.Qdw) * DimUp + i);
-        else t.d = *reinterpret_cast<const dbl2v *>(A.Eup + i);
-        if (!(ABL & 8) || rw < rstep * 2) { t.w0 = A.pseg8[2 * i]; t.w1 = A.pseg8[2 * i + 1]; t.w2 = A.pseg8[2 * i + 2]; t.w3 = A.pseg8[2 * i + 3]; }
-        if (ADD) t.od = *reinterpret_cast<const dbl2v *>(A.out + rw * ld + i);      // lanes in range: this lane alone writes that position, two steps from now
-        if (EPI && A.uprev) t.up = *reinterpret_cast<const dbl2v *>(A.uprev + rw * ld + i);
-    };
-    auto step = [&](int64_t rw, int q, const Ops &cur) {
-        const int p = tid + q * NT;
-        if (p < npair) {
-            const dbl2v xx = *reinterpret_cast<const dbl2v *>(lds + 2 * p);
-            dbl2v dval;
-            if (DIRECT) {           // byte 10 of the code dwords: the impurity word of the up configuration (k_seg_remap)
-                dval.x = cur.d.x + crow[(cur.w1.w >> 16) & 0xffu];
-                dval.y = cur.d.y + crow[(cur.w3.w >> 16) & 0xffu];
-            } else dval = cur.d;
-            const uint32_t c0[5] = {cur.w0.x, cur.w0.y, cur.w0.z, cur.w0.w, cur.w1.x}, k0[3] = {cur.w1.y, cur.w1.z, cur.w1.w};
-            const uint32_t c1[5] = {cur.w2.x, cur.w2.y, cur.w2.z, cur.w2.w, cur.w3.x}, k1[3] = {cur.w3.y, cur.w3.z, cur.w3.w};
-            double a0 = dval.x * xx.x, a1 = dval.y * xx.y;
-#pragma unroll
-            for (int e = 0; e < 10; e++) {
-                const uint32_t code0 = (k0[e >> 2] >> (8 * (e & 3))) & 0xffu, col0 = (c0[e >> 1] >> (16 * (e & 1))) & 0xffffu;
-                const uint32_t code1 = (k1[e >> 2] >> (8 * (e & 3))) & 0xffu, col1 = (c1[e >> 1] >> (16 * (e & 1))) & 0xffffu;
-                double t0 = (ABL & 1) ? 0.25 : tv[code0 & 0x7fu], t1 = (ABL & 1) ? 0.25 : tv[code1 & 0x7fu];
-                t0 = (code0 & 0x80u) ? -t0 : t0; t1 = (code1 & 0x80u) ? -t1 : t1;
-                a0 += t0 * ((ABL & 2) ? xx.x + (double)col0 : lds[col0]); a1 += t1 * ((ABL & 2) ? xx.y + (double)col1 : lds[col1]);
-            }
-            if (ADD) { a0 += cur.od.x; a1 += cur.od.y; }
-            if (EPI) {
-                a0 *= s_cur; a1 *= s_cur;
-                if (A.uprev) { a0 -= c_prev * cur.up.x; a1 -= c_prev * cur.up.y; }
-                asum += (s_cur * xx.x) * a0 + (s_cur * xx.y) * a1;
-            }
-            dbl2v r; r.x = a0; r.y = a1;
-            if (!(ABL & 16) || a0 == 12345.678) *reinterpret_cast<dbl2v *>(A.out + rw * ld + lo + 2 * p) = r;
-        }
-    };
-    auto item = [&](auto par, int64_t rw) {              // par: slot of this item's step 0
-        constexpr int P = decltype(par)::value;
-#pragma unroll
-        for (int q = 0; q < NQ; q++) { const int p = tid + q * NT; if (p < npair) *reinterpret_cast<dbl2v *>(lds + 2 * p) = xr[q]; }
-#pragma unroll
-        for (int h = 0; h < MAXH; h++) if (tid + h * NT < nh) halo[tid + h * NT] = xh[h];
-        if (DIRECT && tid < A.nI) crow[tid] = crn;
-        __syncthreads();
-#pragma unroll
         for (int q = 0; q < NQ; q++) {
-            Ops &slot = o[(P + q) & 1];
-            step(rw, q, slot);
-            load_ops(rw + (int64_t)((q + 2) / NQ) * rstep, (q + 2) % NQ, slot);
-            if (q == 0) fetch_row(rw + rstep);
+            int p = tid + q * NT; p = p < npair ? p : pmax;
+            xr[q] = *reinterpret_cast<const dbl2v *>(vr + lo + 2 * p);
+            if (!DIRECT) dg[q] = *reinterpret_cast<const dbl2v *>(A.diag + rw * DimUp + lo + 2 * p);
         }
-        __syncthreads();
+#pragma unroll
+        for (int h = 0; h < MAXH; h++) xh[h] = vr[(hc[h >> 1] >> (16 * (h & 1))) & 0xffffu];      // entries beyond the list hold column 0
+        if (DIRECT) crn = A.crowtab[(A.dw0 + rw) * A.nI + (tid < A.nI ? tid : 0)];      // Edw + const + cross term of that row (k_crow_table)
     };
     int64_t row = (int64_t)g * 8 + x;
     fetch_row(row);
-    load_ops(row, 0, o[0]);
-    load_ops(row + (int64_t)(1 / NQ) * rstep, 1 % NQ, o[1]);
     while (row < A.nrows) {
-        item(std::integral_constant<int, 0>{}, row); row += rstep;
-        if (NQ & 1) { if (row >= A.nrows) break; item(std::integral_constant<int, 1>{}, row); row += rstep; }
+#pragma unroll
+        for (int q = 0; q < NQ; q++) { const int p = tid + q * NT; if (p < npair) *reinterpret_cast<dbl2v *>(seg + 2 * p) = xr[q]; }
+#pragma unroll
+        for (int h = 0; h < MAXH; h++) if (tid + h * NT < nh) halo[tid + h * NT] = xh[h];
+        if (DIRECT && tid < A.nI) crow[tid] = crn;
+        // the hop words are loop invariant, and so is every LDS address derived from them: left alone the compiler hoists all
+        // 4 * NH * NQ address computations out of the row loop and spills what does not fit (64-100 bytes of scratch, reloaded
+        // in every item through the vector-memory pipe).  Opaque per iteration: addresses are formed next to their reads.
+#pragma unroll
+        for (int q = 0; q < NQ; q++)
+#pragma unroll
+            for (int c = 0; c < 4; c++) asm volatile("" : "+v"(w[q][c].x), "+v"(w[q][c].y), "+v"(w[q][c].z), "+v"(w[q][c].w));
+        dbl2v dcur[NQ];                                  // stored diagonal of this row (the prefetch below overwrites dg)
+#pragma unroll
+        for (int q = 0; q < NQ; q++) dcur[q] = DIRECT ? eup[q] : dg[q];
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < NQ; q++) {
+            const int p = tid + q * NT;
+            dbl2v r = {0.0, 0.0};
+            if (p < npair) {
+                const dbl2v xx = *reinterpret_cast<const dbl2v *>(seg + 2 * p);
+                dbl2v dval = dcur[q];
+                if (DIRECT) {           // byte 10 of the code dwords: the impurity word of the up configuration (k_seg_remap)
+                    dval.x += crow[(w[q][1].w >> 16) & 0xffu];
+                    dval.y += crow[(w[q][3].w >> 16) & 0xffu];
+                }
+                const uint32_t c0[5] = {w[q][0].x, w[q][0].y, w[q][0].z, w[q][0].w, w[q][1].x}, k0[3] = {w[q][1].y, w[q][1].z, w[q][1].w};
+                const uint32_t c1[5] = {w[q][2].x, w[q][2].y, w[q][2].z, w[q][2].w, w[q][3].x}, k1[3] = {w[q][3].y, w[q][3].z, w[q][3].w};
+                double a0 = dval.x * xx.x, a1 = dval.y * xx.y;
+#pragma unroll
+                for (int e = 0; e < NH; e++) {
+                    const uint32_t code0 = (k0[e >> 2] >> (8 * (e & 3))) & 0xffu, col0 = (c0[e >> 1] >> (16 * (e & 1))) & 0xffffu;
+                    const uint32_t code1 = (k1[e >> 2] >> (8 * (e & 3))) & 0xffu, col1 = (c1[e >> 1] >> (16 * (e & 1))) & 0xffffu;
+                    a0 += tv[code0] * seg[col0]; a1 += tv[code1] * seg[col1];
+                }
+                r.x = a0; r.y = a1;
+            }
+            // the whole next row is requested after the first step's arithmetic (its staging registers are free until then) and
+            // BEFORE the first store of this row
+            if (q == 0) fetch_row(row + rstep);
+            if (p < npair) *reinterpret_cast<dbl2v *>(A.out + row * ld + lo + 2 * p) = r;
+        }
+        __syncthreads();
+        row += rstep;
     }
-    if (EPI) { const double rr = block_sum(asum, red); if (tid == 0) A.partial[blockIdx.x] = rr; }
 }
 
 // pelem8 (columns) -> pseg8 (positions in the [segment | halo] LDS image of the segment that owns the element)
@@ -916,7 +909,6 @@ struct DwArgs {
     const double *v, *vfull; double *out;
     const double *scal; double *partial;
     int32_t w, wshift, ntiles, R, chunks;
-    int32_t xpt;               // XCDs that share one tile (1, 2, 4 or 8; 0 = 1): each walks 1/xpt of the row chunks, 8/xpt tiles are in flight at a time
     int32_t ld;                // row pitch of v / vfull / out / uprev2 in doubles (0: DimUp)
     const double *uprev2;      // fused Lanczos iteration (EPI only): out holds the UNSCALED local part; out = s_cur*(out + dw part) - beta*s_prev*uprev2
 };
@@ -931,19 +923,6 @@ __device__ __forceinline__ void xcd_tile_map(uint32_t b, uint32_t ntiles, uint32
     const uint32_t t8 = ntiles & ~7u, nmain = t8 * chunks;
     if (b < nmain) { const uint32_t xcd = b & 7u, sidx = b >> 3, tl = sidx / chunks; chunk = sidx - tl * chunks; tile = (int)(tl * 8u + xcd); }
     else { const uint32_t r = b - nmain, tl = r / chunks; chunk = r - tl * chunks; tile = (int)(t8 + tl); }
-}
-
-// The same dealing with `xpt` XCDs per tile: XCD x works on tile slot x / xpt and walks the row chunks [part*cp, (part+1)*cp),
-// part = x % xpt, cp = ceil(chunks / xpt).  Fewer slabs in flight (8/xpt x 25 MB at Ns=18 instead of 8 x 25 MB next to the
-// 256 MB Infinity Cache); the near dw hops stay inside an XCD's part, the hops on the top log2(xpt) bath levels cross parts.
-// Grid = ceil(ntiles / (8/xpt)) * cp * 8; blocks beyond the last tile or chunk return tile = ntiles.
-__device__ __forceinline__ void xcd_tile_map_shared(uint32_t b, uint32_t ntiles, uint32_t chunks, uint32_t xpt, int &tile, uint32_t &chunk)
-{
-    const uint32_t xcd = b & 7u, sidx = b >> 3, slots = 8u / xpt, cp = (chunks + xpt - 1) / xpt;
-    const uint32_t grp = sidx / cp, c = sidx - grp * cp, part = xcd % xpt, slot = xcd / xpt;
-    chunk = part * cp + c;
-    tile = (int)(grp * slots + slot);
-    if (chunk >= chunks) tile = (int)ntiles;
 }
 
 template <bool EPI>
@@ -974,19 +953,7 @@ __global__ void __launch_bounds__(256) k_dwpass(DwArgs A)
 // Same pass with two iup per lane (16-byte loads/stores; needs DimUp even) and the Hdw rows of
 // the block staged in LDS once, which removes the per-lane table loads: ~5x fewer vector-memory
 // instructions per element than k_dwpass.
-// write-through store: the line leaves the XCD's L2 (plain and nt stores keep it there, MI355X_MICROARCH.md "stores of each
-// flavour"), so a result stream that nobody on this XCD reads again does not push the gathered slab out of the L2
-__device__ __forceinline__ void store_through(dbl2v *p, dbl2v v)
-{
-    asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(p), "v"(v) : "memory");
-}
-// WR = 0: out += dw hops (read-modify-write, optionally with the Lanczos epilogue).  WR = 1 / 2: out = dw hops, nothing of
-// `out` is read (the local pass that follows adds to it and carries the epilogue: hxv(), "dw first"); 2 stores write-through.
-// UNR: every load of a row step is issued before the first one is consumed -- up to 16 gathers in groups of four, then the
-// result / v / u_prev operands.  The rolled form (4 gathers in flight, then a remainder one by one, then the operand loads)
-// is a chain of 4 dependent memory round trips per row step and 8 per workgroup: at Ns=18 (2.3 M workgroups, 2 048
-// resident) that chain alone is the 18 ms the pass took, whatever the traffic (profiles/r03/ns18_product_variants.txt).
-template <bool EPI, bool NT, bool RAGGED, int WR = 0, bool UNR = false>   // RAGGED: rows have different hop counts (multi-orbital models): skip the ELL padding
+template <bool EPI, bool NT, bool RAGGED>   // RAGGED: rows have different hop counts (multi-orbital models): skip the ELL padding
 __global__ void __launch_bounds__(256) k_dwpass2(DwArgs A)
 {
     // dynamic LDS sized by the launch to R*dww entries (was a fixed 64x64 image = 48 KB, i.e. 3 workgroups per CU whatever
@@ -997,8 +964,7 @@ __global__ void __launch_bounds__(256) k_dwpass2(DwArgs A)
     double *tv = dyn_lds;                                               // [row in block][k]
     int32_t *tc = reinterpret_cast<int32_t *>(dyn_lds + A.R * A.dww);
     int tile; uint32_t chunk;
-    if (A.xpt > 1) xcd_tile_map_shared(blockIdx.x, (uint32_t)A.ntiles, (uint32_t)A.chunks, (uint32_t)A.xpt, tile, chunk);
-    else xcd_tile_map(blockIdx.x, (uint32_t)A.ntiles, (uint32_t)A.chunks, tile, chunk);
+    xcd_tile_map(blockIdx.x, (uint32_t)A.ntiles, (uint32_t)A.chunks, tile, chunk);
     double asum = 0.0;
     if (tile < A.ntiles) {
         const int64_t nrows = A.Qdw * A.DimPh, row0 = (int64_t)chunk * A.R;
@@ -1029,31 +995,14 @@ __global__ void __launch_bounds__(256) k_dwpass2(DwArgs A)
                 const int nk = RAGGED ? tn[r] : A.dww;   // hops of this row (ELL padding sits at the end: not gathered)
                 dbl2v *po = reinterpret_cast<dbl2v *>(A.out + e);
                 dbl2v o = {0.0, 0.0}, vl = {0.0, 0.0}, up = {0.0, 0.0};
-                if (UNR) {
-                    dbl2v xg[16];
-#pragma unroll
-                    for (int g = 0; g < 4; g++)
-                        if (g * 4 < nk) {      // wave-uniform
-#pragma unroll
-                            for (int q = 0; q < 4; q++) { const int k = g * 4 + q < nk ? g * 4 + q : nk - 1; xg[g * 4 + q] = *reinterpret_cast<const dbl2v *>(A.vfull + fbase + (int64_t)tcr[k] * ld); }
-                        }
-                    if (!WR) o = NT ? __builtin_nontemporal_load(po) : *po;
-                    if (EPI) { vl = *reinterpret_cast<const dbl2v *>(A.v + e); if (A.uprev2) up = *reinterpret_cast<const dbl2v *>(A.uprev2 + e); }
-#pragma unroll
-                    for (int g = 0; g < 4; g++)
-                        if (g * 4 < nk) {
-#pragma unroll
-                            for (int q = 0; q < 4; q++) { const int k = g * 4 + q; const double t = k < nk ? tvr[k < nk ? k : 0] : 0.0; acc += t * xg[k]; }
-                        }
-                } else {
-                    for (int k = 0; k < nk; k++) {
-                        const dbl2v x = *reinterpret_cast<const dbl2v *>(A.vfull + fbase + (int64_t)tcr[k] * ld);
-                        acc += tvr[k] * x;
-                    }
-                    if (!WR) o = NT ? __builtin_nontemporal_load(po) : *po;
-                    if (EPI) { vl = *reinterpret_cast<const dbl2v *>(A.v + e); if (A.uprev2) up = *reinterpret_cast<const dbl2v *>(A.uprev2 + e); }
+                // rolled gather loop: 4 gathers in flight per lane; issuing all of a row step up front (103-120 VGPRs, half the
+                // residency) measured slower at Ns=18 (profiles/r03/ns18_product_variants.txt)
+                for (int k = 0; k < nk; k++) {
+                    const dbl2v x = *reinterpret_cast<const dbl2v *>(A.vfull + fbase + (int64_t)tcr[k] * ld);
+                    acc += tvr[k] * x;
                 }
-                if (WR) { if (WR == 2) store_through(po, acc); else if (NT) __builtin_nontemporal_store(acc, po); else *po = acc; continue; }
+                o = NT ? __builtin_nontemporal_load(po) : *po;
+                if (EPI) { vl = *reinterpret_cast<const dbl2v *>(A.v + e); if (A.uprev2) up = *reinterpret_cast<const dbl2v *>(A.uprev2 + e); }
                 if (EPI) {
                     if (A.uprev2) o = s_cur * (o + acc) - c_prev2 * up;
                     else o += s_cur * acc;
@@ -1518,6 +1467,7 @@ struct TabArgs {
     uint32_t *pcols, *pcodes;   // optional packed image (k_uppass), zeroed by the caller
     uint32_t *pelem;            // optional element-major packed image (k_uppass2): 6 dwords per row, width <= 8
     uint32_t *pelem8;           // optional element-major image of 8 dwords (k_uppass_big): width <= 10
+    uint32_t *pelem16;          // optional element-major image of 12 dwords (one-configuration-per-lane local passes): width <= 16
     const double *lin; int32_t nlev; int32_t impmask; double pair;  // E[i] = sum lin[l] n_l + pair * C(#imp,2)
     double *E;
 };
@@ -1548,6 +1498,18 @@ struct TabArgs {
                 uint32_t wd_ = 0;                                                                                         \
                 for (int e = 0; e < 4; e++) { const int q = 4 * c + e; wd_ |= (uint32_t)(q < n ? CT(q) : 127u) << (8 * e); } \
                 A.pelem8[(int64_t)8 * i + 5 + c] = wd_;                                                                  \
+            }                                                                                                            \
+        }                                                                                                                \
+        if (A.pelem16) {                                                                                                 \
+            for (int c = 0; c < 8; c++) {                                                                                \
+                uint32_t wd_ = 0;                                                                                         \
+                for (int e = 0; e < 2; e++) { const int q = 2 * c + e; wd_ |= (uint32_t)(q < n ? CJ(q) : i) << (16 * e); } \
+                A.pelem16[(int64_t)12 * i + c] = wd_;                                                                    \
+            }                                                                                                            \
+            for (int c = 0; c < 4; c++) {                                                                                \
+                uint32_t wd_ = 0;                                                                                         \
+                for (int e = 0; e < 4; e++) { const int q = 4 * c + e; wd_ |= (uint32_t)(q < n ? CT(q) : 127u) << (8 * e); } \
+                A.pelem16[(int64_t)12 * i + 8 + c] = wd_;                                                                \
             }                                                                                                            \
         }                                                                                                                \
         if (A.pelem) {                                                                                                   \
@@ -1755,6 +1717,7 @@ struct CsrArgs {
     const int64_t *rowbase; const int32_t *rowcnt;
     int64_t ld;             // row pitch of x / y / uprev / v_local in doubles (the stored columns index that space); rowptr stays dense
     const int64_t *cpre;    // lane-major dw-type blocks stored tile-major (k_csr_il only): block (jb, idw) starts at jb*64*cpre[Qdw] + rows(jb)*cpre[idw]
+    const double *uprev2;   // fused Lanczos iteration (last block, epi): y holds the UNSCALED local part; y = s_cur*(y + this block) - beta*s_prev*uprev2
 };
 
 // Row-block CSR product.  A workgroup owns `rows_per_block` consecutive rows of one idw row.  Their
@@ -1843,11 +1806,12 @@ __global__ void __launch_bounds__(64) k_csr_il(CsrArgs A)
         p0 = ((int64_t)__builtin_amdgcn_readfirstlane((int)(ra >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(ra & 0xffffffffll));
         cnt = __builtin_amdgcn_readfirstlane((int)(re - ra)); len = act ? (int)(re - ra) : 0;
     }
-    double up_i = 0.0, xl_i = 0.0;
+    double up_i = 0.0, xl_i = 0.0, up2_i = 0.0;
     if (act) {
         if (A.epi && A.pass < 2) up_i = A.uprev[vrow0 + tid];
         if (A.epi && (A.pass == 0 || A.pass == 2)) xl_i = A.v_local[vrow0 + tid];
         if (A.pass >= 2) up_i = A.y[vrow0 + tid];        // running value of the earlier blocks
+        if (A.uprev2) up2_i = A.uprev2[vrow0 + tid];
     }
     double s_cur = 1.0, c_prev = 0.0, asum = 0.0;
     if (A.epi) { s_cur = A.scal[SC_SCUR]; c_prev = A.scal[SC_BETA] * A.scal[SC_SPREV]; }
@@ -1892,11 +1856,109 @@ __global__ void __launch_bounds__(64) k_csr_il(CsrArgs A)
         }
         const int64_t row = vrow0 + tid;
         if (A.epi) {
-            const double w = A.pass >= 2 ? up_i + s_cur * acc : s_cur * acc - c_prev * up_i;
+            const double w = A.uprev2 ? s_cur * (up_i + acc) - c_prev * up2_i : (A.pass >= 2 ? up_i + s_cur * acc : s_cur * acc - c_prev * up_i);
             A.y[row] = w; asum = (s_cur * xl_i) * w;
         } else A.y[row] = A.pass >= 2 ? up_i + acc : acc;
     }
     if (A.epi && (A.pass == 0 || A.pass == 2)) { double r = block_sum(asum, red); if (tid == 0) A.partial[blockIdx.x] = r; }
+}
+
+// Local half of the FUSED Lanczos iteration on the explicit CSR (round 4; the stored-factor form is k_uppass2_ax).  The three-pass
+// loop of the explicit storage ends every iteration with w -= alpha v, beta^2 = w.w over three vectors (k_axpy_norm, 0.75 ms of a
+// 9 ms iteration at c3); that pass has the operands of the NEXT iteration's local block, whose gathers stay inside one idw row.
+// A persistent 1024-thread workgroup per idw row forms u_k = r_{k-1} - (alpha s) u_{k-1} on its way into LDS (written back over
+// r, |u_k|^2 summed), then its 16 waves stream the lane-major 64-row blocks of the row's local block (diagonal + up hops, 12 B
+// per entry, row pointer read as before) and gather x from the LDS image (column - idw*ld) instead of from L2; T = unscaled
+// local part.  The dw block (k_csr_il with uprev2) applies the scale, subtracts beta u_{k-1} and takes the alpha dot.
+// The next row's r / u_prev pairs are requested one block step ahead and combined there (as k_uppass2_ax does).
+// Per wave a three-deep pipeline over its blocks: row pointer of block it+2, entries of block it+1 (18 coalesced loads in flight
+// while block it gathers), gathers + result of block it; the next row's r / u_prev pair of the step is requested one step ahead
+// and combined there, so the row switch only re-reads the finished u (written by the same lane, L2-hot) into LDS.
+struct CsrAxArgs {
+    int32_t DimUp; int64_t Qdw, ld;
+    const int64_t *rowptr; const int32_t *cols; const double *vals;
+    double *r; const double *vprev; double *t_out;
+    const double *scal; double *partial; double *acc; const double *zvec;
+};
+template <int C, bool ACC>
+__global__ void __launch_bounds__(1024) k_csr_loc_ax(CsrAxArgs A)
+{
+    extern __shared__ double lds[];
+    constexpr int NT = 1024;
+    const int DimUp = A.DimUp, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int npair = (DimUp + 1) >> 1;                  // the last pair of an odd row ends in the (zero) padding column of the pitched vectors
+    const int64_t ld = A.ld;
+    double *red = lds + ((DimUp + 2) & ~1);
+    const int nq = (npair + NT - 1) / NT;
+    const int nblk = (DimUp + 63) >> 6, nit = (nblk + 15) >> 4;      // 64-row blocks of a row; block steps of a wave (nit >= nq)
+    const double c_ax = A.scal[SC_ALPHA] * A.scal[SC_SCUR];          // alpha_{k-1} * s_{k-1}  (0 at k = 0)
+    const double zk = ACC ? A.zvec[(int)A.scal[SC_K]] : 0.0;
+    double bsum = 0.0;
+    auto combine = [&](int64_t rw, int p, const dbl2v &r, const dbl2v &v) -> dbl2v {
+        const dbl2v u = r - c_ax * v;
+        *reinterpret_cast<dbl2v *>(A.r + rw * ld + 2 * p) = u;
+        bsum += u.x * u.x + u.y * u.y;
+        if (ACC) { dbl2v *pa = reinterpret_cast<dbl2v *>(A.acc + rw * ld + 2 * p); *pa = *pa + zk * u; }
+        return u;
+    };
+    const int pmax = npair - 1;
+    struct Ent { double v[C]; int32_t c[C]; };
+    struct Rp { int64_t ra; int nr, iup0, len; bool valid; };
+    bool first = true;
+    for (int64_t row = blockIdx.x; row < A.Qdw; row += gridDim.x) {
+        const int64_t next = row + gridDim.x; const bool more = next < A.Qdw;
+        const int64_t nrow = more ? next : row;          // no branch around a prefetch load: the last row loads itself again
+        for (int q = 0; q < nq; q++) {
+            const int p = tid + q * NT;
+            if (p < npair) {
+                dbl2v u;
+                if (first) u = combine(row, p, *reinterpret_cast<const dbl2v *>(A.r + row * ld + 2 * p), *reinterpret_cast<const dbl2v *>(A.vprev + row * ld + 2 * p));
+                else u = *reinterpret_cast<const dbl2v *>(A.r + row * ld + 2 * p);      // formed during the previous row's block steps, by this lane
+                *reinterpret_cast<dbl2v *>(lds + 2 * p) = u;
+            }
+        }
+        first = false;
+        __syncthreads();
+        const int64_t xoff = row * ld;                   // stored columns index the pitched vector space: LDS index = column - row*ld
+        auto blk_ptr = [&](int it) -> Rp {               // wave wv takes blocks wv, wv + 16, ...
+            Rp R; const int jb = wv + 16 * it; R.valid = jb < nblk;
+            const int jc = R.valid ? jb : nblk - 1;
+            R.iup0 = jc * 64; R.nr = DimUp - R.iup0; R.nr = R.nr > 64 ? 64 : R.nr;
+            // the row pointer is streamed as by k_csr_il: lane l reads rowptr[l] and rowptr[l+1] of its row; block start = first lane's
+            const int l = lane < R.nr ? lane : 0;
+            const int64_t ra = A.rowptr[row * DimUp + R.iup0 + l], re = A.rowptr[row * DimUp + R.iup0 + l + 1];
+            R.ra = ra - (int64_t)l * C; R.len = (int)(re - ra);      // rows of a block have C entries each (the host selects this kernel only then): start of the block
+            return R;
+        };
+        auto load_ent = [&](const Rp &R, Ent &E) {
+            const int l = lane < R.nr ? lane : 0;
+            const double *pv = A.vals + R.ra + l; const int32_t *pc = A.cols + R.ra + l;
+#pragma unroll
+            for (int e = 0; e < C; e++) { E.v[e] = pv[(int64_t)e * R.nr]; E.c[e] = pc[(int64_t)e * R.nr]; }
+        };
+        Rp r0 = blk_ptr(0), r1 = blk_ptr(1);
+        Ent cur, nxt;
+        load_ent(r0, cur);
+        dbl2v pr, pvv;                                   // pair `it` of the next row
+        { const int p = tid < npair ? tid : pmax; pr = *reinterpret_cast<const dbl2v *>(A.r + nrow * ld + 2 * p); pvv = *reinterpret_cast<const dbl2v *>(A.vprev + nrow * ld + 2 * p); }
+        for (int it = 0; it < nit; it++) {
+            const Rp r2 = blk_ptr(it + 2);
+            dbl2v pr2, pv2;
+            { int p = tid + (it + 1) * NT; p = p < npair ? p : pmax; pr2 = *reinterpret_cast<const dbl2v *>(A.r + nrow * ld + 2 * p); pv2 = *reinterpret_cast<const dbl2v *>(A.vprev + nrow * ld + 2 * p); }
+            if (r1.valid) load_ent(r1, nxt);             // wave-uniform
+            if (more && it < nq) { const int p = tid + it * NT; if (p < npair) combine(next, p, pr, pvv); }
+            if (r0.valid && lane < r0.nr && r0.len == C) {
+                double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+                for (int e = 0; e < C; e++) { const double xv = lds[cur.c[e] - xoff]; if (e & 1) a1 += cur.v[e] * xv; else a0 += cur.v[e] * xv; }
+                A.t_out[row * ld + r0.iup0 + lane] = a0 + a1;
+            }
+            pr = pr2; pvv = pv2; r0 = r1; r1 = r2; cur = nxt;
+        }
+        __syncthreads();
+    }
+    const double rr = block_sum(bsum, red);
+    if (tid == 0) A.partial[blockIdx.x] = rr;
 }
 
 template <int ROWS, int CAPN, bool NT>
@@ -1918,13 +1980,14 @@ __global__ void __launch_bounds__(ROWS) k_csr_spmv2(CsrArgs A)
     else { p0 = A.rowptr[row0]; n = (int)(A.rowptr[row0 + nr] - p0); }
     const int sh = (int)(p0 & 3);
     int ra = 0, re = 0;
-    double up_i = 0.0, xl_i = 0.0;   // epilogue operands, requested before the stream so their latency hides under it
+    double up_i = 0.0, xl_i = 0.0, up2_i = 0.0;   // epilogue operands, requested before the stream so their latency hides under it
     if (tid < nr) {
         if (A.rowbase) { ra = tid * ucnt + sh; re = ra + ucnt; }
         else { ra = (int)(A.rowptr[row0 + tid] - p0) + sh; re = (int)(A.rowptr[row0 + tid + 1] - p0) + sh; }
         if (A.epi && A.pass < 2) up_i = A.uprev[vrow0 + tid];
         if (A.epi && (A.pass == 0 || A.pass == 2)) xl_i = A.v_local[vrow0 + tid];
         if (A.pass >= 2) up_i = A.y[vrow0 + tid];        // running value of the earlier blocks
+        if (A.uprev2) up2_i = A.uprev2[vrow0 + tid];
     }
     {
         const double *gv = A.vals + (p0 - sh); const int32_t *gc = A.cols + (p0 - sh);   // 4-aligned base
@@ -1959,7 +2022,7 @@ __global__ void __launch_bounds__(ROWS) k_csr_spmv2(CsrArgs A)
         for (; k < re; k++) acc0 += sval[k] * A.x[scol[k]];
         const double acc = acc0 + acc1;
         if (A.epi) {
-            const double w = A.pass >= 2 ? up_i + s_cur * acc : s_cur * acc - c_prev * up_i;
+            const double w = A.uprev2 ? s_cur * (up_i + acc) - c_prev * up2_i : (A.pass >= 2 ? up_i + s_cur * acc : s_cur * acc - c_prev * up_i);
             A.y[row] = w; asum = (s_cur * xl_i) * w;
         } else A.y[row] = A.pass >= 2 ? up_i + acc : acc;
     }

@@ -201,7 +201,7 @@ static int lz_iter(S *s, LzVecs &V, int k, double *acc)
 // back-to-back asynchronous launches (200 iterations at N=4900: 3.64 ms vs 3.68 ms) -- not kept.
 static bool lz_small(S *s)
 {
-    return !s->multi && s->nloc <= (int64_t)dbg_int("EDGPU_SMALL_MAXN", 1 << 22);
+    return !s->multi && s->nloc <= (int64_t)XKNOB("EDGPU_SMALL_MAXN", 1 << 22);
 }
 static int lz_iters(S *s, LzVecs &V, int k, int count, double *acc)
 {
@@ -266,7 +266,7 @@ static int lanczos_gs(S *s, int nitermax, double threshold, int ncheck, double *
     g_kpool.in_use = true;
     const int rc = lanczos_gs_impl(s, nitermax, threshold, ncheck, egs, vect_dev, nlanc_out);
     g_kpool.in_use = false;
-    if (rc == EDGPU_OK && !dbg_int("EDGPU_LZ_CACHE", 1)) kpool_release();      // default: keep the buffers for the next search
+    if (rc == EDGPU_OK && !XKNOB("EDGPU_LZ_CACHE", 1)) kpool_release();      // default: keep the buffers for the next search
     return rc;
 }
 static int lanczos_gs_impl(S *s, int nitermax, double threshold, int ncheck, double *egs, double *vect_dev, int *nlanc_out)
@@ -295,8 +295,8 @@ static int lanczos_gs_impl(S *s, int nitermax, double threshold, int ncheck, dou
     // then one weighted sum over the stored vectors instead of SciFortran's second Lanczos pass -- same nlanc, same
     // E0, same vector up to rounding, half the products.  Buffers are taken on demand; if memory runs out the run
     // simply continues with three rotating vectors and falls back to the second pass.
-    const int store_max = dbg_int("EDGPU_LZ_STORE_MAX", 1 << 30);               // tests: cap the number of stored vectors
-    bool store = dbg_int("EDGPU_LZ_STORE", 1) != 0 && store_max >= 4;
+    const int store_max = knob("EDGPU_LZ_STORE_MAX");               // tests: cap the number of stored vectors
+    bool store = knob("EDGPU_LZ_STORE") != 0 && store_max >= 4;
     int64_t budget = 0;       // bytes this call may still add to the cache (one driver query: hipMemGetInfo is slow)
     if (store) {
         if (g_kpool.device != s->device) { g_kpool.in_use = false; kpool_release(); g_kpool.in_use = true; g_kpool.device = s->device; }
@@ -333,7 +333,7 @@ static int lanczos_gs_impl(S *s, int nitermax, double threshold, int ncheck, dou
     };
     if (store) {
         // take what a typical search needs before the first kernel is queued (allocation is cheap on an idle device)
-        const int guess = std::min(std::min(nitermax + 2, store_max), dbg_int("EDGPU_LZ_STORE_GUESS", 100));
+        const int guess = std::min(std::min(nitermax + 2, store_max), XKNOB("EDGPU_LZ_STORE_GUESS", 100));
         if (!slab_mode) for (int k = 0; k < guess; k++) if (!ring_get(k)) break;
     }
     LzVecs V{s->lz[0].p, s->lz[1].p, s->lz[2].p};
@@ -359,7 +359,7 @@ static int lanczos_gs_impl(S *s, int nitermax, double threshold, int ncheck, dou
     // The stopping rule of iteration i only involves alpha/beta up to i, so iterations can be issued ahead of
     // the host check: small (launch-bound) sectors run `chunk` iterations per host round trip and then apply
     // the rule to each of them in order -- same nlanc and E0, at most chunk-1 surplus iterations.
-    const int chunk = lz_small(s) ? std::max(1, dbg_int("EDGPU_LZ_CHUNK", 6)) : 1;
+    const int chunk = lz_small(s) ? std::max(1, XKNOB("EDGPU_LZ_CHUNK", 6)) : 1;
     bool done = false;
     for (int k = 0; k < nitermax && !done;) {
         const int kend = std::min(nitermax, k + chunk);
@@ -628,7 +628,7 @@ static int eigsh_pro(S *s, int nev, int ncv, int maxiter, double tol, double *ev
     // products than the reference's default of 20 (Ns=16, two pairs: 167 products / 0.81 s against 182 / 0.94 s); taken only
     // when the extra vectors fit comfortably (a quarter of the free memory), reported through edgpu_eigsh_ncv_used
     // (one rank only: the free memory differs from rank to rank, and every rank must run the same basis)
-    if (ncv < 32 && Dim >= (1 << 20) && !s->multi && dbg_int("EDGPU_EIGSH_GROW", 1)) {
+    if (ncv < 32 && Dim >= (1 << 20) && !s->multi && XKNOB("EDGPU_EIGSH_GROW", 1)) {
         size_t fr = 0, tot = 0;
         if (hipMemGetInfo(&fr, &tot) == hipSuccess && (size_t)(32 + 5) * (size_t)vlen * 8 < fr / 4) ncv = 32; else (void)hipGetLastError();
     }
@@ -637,9 +637,9 @@ static int eigsh_pro(S *s, int nev, int ncv, int maxiter, double tol, double *ev
     // more restarts, same pairs -- and says so through edgpu_eigsh_ncv_used; below nev + 2 vectors it refuses.  Several ranks
     // must run the same basis: there the request either fits everywhere or every rank returns EDGPU_ENOMEM.
     {
-        const bool fused0 = fused_ok(s) && dbg_int("EDGPU_EIGSH_FUSED", 1) != 0;
+        const bool fused0 = fused_ok(s) && knob("EDGPU_EIGSH_FUSED") != 0;
         const int extra = 3 + (fused0 ? 1 : 0);      // B(m), the buffer ahead, lz[0], lz[3]
-        const int memcap_mb = dbg_int("EDGPU_EIGSH_MEM_MB", 0);
+        const int memcap_mb = knob("EDGPU_EIGSH_MEM_MB");
         auto fit = [&]() -> int64_t {
             size_t fr = 0, tot = 0;
             if (hipMemGetInfo(&fr, &tot) != hipSuccess) { (void)hipGetLastError(); return 1 << 20; }
@@ -673,13 +673,13 @@ static int eigsh_pro(S *s, int nev, int ncv, int maxiter, double tol, double *ev
     s->eig_ncv_used = ncv;
     if (maxiter < 1) maxiter = 1;
     const double eps = 2.220446049250313e-16, tol_eff = std::max(tol, 1e-12), eps23 = std::pow(eps, 2.0 / 3.0);
-    const double tau = std::sqrt(eps) * (double)std::max(1, dbg_int("EDGPU_EIGSH_OMEGA_PCT", 100)) / 100.0;
-    const double sel = (double)std::max(0, dbg_int("EDGPU_EIGSH_SEL_PPM", 100000)) * 1e-6;      // a pass over kept Ritz vectors takes those whose estimate exceeds sel*tau
+    const double tau = std::sqrt(eps) * (double)std::max(1, knob("EDGPU_EIGSH_OMEGA_PCT")) / 100.0;
+    const double sel = (double)std::max(0, XKNOB("EDGPU_EIGSH_SEL_PPM", 100000)) * 1e-6;      // a pass over kept Ritz vectors takes those whose estimate exceeds sel*tau
     const int m = ncv, M = m + 2;
     CHK(lz_prepare(s, m + 4, 1));      // of the three rotating vectors of the plain loops only the first is used here
     if (s->lz[3].n != (size_t)n) CHK(s->lz[3].alloc((size_t)n));
     // the fused iteration (stored factors / on the fly, one rank) forms the local part of H u_{j+1} one buffer ahead
-    const bool fused = fused_ok(s) && dbg_int("EDGPU_EIGSH_FUSED", 1) != 0;
+    const bool fused = fused_ok(s) && knob("EDGPU_EIGSH_FUSED") != 0;
     const int nbuf = m + 1 + (fused ? 1 : 0);
     while ((int)s->eigV.size() < nbuf) s->eigV.push_back(std::make_unique<DevBuf<double>>());
     for (int i = 0; i < nbuf; i++) {
@@ -704,8 +704,8 @@ static int eigsh_pro(S *s, int nev, int ncv, int maxiter, double tol, double *ev
         HIPCHK(hipMemcpyAsync(s->eig_y.p, Yc.data(), (size_t)nv * nout * 8, hipMemcpyHostToDevice, s->stream));
         HIPCHK(hipStreamSynchronize(s->stream));      // Yc may be a temporary of the caller
         const int g2 = (int)std::max<int64_t>(1, std::min<int64_t>(cdiv(vlen, 256 * 2 * 16), 2048));
-        const int rot2 = dbg_int("EDGPU_ROT2", 1);
-        const bool rot_mfma = dbg_int("EDGPU_ROT_MFMA", 1) != 0;      // 0: the one- and two-element kernels that hold the basis of an element in registers
+        const int rot2 = knob("EDGPU_ROT2");
+        const bool rot_mfma = knob("EDGPU_ROT_MFMA") != 0;      // 0: the one- and two-element kernels that hold the basis of an element in registers
         if (rot_mfma) {      // tall-skinny GEMM on the matrix cores, any basis size (Ns=16: 80 -> 40 vectors 212 ms -> ~35 ms, 20 -> 2 slightly faster as well)
             std::vector<double *> vb((size_t)nv); for (int i = 0; i < nv; i++) vb[i] = B(i);
             CHK(launch_basis_rotate_mfma(s->stream, s->device, vb.data(), nv, nout, s->eig_y.p, vlen)); }
@@ -936,7 +936,7 @@ static int eigsh_pro(S *s, int nev, int ncv, int maxiter, double tol, double *ev
     // Safety net: the TRUE residual |H x - theta x| of every returned pair (one product and one pass each).  The Lanczos estimate
     // beta |s_m| that declared them converged assumes a basis orthogonal to sqrt(eps); should that assumption ever fail the
     // residual shows it, and the call is answered by the whole-basis form instead (EDGPU_EIGSH_VERIFY=0 skips the check).
-    if (nconv >= nev && nout < m && dbg_int("EDGPU_EIGSH_VERIFY", 1)) {
+    if (nconv >= nev && nout < m && XKNOB("EDGPU_EIGSH_VERIFY", 1)) {
         double worst = 0.0;
         for (int i = 0; i < nout; i++) {
             double *w = B(m);                              // stale basis vector: free after the final rotation
@@ -978,7 +978,7 @@ static int eigsh_pro(S *s, int nev, int ncv, int maxiter, double tol, double *ev
 static int eigsh_full(S *s, int nev, int ncv, int maxiter, double tol, double *evals, double *evecs_host, int *nconv_out, int *nrestart_out, int *nmatvec_out);
 static int eigsh(S *s, int nev, int ncv, int maxiter, double tol, double *evals, double *evecs_host, int *nconv_out, int *nrestart_out, int *nmatvec_out)
 {
-    if (dbg_int("EDGPU_EIGSH_PRO", 1)) return eigsh_pro(s, nev, ncv, maxiter, tol, evals, evecs_host, nconv_out, nrestart_out, nmatvec_out);
+    if (knob("EDGPU_EIGSH_PRO")) return eigsh_pro(s, nev, ncv, maxiter, tol, evals, evecs_host, nconv_out, nrestart_out, nmatvec_out);
     return eigsh_full(s, nev, ncv, maxiter, tol, evals, evecs_host, nconv_out, nrestart_out, nmatvec_out);
 }
 
@@ -1011,7 +1011,7 @@ static int eigsh_full(S *s, int nev, int ncv, int maxiter, double tol, double *e
     const int gsr = (int)std::max<int64_t>(1, std::min<int64_t>(cdiv(n, 256 * 4), 4096));
     // V_j <- sum_i V_i Y_ij in place; bases above 48 vectors take the 96-capacity instantiation
     auto rotate = [&](int nv, int nout) -> int {
-        if (dbg_int("EDGPU_ROT_MFMA", 1) != 0) {
+        if (knob("EDGPU_ROT_MFMA") != 0) {
             std::vector<double *> vb((size_t)nv); for (int i = 0; i < nv; i++) vb[i] = Vp(i);
             CHK(launch_basis_rotate_mfma(s->stream, s->device, vb.data(), nv, nout, s->eig_y.p, n)); }
         else if (nv <= kMaxBasis) { RotArgs R{}; R.nv = nv; R.nout = nout; R.Y = s->eig_y.p; for (int i = 0; i < nv; i++) R.V[i] = Vp(i);
@@ -1119,7 +1119,7 @@ static int dvdson(S *s, int nev, int maxiter, double tol, double *evals, double 
     if (s->eig_partial.n < (size_t)nb * (mmax + 2)) CHK(s->eig_partial.alloc((size_t)nb * (mmax + 2)));
     if (s->eig_y.n < (size_t)mmax * mmax) CHK(s->eig_y.alloc((size_t)mmax * mmax));
     const SectorHost &H = s->H;
-    const bool rot_mfma = dbg_int("EDGPU_ROT_MFMA", 1) != 0;
+    const bool rot_mfma = knob("EDGPU_ROT_MFMA") != 0;
     auto norm_of = [&](const double *x, double &out) -> int {
         CHK(reduce_dot(s, x, x));
         HIPCHK(hipMemcpyAsync(&out, s->scal.p + SC_TMP, 8, hipMemcpyDeviceToHost, s->stream)); HIPCHK(hipStreamSynchronize(s->stream));

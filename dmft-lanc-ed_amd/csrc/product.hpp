@@ -56,22 +56,25 @@ static int direct_tables(S *s)
 {
     if (s->direct_built && s->direct_cache) return EDGPU_OK;
     const SectorHost &H = s->H; const edgpu_desc &d = H.desc;
-    if (s->kron2 && s->dwf && s->dwf->E.p && s->dwf->map.p && s->cross.p) {
-        // row constants of the on-the-fly diagonal, Edw + econst + cross(up impurity word, dw impurity word), per dw configuration
-        // (two-factor and composite sectors alike: the local-pass kernels read them a row ahead instead of chasing mapdw -> cross)
-        const int32_t nI = 1 << d.Norb; const int64_t nct = H.DimDw * nI;
-        if (s->crow_tab.n != (size_t)nct) CHK(s->crow_tab.alloc((size_t)nct));
-        hipLaunchKernelGGL(k_crow_table, dim3((unsigned)cdiv(nct, 256)), dim3(256), 0, s->stream, (const double *)s->dwf->E.p, (const int32_t *)s->dwf->map.p, (const double *)s->cross.p, H.econst, (int32_t)(nI - 1), nI, H.DimDw, s->crow_tab.p);
-        HIPCHK(hipGetLastError());
-    }
-    if (s->composite) { s->direct_built = true; return EDGPU_OK; }      // composite blocks (ed_total_ud=F) keep their tables; only the diagonal is formed on the fly
+    auto crow_table = [&]() -> int {
+        if (s->kron2 && s->dwf && s->dwf->E.p && s->dwf->map.p && s->cross.p) {
+            // row constants of the on-the-fly diagonal, Edw + econst + cross(up impurity word, dw impurity word), per dw configuration
+            // (two-factor and composite sectors alike: the local-pass kernels read them a row ahead instead of chasing mapdw -> cross)
+            const int32_t nI = 1 << d.Norb; const int64_t nct = H.DimDw * nI;
+            if (s->crow_tab.n != (size_t)nct) CHK(s->crow_tab.alloc((size_t)nct));
+            hipLaunchKernelGGL(k_crow_table, dim3((unsigned)cdiv(nct, 256)), dim3(256), 0, s->stream, (const double *)s->dwf->E.p, (const int32_t *)s->dwf->map.p, (const double *)s->cross.p, H.econst, (int32_t)(nI - 1), nI, H.DimDw, s->crow_tab.p);
+            HIPCHK(hipGetLastError());
+        }
+        return EDGPU_OK;
+    };
+    if (s->composite) { CHK(crow_table()); s->direct_built = true; return EDGPU_OK; }      // composite blocks (ed_total_ud=F) keep their tables; only the diagonal is formed on the fly
     for (int k = 0; k < 2 * H.Ns_Ud; k++) {
         DevFactor &f = *s->fac[k];
         TabArgs T{};
         T.dim = H.fac[k].dim; T.nterms = (int32_t)H.fac[k].terms.size(); T.width = f.width; T.transposed = (k < H.Ns_Ud || s->tr_on) ? 1 : 0;
         T.map = f.map.p; T.rank = f.rank.p; T.talpha = f.talpha.p; T.tbeta = f.tbeta.p; T.tval = f.tval.p;
         T.ellc = f.ellc.p; T.ellv = f.ellv.p; T.lin = f.lin.p; T.nlev = H.fac[k].nbits;
-        T.pcols = f.packed ? f.pcols.p : nullptr; T.pcodes = f.packed ? f.pcodes.p : nullptr; T.pelem = f.packed_elem ? f.pelem.p : nullptr; T.pelem8 = f.packed_elem8 ? f.pelem8.p : nullptr;
+        T.pcols = f.packed ? f.pcols.p : nullptr; T.pcodes = f.packed ? f.pcodes.p : nullptr; T.pelem = f.packed_elem ? f.pelem.p : nullptr; T.pelem8 = f.packed_elem8 ? f.pelem8.p : nullptr; T.pelem16 = f.packed_elem16 ? f.pelem16.p : nullptr;
         T.impmask = d.ed_total_ud ? (1 << d.Norb) - 1 : 0; T.pair = d.ed_total_ud ? d.Ust - d.Jh : 0.0; T.E = f.E.p;
         const auto &tm = H.fac[k].terms;
         bool wave_ok = tm.size() <= 64 && f.width <= 64;
@@ -82,6 +85,7 @@ static int direct_tables(S *s)
         else hipLaunchKernelGGL(k_direct_tables<64>, dim3((unsigned)cdiv(T.dim, 64)), dim3(64), 0, s->stream, T);
     }
     HIPCHK(hipGetLastError());
+    CHK(crow_table());      // reads the per-spin energy table the loop above has just derived
     s->direct_built = true;
     return EDGPU_OK;
 }
@@ -118,6 +122,9 @@ static int transposed_dw_pass(S *s, const double *v, hipStream_t st)
             std::vector<int64_t> s2 = scn, r2 = rcn; s2[c.rank] = 0; r2[c.rank] = 0;       // own block already copied
             HIPCHK(hipStreamSynchronize(st));
             if (c.xch(c.ctx, send, s2.data(), sdp.data(), recv, r2.data(), rdp.data(), P)) return fail(EDGPU_ECOMM, "edgpu: exchange callback failed");
+        } else if (c.kind == Comm::EMULATED) {
+            for (int r = 0; r < P; r++)
+                if (r != c.rank) CHK(emu_fill(recv + rdp[r], rcn[r], send + sdp[c.rank], scn[c.rank], st));
         } else
             return fail(EDGPU_ECOMM, "edgpu: mpi_size>1 but no communicator attached (edgpu_comm_init_*)");
         return EDGPU_OK;
@@ -140,7 +147,9 @@ static int transposed_dw_pass(S *s, const double *v, hipStream_t st)
         TdwFusedArgs F{}; F.DimDw = (int32_t)H.DimDw; F.dww = s->dwf->width; F.P = P; F.Qup = s->Qup;
         for (int r = 0; r <= P; r++) F.dw0[r] = Bk.dw0[r];
         F.ellc = s->dwf->ellc.p; F.ellv = s->dwf->ellv.p; F.blk_in = s->tB.p; F.blk_out = s->tVT.p;
-        if (s->dbg & 2) F.dww = 0;
+#ifdef EDGPU_EXPERIMENTS
+        if (s->dbg & 2) F.dww = 0;      // timing only: no dw hops (wrong results)
+#endif
         static OncePerDevice once;
         if (once.first(s->device)) { if (hipFuncSetAttribute((const void *)k_tdw_blocks, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024) != hipSuccess) (void)hipGetLastError(); }
         std::vector<int64_t> qu(P), u0(P), qd(P), d0(P);
@@ -190,7 +199,9 @@ static int transposed_dw_pass(S *s, const double *v, hipStream_t st)
     hipLaunchKernelGGL(k_tblocks, dim3(bgrid), dim3(256), 0, st, Bk);
     TdwArgs D{}; D.DimDw = (int32_t)H.DimDw; D.dww = s->dwf->width; D.use_lds = 0;
     D.ellc = s->dwf->ellc.p; D.ellv = s->dwf->ellv.p; D.vt = s->tVT.p; D.hvt = s->tHVT.p;
+#ifdef EDGPU_EXPERIMENTS
     if (s->dbg & 2) D.dww = 0;
+#endif
     if (s->Qup > 0 && s->dwf->packed_elem8 && s->up_big && D.dww > 0) {
         // long rows: the packed-image gather kernel of the local pass, applied to H_dw (no diagonal)
         UpBigArgs U{};
@@ -240,9 +251,19 @@ static int fused_form(const S *s)
     if (s->up_pairs && s->up_pairs10 && s->upf->packed_elem8 && s->upf->width <= 10 && odd_cols_ok(s)) return 3;      // pair form with 10 hop slots (8-dword element image)
     return (s->upf->packed && s->upf->width <= 16) ? 1 : 0;
 }
+// explicit CSR: the LDS-row local block (k_csr_loc_ax) needs the split lane-major form with equal row lengths in the local block
+// (a half-filled up sector), the factored tile-major dw block, one rank, no Jx/Jp or phonon blocks, and a row that fits LDS
+static bool csr_fused_ok(const S *s)
+{
+    const SectorHost &H = s->H;
+    return H.desc.storage == EDGPU_STORE_CSR && s->lz_fused_on && s->csr_fused_on && !s->multi && !s->extra && H.DimPh == 1 && s->csr_split &&
+           s->csr_il_loc && s->csr_il_dw && s->csr_uni && s->csr_loc_cnt >= 4 && s->csr_loc_cnt <= 9 && H.DimUp <= 13312 && H.DimUp >= 64 &&
+           (s->csr_ld == H.DimUp || s->csr_ld == ((H.DimUp + 15) & ~(int64_t)15)) && (H.DimUp % 2 == 0 || s->csr_ld > H.DimUp);
+}
 static bool fused_ok(const S *s)
 {
     const SectorHost &H = s->H;
+    if (H.desc.storage == EDGPU_STORE_CSR) return csr_fused_ok(s);
     // Jx/Jp sectors run their non-local pass between the two halves; phonon terms live in the row-wise kernel only
     const bool terms_ok = !s->extra || (s->has_nd && !s->has_ph && s->nd_split);
     return s->lz_fused_on && !s->multi && s->kron2 && terms_ok && s->kron_split && H.desc.storage != EDGPU_STORE_CSR && fused_form(s) != 0 &&
@@ -255,6 +276,32 @@ static int fused_local(S *s, double *r, const double *uprev, double *t, double *
 {
     if (redo) { hipLaunchKernelGGL(k_scalar_step, dim3(1), dim3(1), 0, s->stream, s->scal.p, s->alphas.p, s->betas.p, (const double *)nullptr, -1, 9); HIPCHK(hipGetLastError()); }
     const SectorHost &H = s->H; const edgpu_desc &d = H.desc;
+    if (d.storage == EDGPU_STORE_CSR) {
+        CsrAxArgs U{};
+        U.DimUp = (int32_t)H.DimUp; U.Qdw = H.Qdw; U.ld = s->vld;
+        U.rowptr = s->csr_rowptr.p; U.cols = s->csr_cols.p; U.vals = s->csr_vals.p;
+        U.r = r; U.vprev = uprev; U.t_out = t; U.scal = s->scal.p; U.partial = s->partial.p; U.acc = acc; U.zvec = s->zvec.p;
+        if (s->vld != s->csr_ld) return fail(EDGPU_EINVAL, "edgpu: internal: Lanczos vectors and CSR columns disagree on the row pitch");
+        const size_t lds = (size_t)((H.DimUp + 2) & ~(int64_t)1) * 8 + 32 * 8;
+        const int grid = (int)std::min<int64_t>(H.Qdw, s->up_grid > 0 ? s->up_grid : 256);
+#define CSRAX(C_)                                                                                                               \
+    case C_: {                                                                                                                      \
+        static OncePerDevice once_;                                                                                                 \
+        if (once_.first(s->device)) { (void)hipFuncSetAttribute((const void *)k_csr_loc_ax<C_, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); (void)hipFuncSetAttribute((const void *)k_csr_loc_ax<C_, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); } \
+        if (acc) hipLaunchKernelGGL((k_csr_loc_ax<C_, true>), dim3(grid), dim3(1024), lds, s->stream, U);                           \
+        else hipLaunchKernelGGL((k_csr_loc_ax<C_, false>), dim3(grid), dim3(1024), lds, s->stream, U);                              \
+    } break
+        switch (s->csr_loc_cnt) {
+        CSRAX(4); CSRAX(5); CSRAX(6); CSRAX(7); CSRAX(8); CSRAX(9);
+        default: return fail(EDGPU_EINVAL, "edgpu: internal: fused CSR iteration without a kernel for this row length");
+        }
+#undef CSRAX
+        HIPCHK(hipGetLastError());
+        s->fuse_mode = redo ? 8 : 4; s->fuse_zvec = nullptr;
+        const int rc = reduce_partials(s, grid);
+        s->fuse_mode = -1;
+        return rc;
+    }
     const bool direct = d.storage == EDGPU_STORE_DIRECT;
     if (direct) CHK(direct_tables(s));
     UpAxArgs U{};
@@ -314,6 +361,22 @@ static int fused_local(S *s, double *r, const double *uprev, double *t, double *
 static int fused_dw(S *s, const double *u, double *t, const double *uprev)
 {
     const SectorHost &H = s->H;
+    if (H.desc.storage == EDGPU_STORE_CSR) {      // dw block of the split explicit CSR with the fused epilogue (k_csr_il, uprev2)
+        CsrArgs A{};
+        A.ld = s->csr_ld; A.nrows = s->nloc_el; A.DimUp = (int32_t)H.DimUp; A.Qdw = H.Qdw; A.tile = s->csr_tile;
+        A.rows_per_block = s->csrD_rpb; A.blocks_per_row = s->csrD_bpr; A.coltiles = 1; A.xcd_rows = 0;
+        A.rowptr = s->csrD_rowptr.p; A.cols = s->csrD_cols.p; A.vals = s->csrD_vals.p;
+        A.rowbase = s->csrD_base.p; A.rowcnt = s->csrD_cnt.p; A.cpre = s->csr_tm ? s->csrD_cpre.p : nullptr;
+        A.x = u; A.y = t; A.v_local = u; A.uprev = nullptr; A.uprev2 = uprev; A.scal = s->scal.p; A.partial = s->partial.p; A.epi = 1; A.pass = 2;
+        const int64_t nb = (int64_t)s->csrD_bpr * H.Qdw;
+        if (s->csrD_nt != 0) hipLaunchKernelGGL((k_csr_il<true, 1>), dim3((unsigned)nb), dim3(64), 0, s->stream, A);
+        else hipLaunchKernelGGL((k_csr_il<false, 1>), dim3((unsigned)nb), dim3(64), 0, s->stream, A);
+        HIPCHK(hipGetLastError());
+        s->fuse_mode = 5; s->fuse_zvec = nullptr;
+        const int rc = reduce_partials(s, nb);
+        s->fuse_mode = -1;
+        return rc;
+    }
     DwArgs D{};
     D.DimUp = dw_cols(s, s->vld); D.DimDw = (int32_t)H.DimDw; D.DimPh = H.DimPh; D.Qdw = H.Qdw; D.dw0 = H.dw0;
     D.dwc = s->dwf->ellc.p; D.dwv = s->dwf->ellv.p; D.dww = s->dwf->width; D.v = u; D.vfull = u; D.out = t; D.scal = s->scal.p; D.partial = s->partial.p;
@@ -326,18 +389,16 @@ static int fused_dw(S *s, const double *u, double *t, const double *uprev)
     const int64_t nblocks = (int64_t)D.ntiles * D.chunks;
     const bool nt = s->dw_variant != 2, rag = s->dwf->ragged;
     const size_t dlds = std::max<size_t>((size_t)D.R * D.dww * 12 + 16, (size_t)s->dw_lds_kb * 1024);
-#define DW2_LAUNCH_U(N_, R_, U_)                                                                                                \
+#define DW2_LAUNCH(N_, R_)                                                                                                      \
     do {                                                                                                                            \
         static OncePerDevice once_;                                                                                                 \
         if (dlds > 60 * 1024 && once_.first(s->device)) {                                                                           \
-            if (hipFuncSetAttribute((const void *)k_dwpass2<true, N_, R_, 0, U_>, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024) != hipSuccess) (void)hipGetLastError(); \
+            if (hipFuncSetAttribute((const void *)k_dwpass2<true, N_, R_>, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024) != hipSuccess) (void)hipGetLastError(); \
         }                                                                                                                           \
-        hipLaunchKernelGGL((k_dwpass2<true, N_, R_, 0, U_>), dim3((unsigned)nblocks), dim3(256), dlds, s->stream, D);               \
+        hipLaunchKernelGGL((k_dwpass2<true, N_, R_>), dim3((unsigned)nblocks), dim3(256), dlds, s->stream, D);                      \
     } while (0)
-#define DW2_LAUNCH(N_, R_) do { if (s->dw_unr && D.dww <= 16) DW2_LAUNCH_U(N_, R_, true); else DW2_LAUNCH_U(N_, R_, false); } while (0)
     if (nt) { if (rag) DW2_LAUNCH(true, true); else DW2_LAUNCH(true, false); } else { if (rag) DW2_LAUNCH(false, true); else DW2_LAUNCH(false, false); }
 #undef DW2_LAUNCH
-#undef DW2_LAUNCH_U
     HIPCHK(hipGetLastError());
     s->fuse_mode = 5; s->fuse_zvec = nullptr;
     const int rc = reduce_partials(s, nblocks);
@@ -457,8 +518,10 @@ static int hxv(S *s, const double *v, double *out, bool epi, const double *uprev
         A.impmask = (1 << d.Norb) - 1; A.nI = 1 << d.Norb; A.econst = H.econst; A.w0 = d.w0_ph; A.gsum = H.gph_sum; A.Jx = d.Jx; A.Jp = d.Jp;
         A.gup = s->gup.p; A.gdw = s->gdw.p;
         A.v = v; A.vfull = multi ? s->vfull.p : v; A.out = out; A.uprev = uprev; A.scal = s->scal.p; A.partial = s->partial.p;
-        if (s->dbg & 1) A.upw = 0;
+#ifdef EDGPU_EXPERIMENTS
+        if (s->dbg & 1) A.upw = 0;      // timing only: no up hops / no dw hops (wrong results)
         if (s->dbg & 2) A.dww = 0;
+#endif
         int base = (direct ? KF_DIRECT : 0) | (epi ? KF_EPI : 0) | (s->extra ? (KF_PH | KF_ND) : 0);
         nblocks = H.Qdw * H.DimPh;
         // phonon terms live in the fused kernel only; Jx/Jp (without phonons) have their own pass
@@ -469,11 +532,11 @@ static int hxv(S *s, const double *v, double *out, bool epi, const double *uprev
             const bool plain = !s->extra || nd_pass;      // local pass = stored/on-the-fly diagonal + up hops only
             // k_uppass_halo writes the unscaled local part; under the Lanczos epilogue the vectorised dw pass finishes it (uprev2)
             const bool dw_vec2 = s->dw_variant >= 2 && (H.DimUp % 2 == 0 || ld > H.DimUp) && s->dw_w >= 4 && s->dwf->width <= 64;      // odd DimUp: pitched vectors only (dw_cols)
-            const bool halo_can = !s->use_lds && plain && s->upf->seg_ok && s->up_halo && (!epi || (dw_vec2 && !s->extra && !s->tr_on));
+            const bool halo_can = !s->use_lds && plain && H.DimPh == 1 && s->upf->seg_ok && s->up_halo && (!epi || (dw_vec2 && !s->extra && !s->tr_on));
             bool halo_epi = false;
             const bool persistent = s->up_persistent && plain && s->upf->packed && s->upf->width <= 16 && s->use_lds && H.DimUp <= 13312;
-            // the column-tiled dw pass; wr > 0: write-only form (out = dw hops), see k_dwpass2
-            auto run_dw = [&](int wr, bool dw_epi, const double *uprev2) -> int {
+            // the column-tiled dw pass
+            auto run_dw = [&](bool dw_epi, const double *uprev2) -> int {
                 DwArgs D{};
                 D.DimUp = A.DimUp; D.DimDw = A.DimDw; D.DimPh = A.DimPh; D.Qdw = A.Qdw; D.dw0 = A.dw0;
                 D.dwc = A.dwc; D.dwv = A.dwv; D.dww = A.dww; D.v = v; D.vfull = A.vfull; D.out = out; D.scal = s->scal.p; D.partial = s->partial.p;
@@ -486,41 +549,28 @@ static int hxv(S *s, const double *v, double *out, bool epi, const double *uprev
                 D.R = vec2 ? std::min(64, s->dw_rows) : 256 / D.w;
                 D.chunks = (int32_t)cdiv(H.Qdw * H.DimPh, D.R);
                 nblocks = (int64_t)D.ntiles * D.chunks;
-                D.xpt = vec2 ? s->dw_xpt : 1;
-                if (D.xpt > 1) nblocks = cdiv(D.ntiles, 8 / D.xpt) * cdiv(D.chunks, D.xpt) * 8;
                 if (!vec2) {
-                    if (wr) return fail(EDGPU_EINVAL, "edgpu: internal: write-only dw pass needs the vectorised kernel");
                     if (dw_epi) hipLaunchKernelGGL(k_dwpass<true>, dim3((unsigned)nblocks), dim3(256), 0, s->stream, D);
                     else hipLaunchKernelGGL(k_dwpass<false>, dim3((unsigned)nblocks), dim3(256), 0, s->stream, D);
                 } else {
                     const bool nt = dv != 2, rag = s->dwf->ragged;
                     // extra LDS (EDGPU_DW_LDS_KB) caps the workgroups per CU; with 16-row chunks full residency measured best (Ns=16 and Ns=18 sweeps, round 2)
                     const size_t dlds = std::max<size_t>((size_t)D.R * D.dww * 12 + 16, (size_t)s->dw_lds_kb * 1024);
-#define DW_LAUNCH_U(E_, N_, R_, W_, U_)                                                                                         \
+#define DW_LAUNCH(E_, N_, R_)                                                                                                   \
     do {                                                                                                                            \
         static OncePerDevice once_;                                                                                                 \
         if (dlds > 60 * 1024 && once_.first(s->device)) {      /* static LDS of the kernel comes on top: stay below the 160 KB of a CU */ \
-            if (hipFuncSetAttribute((const void *)k_dwpass2<E_, N_, R_, W_, U_>, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024) != hipSuccess) (void)hipGetLastError(); \
+            if (hipFuncSetAttribute((const void *)k_dwpass2<E_, N_, R_>, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024) != hipSuccess) (void)hipGetLastError(); \
         }                                                                                                                           \
-        hipLaunchKernelGGL((k_dwpass2<E_, N_, R_, W_, U_>), dim3((unsigned)nblocks), dim3(256), dlds, s->stream, D);                \
+        hipLaunchKernelGGL((k_dwpass2<E_, N_, R_>), dim3((unsigned)nblocks), dim3(256), dlds, s->stream, D);                        \
     } while (0)
-#define DW_LAUNCH(E_, N_, R_, W_) do { if (unr) DW_LAUNCH_U(E_, N_, R_, W_, true); else DW_LAUNCH_U(E_, N_, R_, W_, false); } while (0)
-                    const bool unr = s->dw_unr && D.dww <= 16;
-                    if (wr == 2) { if (rag) DW_LAUNCH(false, false, true, 2); else DW_LAUNCH(false, false, false, 2); }
-                    else if (wr == 1) { if (rag) DW_LAUNCH(false, false, true, 1); else DW_LAUNCH(false, false, false, 1); }
-                    else if (dw_epi) { if (nt) { if (rag) DW_LAUNCH(true, true, true, 0); else DW_LAUNCH(true, true, false, 0); } else { if (rag) DW_LAUNCH(true, false, true, 0); else DW_LAUNCH(true, false, false, 0); } }
-                    else { if (nt) { if (rag) DW_LAUNCH(false, true, true, 0); else DW_LAUNCH(false, true, false, 0); } else { if (rag) DW_LAUNCH(false, false, true, 0); else DW_LAUNCH(false, false, false, 0); } }
+                    if (dw_epi) { if (nt) { if (rag) DW_LAUNCH(true, true, true); else DW_LAUNCH(true, true, false); } else { if (rag) DW_LAUNCH(true, false, true); else DW_LAUNCH(true, false, false); } }
+                    else { if (nt) { if (rag) DW_LAUNCH(false, true, true); else DW_LAUNCH(false, true, false); } else { if (rag) DW_LAUNCH(false, false, true); else DW_LAUNCH(false, false, false); } }
 #undef DW_LAUNCH
-#undef DW_LAUNCH_U
                 }
                 HIPCHK(hipGetLastError());
                 return EDGPU_OK;
             };
-            // Rows beyond LDS on one rank: the dw pass goes FIRST and only writes (no read-modify-write of the result, stores
-            // that leave the L2), so the XCD's L2 holds nothing but the slab the dw hops gather from; the local pass, which
-            // streams whole rows through LDS and has bandwidth to spare, adds its part on top and carries the Lanczos epilogue.
-            const bool dw_first = halo_can && !persistent && !multi && !nd_pass && dw_vec2 && !s->tr_on && s->dw_first > 0 && !(s->dbg & 2);
-            bool dw_done = false;
             const bool rows_pair = (H.DimUp % 2 == 0) || (ld > H.DimUp && s->pad_allowed);      // odd rows: pair kernels on pitched vectors only (the last pair ends in the padding column)
             const int32_t up_cols = (int32_t)(H.DimUp + (H.DimUp & 1)), up_dtrue = (H.DimUp & 1) ? (int32_t)H.DimUp : 0;
             const bool pairs10 = persistent && rows_pair && s->up_pairs && s->up_pairs10 && !(s->upf->packed_elem && s->upf->width <= 8) && s->upf->packed_elem8 && s->upf->width <= 10;
@@ -608,57 +658,25 @@ static int hxv(S *s, const double *v, double *out, bool epi, const double *uprev
                 U.DimUp = A.DimUp; U.DimPh = A.DimPh; U.nseg = f0.nseg; U.seglen = f0.seglen; U.halocap = f0.seg_maxhalo;
                 U.Qdw = A.Qdw; U.dw0 = A.dw0; U.nrows = H.Qdw * H.DimPh;
                 U.pseg8 = reinterpret_cast<const uint4 *>(f0.pseg8.p); U.ext = f0.seg_ext.p; U.ext_off = f0.seg_ext_off.p; U.tval = f0.ptval.p; U.nterms = f0.pterms;
-                U.diag = A.diag; U.Eup = A.Eup; U.Edw = A.Edw; U.cross = A.cross; U.mapup = A.mapup; U.mapdw = A.mapdw; U.impmask = A.impmask; U.nI = A.nI; U.econst = A.econst;
+                U.diag = A.diag; U.Eup = A.Eup; U.nI = A.nI;
                 U.v = v; U.out = out; U.ld = (int32_t)ld;
-                U.uprev = uprev; U.scal = s->scal.p; U.partial = s->partial.p;
                 if (direct) { U.crowtab = s->crow_tab.p; if (!U.crowtab) return fail(EDGPU_EINVAL, "edgpu: internal: row-constant table of the on-the-fly form missing"); }      // built with the other on-the-fly tables (direct_tables)
-                const size_t lds = ((size_t)U.seglen + U.halocap + 128 + 32 + 16) * 8;
+                const size_t lds = ((size_t)256 + U.seglen + U.halocap + 32) * 8;
                 const unsigned grid = (unsigned)std::max(8 * U.nseg, s->up_grid & ~7);
-                if (dw_first) { CHK(run_dw(s->dw_first, false, nullptr)); dw_done = true; nblocks = grid; }
-                else halo_epi = epi;     // the scale and the -beta*u_prev term move to the dw pass (DwArgs.uprev2): this pass writes the unscaled local part
-#define HALO_LAUNCH(D_, Q_, H_, A_, E_)                                                                                         \
+                halo_epi = epi;     // the scale and the -beta*u_prev term move to the dw pass (DwArgs.uprev2): this pass writes the unscaled local part
+#define HALO_LAUNCH(D_, Q_, H_, N_)                                                                                             \
     do {                                                                                                                            \
         static OncePerDevice once_;                                                                                                 \
-        if (once_.first(s->device)) (void)hipFuncSetAttribute((const void *)k_uppass_halo<D_, Q_, H_, A_, E_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
-        hipLaunchKernelGGL((k_uppass_halo<D_, Q_, H_, A_, E_>), dim3(grid), dim3(1024), lds, s->stream, U);                         \
+        if (once_.first(s->device)) (void)hipFuncSetAttribute((const void *)k_uppass_halo<D_, Q_, H_, N_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+        hipLaunchKernelGGL((k_uppass_halo<D_, Q_, H_, N_>), dim3(grid), dim3(1024), lds, s->stream, U);                             \
     } while (0)
-#define HALO_AE(D_, Q_, H_) do { if (!dw_first) HALO_LAUNCH(D_, Q_, H_, false, false); else if (epi) HALO_LAUNCH(D_, Q_, H_, true, true); else HALO_LAUNCH(D_, Q_, H_, true, false); } while (0)
-#define HALO_Q(D_, H_) do { if (nq == 1) HALO_AE(D_, 1, H_); else if (nq == 2) HALO_AE(D_, 2, H_); else HALO_AE(D_, 3, H_); } while (0)
-                const int nt = s->up_halo_nt;
-                const int nq = (int)cdiv(U.seglen / 2, nt);
-                const int abl = ((s->dbg >> 4) & 3) | s->abl;      // EDGPU_DEBUG bits 16 / 32, EDGPU_ABL: timing ablations (wrong results)
-                if (nt == 512 && !dw_first && nq <= 2 && U.halocap <= 12 * 512) {
-                    // two workgroups of 512 threads per CU (needs segments of <= 2048 elements and <= 6144 halo values)
-                    const unsigned grid5 = (unsigned)std::max(8 * U.nseg, (2 * s->up_grid) & ~7);
-#define HALO5(D_, Q_, H_)                                                                                                       \
-    do {                                                                                                                            \
-        static OncePerDevice once_;                                                                                                 \
-        if (once_.first(s->device)) (void)hipFuncSetAttribute((const void *)k_uppass_halo<D_, Q_, H_, false, false, 0, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
-        hipLaunchKernelGGL((k_uppass_halo<D_, Q_, H_, false, false, 0, 512>), dim3(grid5), dim3(512), lds, s->stream, U);           \
-    } while (0)
-                    const bool h8 = U.halocap <= 8 * 512;
-                    if (direct) { if (nq == 1) { if (h8) HALO5(true, 1, 8); else HALO5(true, 1, 12); } else { if (h8) HALO5(true, 2, 8); else HALO5(true, 2, 12); } }
-                    else { if (nq == 1) { if (h8) HALO5(false, 1, 8); else HALO5(false, 1, 12); } else { if (h8) HALO5(false, 2, 8); else HALO5(false, 2, 12); } }
-#undef HALO5
-                    halo_epi = epi;
-                } else
-                if (abl && direct && nq == 2 && U.halocap <= 8 * 1024 && !dw_first) {
-#define HALO_ABL(V_)                                                                                                            \
-    case V_: {                                                                                                                      \
-        static OncePerDevice once_;                                                                                                 \
-        if (once_.first(s->device)) (void)hipFuncSetAttribute((const void *)k_uppass_halo<true, 2, 8, false, false, V_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
-        hipLaunchKernelGGL((k_uppass_halo<true, 2, 8, false, false, V_>), dim3(grid), dim3(1024), lds, s->stream, U);               \
-    } break
-                    switch (abl) {
-                    HALO_ABL(1); HALO_ABL(2); HALO_ABL(3); HALO_ABL(4); HALO_ABL(8); HALO_ABL(12); HALO_ABL(16); HALO_ABL(28); HALO_ABL(31);
-                    default: return fail(EDGPU_EINVAL, "edgpu: EDGPU_ABL takes 1,2,3,4,8,12,16,28,31");
-                    }
-#undef HALO_ABL
-                } else
+#define HALO_N(D_, Q_, H_) do { if (f0.width <= 9) HALO_LAUNCH(D_, Q_, H_, 9); else HALO_LAUNCH(D_, Q_, H_, 10); } while (0)
+#define HALO_Q(D_, H_) do { if (nq == 1) HALO_N(D_, 1, H_); else if (nq == 2) HALO_N(D_, 2, H_); else HALO_N(D_, 3, H_); } while (0)
+                const int nq = (int)cdiv(U.seglen / 2, 1024);
                 if (U.halocap <= 8 * 1024) { if (direct) HALO_Q(true, 8); else HALO_Q(false, 8); }
                 else { if (direct) HALO_Q(true, 12); else HALO_Q(false, 12); }
 #undef HALO_Q
-#undef HALO_AE
+#undef HALO_N
 #undef HALO_LAUNCH
                 HIPCHK(hipGetLastError());
             } else if (ld) {
@@ -695,7 +713,7 @@ static int hxv(S *s, const double *v, double *out, bool epi, const double *uprev
                     else hipLaunchKernelGGL(k_ndpass<false>, dim3((unsigned)(H.Qdw * H.DimPh)), dim3(256), 0, s->stream, Nd);
                     HIPCHK(hipGetLastError());
                 }
-                if (!dw_done) CHK(run_dw(0, epi, halo_epi ? uprev : nullptr));
+                CHK(run_dw(epi, halo_epi ? uprev : nullptr));
             }
         }
     } else {

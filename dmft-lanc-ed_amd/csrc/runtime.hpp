@@ -8,6 +8,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
+#include <limits>
 #include <map>
 #include <memory>
 #include <string>
@@ -128,7 +130,7 @@ static Rccl g_rccl;
 constexpr int kNcclDouble = 8, kNcclSum = 0;
 
 struct Comm {
-    enum Kind { NONE, RCCL, CALLBACK } kind = NONE;
+    enum Kind { NONE, RCCL, CALLBACK, EMULATED } kind = NONE;      // EMULATED: one rank of `size` measured alone (edgpu_comm_create_emulated)
     int rank = 0, size = 1;
     void *nccl = nullptr;
     bool owned = false;      // the sector created `nccl` itself (edgpu_comm_init_rccl) and destroys it; attached communicators are not owned
@@ -211,6 +213,8 @@ struct edgpu_sector_s {
     // lane-major image of the 64-row blocks (k_csr_il): the local block when every up configuration has the same number of
     // hops, the dw-type blocks always (their rows are uniform per idw row)
     bool csr_il_loc = false, csr_il_dw = false; bool csrL_nt = false;
+    int csr_loc_cnt = 0;      // entries per row of the local block when every row has the same number (half-filled up sector: 1 + Ns/2), else 0
+    bool csr_fused_on = true; // EDGPU_CSR_FUSED: fused Lanczos iteration on the explicit CSR (k_csr_loc_ax)
     // single rank: the stored columns index vectors whose rows are padded to the 128-B line (csr_ld doubles per row; == DimUp
     // when off); the Lanczos loops then run on pitched vectors, a caller's dense vectors go through csr_xs / csr_ys
     int axpy_nb = 512;      // workgroups of the axpy+norm pass of the three-pass iteration
@@ -258,12 +262,7 @@ struct edgpu_sector_s {
     bool up_elem16 = true;    // one-configuration-per-lane local passes read the element-major 12-dword image (EDGPU_UP_ELEM16=0: the slot-major one)
     bool pad_allowed = true;  // EDGPU_PAD != 0: work vectors of the Lanczos loops may carry a padded row pitch
     bool up_pairs10 = true;   // pair form of the LDS-row local passes for 9-10 up hops (EDGPU_UP_PAIRS10=0: one configuration per lane, as before round 3)
-    int abl = 0;              // EDGPU_ABL: timing ablations of k_uppass_halo (wrong results; scripts/prof_halo2.sh)
     int dbg = 0; bool tables_wave = true; int dw_lds_kb = 0; bool lz_fused_on = true;
-    int up_halo_nt = 1024;    // threads per workgroup of k_uppass_halo (512: two workgroups per CU, with EDGPU_UP_SEGMAX=2048)
-    bool dw_unr = false;      // dw pass with every load of a row step issued up front (k_dwpass2<..., UNR>; <= 16 dw hops per row): measured slower (occupancy 4 instead of 8 waves per SIMD), kept as a knob
-    int dw_xpt = 1;           // XCDs sharing one column tile of the dw pass (k_dwpass2: xcd_tile_map_shared)
-    int dw_first = 0;         // rows beyond LDS, one rank: dw pass first as a write-only pass (1: plain stores, 2: write-through), local pass adds + epilogue; 0 (default): local pass first -- the write-only form cuts the dw pass's reads by 30 % but the local pass pays them back (profiles/r03/ns18_product_variants.txt)
     int eig_ncv_used = 0;     // basis size the last edgpu_eigsh call actually ran with
     // Lanczos iteration fusion (single rank)
     // several ranks: one 16-byte all-reduce per Lanczos iteration instead of two of 8 bytes (EDGPU_ONE_ALLREDUCE=1; lz_iter_deferred)
@@ -307,7 +306,105 @@ using S = edgpu_sector_s;
 static int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 // launch attributes (dynamic LDS limit) are set once per function AND device
 struct OncePerDevice { bool done[64] = {}; bool first(int dev) { if (dev < 0 || dev >= 64) return true; const bool f = !done[dev]; done[dev] = true; return f; } };
-static int dbg_flags() { const char *e = getenv("EDGPU_DEBUG"); return e ? atoi(e) : 0; }
-static int dbg_int(const char *name, int dflt) { const char *e = getenv(name); return e ? atoi(e) : dflt; }
+
+// ---------------------------------------------------------------------------------------
+// Environment switches.  The shipping library reads exactly the names of this table (edgpu_knob_count / edgpu_knob_info export
+// it; tests/test_knobs_cpu.py checks it against the call sites, against scripts/README.md and against the strings of the
+// binary): forms whose choice awaits a multi-GPU measurement, fallbacks that a test exercises, and the hooks the tests use to
+// drive large-sector code paths on small sectors.  Every other tuning value is a compile-time constant (XKNOB) that becomes an
+// environment switch only in the experiments build (build.sh exp: -DEDGPU_EXPERIMENTS, libedgpu_exp.so, used by scripts/).
+// A value of -1 means "decided by the library" (size thresholds).  Unknown EDGPU_* names in the environment are reported once.
+// ---------------------------------------------------------------------------------------
+struct KnobDef { const char *name; int dflt; const char *kind; const char *doc; const char *test; };
+static const KnobDef kKnobs[] = {
+    // product forms
+    {"EDGPU_KRON_SPLIT", -1, "form", "two-pass product (local pass + column-tiled dw pass) of the stored-factor / on-the-fly operator; -1: once a vector exceeds 48 MB", "test_gpu_parity.py::test_large_sector_code_paths_on_small_sectors"},
+    {"EDGPU_CSR_SPLIT", -1, "form", "explicit CSR stored as two blocks H_loc + H_dw; -1: once a vector exceeds 48 MB", "test_gpu_parity.py::test_large_sector_code_paths_on_small_sectors"},
+    {"EDGPU_COMPOSITE", 1, "fallback", "ed_total_ud=F through composite up/dw blocks; 0: generic mixed-radix kernel", "test_gpu_parity.py::test_large_sector_code_paths_on_small_sectors"},
+    {"EDGPU_ND_SPLIT", 1, "fallback", "Jx/Jp terms in a pass of their own; 0: inside the row-wise kernel", "test_gpu_parity.py::test_c5_full_size_properties"},
+    {"EDGPU_LZ_FUSED", 1, "fallback", "fused two-pass Lanczos iteration; 0: product + axpy/norm pass", "test_gpu_parity.py::test_fused_iteration_equals_three_pass_iteration"},
+    {"EDGPU_PAD", 1, "fallback", "Lanczos work vectors with the row pitch padded to the 128-B line; 0: dense rows", "test_gpu_parity.py::test_fused_iteration_equals_three_pass_iteration"},
+    {"EDGPU_ODD_PAIRS", 1, "fallback", "column-pair kernels on pitched vectors for odd DimUp; 0: scalar forms", "test_gpu_parity.py::test_odd_row_length_uses_the_pair_kernels_on_pitched_vectors"},
+    {"EDGPU_UP_PAIRS10", 1, "fallback", "pair form of the local pass for 9-10 up hops; 0: one configuration per lane", "test_gpu_parity.py::test_pair_form_with_ten_hop_slots"},
+    {"EDGPU_UP_PERSISTENT", 1, "fallback", "persistent LDS-row local pass; 0: row-wise kernel without the dw hops", "test_gpu_parity.py::test_large_sector_code_paths_on_small_sectors"},
+    {"EDGPU_UP_PAIRS", 1, "fallback", "two up configurations per lane in the local pass; 0: one", "test_gpu_parity.py::test_large_sector_code_paths_on_small_sectors"},
+    {"EDGPU_UP_THREADS", 1024, "fallback", "threads of the one-configuration-per-lane local pass (1024 or 512)", "test_gpu_parity.py::test_large_sector_code_paths_on_small_sectors"},
+    {"EDGPU_UP_GRID", 256, "test hook", "workgroups of the persistent local passes (tests: idle and odd counts)", "test_gpu_parity.py::test_large_sector_code_paths_on_small_sectors"},
+    {"EDGPU_UP_HALO", 1, "fallback", "segment + halo local pass for rows beyond LDS; 0: gather kernel k_uppass_big", "test_gpu_parity.py::test_large_sector_code_paths_on_small_sectors"},
+    {"EDGPU_UP_BIG", 1, "fallback", "packed-image gather kernel for rows beyond LDS; 0: row-wise kernel", "test_gpu_parity.py::test_large_sector_code_paths_on_small_sectors"},
+    {"EDGPU_UP_SEGMAX", 4096, "test hook", "longest row segment of the segment + halo local pass (tests: many short segments)", "test_gpu_parity.py::test_large_sector_code_paths_on_small_sectors"},
+    {"EDGPU_ROW_SPLIT", 4, "fallback", "workgroups per row of the gather kernel for rows beyond LDS", "test_gpu_parity.py::test_large_sector_code_paths_on_small_sectors"},
+    {"EDGPU_DW_W", 64, "test hook", "column-tile width of the dw pass (tests: narrow tiles on small sectors)", "test_gpu_parity.py::test_large_sector_code_paths_on_small_sectors"},
+    {"EDGPU_DW_ROWS", 16, "test hook", "rows per workgroup of the dw pass", "test_gpu_parity.py::test_large_sector_code_paths_on_small_sectors"},
+    {"EDGPU_DW_VARIANT", 2, "fallback", "dw pass: 2 two columns per lane, 3 the same with non-temporal result accesses, 1 one column per lane", "test_gpu_parity.py::test_large_sector_code_paths_on_small_sectors"},
+    // explicit CSR
+    {"EDGPU_CSR_IL", 3, "fallback", "lane-major 64-row blocks: bit 0 local block, bit 1 dw-type blocks; 0: row-major blocks staged through LDS", "test_gpu_parity.py::test_large_sector_code_paths_on_small_sectors"},
+    {"EDGPU_CSR_TM", 1, "fallback", "tile-major storage of the lane-major dw-type blocks", "test_gpu_parity.py::test_large_sector_code_paths_on_small_sectors"},
+    {"EDGPU_CSR_JAG", 1, "fallback", "lane-major local block also when its rows differ in length (level-packed)", "test_gpu_parity.py::test_split_csr_with_rows_of_different_lengths"},
+    {"EDGPU_CSR_PITCH", 1, "fallback", "columns in the pitched vector space on one rank", "test_gpu_parity.py::test_large_sector_code_paths_on_small_sectors"},
+    {"EDGPU_CSR_UNI", 1, "fallback", "factored row pointer of the dw-type blocks", "test_gpu_parity.py::test_large_sector_code_paths_on_small_sectors"},
+    {"EDGPU_CSRD_ROWS", 64, "test hook", "rows per block of the row-major dw block", "test_gpu_parity.py::test_large_sector_code_paths_on_small_sectors"},
+    {"EDGPU_CSRD_NT", 1, "fallback", "non-temporal entry loads of the dw block", "test_gpu_parity.py::test_large_sector_code_paths_on_small_sectors"},
+    // Lanczos loops and eigensolvers
+    {"EDGPU_CSR_FUSED", 1, "fallback", "fused Lanczos iteration on the explicit CSR (LDS-row local block carrying the axpy+norm pass); 0: product + axpy/norm pass", "test_gpu_parity.py::test_fused_iteration_equals_three_pass_iteration"},
+    {"EDGPU_LZ_STORE", 1, "fallback", "keep the Krylov vectors of a ground-state search in HBM; 0: second Lanczos pass", "test_gpu_parity.py::test_ground_state_with_stored_krylov_vectors"},
+    {"EDGPU_LZ_STORE_MAX", 1 << 30, "test hook", "cap on the stored Krylov vectors (tests: running out mid-search)", "test_gpu_parity.py::test_ground_state_with_stored_krylov_vectors"},
+    {"EDGPU_EIGSH_PRO", 1, "fallback", "thick-restart Lanczos with partial re-orthogonalisation; 0: whole-basis form", "test_eigsh.py::test_eigsh_alternative_forms"},
+    {"EDGPU_EIGSH_FUSED", 1, "fallback", "fused two-pass products inside edgpu_eigsh", "test_eigsh.py::test_eigsh_alternative_forms"},
+    {"EDGPU_EIGSH_OMEGA_PCT", 100, "test hook", "re-orthogonalisation trigger in % of sqrt(eps) (tests: always / never)", "test_eigsh.py::test_eigsh_alternative_forms"},
+    {"EDGPU_EIGSH_MEM_MB", 0, "test hook", "pretend only this much device memory is free for the basis", "test_eigsh.py::test_eigsh_runs_with_the_basis_that_fits"},
+    {"EDGPU_ROT2", 1, "fallback", "restart rotation with 16-byte accesses on contiguous pieces", "test_eigsh.py::test_eigsh_alternative_forms"},
+    {"EDGPU_ROT_MFMA", 1, "fallback", "restart rotation on the f64 matrix cores; 0: register-resident kernels", "test_eigsh.py::test_eigsh_alternative_forms"},
+    // several ranks: forms awaiting a measurement on xGMI
+    {"EDGPU_HALO", 1, "multi-GPU", "needed-rows exchange; 0: all-gather of the input vector", "test_multirank.py::test_multirank_fallback_forms"},
+    {"EDGPU_DW_TRANSPOSE", 0, "multi-GPU", "dw hops through the distributed transpose (the reference's MPI scheme)", "test_multirank.py::test_multirank_distributed_transpose"},
+    {"EDGPU_TR_CHUNKS", 4, "multi-GPU", "pipeline chunks of the transpose exchange", "test_multirank.py::test_multirank_distributed_transpose"},
+    {"EDGPU_ONE_ALLREDUCE", 0, "multi-GPU", "deferred norm: one 16-byte all-reduce per Lanczos iteration", "test_multirank.py::test_multirank_one_allreduce_per_iteration"},
+    {"EDGPU_RELAY", 0, "multi-GPU", "two-phase relay routing of the needed-rows exchange (>= 3 ranks)", "test_multirank.py::test_multirank_relay_routing"},
+    {"EDGPU_CSR_THREE", 1, "multi-GPU", "explicit CSR of several ranks in three blocks (own-row dw hops overlap the exchange)", "test_multirank.py::test_multirank_fallback_forms"},
+    {"EDGPU_CSR_PITCH_MULTI", 1, "multi-GPU", "pitched x-space and messages for the explicit CSR of several ranks", "test_multirank.py::test_multirank_fallback_forms"},
+    // diagnostics
+    {"EDGPU_DEBUG", 0, "debug", "bit 4: no LDS staging of rows (forces the long-row kernels on small sectors; tests), bit 8: solver statistics on stderr", "test_gpu_parity.py::test_large_sector_code_paths_on_small_sectors"},
+};
+static const char *const kKnobStrings[] = {"EDGPU_RCCL_LIB", "EDGPU_HIP_RUNTIME", "EDGPU_LIBRARY"};      // path-valued names (the last two are read by the Python binding)
+constexpr int kNumKnobs = (int)(sizeof(kKnobs) / sizeof(kKnobs[0]));
+static const KnobDef *knob_find(const char *name)
+{
+    for (int i = 0; i < kNumKnobs; i++) if (strcmp(kKnobs[i].name, name) == 0) return &kKnobs[i];
+    return nullptr;
+}
+// value of a table knob (its default when the variable is unset)
+static int knob(const char *name)
+{
+    const KnobDef *k = knob_find(name);
+    if (!k) { fprintf(stderr, "edgpu: internal: environment switch %s is not in the table\n", name); abort(); }
+    const char *e = getenv(name);
+    return e ? atoi(e) : k->dflt;
+}
+#ifdef EDGPU_EXPERIMENTS
+static int xknob_env(const char *name, int dflt) { const char *e = getenv(name); return e ? atoi(e) : dflt; }
+#define XKNOB(name, dflt) xknob_env(name, dflt)
+#else
+#define XKNOB(name, dflt) (dflt)      // shipping build: a constant, the name does not reach the binary
+#endif
+static int dbg_flags() { return knob("EDGPU_DEBUG"); }
+extern "C" char **environ;
+static void warn_unknown_knobs()
+{
+    static bool done = false;
+    if (done) return;
+    done = true;
+    for (char **e = environ; e && *e; e++) {
+        if (strncmp(*e, "EDGPU_", 6) != 0) continue;
+        const char *eq = strchr(*e, '=');
+        const std::string name(*e, eq ? (size_t)(eq - *e) : strlen(*e));
+        bool known = knob_find(name.c_str()) != nullptr;
+        for (const char *sname : kKnobStrings) known = known || name == sname;
+#ifdef EDGPU_EXPERIMENTS
+        known = true;
+#endif
+        if (!known) fprintf(stderr, "edgpu: warning: environment variable %s is not a switch of this library (edgpu_knob_info lists them; tuning switches exist in the experiments build only)\n", name.c_str());
+    }
+}
 
 }  // namespace edgpu

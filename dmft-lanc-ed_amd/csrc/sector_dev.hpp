@@ -14,10 +14,17 @@ static int upload_factor(S *s, int k)
     const Factor &f = comp ? s->H.cfac[-1 - k] : s->H.fac[k];
     const bool is_up = comp ? k == -1 : k < s->H.Ns_Ud;
     auto df = std::make_unique<DevFactor>();
+    // storage=DIRECT holds no operator image: every hop image and energy table below is derived on the device from the bit patterns
+    // by the first product (direct_tables / k_direct_tables*).  The buffers are sized here as for the stored form but their first
+    // `dim` entries are filled with a marker (column 0, NaN amplitudes / energies) instead of the host's values, so that an image
+    // the table kernels fail to emit shows up as NaN or as a wrong product in every DIRECT parity test.  ed_total_ud=F sectors
+    // keep their (composite and per-orbital) tables; the structure-only lists (segment halo lists, x-space row maps) stay.
+    const bool derive = !comp && s->H.desc.ed_total_ud != 0 && s->H.desc.storage == EDGPU_STORE_DIRECT;
+    const double qnan = std::numeric_limits<double>::quiet_NaN();
     CHK(df->map.upload(f.map)); CHK(df->rank.upload(f.rank));
     std::vector<int32_t> rp32(f.rowptr.begin(), f.rowptr.end());
     CHK(df->rowptr.upload(rp32)); CHK(df->cols.upload(f.cols)); CHK(df->vals.upload(f.vals));
-    { std::vector<double> e1(f.E); e1.push_back(0.0); CHK(df->E.upload(e1)); }      // one zero behind the end: the last pair of an odd row (pair kernels on pitched vectors)
+    { std::vector<double> e1(f.E); if (derive) std::fill(e1.begin(), e1.end(), qnan); e1.push_back(0.0); CHK(df->E.upload(e1)); }      // one zero behind the end: the last pair of an odd row (pair kernels on pitched vectors)
     df->width = std::max(f.width, 1);
     for (int32_t i = 0; i < f.dim; i++) if (f.rowptr[i + 1] - f.rowptr[i] < df->width) { df->ragged = true; break; }
     if (df->width > 64) return fail(EDGPU_EUNSUPPORTED, "edgpu: more than 64 hops per spin configuration");
@@ -31,6 +38,7 @@ static int upload_factor(S *s, int k)
             size_t o = transposed ? (size_t)q * f.dim + i : (size_t)i * df->width + q;
             ec[o] = has ? f.cols[p] : i; ev[o] = has ? f.vals[p] : 0.0;
         }
+    if (derive) { std::fill(ec.begin(), ec.end(), 0); std::fill(ev.begin(), ev.end(), qnan); }
     CHK(df->ellc.upload(ec)); CHK(df->ellv.upload(ev));
     // packed image for the persistent local pass: 16-bit column + (sign | term index) byte per hop;
     // padded slots use code 127 -> amplitude 0.  Only when every entry is a single hop term.
@@ -53,7 +61,8 @@ static int upload_factor(S *s, int k)
                 if (q < 2 * ncw) pc[(size_t)(q / 2) * f.dim + i] |= col << (16 * (q & 1));
                 pd[(size_t)(q / 4) * f.dim + i] |= code << (8 * (q & 3));
             }
-        if (ok) { CHK(df->pcols.upload(pc)); CHK(df->pcodes.upload(pd)); CHK(df->ptval.upload(tvl)); df->packed = true; df->pterms = 128; }
+        // (the element-major images below are composed from pc / pd BEFORE those are cleared for the on-the-fly form)
+        auto clear_rows = [&](std::vector<uint32_t> &img, int dwords) { if (derive) std::fill(img.begin(), img.begin() + (size_t)dwords * f.dim, 0u); };
         // odd dim: one more element in the element-major images, a padding configuration without hops (columns = its own index,
         // codes 127): the pair kernels then run odd rows on pitched vectors, whose padding column it stands for
         const int32_t dimp = f.dim + (f.dim & 1);
@@ -73,7 +82,7 @@ static int upload_factor(S *s, int k)
                     pe[(size_t)8 * i + 5 + q / 4] |= code << (8 * (q & 3));
                 }
             }
-            CHK(df->pelem8.upload(pe)); df->packed_elem8 = true;
+            clear_rows(pe, 8); CHK(df->pelem8.upload(pe)); df->packed_elem8 = true;
         }
         if (ok && W <= 16) {                        // element-major image of 12 dwords (8 of columns, 4 of codes: 16 hop slots) for the one-configuration-per-lane kernels:
             std::vector<uint32_t> pe((size_t)12 * f.dim, 0u);      // three 16-byte loads per configuration instead of up to eleven 4-byte ones from the slot-major image
@@ -81,7 +90,7 @@ static int upload_factor(S *s, int k)
                 for (int c = 0; c < 8; c++) pe[(size_t)12 * i + c] = c < ncw ? pc[(size_t)c * f.dim + i] : ((uint32_t)i | ((uint32_t)i << 16));
                 for (int c = 0; c < 4; c++) pe[(size_t)12 * i + 8 + c] = c < ndw ? pd[(size_t)c * f.dim + i] : 0x7f7f7f7fu;
             }
-            CHK(df->pelem16.upload(pe)); df->packed_elem16 = true;
+            clear_rows(pe, 12); CHK(df->pelem16.upload(pe)); df->packed_elem16 = true;
         }
         if (ok && W <= 8) {                         // element-major image for the pair kernel: 6 dwords per up configuration
             std::vector<uint32_t> pe((size_t)6 * dimp, 0u);
@@ -90,8 +99,9 @@ static int upload_factor(S *s, int k)
                 for (int c = 0; c < 4; c++) pe[(size_t)6 * i + c] = c < ncw ? pc[(size_t)c * f.dim + i] : ((uint32_t)i | ((uint32_t)i << 16));
                 for (int c = 0; c < 2; c++) pe[(size_t)6 * i + 4 + c] = c < ndw ? pd[(size_t)c * f.dim + i] : 0x7f7f7f7fu;
             }
-            CHK(df->pelem.upload(pe)); df->packed_elem = true;
+            clear_rows(pe, 6); CHK(df->pelem.upload(pe)); df->packed_elem = true;
         }
+        if (ok) { if (derive) { std::fill(pc.begin(), pc.end(), 0u); std::fill(pd.begin(), pd.end(), 0u); } CHK(df->pcols.upload(pc)); CHK(df->pcodes.upload(pd)); CHK(df->ptval.upload(tvl)); df->packed = true; df->pterms = 128; }
     }
     std::vector<int32_t> ta, tb; std::vector<double> tv;
     for (auto &t : f.terms) { ta.push_back(t.alpha); tb.push_back(t.beta); tv.push_back(t.t); }
@@ -126,7 +136,7 @@ static int build_up_segments(S *s)
     const Factor &f = *s->hup; DevFactor &df = *s->upf;
     if (!df.packed_elem8 || f.dim % 2 || f.dim > 65536) return EDGPU_OK;
     // first choice: two pairs and eight halo values per lane (the kernel variant that fits 128 registers without spilling)
-    const int32_t lim[2][2] = {{std::min(dbg_int("EDGPU_UP_SEGMAX", 4096), kHaloSegMax), std::min(dbg_int("EDGPU_UP_HALOMAX", 8192), kHaloMax)}, {kHaloSegMax, kHaloMax}};
+    const int32_t lim[2][2] = {{std::min(knob("EDGPU_UP_SEGMAX"), kHaloSegMax), std::min(XKNOB("EDGPU_UP_HALOMAX", 8192), kHaloMax)}, {kHaloSegMax, kHaloMax}};
     for (int pass = 0; pass < 2; pass++)
         for (int nseg = 2; nseg <= 64; nseg *= 2) {
             const int32_t seglen = (int32_t)((cdiv(f.dim, nseg) + 1) & ~(int64_t)1);
@@ -142,7 +152,7 @@ static int build_up_segments(S *s)
                 maxh = std::max<int32_t>(maxh, (int32_t)e.size());
                 ext.insert(ext.end(), e.begin(), e.end()); off.push_back((int32_t)ext.size());
             }
-            if (!ok || ((size_t)seglen + maxh + 160) * 8 > 156 * 1024) continue;
+            if (!ok || ((size_t)seglen + maxh + 256 + 32 + 16) * 8 > 156 * 1024) continue;      // + signed amplitude table, row constants
             if (ext.empty()) ext.push_back(0);
             CHK(df.seg_ext.upload(ext)); CHK(df.seg_ext_off.upload(off)); CHK(df.pseg8.alloc((size_t)8 * f.dim));
             df.nseg = nseg; df.seglen = seglen; df.seg_maxhalo = maxh; df.seg_ok = true;
@@ -294,7 +304,7 @@ static int setup_halo(S *s)
     if (H.Jhflag) CHK(s->xmap_dev.upload(xmap));      // the non-local pass finds its partner rows through this
     HIPCHK(hipEventCreateWithFlags(&s->ev_pack, hipEventDisableTiming));
     s->halo = true;
-    if (P >= 3 && H.DimPh == 1 && dbg_int("EDGPU_RELAY", 0) != 0) CHK(relay_plan(s));
+    if (P >= 3 && H.DimPh == 1 && knob("EDGPU_RELAY") != 0) CHK(relay_plan(s));
     return EDGPU_OK;
 }
 
@@ -372,11 +382,11 @@ static int build_csr(S *s)
     // Two storage forms of the same explicit matrix: one CSR, or (default for large sectors) two CSR
     // blocks H = H_loc + H_dw so that each block can be streamed in the order that keeps ITS gathers
     // cache resident (rows for the up hops, XCD-owned column tiles for the dw hops).
-    s->csr_split = dbg_int("EDGPU_CSR_SPLIT", (H.DimUp * H.DimDw * 8 > ((int64_t)48 << 20)) ? 1 : 0) != 0 || H.Jhflag || H.DimPh > 1;      // the non-local / phonon passes go between the local and the dw block
+    { const int k = knob("EDGPU_CSR_SPLIT"); s->csr_split = (k < 0 ? H.DimUp * H.DimDw * 8 > ((int64_t)48 << 20) : k != 0) || H.Jhflag || H.DimPh > 1; }      // the non-local / phonon passes go between the local and the dw block
     s->csrL_nnz = H.Qdw * uppre[up.dim]; s->csrD_nnz = s->csr_nnz - s->csrL_nnz;
     s->csr_ld = H.DimUp;
     // several ranks: only with the needed-rows exchange, whose messages carry the pitch (EDGPU_CSR_PITCH_MULTI=0: dense rows as in round 2)
-    if ((!s->multi || (s->halo && dbg_int("EDGPU_CSR_PITCH_MULTI", 1) != 0)) && s->csr_split && !H.Jhflag && H.DimPh == 1 && (H.DimUp % 16) != 0 && dbg_int("EDGPU_PAD", 1) != 0 && dbg_int("EDGPU_CSR_PITCH", 1) != 0) {
+    if ((!s->multi || (s->halo && knob("EDGPU_CSR_PITCH_MULTI") != 0)) && s->csr_split && !H.Jhflag && H.DimPh == 1 && (H.DimUp % 16) != 0 && knob("EDGPU_PAD") != 0 && knob("EDGPU_CSR_PITCH") != 0) {
         const int64_t ld = (H.DimUp + 15) & ~(int64_t)15;
         if (ld * s->nhalo < ((int64_t)1 << 31)) s->csr_ld = ld;
     }
@@ -397,12 +407,13 @@ static int build_csr(S *s)
         {   // lane-major block images (k_csr_il): 64-row blocks whose rows all have the same length
             bool up_uniform = true;
             for (int i = 1; i < up.dim; i++) up_uniform = up_uniform && (up.rowptr[i + 1] - up.rowptr[i] == up.rowptr[1] - up.rowptr[0]);
-            const int il = dbg_int("EDGPU_CSR_IL", 3);      // bit 0: local block, bit 1: dw-type blocks
-            s->csr_il_loc = (il & 1) && (up_uniform || dbg_int("EDGPU_CSR_JAG", 1) != 0);      // rows of different lengths: packed level by level (k_csr_il, jagged path)
+            const int il = knob("EDGPU_CSR_IL");      // bit 0: local block, bit 1: dw-type blocks
+            s->csr_il_loc = (il & 1) && (up_uniform || knob("EDGPU_CSR_JAG") != 0);      // rows of different lengths: packed level by level (k_csr_il, jagged path)
             s->csr_il_dw = (il & 2) != 0;
+            s->csr_loc_cnt = up_uniform ? (int)(1 + up.rowptr[1] - up.rowptr[0]) : 0;
         }
         A.rpb = 64;
-        s->csr_three = s->halo && !H.Jhflag && dbg_int("EDGPU_CSR_THREE", 1) != 0;      // the stored non-local block reads own and received rows from one x buffer: keep the own-row copy
+        s->csr_three = s->halo && !H.Jhflag && knob("EDGPU_CSR_THREE") != 0;      // the stored non-local block reads own and received rows from one x buffer: keep the own-row copy
         // per local dw row: its dw hops into the rank's own rows (x-space row < Qdw; three-block form only) and the others.
         // Every row of one idw row holds the same number of them: factored row pointers base[idw] + iup * cnt[idw].
         std::vector<int64_t> bD(H.Qdw + 1, 0), bO(H.Qdw + 1, 0), pD(H.Qdw + 1, 0), pO(H.Qdw + 1, 0); std::vector<int32_t> cD(H.Qdw, 0), cO(H.Qdw, 0);
@@ -416,10 +427,10 @@ static int build_csr(S *s)
                 bD[q + 1] = bD[q] + (int64_t)nh * up.dim; bO[q + 1] = bO[q] + (int64_t)no * up.dim;
             }
         }
-        s->csr_uni = dbg_int("EDGPU_CSR_UNI", 1) != 0;
+        s->csr_uni = knob("EDGPU_CSR_UNI") != 0;
         // tile-major storage of the lane-major dw-type blocks: the blocks of one column tile (all idw) are contiguous, in the
         // order the XCD that owns the tile walks them -- block (jb, idw) starts at jb*64*ctot + rows(jb)*cpre[idw]
-        s->csr_tm = s->csr_il_dw && s->csr_uni && dbg_int("EDGPU_CSR_TM", 1) != 0;
+        s->csr_tm = s->csr_il_dw && s->csr_uni && knob("EDGPU_CSR_TM") != 0;
         s->h_cntD = cD; s->h_cntO = cO;
         CHK(s->csrD_base.upload(bD)); CHK(s->csrD_cnt.upload(cD)); CHK(s->csrD_cpre.upload(pD));
         if (s->csr_three) { CHK(s->csrO_base.upload(bO)); CHK(s->csrO_cnt.upload(cO)); CHK(s->csrO_cpre.upload(pO)); s->csrO_nnz = bO[H.Qdw]; s->csrD_nnz = bD[H.Qdw]; }
@@ -442,20 +453,20 @@ static int build_csr(S *s)
         A.il = 0; A.tm = 0;
         int64_t ndmax = 0;
         for (int64_t q = 0; q < H.Qdw; q++) ndmax = std::max<int64_t>(ndmax, dw.rowptr[H.dw0 + q + 1] - dw.rowptr[H.dw0 + q]);
-        s->csrD_rpb = s->csr_il_dw ? 64 : (int32_t)std::min<int64_t>(dbg_int("EDGPU_CSRD_ROWS", 64), 1152 / std::max<int64_t>(ndmax, 1));
+        s->csrD_rpb = s->csr_il_dw ? 64 : (int32_t)std::min<int64_t>(knob("EDGPU_CSRD_ROWS"), 1152 / std::max<int64_t>(ndmax, 1));
         if (s->csrD_rpb < 1) return fail(EDGPU_EUNSUPPORTED, "edgpu: a CSR row exceeds the LDS tile");
         s->csrD_bpr = (int32_t)cdiv(H.DimUp, s->csrD_rpb);
-        s->csrD_nt = dbg_int("EDGPU_CSRD_NT", 1); s->csrL_nt = dbg_int("EDGPU_CSRL_NT", 0) != 0;      // measured: plain loads for the row-ordered local block (8.12 vs 8.43 ms per product at c3), non-temporal ones for the tile-ordered dw block
+        s->csrD_nt = knob("EDGPU_CSRD_NT"); s->csrL_nt = XKNOB("EDGPU_CSRL_NT", 0) != 0;      // measured: plain loads for the row-ordered local block (8.12 vs 8.43 ms per product at c3), non-temporal ones for the tile-ordered dw block
         maxrow = 1 + upmax;
-        s->csrL_small = (1 + upmax) * 64 <= 640 && dbg_int("EDGPU_CSR_SMALL", 1);     // smaller LDS image -> more resident workgroups
-        s->csrD_small = ndmax * s->csrD_rpb <= 640 && dbg_int("EDGPU_CSR_SMALL", 1);
+        s->csrL_small = (1 + upmax) * 64 <= 640 && XKNOB("EDGPU_CSR_SMALL", 1);     // smaller LDS image -> more resident workgroups
+        s->csrD_small = ndmax * s->csrD_rpb <= 640 && XKNOB("EDGPU_CSR_SMALL", 1);
     }
     HIPCHK(hipGetLastError());
-    s->csr_xcd_rows = dbg_int("EDGPU_CSR_XCD", 0);
+    s->csr_xcd_rows = XKNOB("EDGPU_CSR_XCD", 0);
     s->csr_rpb = s->csr_il_loc ? 64 : (int32_t)std::min<int64_t>(64, 1152 / std::max<int64_t>(maxrow, 1));      // one wave per row block
     if (s->csr_rpb < 1) return fail(EDGPU_EUNSUPPORTED, "edgpu: a CSR row exceeds the LDS tile");
     s->csr_bpr = (int32_t)cdiv(H.DimUp, s->csr_rpb);
-    s->csr_tile = std::max(1, std::min(dbg_int("EDGPU_CSR_TILE", 1 << 20), s->csr_bpr));
+    s->csr_tile = std::max(1, std::min(XKNOB("EDGPU_CSR_TILE", 1 << 20), s->csr_bpr));
     if (H.Jhflag) CHK(build_csr_nd(s));
     if (H.DimPh > 1) {
         CHK(s->csr_gel.alloc((size_t)s->nloc_el));
@@ -482,6 +493,7 @@ static int64_t max_partials(const S *s)
 static int create(const edgpu_desc *desc, S **out)
 {
     CHK(require_device());
+    warn_unknown_knobs();
     auto s = std::unique_ptr<S>(new S());
     std::string e = s->H.init(*desc);
     if (!e.empty()) return fail(EDGPU_EINVAL, e);
@@ -498,13 +510,13 @@ static int create(const edgpu_desc *desc, S **out)
     s->extra = H.DimPh > 1 || H.Jhflag; s->has_ph = H.DimPh > 1; s->has_nd = H.Jhflag;
     s->nloc_el = H.DimUp * H.Qdw; s->nloc = s->nloc_el * H.DimPh; s->vecdim = s->nloc;
     s->multi = desc->mpi_size > 1 || (desc->reserved & 1);   // reserved bit 0: run the exchange path even on one rank (tests)
-    s->lz_fused_on = dbg_int("EDGPU_LZ_FUSED", 1) != 0;
-    s->dbg = dbg_flags(); s->abl = dbg_int("EDGPU_ABL", 0); s->one_ar = dbg_int("EDGPU_ONE_ALLREDUCE", 0) != 0; s->up_pairs10 = dbg_int("EDGPU_UP_PAIRS10", 1) != 0; s->direct_cache = dbg_int("EDGPU_DIRECT_CACHE", 1) != 0; s->up_elem16 = dbg_int("EDGPU_UP_ELEM16", 1) != 0; s->pad_allowed = dbg_int("EDGPU_PAD", 1) != 0 && dbg_int("EDGPU_ODD_PAIRS", 1) != 0; s->tables_wave = dbg_int("EDGPU_TABLES_WAVE", 1) != 0; s->dw_lds_kb = std::min(dbg_int("EDGPU_DW_LDS_KB", 0), 150);
+    s->lz_fused_on = knob("EDGPU_LZ_FUSED") != 0; s->csr_fused_on = knob("EDGPU_CSR_FUSED") != 0;
+    s->dbg = dbg_flags(); s->one_ar = knob("EDGPU_ONE_ALLREDUCE") != 0; s->up_pairs10 = knob("EDGPU_UP_PAIRS10") != 0; s->direct_cache = XKNOB("EDGPU_DIRECT_CACHE", 1) != 0; s->up_elem16 = XKNOB("EDGPU_UP_ELEM16", 1) != 0; s->pad_allowed = knob("EDGPU_PAD") != 0 && knob("EDGPU_ODD_PAIRS") != 0; s->tables_wave = XKNOB("EDGPU_TABLES_WAVE", 1) != 0; s->dw_lds_kb = std::min(XKNOB("EDGPU_DW_LDS_KB", 0), 150);
     // distributed-transpose dw pass: opt-in (EDGPU_DW_TRANSPOSE=1) until an 8-GPU run has shown it correct and faster than the
     // needed-rows exchange; at most 64 ranks (larger jobs use the needed-rows exchange)
-    s->tr_on = s->multi && s->two_factor && !s->extra && desc->storage != EDGPU_STORE_CSR && dbg_int("EDGPU_DW_TRANSPOSE", 0) != 0 && H.DimUp >= desc->mpi_size && desc->mpi_size <= 64;
+    s->tr_on = s->multi && s->two_factor && !s->extra && desc->storage != EDGPU_STORE_CSR && knob("EDGPU_DW_TRANSPOSE") != 0 && H.DimUp >= desc->mpi_size && desc->mpi_size <= 64;
     for (int k = 0; k < 2 * H.Ns_Ud; k++) CHK(upload_factor(s.get(), k));
-    s->composite = !s->two_factor && H.cfac.size() == 2 && dbg_int("EDGPU_COMPOSITE", 1) != 0;
+    s->composite = !s->two_factor && H.cfac.size() == 2 && knob("EDGPU_COMPOSITE") != 0;
     s->kron2 = s->two_factor || s->composite;
     if (s->composite) { CHK(upload_factor(s.get(), -1)); CHK(upload_factor(s.get(), -2)); s->upf = s->cdev[0].get(); s->dwf = s->cdev[1].get(); s->hup = &H.cfac[0]; s->hdw = &H.cfac[1]; }
     else if (s->two_factor) { s->upf = s->fac[0].get(); s->dwf = s->fac[1].get(); s->hup = &H.fac[0]; s->hdw = &H.fac[1]; }
@@ -520,31 +532,27 @@ static int create(const edgpu_desc *desc, S **out)
     if (s->kron2) {
         size_t rowbytes = (size_t)H.DimUp * sizeof(double);
         s->use_lds = rowbytes + 128 <= 150 * 1024 && !(dbg_flags() & 4);
-        if (dbg_int("EDGPU_KRON_THREADS", 0)) s->kron_threads_override = dbg_int("EDGPU_KRON_THREADS", 0);
+        if (XKNOB("EDGPU_KRON_THREADS", 0)) s->kron_threads_override = XKNOB("EDGPU_KRON_THREADS", 0);
         s->kron_threads = H.DimUp >= 4096 ? 1024 : (H.DimUp >= 1024 ? 512 : 256);
         if (s->kron_threads_override) s->kron_threads = s->kron_threads_override;
         s->kron_lds = (s->use_lds ? rowbytes : 0) + 16 * sizeof(double);
         // two-pass product (local pass + column-tiled dw pass) once the vector no longer fits the caches
-        s->kron_split = dbg_int("EDGPU_KRON_SPLIT", (H.DimUp * H.DimDw * 8 > ((int64_t)48 << 20)) ? 1 : 0) != 0;
+        { const int k = knob("EDGPU_KRON_SPLIT"); s->kron_split = k < 0 ? H.DimUp * H.DimDw * 8 > ((int64_t)48 << 20) : k != 0; }
         // tile width of the dw pass: 64 columns measured best at Ns=16 (slab 6.6 MB, half of the gathers hit
         // L2) and at Ns=18 (slab 25 MB: no re-use left, but narrower tiles lose more to short segments)
-        s->dw_w = dbg_int("EDGPU_DW_W", 64);
-        s->dw_variant = dbg_int("EDGPU_DW_VARIANT", 2);
-        s->up_persistent = dbg_int("EDGPU_UP_PERSISTENT", 1) != 0;
-        s->up_grid = dbg_int("EDGPU_UP_GRID", 256);
-        s->up_pairs = dbg_int("EDGPU_UP_PAIRS", 1) != 0;
-        s->row_split = std::max(1, std::min(32, dbg_int("EDGPU_ROW_SPLIT", 4)));
-        s->up_big = dbg_int("EDGPU_UP_BIG", 1) != 0;
-        s->up_halo = dbg_int("EDGPU_UP_HALO", 1) != 0;
+        s->dw_w = knob("EDGPU_DW_W");
+        s->dw_variant = knob("EDGPU_DW_VARIANT");
+        s->up_persistent = knob("EDGPU_UP_PERSISTENT") != 0;
+        s->up_grid = knob("EDGPU_UP_GRID");
+        s->up_pairs = knob("EDGPU_UP_PAIRS") != 0;
+        s->row_split = std::max(1, std::min(32, knob("EDGPU_ROW_SPLIT")));
+        s->up_big = knob("EDGPU_UP_BIG") != 0;
+        s->up_halo = knob("EDGPU_UP_HALO") != 0;
 
         if (!s->use_lds && s->up_halo && !s->tr_on) CHK(build_up_segments(s.get()));
-        s->nd_split = dbg_int("EDGPU_ND_SPLIT", 1) != 0;
-        s->up_threads = dbg_int("EDGPU_UP_THREADS", 1024) == 512 ? 512 : 1024;
-        s->dw_rows = std::max(1, std::min(64, dbg_int("EDGPU_DW_ROWS", 16)));
-        s->dw_first = std::max(0, std::min(2, dbg_int("EDGPU_DW_FIRST", 0)));
-        s->dw_unr = dbg_int("EDGPU_DW_UNR", 0) != 0;
-        s->up_halo_nt = dbg_int("EDGPU_UP_NT", 1024) == 512 ? 512 : 1024;
-        { const int x = dbg_int("EDGPU_DW_XPT", 1); s->dw_xpt = (x == 2 || x == 4 || x == 8) ? x : 1; }
+        s->nd_split = knob("EDGPU_ND_SPLIT") != 0;
+        s->up_threads = knob("EDGPU_UP_THREADS") == 512 ? 512 : 1024;
+        s->dw_rows = std::max(1, std::min(64, knob("EDGPU_DW_ROWS")));
         if (s->dw_w != 8 && s->dw_w != 16 && s->dw_w != 32 && s->dw_w != 64 && s->dw_w != 128 && s->dw_w != 256) s->dw_w = 32;
     }
     // operator storage
@@ -559,14 +567,14 @@ static int create(const edgpu_desc *desc, S **out)
     s->nnz_total = (s->nloc_el + nnz_fac) * H.DimPh;
     s->multi = desc->mpi_size > 1 || (desc->reserved & 1);   // reserved bit 0: run the exchange path even on one rank (tests)
     s->nhalo = H.DimDw;
-    if (s->multi && !s->tr_on && s->kron2 && (!s->extra || (s->has_nd && !s->has_ph && s->nd_split)) && dbg_int("EDGPU_HALO", 1)) CHK(setup_halo(s.get()));
+    if (s->multi && !s->tr_on && s->kron2 && (!s->extra || (s->has_nd && !s->has_ph && s->nd_split)) && knob("EDGPU_HALO")) CHK(setup_halo(s.get()));
     if (s->tr_on) {     // up-block of this rank in the transposed space (same rule as the dw split)
         const int64_t P = s->comm.size, r = s->comm.rank, q = H.DimUp / P, rem = H.DimUp % P;
         s->Qup = r < rem ? q + 1 : q; s->up0 = r < rem ? r * (q + 1) : r * q + rem;
         CHK(s->tA.alloc((size_t)s->nloc_el)); CHK(s->tB.alloc((size_t)(s->Qup * H.DimDw)));
         CHK(s->tVT.alloc((size_t)(s->Qup * H.DimDw))); CHK(s->tHVT.alloc((size_t)(s->Qup * H.DimDw)));
         s->tr_lds = (size_t)H.DimDw * 8 + 128 <= 150 * 1024 && !(dbg_flags() & 4);
-        s->tr_chunks = std::max(1, std::min(32, dbg_int("EDGPU_TR_CHUNKS", 4)));
+        s->tr_chunks = std::max(1, std::min(32, knob("EDGPU_TR_CHUNKS")));
     }
     if (desc->storage != EDGPU_STORE_DIRECT) { CHK(build_diag(s.get())); s->bytes_stored = s->nloc_el * 8; }
     if (desc->storage == EDGPU_STORE_CSR) {
@@ -579,9 +587,9 @@ static int create(const edgpu_desc *desc, S **out)
         CHK(s->vfull.alloc(nx));
         if (xspace_ld(s.get()) > H.DimUp) HIPCHK(hipMemsetAsync(s->vfull.p, 0, nx * 8, s->stream));
     }
-    s->axpy_nb = std::max(1, dbg_int("EDGPU_AXPY_NB", 512));
+    s->axpy_nb = std::max(1, XKNOB("EDGPU_AXPY_NB", 512));
     s->vld = H.DimUp; s->vlen = s->nloc;
-    s->pad_on = (fused_ok(s.get()) || pitch_ok(s.get())) && (H.DimUp % 16) != 0 && dbg_int("EDGPU_PAD", 1) != 0;
+    s->pad_on = (fused_ok(s.get()) || pitch_ok(s.get())) && (H.DimUp % 16) != 0 && knob("EDGPU_PAD") != 0;
     if (s->pad_on) { s->vld = (H.DimUp + 15) & ~(int64_t)15; s->vlen = (s->nloc / H.DimUp) * s->vld; }
     s->npartial = max_partials(s.get());
     CHK(s->partial.alloc((size_t)s->npartial));

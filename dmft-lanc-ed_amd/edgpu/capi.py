@@ -3,7 +3,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libedgpu.so")
+# EDGPU_LIBRARY: another build of the library (scripts/: the experiments build libedgpu_exp.so); default: the in-tree product
+LIB_PATH = os.environ.get("EDGPU_LIBRARY") or os.path.join(_HERE, "libedgpu.so")
 
 EDGPU_ABI_VERSION = 1
 MAX_ORB = 5
@@ -25,10 +26,10 @@ SYMBOLS = [
     "edgpu_eigsh", "edgpu_eigsh_ncv_cap", "edgpu_eigsh_ncv_used", "edgpu_lanczos_is_fused", "edgpu_sector_describe", "edgpu_dvdson", "edgpu_cache_release", "edgpu_twin_reorder", "edgpu_imp_density_offdiag", "edgpu_imp_histogram", "edgpu_local_energy", "edgpu_apply_op", "edgpu_gf_lanczos", "edgpu_chi_lanczos", "edgpu_phonon_lanczos",
     "edgpu_sp_init_matrix", "edgpu_sp_init_matrix_mpi", "edgpu_sp_load_matrix", "edgpu_sp_insert_element", "edgpu_sp_delete_matrix", "edgpu_sp_dump_matrix", "edgpu_sp_row", "edgpu_sp_matvec", "edgpu_sp_matvec_device",
     "edgpu_comm_unique_id", "edgpu_comm_init_rccl", "edgpu_comm_init_callbacks",
-    "edgpu_comm_create_rccl", "edgpu_comm_create_callbacks", "edgpu_comm_sub", "edgpu_comm_destroy", "edgpu_sector_attach_comm",
+    "edgpu_comm_create_rccl", "edgpu_comm_create_callbacks", "edgpu_comm_create_emulated", "edgpu_comm_sub", "edgpu_comm_destroy", "edgpu_sector_attach_comm",
     "edgpu_comm_count", "edgpu_comm_allreduce_sum", "edgpu_sector_exchange_info", "edgpu_sector_relay_info",
     "edgpu_device_count", "edgpu_malloc", "edgpu_free", "edgpu_memcpy_h2d", "edgpu_memcpy_d2h", "edgpu_memset",
-    "edgpu_device_synchronize", "edgpu_last_error", "edgpu_abi_version",
+    "edgpu_device_synchronize", "edgpu_last_error", "edgpu_abi_version", "edgpu_knob_count", "edgpu_knob_info",
 ]
 
 
@@ -178,6 +179,7 @@ def lib():
         "edgpu_comm_init_callbacks": (C.c_int, [vp, ALLGATHERV_FN, EXCHANGE_FN, ALLREDUCE_FN, vp]),
         "edgpu_comm_create_rccl": (C.c_int, [vp, i32, i32, i32, P(vp)]),
         "edgpu_comm_create_callbacks": (C.c_int, [i32, i32, ALLGATHERV_FN, EXCHANGE_FN, ALLREDUCE_FN, vp, P(vp)]),
+        "edgpu_comm_create_emulated": (C.c_int, [i32, i32, P(vp)]),
         "edgpu_comm_sub": (C.c_int, [vp, i32, P(vp), P(i32)]),
         "edgpu_comm_destroy": (C.c_int, [vp]),
         "edgpu_sector_attach_comm": (C.c_int, [vp, vp]),
@@ -194,6 +196,8 @@ def lib():
         "edgpu_device_synchronize": (C.c_int, []),
         "edgpu_last_error": (C.c_char_p, []),
         "edgpu_abi_version": (C.c_int, []),
+        "edgpu_knob_count": (C.c_int, []),
+        "edgpu_knob_info": (C.c_int, [i32, P(C.c_char_p), P(i32), P(C.c_char_p), P(C.c_char_p), P(C.c_char_p)]),
     }
     for name, (res, args) in sig.items():
         f = getattr(L, name)
@@ -201,6 +205,19 @@ def lib():
         f.argtypes = args
     _lib = L
     return L
+
+
+def knobs():
+    """the environment switches of the loaded library: list of dicts (name, default, kind, doc, covered_by)"""
+    L = lib()
+    out = []
+    for i in range(L.edgpu_knob_count()):
+        n, k, d, t = C.c_char_p(), C.c_char_p(), C.c_char_p(), C.c_char_p()
+        dv = C.c_int32()
+        if L.edgpu_knob_info(i, C.byref(n), C.byref(dv), C.byref(k), C.byref(d), C.byref(t)) != 0:
+            raise EdgpuError(-1, L.edgpu_last_error().decode())
+        out.append({"name": n.value.decode(), "default": dv.value, "kind": k.value.decode(), "doc": d.value.decode(), "covered_by": t.value.decode()})
+    return out
 
 
 def check(rc):

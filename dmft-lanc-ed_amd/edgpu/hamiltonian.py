@@ -432,6 +432,14 @@ class Communicator:
         check(capi.lib().edgpu_comm_create_callbacks(rank, size, cb[0], cb[1], cb[2], None, C.byref(c)))
         return cls(c, rank, size, cb)
 
+    @classmethod
+    def emulated(cls, rank, size):
+        """Measurement aid: stands for rank `rank` of `size` on one GPU (edgpu_comm_create_emulated): exchanges become device
+        copies of the same byte count, all-reduces return the local value.  Timings are real, results are not."""
+        c = C.c_void_p()
+        check(capi.lib().edgpu_comm_create_emulated(rank, size, C.byref(c)))
+        return cls(c, rank, size)
+
     def sub(self, nranks):
         """Communicator of the first `nranks` ranks (collective; cached); None on the ranks left out."""
         if nranks == self.size:

@@ -259,6 +259,12 @@ typedef struct edgpu_comm_s *edgpu_comm;
 int edgpu_comm_create_rccl(const void *id128, int32_t rank, int32_t size, int32_t device /* -1: current */, edgpu_comm *out);
 int edgpu_comm_create_callbacks(int32_t rank, int32_t size, edgpu_allgatherv_fn ag, edgpu_exchange_fn xch, edgpu_allreduce_fn ar,
                                 void *ctx, edgpu_comm *out);
+/* MEASUREMENT AID: a communicator that stands for rank `rank` of a `size`-rank job on ONE GPU.  A sector created with the same
+ * mpi_rank / mpi_size and attached to it has the partition, row lists, x-space, packing kernels and stream structure of the real
+ * job; what the peers would deliver is replaced by device-to-device copies of the same byte count on the comm stream, and the
+ * all-reduces return the rank's own partial sums.  Timings and HBM traffic of one rank of P are real; the numbers computed are
+ * not a result (bench.py --emulate-rank; ED_HAMILTONIAN.f90:96-110 is the partition it stands in for). */
+int edgpu_comm_create_emulated(int32_t rank, int32_t size, edgpu_comm *out);
 /* Sectors with fewer dw columns than ranks run on the first DimDw ranks (ED_HAMILTONIAN.f90:65-93: MPI_Group_incl +
  * MPI_Comm_create).  edgpu_comm_sub is that shrunk communicator: COLLECTIVE over `parent` (every rank calls it),
  * cached inside the parent (one split per distinct size); ranks outside get *out = NULL, *is_member = 0 and do not
@@ -321,6 +327,14 @@ int edgpu_device_synchronize(void);
 
 const char *edgpu_last_error(void);
 int edgpu_abi_version(void);
+
+/* ---- environment switches ------------------------------------------------------------------
+ * The integer-valued EDGPU_* environment variables this build of the library reads (at sector creation), with their
+ * defaults (-1: decided by the library), a one-word kind ("form", "fallback", "multi-GPU", "test hook", "debug"), what they
+ * select and the test that covers the non-default value.  Any other EDGPU_* name found in the environment is reported on
+ * stderr once.  The reference has no counterpart (its switches are input-file variables, ED_INPUT_VARS.f90). */
+int edgpu_knob_count(void);
+int edgpu_knob_info(int32_t i, const char **name, int32_t *default_value, const char **kind, const char **doc, const char **covered_by);
 
 #ifdef __cplusplus
 }

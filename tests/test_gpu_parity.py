@@ -277,12 +277,7 @@ def test_large_sector_code_paths_on_small_sectors(edgpu_mod, monkeypatch, name, 
                 {"EDGPU_CSR_SPLIT": "1", "EDGPU_CSR_PITCH": "0", "EDGPU_KRON_SPLIT": "1"},      # explicit CSR with columns in the dense vector space
                 {"EDGPU_KRON_SPLIT": "1", "EDGPU_DEBUG": "4"},                                  # long-row path: one workgroup per row segment, halo in LDS (k_uppass_halo)
                 {"EDGPU_KRON_SPLIT": "1", "EDGPU_DEBUG": "4", "EDGPU_UP_GRID": "24", "EDGPU_LZ_FUSED": "0"},     # ... with idle workgroups (3 per XCD, 2 segments)
-                # round-3 variants of the long-row product (kept as knobs, slower at Ns=18): dw pass first and write-only (plain /
-                # write-through stores) with the local pass adding + carrying the epilogue; 2 and 8 XCDs per column tile; every load
-                # of a dw row step up front; 512-thread workgroups of the local pass
-                {"EDGPU_KRON_SPLIT": "1", "EDGPU_DEBUG": "4", "EDGPU_DW_FIRST": "1", "EDGPU_LZ_FUSED": "0"},
-                {"EDGPU_KRON_SPLIT": "1", "EDGPU_DEBUG": "4", "EDGPU_DW_FIRST": "2", "EDGPU_DW_XPT": "2", "EDGPU_DW_UNR": "1", "EDGPU_LZ_FUSED": "0"},
-                {"EDGPU_KRON_SPLIT": "1", "EDGPU_DEBUG": "4", "EDGPU_DW_XPT": "8", "EDGPU_DW_UNR": "1", "EDGPU_UP_NT": "512", "EDGPU_UP_SEGMAX": "64"},
+                {"EDGPU_KRON_SPLIT": "1", "EDGPU_DEBUG": "4", "EDGPU_UP_SEGMAX": "64"},      # ... with many short segments (up to 64 per row)
                 {"EDGPU_KRON_SPLIT": "1", "EDGPU_DEBUG": "4", "EDGPU_UP_HALO": "0", "EDGPU_ROW_SPLIT": "3"},       # long-row fallback: no LDS staging, packed 8-dword image (k_uppass_big)
                 {"EDGPU_KRON_SPLIT": "1", "EDGPU_DEBUG": "4", "EDGPU_UP_BIG": "0", "EDGPU_ROW_SPLIT": "1"}):
         for k, val in env.items():

@@ -112,6 +112,24 @@ def test_multirank_large_sector_forms(edgpu_mod, case, size):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("case,size,env", [("c_nb7_half", 2, {"EDGPU_HALO": "0"}), ("nb5_offhalf_2_4", 3, {"EDGPU_HALO": "0", "EDGPU_KRON_SPLIT": "1", "EDGPU_CSR_SPLIT": "1"}),
+                                           ("c_nb7_half", 3, {"EDGPU_KRON_SPLIT": "1", "EDGPU_CSR_SPLIT": "1", "EDGPU_CSR_THREE": "0"}),
+                                           ("nb5_offhalf_2_4", 2, {"EDGPU_KRON_SPLIT": "1", "EDGPU_CSR_SPLIT": "1", "EDGPU_CSR_PITCH_MULTI": "0"})])
+def test_multirank_fallback_forms(edgpu_mod, case, size, env):
+    """The fallbacks of the several-rank forms that are on by default: all-gather of the input vector instead of the needed-rows
+    exchange (EDGPU_HALO=0, the reference's allgather_vector_MPI), the explicit CSR of a rank in two blocks + own-row copy
+    instead of three (EDGPU_CSR_THREE=0), dense rows in the x-space and in the messages (EDGPU_CSR_PITCH_MULTI=0)."""
+    res = _launch("gpu", case, size, extra_env=env)
+    name, m, nu, nd = [z for z in __import__("cases").zoo() if z[0] == case][0]
+    from oracle import oracle
+    e_dense = np.linalg.eigvalsh(oracle.Sector(m, nu, nd).hmat())[0]
+    for r in res:
+        for k, v in r.items():
+            if k.startswith("e0_"):
+                assert abs(v - e_dense) < 1e-10, (env, k, v, e_dense)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("case,size,env", [("c_nb7_half", 3, {}), ("nb5_offhalf_2_4", 4, {}), ("nb6_even", 2, {"EDGPU_DEBUG": "4"}),
                                            ("nspin2_random_bath", 3, {}), ("norb2_normal_offdiag_hloc", 2, {}),
                                            ("c_nb7_half", 3, {"EDGPU_TR_CHUNKS": "1"}), ("c_nb7_half", 4, {"EDGPU_TR_CHUNKS": "7"}),
