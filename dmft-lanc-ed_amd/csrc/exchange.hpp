@@ -71,13 +71,12 @@ static int halo_exchange(S *s, const double *v_local, hipStream_t st)
     const int64_t rowlen = xspace_ld(s);
     if (nsend_rows > 0) {
         PackArgs K{}; K.DimUp = (int32_t)H.DimUp; K.DimPh = H.DimPh; K.Qdw = H.Qdw; K.nrows = nsend_rows; K.list = s->send_list.p; K.v = v_local; K.out = s->sendbuf.p; K.ld = rowlen;
-        const int64_t tot = nsend_rows * H.DimPh * cdiv(rowlen, 2);
-        hipLaunchKernelGGL(k_pack_rows, dim3((unsigned)std::min<int64_t>(cdiv(tot, 256), 65536)), dim3(256), 0, st, K);
+        hipLaunchKernelGGL(k_pack_rows, dim3((unsigned)std::min<int64_t>(nsend_rows * H.DimPh, 8192)), dim3(256), 0, st, K);
         HIPCHK(hipGetLastError());
     }
     if (s->relay_on) {      // two-phase relay routing (relay_plan, sector_dev.hpp); DimPh == 1
         double *x = s->vfull.p, *xr = x + H.Qdw * rowlen, *stg = s->relay_stage.p; const double *sb = s->sendbuf.p;
-        if (!s->csr_three) HIPCHK(hipMemcpyAsync(x, v_local, (size_t)(H.Qdw * rowlen) * 8, hipMemcpyDeviceToDevice, st));
+        if (!s->csr_three && !s->x_own_in_v) HIPCHK(hipMemcpyAsync(x, v_local, (size_t)(H.Qdw * rowlen) * 8, hipMemcpyDeviceToDevice, st));
         for (int phase = 1; phase <= 2; phase++) {
             // per peer: the direct piece and the relayed piece of this phase, each with the buffer it leaves from / lands in
             auto pieces = [&](int b, const S::RelayPiece *&sd, const S::RelayPiece *&sr, const S::RelayPiece *&rd, const S::RelayPiece *&rr) {
@@ -128,7 +127,7 @@ static int halo_exchange(S *s, const double *v_local, hipStream_t st)
     for (int iph = 0; iph < H.DimPh; iph++) {
         double *x = s->vfull.p + (int64_t)iph * s->nhalo * rowlen;
         // own rows of the x-space: not needed by the three-block CSR (its received-row block never reads them)
-        if (!s->csr_three) HIPCHK(hipMemcpyAsync(x, v_local + (int64_t)iph * s->nloc_el, (size_t)(H.Qdw * rowlen) * 8, hipMemcpyDeviceToDevice, st));      // DimPh > 1: rowlen == DimUp
+        if (!s->csr_three && !s->x_own_in_v) HIPCHK(hipMemcpyAsync(x, v_local + (int64_t)iph * s->nloc_el, (size_t)(H.Qdw * rowlen) * 8, hipMemcpyDeviceToDevice, st));      // DimPh > 1: rowlen == DimUp
         const double *sb = s->sendbuf.p + (int64_t)iph * nsend_rows * rowlen;
         if (P == 1) continue;
         if (c.kind == Comm::RCCL) {

@@ -911,6 +911,7 @@ struct DwArgs {
     int32_t w, wshift, ntiles, R, chunks;
     int32_t ld;                // row pitch of v / vfull / out / uprev2 in doubles (0: DimUp)
     const double *uprev2;      // fused Lanczos iteration (EPI only): out holds the UNSCALED local part; out = s_cur*(out + dw part) - beta*s_prev*uprev2
+    int32_t own_in_v;          // several ranks, needed-rows exchange: x-space rows < Qdw (the rank's own rows) are read from v itself, only received rows from vfull (no own-row copy per product)
 };
 
 // Column tiles dealt to the XCDs (workgroups go round-robin over the 8 XCDs): XCD x owns tiles x, x+8, ... and walks all row
@@ -997,6 +998,14 @@ __global__ void __launch_bounds__(256) k_dwpass2(DwArgs A)
                 dbl2v o = {0.0, 0.0}, vl = {0.0, 0.0}, up = {0.0, 0.0};
                 // rolled gather loop: 4 gathers in flight per lane; issuing all of a row step up front (103-120 VGPRs, half the
                 // residency) measured slower at Ns=18 (profiles/r03/ns18_product_variants.txt)
+                if (A.own_in_v) {
+                    const int64_t obase = (int64_t)iph * A.Qdw * ld + iup;
+                    for (int k = 0; k < nk; k++) {
+                        const int64_t xr = tcr[k];
+                        const dbl2v x = *reinterpret_cast<const dbl2v *>(xr < A.Qdw ? A.v + obase + xr * ld : A.vfull + fbase + xr * ld);
+                        acc += tvr[k] * x;
+                    }
+                } else
                 for (int k = 0; k < nk; k++) {
                     const dbl2v x = *reinterpret_cast<const dbl2v *>(A.vfull + fbase + (int64_t)tcr[k] * ld);
                     acc += tvr[k] * x;
@@ -1616,13 +1625,18 @@ __global__ void __launch_bounds__(256) k_direct_tables_wave(TabArgs A)
 // ---------------------------------------------------------------------------------------------
 // rows a peer needs, copied out of the shard into one contiguous message per peer
 struct PackArgs { int32_t DimUp, DimPh; int64_t Qdw, nrows; const int32_t *list; const double *v; double *out; int64_t ld; };      // ld: row pitch of v and of the packed rows (DimUp, or the padded pitch of the explicit CSR)
+// One workgroup per packed row (grid-stride over rows): 16-byte accesses where the pitch keeps rows 16-byte aligned, no index
+// arithmetic per element.  (The first form ran one 64-bit division per element over a flat index: 2.9 ms for the 3.9 GB a rank of
+// eight packs at Ns=18, 0.99 ms for 266 MB at Ns=16 -- on the critical path in front of every exchange; profiles/r04/rank_of_8_*.txt.)
 __global__ void __launch_bounds__(256) k_pack_rows(PackArgs A)
 {
-    const int64_t total = A.nrows * A.DimPh * (int64_t)A.DimUp;
-    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t r = e / A.DimUp; const int i = (int)(e - r * A.DimUp);
+    const int64_t nr = A.nrows * A.DimPh;
+    const bool vec = (A.ld & 1) == 0 && (A.DimUp & 1) == 0 && ((reinterpret_cast<uintptr_t>(A.v) | reinterpret_cast<uintptr_t>(A.out)) & 15) == 0;      // every row start is 16-byte aligned on both sides
+    for (int64_t r = blockIdx.x; r < nr; r += gridDim.x) {
         const int64_t iph = r / A.nrows, q = r - iph * A.nrows;
-        A.out[r * A.ld + i] = A.v[(iph * A.Qdw + A.list[q]) * A.ld + i];      // padding columns of the message rows stay zero (buffer cleared once)
+        const double *src = A.v + (iph * A.Qdw + A.list[q]) * A.ld; double *dst = A.out + r * A.ld;      // padding columns of the message rows stay zero (buffer cleared once)
+        if (vec) { for (int i = threadIdx.x; i < (A.DimUp >> 1); i += 256) reinterpret_cast<dbl2v *>(dst)[i] = reinterpret_cast<const dbl2v *>(src)[i]; }
+        else for (int i = threadIdx.x; i < A.DimUp; i += 256) dst[i] = src[i];
     }
 }
 
@@ -1904,6 +1918,30 @@ __global__ void __launch_bounds__(1024) k_csr_loc_ax(CsrAxArgs A)
     const int pmax = npair - 1;
     struct Ent { double v[C]; int32_t c[C]; };
     struct Rp { int64_t ra; int nr, iup0, len; bool valid; };
+    // the block sequence of a wave runs on across rows: (row, wv), (row, wv+16), ..., (row + grid, wv), ...; step t of the pipeline
+    // requests the row pointer of block t+2 and the entries of block t+1 while block t gathers, also across a row switch
+    auto blk_ptr = [&](int64_t rw, int it) -> Rp {
+        Rp R; const int jb = wv + 16 * it; R.valid = jb < nblk && rw < A.Qdw;
+        const int jc = jb < nblk ? jb : nblk - 1; const int64_t rc = rw < A.Qdw ? rw : A.Qdw - 1;
+        R.iup0 = jc * 64; R.nr = DimUp - R.iup0; R.nr = R.nr > 64 ? 64 : R.nr;
+        // the row pointer is streamed as by k_csr_il: lane l reads rowptr[l] and rowptr[l+1] of its row; block start = first lane's
+        const int l = lane < R.nr ? lane : 0;
+        const int64_t ra = A.rowptr[rc * DimUp + R.iup0 + l], re = A.rowptr[rc * DimUp + R.iup0 + l + 1];
+        R.ra = ra - (int64_t)l * C; R.len = (int)(re - ra);      // rows of a block have C entries each (the host selects this kernel only then): start of the block
+        return R;
+    };
+    auto load_ent = [&](const Rp &R, Ent &E) {
+        const int l = lane < R.nr ? lane : 0;
+        const double *pv = A.vals + R.ra + l; const int32_t *pc = A.cols + R.ra + l;
+#pragma unroll
+        for (int e = 0; e < C; e++) { E.v[e] = pv[(int64_t)e * R.nr]; E.c[e] = pc[(int64_t)e * R.nr]; }
+    };
+    auto advance = [&](int64_t &rw, int &it) { if (++it == nit) { it = 0; rw += gridDim.x; } };
+    int64_t prow = blockIdx.x; int pit = 0;              // position of the row-pointer prefetch: two blocks ahead of the one that gathers
+    Rp r0 = blk_ptr(prow, pit); advance(prow, pit);
+    Rp r1 = blk_ptr(prow, pit); advance(prow, pit);
+    Ent cur, nxt;
+    if (r0.valid) load_ent(r0, cur);
     bool first = true;
     for (int64_t row = blockIdx.x; row < A.Qdw; row += gridDim.x) {
         const int64_t next = row + gridDim.x; const bool more = next < A.Qdw;
@@ -1920,40 +1958,19 @@ __global__ void __launch_bounds__(1024) k_csr_loc_ax(CsrAxArgs A)
         first = false;
         __syncthreads();
         const int64_t xoff = row * ld;                   // stored columns index the pitched vector space: LDS index = column - row*ld
-        auto blk_ptr = [&](int it) -> Rp {               // wave wv takes blocks wv, wv + 16, ...
-            Rp R; const int jb = wv + 16 * it; R.valid = jb < nblk;
-            const int jc = R.valid ? jb : nblk - 1;
-            R.iup0 = jc * 64; R.nr = DimUp - R.iup0; R.nr = R.nr > 64 ? 64 : R.nr;
-            // the row pointer is streamed as by k_csr_il: lane l reads rowptr[l] and rowptr[l+1] of its row; block start = first lane's
-            const int l = lane < R.nr ? lane : 0;
-            const int64_t ra = A.rowptr[row * DimUp + R.iup0 + l], re = A.rowptr[row * DimUp + R.iup0 + l + 1];
-            R.ra = ra - (int64_t)l * C; R.len = (int)(re - ra);      // rows of a block have C entries each (the host selects this kernel only then): start of the block
-            return R;
-        };
-        auto load_ent = [&](const Rp &R, Ent &E) {
-            const int l = lane < R.nr ? lane : 0;
-            const double *pv = A.vals + R.ra + l; const int32_t *pc = A.cols + R.ra + l;
-#pragma unroll
-            for (int e = 0; e < C; e++) { E.v[e] = pv[(int64_t)e * R.nr]; E.c[e] = pc[(int64_t)e * R.nr]; }
-        };
-        Rp r0 = blk_ptr(0), r1 = blk_ptr(1);
-        Ent cur, nxt;
-        load_ent(r0, cur);
-        dbl2v pr, pvv;                                   // pair `it` of the next row
-        { const int p = tid < npair ? tid : pmax; pr = *reinterpret_cast<const dbl2v *>(A.r + nrow * ld + 2 * p); pvv = *reinterpret_cast<const dbl2v *>(A.vprev + nrow * ld + 2 * p); }
         for (int it = 0; it < nit; it++) {
-            const Rp r2 = blk_ptr(it + 2);
-            dbl2v pr2, pv2;
-            { int p = tid + (it + 1) * NT; p = p < npair ? p : pmax; pr2 = *reinterpret_cast<const dbl2v *>(A.r + nrow * ld + 2 * p); pv2 = *reinterpret_cast<const dbl2v *>(A.vprev + nrow * ld + 2 * p); }
+            const Rp r2 = blk_ptr(prow, pit); advance(prow, pit);
+            dbl2v pr, pvv;                               // pair `it` of the next row: requested here, combined at the end of the step
+            { int p = tid + it * NT; p = p < npair ? p : pmax; pr = *reinterpret_cast<const dbl2v *>(A.r + nrow * ld + 2 * p); pvv = *reinterpret_cast<const dbl2v *>(A.vprev + nrow * ld + 2 * p); }
             if (r1.valid) load_ent(r1, nxt);             // wave-uniform
-            if (more && it < nq) { const int p = tid + it * NT; if (p < npair) combine(next, p, pr, pvv); }
             if (r0.valid && lane < r0.nr && r0.len == C) {
                 double a0 = 0.0, a1 = 0.0;
 #pragma unroll
                 for (int e = 0; e < C; e++) { const double xv = lds[cur.c[e] - xoff]; if (e & 1) a1 += cur.v[e] * xv; else a0 += cur.v[e] * xv; }
                 A.t_out[row * ld + r0.iup0 + lane] = a0 + a1;
             }
-            pr = pr2; pvv = pv2; r0 = r1; r1 = r2; cur = nxt;
+            if (more && it < nq) { const int p = tid + it * NT; if (p < npair) combine(next, p, pr, pvv); }
+            r0 = r1; r1 = r2; cur = nxt;
         }
         __syncthreads();
     }
@@ -2266,6 +2283,129 @@ __global__ void __launch_bounds__(1024) k_reduce_final_step(const double *__rest
     for (int64_t i = threadIdx.x; i < n; i += blockDim.x) s += in[i];
     double r = block_sum(s, red);
     if (threadIdx.x == 0) { scal[SC_TMP] = r; scalar_step(scal, alphas, betas, zvec, -1, mode); }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Whole Lanczos loop of a SMALL sector in ONE workgroup (round 4).  A sector of N <= 16 384 states is launch bound: an
+// iteration of the device loop above is four kernels of a few microseconds of work each, 24-30 us in all (profiles/r03/
+// small_sectors.txt), and the reference's everyday sectors (Ns <= 12, O(Ns^2) of them per DMFT iteration, 200-step legs per
+// state: ED_DIAG.f90:83-276, ED_GF_NORMAL.f90:224-239) are of that size.  Here 1024 threads keep v_k in LDS (the gathers of
+// both hop families read it), their share of w and v_{k-1} in registers, and run `nsteps` iterations of SciFortran's
+// lanczos_iteration (w = H v_k - beta_k v_{k-1}; alpha_k = v_k.w; w -= alpha_k v_k; beta_{k+1} = |w|) between two barriers each;
+// alpha/beta go to the coefficient arrays, v_k optionally to a Krylov slab (the eigenvector is a weighted sum over it).
+// Layout: the two-factor index i = iup + idw*DimUp is split into a LANE dimension A (the longer of the two, <= 1024) and a
+// wave-uniform dimension B.  Wave w owns the 64-wide chunk c = w % nC of A and the B rows (w / nC) + (16/nC)*j: the hop entries
+// of its A configuration stay in registers for the whole launch, those of B are wave-uniform scalar loads -- per element the
+// loop touches LDS only (plus one L1-resident table read for the on-site coupling).
+// ---------------------------------------------------------------------------------------------
+struct LzWgArgs {
+    int32_t DimA, DimB, sA, sB;            // flat index = a*sA + b*sB
+    int32_t nC, E;                         // chunks of A (power of two, <= 16); B rows per wave
+    const int32_t *cA; const double *vA; int32_t wA, ksA, asA;      // hop entry k of configuration a: cA[k*ksA + a*asA]
+    const int32_t *cB; const double *vB; int32_t wB, ksB, bsB;
+    const double *EA, *EB; const int32_t *mapA, *mapB; const double *cross; int32_t multA, multB, impmask; double econst;
+    double *v, *vprev;                     // v_k (any norm on entry when k0 == 0), v_{k-1}; both updated for a following launch
+    double *alphas, *betas; int32_t k0, nsteps; double threshold;
+    double *krylov; int64_t kstride;       // optional: v_k stored at krylov + k*kstride
+    int32_t *done;                         // out: iterations completed (k0 + nsteps, or fewer when beta fell below the threshold)
+};
+// VPREG: v_{k-1} stays in registers (EMAX <= 8); otherwise it lives in A.vprev (L2-resident, 8 bytes read and written per element
+// and iteration) -- with 16-20 elements per lane two register arrays do not fit 128 registers
+template <int EMAX, int WA, bool VPREG>
+__global__ void __launch_bounds__(1024) k_lanczos_wg(LzWgArgs A)
+{
+    extern __shared__ double lds[];
+    __shared__ double red[16]; __shared__ double bc[2];
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int N = A.DimA * A.DimB;
+    const int c = wv % A.nC, b0 = wv / A.nC, TB = 16 / A.nC;
+    const int a = 64 * c + lane; const bool aok = a < A.DimA;
+    const int ac = aok ? a : 0;
+    // register-resident tables of this lane's A configuration
+    int32_t colA[WA]; double valA[WA];
+#pragma unroll
+    for (int k = 0; k < WA; k++) { const bool h = k < A.wA; colA[k] = h ? A.cA[(int64_t)k * A.ksA + (int64_t)ac * A.asA] * A.sA : 0; valA[k] = (h && aok) ? A.vA[(int64_t)k * A.ksA + (int64_t)ac * A.asA] : 0.0; }
+    const double eA = A.EA[ac] + A.econst; const int impA = (A.mapA[ac] & A.impmask) * A.multA;
+    auto bsum = [&](double x) -> double {      // sum over the workgroup, same value on every thread
+        x = wave_sum(x);
+        __syncthreads();
+        if (lane == 0) red[wv] = x;
+        __syncthreads();
+        double r = 0.0;
+#pragma unroll
+        for (int i = 0; i < 16; i++) r += red[i];
+        return r;
+    };
+    double w[EMAX], vp[VPREG ? EMAX : 1];
+    // start: v_k into LDS; k0 == 0: normalise the input and clear v_{-1}
+    for (int i = tid; i < N; i += 1024) lds[i] = A.v[i];
+#pragma unroll
+    for (int j = 0; j < EMAX; j++) {
+        const int b = b0 + TB * j; const bool in = j < A.E && aok && b < A.DimB;
+        if (VPREG) vp[j] = (A.k0 > 0 && in) ? A.vprev[a * A.sA + b * A.sB] : 0.0;
+        else if (A.k0 == 0 && in) A.vprev[a * A.sA + b * A.sB] = 0.0;
+    }
+    __syncthreads();
+    double beta = A.k0 > 0 ? A.betas[A.k0] : 0.0;
+    if (A.k0 == 0) {
+        double n2 = 0.0;
+#pragma unroll
+        for (int j = 0; j < EMAX; j++) { const int b = b0 + TB * j; if (j < A.E && aok && b < A.DimB) { const double x = lds[a * A.sA + b * A.sB]; n2 += x * x; } }
+        n2 = bsum(n2);
+        const double sc = n2 > 0.0 ? 1.0 / sqrt(n2) : 0.0;
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < EMAX; j++) { const int b = b0 + TB * j; if (j < A.E && aok && b < A.DimB) lds[a * A.sA + b * A.sB] *= sc; }
+        __syncthreads();
+    }
+    int k = A.k0; const int kend = A.k0 + A.nsteps;
+    for (; k < kend; k++) {
+        // everything derived from the row numbers is loop invariant; hoisted out of the k loop it would need ~6 registers per
+        // element (addresses, row energies, coupling entries): opaque per iteration, so that it is recomputed next to its use
+        int b0v = b0; asm volatile("" : "+s"(b0v));
+        if (A.krylov) { double *kv = A.krylov + (int64_t)k * A.kstride; for (int i = tid; i < N; i += 1024) kv[i] = lds[i]; }
+        double asum = 0.0;
+#pragma unroll
+        for (int j = 0; j < EMAX; j++) {
+            const int b = __builtin_amdgcn_readfirstlane(b0v + TB * j);
+            if (j < A.E && b < A.DimB) {
+                const int ib = b * A.sB, ia = a * A.sA;
+                const int impB = (A.mapB[b] & A.impmask) * A.multB;
+                double acc = 0.0;
+                if (aok) {
+                    const double x = lds[ia + ib];
+                    acc = (eA + A.EB[b] + A.cross[impA + impB]) * x;
+#pragma unroll
+                    for (int q = 0; q < WA; q++) acc += valA[q] * lds[colA[q] + ib];
+                    for (int q = 0; q < A.wB; q++) acc += A.vB[(int64_t)q * A.ksB + (int64_t)b * A.bsB] * lds[ia + A.cB[(int64_t)q * A.ksB + (int64_t)b * A.bsB] * A.sB];
+                    acc -= beta * (VPREG ? vp[j] : A.vprev[ia + ib]);
+                    asum += x * acc;
+                }
+                w[j] = acc;
+            }
+            __builtin_amdgcn_sched_barrier(0);      // one element at a time: hoisting the loads of all E elements to the top costs more registers than a lane has
+        }
+        const double alpha = bsum(asum);
+        double nsum = 0.0;
+#pragma unroll
+        for (int j = 0; j < EMAX; j++) {
+            const int b = b0v + TB * j;
+            if (j < A.E && aok && b < A.DimB) { const double x = lds[a * A.sA + b * A.sB]; w[j] -= alpha * x; if (VPREG) vp[j] = x; else A.vprev[a * A.sA + b * A.sB] = x; nsum += w[j] * w[j]; }
+        }
+        const double bnew = sqrt(bsum(nsum));            // the second barrier inside bsum also ends every read of v_k in LDS
+        const double sc = bnew > 0.0 ? 1.0 / bnew : 0.0;
+#pragma unroll
+        for (int j = 0; j < EMAX; j++) { const int b = b0v + TB * j; if (j < A.E && aok && b < A.DimB) lds[a * A.sA + b * A.sB] = w[j] * sc; }
+        if (tid == 0) { A.alphas[k] = alpha; A.betas[k + 1] = bnew; }
+        beta = bnew;
+        __syncthreads();
+        if (bnew < A.threshold) { k++; break; }          // invariant subspace: same decision on every thread
+    }
+    // state for a following launch: v_k, v_{k-1}
+    for (int i = tid; i < N; i += 1024) A.v[i] = lds[i];
+#pragma unroll
+    for (int j = 0; j < EMAX; j++) { const int b = b0 + TB * j; if (VPREG && j < A.E && aok && b < A.DimB) A.vprev[a * A.sA + b * A.sB] = vp[j]; }
+    if (tid == 0) *A.done = k;
 }
 
 // x[i] *= scal[idx]

@@ -259,9 +259,127 @@ static int fetch_coeffs(S *s, int k, std::vector<double> &al, std::vector<double
     return EDGPU_OK;
 }
 
+// ---- whole Lanczos loop in one workgroup (k_lanczos_wg): sectors of up to ~19 000 states -----------------------------------
+struct WgPlan { bool ok = false; bool a_is_up = true; int nC = 1, E = 1, emax = 8, wa = 6; };
+static WgPlan wg_plan(const S *s)
+{
+    WgPlan P;
+    const SectorHost &H = s->H;
+    if (!s->lz_wg_on || s->multi || !s->two_factor || s->extra || H.DimPh != 1 || !s->upf || !s->dwf) return P;
+    const int64_t N = H.DimUp * H.DimDw;
+    if (N < 2 || N * 8 > 150 * 1024) return P;
+    P.a_is_up = H.DimUp >= H.DimDw;
+    const int64_t DimA = P.a_is_up ? H.DimUp : H.DimDw, DimB = P.a_is_up ? H.DimDw : H.DimUp;
+    const int wA = P.a_is_up ? s->upf->width : s->dwf->width;
+    if (DimA > 1024 || wA > 12) return P;
+    int nC = 1; while (nC * 64 < DimA) nC *= 2;
+    P.nC = nC; P.E = (int)cdiv(DimB, 16 / nC);
+    if (P.E > 20) return P;
+    P.emax = P.E <= 8 ? 8 : (P.E <= 16 ? 16 : 20); P.wa = wA <= 6 ? 6 : 12;
+    P.ok = true;
+    return P;
+}
+// `nsteps` iterations from iteration k0 on: v = v_k (any norm when k0 == 0), vprev = v_{k-1}; coefficients into s->alphas / s->betas;
+// v_k stored at krylov + k*kstride when krylov != nullptr.  *done = iterations completed so far (after a stream synchronisation).
+static int lanczos_wg_steps(S *s, const WgPlan &P, double *v, double *vprev, int k0, int nsteps, double threshold, double *krylov, int64_t kstride, int *done)
+{
+    const SectorHost &H = s->H; const edgpu_desc &d = H.desc;
+    if (d.storage == EDGPU_STORE_DIRECT) CHK(direct_tables(s));
+    if (!s->wg_done.p) CHK(s->wg_done.alloc(1));
+    LzWgArgs A{};
+    const DevFactor &fa = P.a_is_up ? *s->upf : *s->dwf, &fb = P.a_is_up ? *s->dwf : *s->upf;
+    A.DimA = (int32_t)(P.a_is_up ? H.DimUp : H.DimDw); A.DimB = (int32_t)(P.a_is_up ? H.DimDw : H.DimUp);
+    A.sA = P.a_is_up ? 1 : (int32_t)H.DimUp; A.sB = P.a_is_up ? (int32_t)H.DimUp : 1;
+    A.nC = P.nC; A.E = P.E;
+    // ELL images: the up factor is stored [k][iup] (transposed), the dw factor [idw][k]
+    A.cA = fa.ellc.p; A.vA = fa.ellv.p; A.wA = fa.width; A.ksA = P.a_is_up ? (int32_t)H.DimUp : 1; A.asA = P.a_is_up ? 1 : fa.width;
+    A.cB = fb.ellc.p; A.vB = fb.ellv.p; A.wB = fb.width; A.ksB = P.a_is_up ? 1 : (int32_t)H.DimUp; A.bsB = P.a_is_up ? fb.width : 1;
+    A.EA = fa.E.p; A.EB = fb.E.p; A.mapA = fa.map.p; A.mapB = fb.map.p; A.cross = s->cross.p;
+    const int nI = 1 << d.Norb;
+    A.multA = P.a_is_up ? nI : 1; A.multB = P.a_is_up ? 1 : nI; A.impmask = nI - 1; A.econst = H.econst;
+    A.v = v; A.vprev = vprev; A.alphas = s->alphas.p; A.betas = s->betas.p; A.k0 = k0; A.nsteps = nsteps; A.threshold = threshold;
+    A.krylov = krylov; A.kstride = kstride; A.done = s->wg_done.p;
+    const size_t lds = (size_t)(H.DimUp * H.DimDw) * 8;
+#define WG_LAUNCH(E_, W_, R_)                                                                                                   \
+    do {                                                                                                                            \
+        static OncePerDevice once_;                                                                                                 \
+        if (once_.first(s->device)) (void)hipFuncSetAttribute((const void *)k_lanczos_wg<E_, W_, R_>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024); \
+        hipLaunchKernelGGL((k_lanczos_wg<E_, W_, R_>), dim3(1), dim3(1024), lds, s->stream, A);                                     \
+    } while (0)
+    if (P.wa == 6) { if (P.emax == 8) WG_LAUNCH(8, 6, true); else if (P.emax == 16) WG_LAUNCH(16, 6, false); else WG_LAUNCH(20, 6, false); }
+    else { if (P.emax == 8) WG_LAUNCH(8, 12, true); else if (P.emax == 16) WG_LAUNCH(16, 12, false); else WG_LAUNCH(20, 12, false); }
+#undef WG_LAUNCH
+    HIPCHK(hipGetLastError());
+    if (done) { HIPCHK(hipMemcpyAsync(done, s->wg_done.p, 4, hipMemcpyDeviceToHost, s->stream)); HIPCHK(hipStreamSynchronize(s->stream)); }
+    return EDGPU_OK;
+}
+// sp_lanc_eigh on such a sector: chunks of iterations per launch with the Krylov vectors kept, SciFortran's stopping rule applied to
+// each iteration in order on the host (same nlanc and E0 as the per-iteration loop, a few surplus iterations), the eigenvector as
+// one weighted sum over the stored vectors
+static int lanczos_gs_wg(S *s, const WgPlan &P, int nitermax, double threshold, int ncheck, double *egs, double *vect_dev, int *nlanc_out)
+{
+    const SectorHost &H = s->H;
+    const int64_t N = s->nloc;
+    if ((int64_t)nitermax > H.Dim) nitermax = (int)H.Dim;
+    CHK(lz_prepare(s, nitermax));
+    if (s->lz[3].n != (size_t)N) CHK(s->lz[3].alloc((size_t)N));
+    double *v = s->lz[0].p, *vprev = s->lz[1].p, *acc = s->lz[3].p;
+    HIPCHK(hipMemcpyAsync(v, vect_dev, (size_t)N * 8, hipMemcpyDeviceToDevice, s->stream));
+    CHK(reduce_dot(s, v, v));
+    double nrm2;
+    HIPCHK(hipMemcpyAsync(&nrm2, s->scal.p + SC_TMP, 8, hipMemcpyDeviceToHost, s->stream)); HIPCHK(hipStreamSynchronize(s->stream));
+    if (nrm2 == 0.0) {      // zero input => library-generated start vector (ED_DIAG.f90:147 passes eig_basis=0)
+        hipLaunchKernelGGL(k_random_start, dim3(2048), dim3(256), 0, s->stream, v, H.DimUp, H.Qdw, H.dw0, H.DimDw, H.DimPh, (uint64_t)1234567);
+        HIPCHK(hipGetLastError());
+    }
+    const int64_t kstride = (N + 1) & ~(int64_t)1;
+    const size_t want = (size_t)(nitermax + 1) * (size_t)kstride;
+    if (s->wg_slab.n < want) CHK(s->wg_slab.alloc(want));
+    std::vector<double> al, be;
+    int nlanc = 0, done = 0; double esave = 0.0, e0 = 0.0; bool stop = false;
+    const int chunk = 16;
+    for (int k = 0; k < nitermax && !stop;) {
+        const int n = std::min(chunk, nitermax - k);
+        CHK(lanczos_wg_steps(s, P, v, vprev, k, n, threshold, s->wg_slab.p, kstride, &done));
+        if (done <= k) return fail(EDGPU_EHIP, "edgpu: internal: the workgroup Lanczos kernel made no progress");
+        CHK(fetch_coeffs(s, done - 1, al, be));      // a kernel that stopped early (beta below the threshold) is caught by the first test below
+        for (; k < done; k++) {
+            nlanc = k + 1;
+            if (std::fabs(be[k + 1]) < threshold) { stop = true; break; }
+            if (!tridiag_lowest(al.data(), be.data(), nlanc, &e0, nullptr)) return fail(EDGPU_ENOTCONVERGED, "edgpu: tridiagonal QL did not converge");
+            if (nlanc >= ncheck && std::fabs(e0 - esave) <= threshold) { stop = true; break; }
+            esave = e0;
+        }
+    }
+    std::vector<double> z;
+    if (!tridiag_lowest(al.data(), be.data(), nlanc, &e0, &z)) return fail(EDGPU_ENOTCONVERGED, "edgpu: tridiagonal QL did not converge");
+    *egs = e0; *nlanc_out = nlanc;
+    HIPCHK(hipMemsetAsync(acc, 0, (size_t)N * 8, s->stream));
+    if (s->eig_h.n < (size_t)(kMaxBasis + 2)) CHK(s->eig_h.alloc((size_t)kMaxBasis + 2));
+    const int nbk = (int)std::max<int64_t>(1, std::min<int64_t>(cdiv(N, 256 * 4), 4096));
+    std::vector<double> coef(nlanc);
+    for (int k = 0; k < nlanc; k++) coef[k] = -z[k];      // k_multiaxpy subtracts; the stored vectors are normalised
+    for (int k0 = 0; k0 < nlanc; k0 += kMaxBasis) {
+        BasisArgs B{}; B.nv = std::min(kMaxBasis, nlanc - k0);
+        for (int i = 0; i < B.nv; i++) B.V[i] = s->wg_slab.p + (int64_t)(k0 + i) * kstride;
+        HIPCHK(hipMemcpyAsync(s->eig_h.p, coef.data() + k0, (size_t)B.nv * 8, hipMemcpyHostToDevice, s->stream));
+        HIPCHK(hipStreamSynchronize(s->stream));
+        launch_multiaxpy(s->stream, nbk, B, (const double *)s->eig_h.p, acc, N);
+        HIPCHK(hipGetLastError());
+    }
+    CHK(reduce_dot(s, acc, acc, N));
+    hipLaunchKernelGGL(k_scalar_step, dim3(1), dim3(1), 0, s->stream, s->scal.p, s->alphas.p, s->betas.p, (const double *)nullptr, 0, 2);
+    hipLaunchKernelGGL(k_scale, dim3(nbk), dim3(256), 0, s->stream, acc, s->scal.p, (int)SC_SCUR, N);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(vect_dev, acc, (size_t)N * 8, hipMemcpyDeviceToDevice, s->stream));
+    HIPCHK(hipStreamSynchronize(s->stream));
+    return EDGPU_OK;
+}
+
 static int lanczos_gs_impl(S *s, int nitermax, double threshold, int ncheck, double *egs, double *vect_dev, int *nlanc_out);
 static int lanczos_gs(S *s, int nitermax, double threshold, int ncheck, double *egs, double *vect_dev, int *nlanc_out)
 {
+    if (nitermax >= 1) { const WgPlan P = wg_plan(s); if (P.ok) return lanczos_gs_wg(s, P, nitermax, threshold, ncheck < 1 ? 10 : ncheck, egs, vect_dev, nlanc_out); }
     // the cached Krylov vectors must survive an out-of-memory retry of any allocation made while the search runs
     g_kpool.in_use = true;
     const int rc = lanczos_gs_impl(s, nitermax, threshold, ncheck, egs, vect_dev, nlanc_out);
@@ -448,6 +566,25 @@ static int lanczos_tridiag(S *s, const double *vin_dev, int nlanc, double thresh
 {
     if (nlanc < 1) return fail(EDGPU_EINVAL, "edgpu_lanczos_tridiag: nlanc < 1");
     CHK(lz_prepare(s, nlanc));
+    {
+        const WgPlan P = wg_plan(s);
+        if (P.ok) {      // the whole leg in one launch of one workgroup
+            int done = 0;
+            HIPCHK(hipMemcpyAsync(s->lz[0].p, vin_dev, (size_t)s->nloc * 8, hipMemcpyDeviceToDevice, s->stream));
+            CHK(lanczos_wg_steps(s, P, s->lz[0].p, s->lz[1].p, 0, nlanc, threshold, nullptr, 0, &done));
+            std::vector<double> al, be;
+            CHK(fetch_coeffs(s, std::max(done, 1) - 1, al, be));
+            for (int i = 0; i < nlanc; i++) { alanc[i] = 0.0; blanc[i] = 0.0; }
+            int used = 0;
+            for (int i = 0; i < done; i++) {
+                alanc[i] = al[i]; used = i + 1;
+                if (std::fabs(be[i + 1]) < threshold) break;
+                if (i + 1 < nlanc) blanc[i + 1] = be[i + 1];
+            }
+            *nused = used;
+            return EDGPU_OK;
+        }
+    }
     OneArScope one_ar_scope(s);
     const bool fused = fused_ok(s);
     LzVecs V{s->lz[0].p, s->lz[1].p, s->lz[2].p};

@@ -143,19 +143,55 @@ static int g_comm_created = 0;      // native (RCCL) communicators this process 
 // the next ground-state search; any allocation that fails gives them back first (kpool_release) and retries.
 static void kpool_release();
 
+// Small device blocks (tables, partial sums, work vectors of small sectors) are recycled through a process-wide pool of
+// power-of-two size classes instead of going back to the driver: a sector of the everyday size (Ns <= 12) holds ~50 of them and
+// the host builds and deletes O(Ns^2) sectors plus the Green's-function target sectors per DMFT iteration (ED_DIAG.f90:83-276);
+// hipFree alone was ~4 ms per deleted sector (profiles/r04/sector_sweep_ns12_before.txt).  Blocks above 4 MiB go to the driver as
+// before.  A block is handed out again only after the sector that held it has synchronised its device (destroy()) or, for
+// temporaries, in stream order.  edgpu_cache_release() and any failed allocation return the pool to the driver.
+struct SmallPool {
+    static constexpr size_t kMaxBlock = (size_t)4 << 20, kMaxHeld = (size_t)1 << 30;
+    std::map<std::pair<int, size_t>, std::vector<void *>> free_;      // (device, class bytes) -> blocks
+    size_t held = 0;
+    static size_t cls(size_t bytes) { size_t c = 256; while (c < bytes) c <<= 1; return c; }
+    void *take(int dev, size_t c) { auto it = free_.find({dev, c}); if (it == free_.end() || it->second.empty()) return nullptr; void *q = it->second.back(); it->second.pop_back(); held -= c; return q; }
+    bool give(int dev, size_t c, void *q) { if (held + c > kMaxHeld) return false; free_[{dev, c}].push_back(q); held += c; return true; }
+    void drain() { for (auto &kv : free_) for (void *q : kv.second) (void)hipFree(q); free_.clear(); held = 0; }
+};
+static SmallPool g_spool;
+
 template <class T> struct DevBuf {
     T *p = nullptr; size_t n = 0;
+    size_t pooled = 0; int pdev = -1;      // size class and device of a pooled block (0: a driver allocation of its own)
     int alloc(size_t count)
     {
         release(); n = count; if (!count) return EDGPU_OK;
-        hipError_t e = hipMalloc((void **)&p, count * sizeof(T));
-        if (e == hipErrorOutOfMemory) { (void)hipGetLastError(); kpool_release(); e = hipMalloc((void **)&p, count * sizeof(T)); }
+        const size_t bytes = count * sizeof(T);
+        if (bytes <= SmallPool::kMaxBlock) {
+            int dev = 0; (void)hipGetDevice(&dev);
+            const size_t c = SmallPool::cls(bytes);
+            void *q = g_spool.take(dev, c);
+            if (!q) {
+                hipError_t e = hipMalloc(&q, c);
+                if (e == hipErrorOutOfMemory) { (void)hipGetLastError(); kpool_release(); e = hipMalloc(&q, c); }
+                if (e != hipSuccess) { p = nullptr; n = 0; }
+                HIPCHK(e);
+            }
+            p = static_cast<T *>(q); pooled = c; pdev = dev;
+            return EDGPU_OK;
+        }
+        hipError_t e = hipMalloc((void **)&p, bytes);
+        if (e == hipErrorOutOfMemory) { (void)hipGetLastError(); kpool_release(); e = hipMalloc((void **)&p, bytes); }
         if (e != hipSuccess) { p = nullptr; n = 0; }
         HIPCHK(e);
         return EDGPU_OK;
     }
     int upload(const std::vector<T> &h) { CHK(alloc(h.size())); if (h.size()) HIPCHK(hipMemcpy(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice)); return EDGPU_OK; }
-    void release() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
+    void release()
+    {
+        if (p) { if (!pooled || !g_spool.give(pdev, pooled, p)) (void)hipFree(p); }
+        p = nullptr; n = 0; pooled = 0; pdev = -1;
+    }
     ~DevBuf() { release(); }
 };
 
@@ -170,6 +206,7 @@ static void kpool_release()
     g_kpool.buf.clear(); g_kpool.cap.clear();
     if (g_kpool.slab) (void)hipFree(g_kpool.slab);
     g_kpool.slab = nullptr; g_kpool.slab_cap = 0;
+    g_spool.drain();
 }
 
 struct DevFactor {
@@ -214,6 +251,9 @@ struct edgpu_sector_s {
     // hops, the dw-type blocks always (their rows are uniform per idw row)
     bool csr_il_loc = false, csr_il_dw = false; bool csrL_nt = false;
     int csr_loc_cnt = 0;      // entries per row of the local block when every row has the same number (half-filled up sector: 1 + Ns/2), else 0
+    bool x_own_in_v = false;  // several ranks, stored-factor / on-the-fly forms with the needed-rows exchange: the dw pass reads the rank's own rows from the input vector, the x-space only holds received rows
+    bool lz_wg_on = true;     // EDGPU_LZ_WG: sectors that fit LDS run their Lanczos loops in one workgroup (k_lanczos_wg)
+    DevBuf<int32_t> wg_done; DevBuf<double> wg_slab;      // iteration count written by that kernel; its Krylov slab
     bool csr_fused_on = true; // EDGPU_CSR_FUSED: fused Lanczos iteration on the explicit CSR (k_csr_loc_ax)
     // single rank: the stored columns index vectors whose rows are padded to the 128-B line (csr_ld doubles per row; == DimUp
     // when off); the Lanczos loops then run on pitched vectors, a caller's dense vectors go through csr_xs / csr_ys
@@ -346,9 +386,10 @@ static const KnobDef kKnobs[] = {
     {"EDGPU_CSRD_ROWS", 64, "test hook", "rows per block of the row-major dw block", "test_gpu_parity.py::test_large_sector_code_paths_on_small_sectors"},
     {"EDGPU_CSRD_NT", 1, "fallback", "non-temporal entry loads of the dw block", "test_gpu_parity.py::test_large_sector_code_paths_on_small_sectors"},
     // Lanczos loops and eigensolvers
-    {"EDGPU_CSR_FUSED", 1, "fallback", "fused Lanczos iteration on the explicit CSR (LDS-row local block carrying the axpy+norm pass); 0: product + axpy/norm pass", "test_gpu_parity.py::test_fused_iteration_equals_three_pass_iteration"},
+    {"EDGPU_CSR_FUSED", 1, "fallback", "fused Lanczos iteration on the explicit CSR (LDS-row local block carrying the axpy+norm pass); 0: product + axpy/norm pass", "test_gpu_parity.py::test_fused_iteration_on_the_explicit_csr"},
     {"EDGPU_LZ_STORE", 1, "fallback", "keep the Krylov vectors of a ground-state search in HBM; 0: second Lanczos pass", "test_gpu_parity.py::test_ground_state_with_stored_krylov_vectors"},
     {"EDGPU_LZ_STORE_MAX", 1 << 30, "test hook", "cap on the stored Krylov vectors (tests: running out mid-search)", "test_gpu_parity.py::test_ground_state_with_stored_krylov_vectors"},
+    {"EDGPU_LZ_WG", 1, "fallback", "sectors of up to ~19 000 states run their Lanczos loops (sp_lanc_eigh, sp_lanc_tridiag and the legs built on it) in one workgroup; 0: per-iteration launches", "test_small_sector_lanczos.py::test_workgroup_lanczos_equals_the_launch_per_iteration_loop"},
     {"EDGPU_EIGSH_PRO", 1, "fallback", "thick-restart Lanczos with partial re-orthogonalisation; 0: whole-basis form", "test_eigsh.py::test_eigsh_alternative_forms"},
     {"EDGPU_EIGSH_FUSED", 1, "fallback", "fused two-pass products inside edgpu_eigsh", "test_eigsh.py::test_eigsh_alternative_forms"},
     {"EDGPU_EIGSH_OMEGA_PCT", 100, "test hook", "re-orthogonalisation trigger in % of sqrt(eps) (tests: always / never)", "test_eigsh.py::test_eigsh_alternative_forms"},

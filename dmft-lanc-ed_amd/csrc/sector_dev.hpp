@@ -501,7 +501,13 @@ static int create(const edgpu_desc *desc, S **out)
     if (desc->device >= 0) HIPCHK(hipSetDevice(desc->device));
     HIPCHK(hipGetDevice(&s->device));
     HIPCHK(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
-    HIPCHK(hipStreamCreateWithFlags(&s->cstream, hipStreamNonBlocking));
+    {   // the comm stream carries the packing kernel and the exchange, which the dw pass waits for: highest priority, so that its
+        // workgroups are dispatched ahead of the local pass that runs beside it (emulated rank of eight: k_pack_rows took 0.62 ms
+        // next to the local block where it takes 0.12 ms alone, profiles/r04/rank_of_8_ns16csr.txt)
+        int lo = 0, hi = 0;
+        if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) { (void)hipGetLastError(); hi = 0; }
+        HIPCHK(hipStreamCreateWithPriority(&s->cstream, hipStreamNonBlocking, hi));
+    }
     HIPCHK(hipEventCreate(&s->ev_a)); HIPCHK(hipEventCreate(&s->ev_b));
     HIPCHK(hipEventCreateWithFlags(&s->ev_gather, hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&s->ev_ready, hipEventDisableTiming));
     SectorHost &H = s->H;
@@ -510,7 +516,7 @@ static int create(const edgpu_desc *desc, S **out)
     s->extra = H.DimPh > 1 || H.Jhflag; s->has_ph = H.DimPh > 1; s->has_nd = H.Jhflag;
     s->nloc_el = H.DimUp * H.Qdw; s->nloc = s->nloc_el * H.DimPh; s->vecdim = s->nloc;
     s->multi = desc->mpi_size > 1 || (desc->reserved & 1);   // reserved bit 0: run the exchange path even on one rank (tests)
-    s->lz_fused_on = knob("EDGPU_LZ_FUSED") != 0; s->csr_fused_on = knob("EDGPU_CSR_FUSED") != 0;
+    s->lz_fused_on = knob("EDGPU_LZ_FUSED") != 0; s->csr_fused_on = knob("EDGPU_CSR_FUSED") != 0; s->lz_wg_on = knob("EDGPU_LZ_WG") != 0;
     s->dbg = dbg_flags(); s->one_ar = knob("EDGPU_ONE_ALLREDUCE") != 0; s->up_pairs10 = knob("EDGPU_UP_PAIRS10") != 0; s->direct_cache = XKNOB("EDGPU_DIRECT_CACHE", 1) != 0; s->up_elem16 = XKNOB("EDGPU_UP_ELEM16", 1) != 0; s->pad_allowed = knob("EDGPU_PAD") != 0 && knob("EDGPU_ODD_PAIRS") != 0; s->tables_wave = XKNOB("EDGPU_TABLES_WAVE", 1) != 0; s->dw_lds_kb = std::min(XKNOB("EDGPU_DW_LDS_KB", 0), 150);
     // distributed-transpose dw pass: opt-in (EDGPU_DW_TRANSPOSE=1) until an 8-GPU run has shown it correct and faster than the
     // needed-rows exchange; at most 64 ranks (larger jobs use the needed-rows exchange)
@@ -568,6 +574,8 @@ static int create(const edgpu_desc *desc, S **out)
     s->multi = desc->mpi_size > 1 || (desc->reserved & 1);   // reserved bit 0: run the exchange path even on one rank (tests)
     s->nhalo = H.DimDw;
     if (s->multi && !s->tr_on && s->kron2 && (!s->extra || (s->has_nd && !s->has_ph && s->nd_split)) && knob("EDGPU_HALO")) CHK(setup_halo(s.get()));
+    // the vectorised dw pass takes the rank's own rows from the input vector: no own-row copy into the x-space per product
+    s->x_own_in_v = s->halo && s->kron2 && desc->storage != EDGPU_STORE_CSR && !s->extra && !s->tr_on && H.DimPh == 1 && s->dw_variant >= 2 && H.DimUp % 2 == 0 && s->dw_w >= 4 && s->dwf->width <= 64;
     if (s->tr_on) {     // up-block of this rank in the transposed space (same rule as the dw split)
         const int64_t P = s->comm.size, r = s->comm.rank, q = H.DimUp / P, rem = H.DimUp % P;
         s->Qup = r < rem ? q + 1 : q; s->up0 = r < rem ? r * (q + 1) : r * q + rem;

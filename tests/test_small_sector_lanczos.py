@@ -1,0 +1,86 @@
+"""Round 4: sectors whose vector fits LDS (up to ~19 000 states) run their Lanczos loops in ONE workgroup (k_lanczos_wg):
+sp_lanc_eigh, sp_lanc_tridiag and the Green's-function / susceptibility legs built on it.  Against the launch-per-iteration
+loop (EDGPU_LZ_WG=0), the oracle's restatement of SciFortran's recurrence, and dense diagonalisation."""
+import numpy as np
+import pytest
+
+from oracle import oracle
+
+pytestmark = pytest.mark.gpu
+
+
+def _sectors():
+    from edgpu import model
+    out = []
+    m7, _, _ = model.half_filled_c(7)       # Ns = 8
+    m9, _, _ = model.half_filled_c(9)       # Ns = 10
+    m11, _, _ = model.half_filled_c(11)     # Ns = 12
+    for m, nu, nd in ((m7, 4, 4), (m7, 3, 5), (m7, 6, 2), (m7, 1, 4), (m9, 5, 3), (m9, 3, 3), (m9, 2, 6), (m9, 9, 4), (m9, 4, 9),
+                      (m11, 2, 3), (m11, 10, 2), (m11, 11, 5), (m11, 1, 6), (m11, 3, 2), (m11, 12, 12)):
+        out.append((m, [nu], [nd]))
+    return out
+
+
+@pytest.mark.parametrize("st", ["kron", "direct"])
+def test_workgroup_lanczos_equals_the_launch_per_iteration_loop(edgpu_mod, monkeypatch, st):
+    for m, nu, nd in _sectors():
+        S = oracle.Sector(m, nu, nd)
+        v0 = np.random.RandomState(3).uniform(0, 1, S.Dim)
+        n = min(40, S.Dim)
+        res = {}
+        for tag, env in (("wg", {}), ("plain", {"EDGPU_LZ_WG": "0"})):
+            for k, v in env.items():
+                monkeypatch.setenv(k, v)
+            G = edgpu_mod.HvSector(m, nu, nd, storage=st)
+            a, b, used = G.sp_lanc_tridiag(v0, n)
+            e0, x, nl = G.sp_lanc_eigh(v0, nitermax=min(300, S.Dim), threshold=1e-13)
+            ez, xz, nlz = G.sp_lanc_eigh(None, nitermax=min(300, S.Dim), threshold=1e-13)       # library start vector
+            res[tag] = (a, b, used, e0, x, nl, ez)
+            G.close()
+            for k in env:
+                monkeypatch.delenv(k)
+        a_ref, b_ref, used_ref = oracle.sp_lanc_tridiag(S.spmatvec, v0, n)
+        for tag, (a, b, used, e0, x, nl, ez) in res.items():
+            assert used == used_ref and b[0] == 0.0, (tag, nu, nd, used, used_ref)
+            k = min(used, 16 if S.Dim < 2000 else 30)
+            np.testing.assert_allclose(a[:k], a_ref[:k], rtol=1e-9, atol=1e-9)
+            np.testing.assert_allclose(b[1:k], b_ref[1:k], rtol=1e-9, atol=1e-9)
+            assert abs(np.linalg.norm(x) - 1.0) < 1e-12
+            assert np.linalg.norm(S.spmatvec(x) - e0 * x) < 1e-6, (tag, nu, nd)
+        assert abs(res["wg"][3] - res["plain"][3]) <= 1e-10 and abs(res["wg"][5] - res["plain"][5]) <= 1, (nu, nd, res["wg"][3], res["plain"][3], res["wg"][5], res["plain"][5])
+        assert abs(res["wg"][6] - res["plain"][6]) <= 1e-10
+        if S.Dim <= 5000:
+            w = np.linalg.eigvalsh(S.hmat())
+            assert abs(res["wg"][3] - w[0]) <= 1e-10 or abs(res["wg"][3] - w[np.argmin(np.abs(w - res["wg"][3]))]) <= 1e-10      # a start vector may miss the lowest level's symmetry class: an eigenvalue in any case
+
+
+def test_workgroup_green_function_leg(edgpu_mod, monkeypatch):
+    """c^+ and c legs from a small sector's ground state (edgpu_gf_lanczos): the workgroup form against the launch-per-iteration one."""
+    import edgpu
+    from edgpu import model
+    m, _, _ = model.half_filled_c(9)
+    out = {}
+    for tag, env in (("wg", {}), ("plain", {"EDGPU_LZ_WG": "0"})):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        G = edgpu_mod.HvSector(m, [5], [5], storage="kron")          # 63 504 states: launch-per-iteration loop in both runs
+        e0, x, nl = G.sp_lanc_eigh(None, nitermax=300, threshold=1e-13)
+        legs = []
+        for (tu, td, dag, spin) in ((6, 5, True, 1), (4, 5, False, 1)):
+            T = edgpu_mod.HvSector(m, [tu], [td], storage="kron")
+            legs.append(edgpu.gf_lanczos(G, T, 1, spin, dag, x, 60))
+            T.close()
+        G2 = edgpu_mod.HvSector(m, [8], [2], storage="direct")       # 2 025 states: workgroup loop
+        e2, x2, _ = G2.sp_lanc_eigh(None, nitermax=300, threshold=1e-13)
+        T2 = edgpu_mod.HvSector(m, [9], [2], storage="direct")       # 450 states
+        legs.append(edgpu.gf_lanczos(G2, T2, 1, 1, True, x2, 60))
+        T2.close(); G2.close(); G.close()
+        out[tag] = (e0, e2, legs)
+        for k in env:
+            monkeypatch.delenv(k)
+    assert abs(out["wg"][0] - out["plain"][0]) < 1e-10 and abs(out["wg"][1] - out["plain"][1]) < 1e-10
+    for (n2a, aa, ba, ua), (n2b, ab, bb, ub) in zip(out["wg"][2], out["plain"][2]):
+        assert abs(n2a - n2b) < 1e-10 and ua == ub
+        k = min(ua, 25)
+        np.testing.assert_allclose(aa[:k], ab[:k], rtol=1e-8, atol=1e-8)
+        np.testing.assert_allclose(ba[1:k], bb[1:k], rtol=1e-8, atol=1e-8)
