@@ -2895,6 +2895,57 @@ __global__ void __launch_bounds__(256) k_dvd_resid(DvdArgs A, double *__restrict
     if (threadIdx.x == 0) partial[blockIdx.x] = s;
 }
 
+// Davidson step for SMALL search spaces (nv <= NV <= 12; round 4): residual, preconditioned correction AND the first Gram-Schmidt
+// dots in ONE pass over V and W.  The V values of an element stay in registers until its correction t is known, so that
+// h_i = V_i . t (and |t|^2, |r|^2) are summed on the way: the separate multi-dot pass over the basis (nv more vector reads per
+// iteration) is gone.  partial[b*(nv+2) + i]: i < nv: V_i.t ; nv: |t|^2 ; nv+1: |r|^2  (layout of k_multidot_final).
+template <int NV>
+__global__ void __launch_bounds__(256) k_dvd_step(DvdArgs A, double *__restrict__ t, int64_t n, double *__restrict__ partial)
+{
+    __shared__ double red[4];
+    __shared__ double cs[NV];
+    const int nv = A.nv;
+    for (int i = threadIdx.x; i < NV; i += blockDim.x) cs[i] = i < nv ? A.y[i] : 0.0;
+    __syncthreads();
+    const double theta = A.theta;
+    auto finish = [&](int64_t e, double r) -> double {
+        const int64_t iph = A.nel >= n ? 0 : e / A.nel;
+        double den = theta - (A.diag[e - iph * A.nel] + A.w0 * (double)iph);
+        if (fabs(den) < 1e-8) den = den < 0.0 ? -1e-8 : 1e-8;
+        return r / den;
+    };
+    double hs[NV], tt = 0.0, rr = 0.0;
+#pragma unroll
+    for (int i = 0; i < NV; i++) hs[i] = 0.0;
+    const int64_t n2 = n >> 1;
+    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < n2; p += (int64_t)gridDim.x * blockDim.x) {
+        dbl2_t vv[NV], wv[NV];
+#pragma unroll
+        for (int i = 0; i < NV; i++) { const int ic = i < nv ? i : 0; vv[i] = reinterpret_cast<const dbl2_t *>(A.V[ic])[p]; wv[i] = reinterpret_cast<const dbl2_t *>(A.W[ic])[p]; }
+        dbl2_t r; r.x = 0.0; r.y = 0.0;
+#pragma unroll
+        for (int i = 0; i < NV; i++) { const double c = cs[i]; r.x += c * (wv[i].x - theta * vv[i].x); r.y += c * (wv[i].y - theta * vv[i].y); }
+        dbl2_t o; o.x = finish(2 * p, r.x); o.y = finish(2 * p + 1, r.y);
+        reinterpret_cast<dbl2_t *>(t)[p] = o;
+        rr += r.x * r.x + r.y * r.y; tt += o.x * o.x + o.y * o.y;
+#pragma unroll
+        for (int i = 0; i < NV; i++) if (i < nv) hs[i] += vv[i].x * o.x + vv[i].y * o.y;
+    }
+    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+        const int64_t e = n - 1; double r = 0.0;
+#pragma unroll
+        for (int i = 0; i < NV; i++) if (i < nv) r += cs[i] * (A.W[i][e] - theta * A.V[i][e]);
+        const double o = finish(e, r);
+        t[e] = o; rr += r * r; tt += o * o;
+#pragma unroll
+        for (int i = 0; i < NV; i++) if (i < nv) hs[i] += A.V[i][e] * o;
+    }
+#pragma unroll
+    for (int i = 0; i < NV; i++) { if (i < nv) { const double sI = block_sum(hs[i], red); if (threadIdx.x == 0) partial[(int64_t)blockIdx.x * (nv + 2) + i] = sI; } }
+    { const double sT = block_sum(tt, red); if (threadIdx.x == 0) partial[(int64_t)blockIdx.x * (nv + 2) + nv] = sT; }
+    { const double sR = block_sum(rr, red); if (threadIdx.x == 0) partial[(int64_t)blockIdx.x * (nv + 2) + nv + 1] = sR; }
+}
+
 __global__ void __launch_bounds__(256) k_scale_copy(double *__restrict__ y, const double *__restrict__ x, double a, int64_t n)
 {
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) y[e] = a * x[e];

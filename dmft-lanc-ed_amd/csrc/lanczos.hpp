@@ -1235,7 +1235,12 @@ static int dvdson(S *s, int nev, int maxiter, double tol, double *evals, double 
     const int64_t Dim = s->H.Dim, n = s->nloc;
     if (nev < 1) return fail(EDGPU_EINVAL, "edgpu_dvdson: nev < 1");
     if ((int64_t)nev >= Dim) return fail(EDGPU_EINVAL, "edgpu_dvdson: nev must be smaller than the sector dimension (the reference switches to LAPACK there, ED_DIAG.f90:105-107)");
-    int mmax = std::min<int64_t>(std::min<int64_t>(kMaxBasis, Dim), std::max(2 * nev + 8, 16));
+    // Search space: 2*nev + 6 vectors (10 for the two pairs ED_DIAG.f90:189-203 asks for) with GD+1 restarts -- the restarted space
+    // keeps the lowest nev + 2 Ritz vectors AND the previous iterate of the target pair (Stathopoulos & Saad's "+k" vectors: the
+    // restarted method then converges like the unrestarted one), so a small space loses no products while every pass over the
+    // space is half as long as with the 16 vectors of rounds 2-3 (c3: 3.0 s -> profiles/r04/dvdson_c3.txt).
+    int mmax = std::min<int64_t>(std::min<int64_t>(kMaxBasis, Dim), std::max(2 * nev + 6, 10));
+    const bool small = mmax <= 12 && s->dvd_fused_on;      // k_dvd_step: residual, correction and the Gram-Schmidt dots in one pass
     if (mmax <= nev) return fail(EDGPU_EINVAL, "edgpu_dvdson: too many eigenpairs requested for the search space");
     if (maxiter < 1) maxiter = 1;
     const double tol_eff = std::max(tol, 1e-11);
@@ -1253,7 +1258,7 @@ static int dvdson(S *s, int nev, int maxiter, double tol, double *evals, double 
     const int nb = (int)std::max<int64_t>(1, std::min<int64_t>(cdiv(n, 256 * 8), 1024));
     const int gs = (int)std::max<int64_t>(1, std::min<int64_t>(cdiv(n, 256 * 4), 4096));
     if (s->eig_h.n < (size_t)(mmax + 3)) CHK(s->eig_h.alloc((size_t)mmax + 3));
-    if (s->eig_partial.n < (size_t)nb * (mmax + 2)) CHK(s->eig_partial.alloc((size_t)nb * (mmax + 2)));
+    if (s->eig_partial.n < (size_t)nb * (mmax + 3)) CHK(s->eig_partial.alloc((size_t)nb * (mmax + 3)));
     if (s->eig_y.n < (size_t)mmax * mmax) CHK(s->eig_y.alloc((size_t)mmax * mmax));
     const SectorHost &H = s->H;
     const bool rot_mfma = knob("EDGPU_ROT_MFMA") != 0;
@@ -1278,7 +1283,7 @@ static int dvdson(S *s, int nev, int maxiter, double tol, double *evals, double 
     HIPCHK(hipGetLastError());
     double nrm; CHK(norm_of(Vp(0), nrm));
     hipLaunchKernelGGL(k_scale_copy, dim3(gs), dim3(256), 0, s->stream, Vp(0), (const double *)Vp(0), 1.0 / nrm, n);
-    std::vector<double> G((size_t)mmax * mmax, 0.0), theta, Y;
+    std::vector<double> G((size_t)mmax * mmax, 0.0), theta, Y, yprev;
     int m = 0, nmv = 0, nconv = 0, it = 0;
     // append V[m] (already orthonormal to the space): W[m] = H V[m], new column of G
     auto extend = [&]() -> int {
@@ -1298,35 +1303,84 @@ static int dvdson(S *s, int nev, int maxiter, double tol, double *evals, double 
         HIPCHK(hipMemcpyAsync(s->eig_y.p, Y.data() + (size_t)m * k, (size_t)m * 8, hipMemcpyHostToDevice, s->stream));
         DvdArgs D{}; D.nv = m; for (int i = 0; i < m; i++) { D.V[i] = Vp(i); D.W[i] = Wp(i); }
         D.y = s->eig_y.p; D.theta = theta[k]; D.diag = s->diag.p; D.nel = s->nloc_el; D.w0 = H.DimPh > 1 ? H.desc.w0_ph : 0.0;
-        hipLaunchKernelGGL(k_dvd_resid, dim3(nb), dim3(256), 0, s->stream, D, t, n, s->eig_partial.p);
-        hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(1024), 0, s->stream, (const double *)s->eig_partial.p, (int64_t)nb, s->scal.p + SC_TMP);
-        HIPCHK(hipGetLastError());
-        CHK(allreduce_tmp(s));
-        double r2; HIPCHK(hipMemcpyAsync(&r2, s->scal.p + SC_TMP, 8, hipMemcpyDeviceToHost, s->stream)); HIPCHK(hipStreamSynchronize(s->stream));
+        double r2 = 0.0, t2 = 0.0; std::vector<double> hfirst;
+        if (small) {      // ... and the dots V_i . t of the first Gram-Schmidt pass, |t|^2, |r|^2 on the way
+            hipLaunchKernelGGL(k_dvd_step<12>, dim3(nb), dim3(256), 0, s->stream, D, t, n, s->eig_partial.p);
+            hipLaunchKernelGGL(k_multidot_final, dim3(1), dim3(256), 0, s->stream, (const double *)s->eig_partial.p, nb, m + 2, s->eig_h.p);
+            HIPCHK(hipGetLastError());
+            CHK(allreduce_dev(s, s->eig_h.p, m + 2));
+            hfirst.resize((size_t)m + 2);
+            HIPCHK(hipMemcpyAsync(hfirst.data(), s->eig_h.p, (size_t)(m + 2) * 8, hipMemcpyDeviceToHost, s->stream)); HIPCHK(hipStreamSynchronize(s->stream));
+            t2 = hfirst[m]; r2 = hfirst[m + 1];
+        } else {
+            hipLaunchKernelGGL(k_dvd_resid, dim3(nb), dim3(256), 0, s->stream, D, t, n, s->eig_partial.p);
+            hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(1024), 0, s->stream, (const double *)s->eig_partial.p, (int64_t)nb, s->scal.p + SC_TMP);
+            HIPCHK(hipGetLastError());
+            CHK(allreduce_tmp(s));
+            HIPCHK(hipMemcpyAsync(&r2, s->scal.p + SC_TMP, 8, hipMemcpyDeviceToHost, s->stream)); HIPCHK(hipStreamSynchronize(s->stream));
+        }
         if (std::sqrt(r2) <= tol_eff * std::max(1.0, std::fabs(theta[k]))) {
             nconv++;
+            yprev.clear();
             if (nconv >= nev || nconv >= m) break;
             continue;                                          // next pair, same space
         }
-        if (m == mmax) {     // thick restart: lowest `keep` Ritz vectors, V and W rotated alike, G = diag(theta)
-            const int keep = std::min(mmax - 1, nev + 4);
-            HIPCHK(hipMemcpyAsync(s->eig_y.p, Y.data(), (size_t)m * keep * 8, hipMemcpyHostToDevice, s->stream));
+        bool restarted = false;
+        if (m == mmax) {     // thick restart (GD+1): lowest `keep` Ritz vectors + the previous iterate of the target pair, V and W rotated alike
+            int keep = std::min(mmax - 2, nev + 2);
+            std::vector<double> Cm((size_t)m * (keep + 1), 0.0);
+            for (int j = 0; j < keep; j++) for (int i = 0; i < m; i++) Cm[(size_t)m * j + i] = Y[(size_t)m * j + i];
+            double gpp = 0.0; bool plus = false;
+            if (!yprev.empty() && (int)yprev.size() <= m) {
+                std::vector<double> pv((size_t)m, 0.0);
+                for (size_t i = 0; i < yprev.size(); i++) pv[i] = yprev[i];
+                for (int pass = 0; pass < 2; pass++)
+                    for (int j = 0; j < keep; j++) { double d = 0.0; for (int i = 0; i < m; i++) d += Y[(size_t)m * j + i] * pv[i]; for (int i = 0; i < m; i++) pv[i] -= d * Y[(size_t)m * j + i]; }
+                double nn = 0.0; for (int i = 0; i < m; i++) nn += pv[i] * pv[i];
+                if (nn > 1e-16) {
+                    nn = 1.0 / std::sqrt(nn);
+                    for (int i = 0; i < m; i++) { pv[i] *= nn; Cm[(size_t)m * keep + i] = pv[i]; }
+                    for (int i = 0; i < m; i++) for (int j = 0; j < m; j++) gpp += pv[i] * G[(size_t)i * mmax + j] * pv[j];
+                    plus = true;
+                }
+            }
+            const int nout = keep + (plus ? 1 : 0);
+            HIPCHK(hipMemcpyAsync(s->eig_y.p, Cm.data(), (size_t)m * nout * 8, hipMemcpyHostToDevice, s->stream));
             for (int half = 0; half < 2; half++) {
                 if (rot_mfma) { std::vector<double *> vb((size_t)m); for (int i = 0; i < m; i++) vb[i] = half ? Wp(i) : Vp(i);
-                    CHK(launch_basis_rotate_mfma(s->stream, s->device, vb.data(), m, keep, s->eig_y.p, n)); continue; }
-                RotArgs Rt{}; Rt.nv = m; Rt.nout = keep; Rt.Y = s->eig_y.p; for (int i = 0; i < m; i++) Rt.V[i] = half ? Wp(i) : Vp(i);
-                hipLaunchKernelGGL(k_basis_rotate<kMaxBasis>, dim3(gs), dim3(256), (size_t)m * keep * 8, s->stream, Rt, n);
+                    CHK(launch_basis_rotate_mfma(s->stream, s->device, vb.data(), m, nout, s->eig_y.p, n)); continue; }
+                RotArgs Rt{}; Rt.nv = m; Rt.nout = nout; Rt.Y = s->eig_y.p; for (int i = 0; i < m; i++) Rt.V[i] = half ? Wp(i) : Vp(i);
+                hipLaunchKernelGGL(k_basis_rotate<kMaxBasis>, dim3(gs), dim3(256), (size_t)m * nout * 8, s->stream, Rt, n);
             }
             HIPCHK(hipGetLastError());
+            HIPCHK(hipStreamSynchronize(s->stream));          // Cm lives on this frame
             std::fill(G.begin(), G.end(), 0.0);
             for (int i = 0; i < keep; i++) G[(size_t)i * mmax + i] = theta[i];
-            m = keep;
+            if (plus) G[(size_t)keep * mmax + keep] = gpp;     // the Ritz vectors are G-orthogonal to everything orthogonal to them
+            m = nout; restarted = true;
+            yprev.clear();
             // the correction was computed against the old basis: still a valid new direction
+        } else {
+            yprev.assign(Y.begin() + (size_t)m * k, Y.begin() + (size_t)m * (k + 1));      // this iterate, in the basis of this iteration (the next one has one vector more: coefficient 0)
         }
-        // orthogonalise t against the space (classical Gram-Schmidt, twice), normalise, append
-        std::vector<double *> bas(m); for (int i = 0; i < m; i++) bas[i] = Vp(i);
-        std::vector<double> hj; double tn;
-        CHK(orthogonalise_cgs(s, bas.data(), m, 0, t, n, nb, hj, tn));
+        // orthogonalise t against the space, normalise, append
+        double tn = 0.0;
+        bool done_orth = false;
+        if (small && !restarted) {      // first pass with the dots that came with the correction; DGKS: a second, full pass only when the vector shrank
+            BasisArgs Bu{}; Bu.nv = m; for (int i = 0; i < m; i++) Bu.V[i] = Vp(i);
+            launch_multiaxpy_norm(s->stream, nb, Bu, (const double *)s->eig_h.p, t, n, s->eig_partial.p);
+            hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(1024), 0, s->stream, (const double *)s->eig_partial.p, (int64_t)nb, s->scal.p + SC_TMP);
+            HIPCHK(hipGetLastError());
+            CHK(allreduce_tmp(s));
+            double after = 0.0;
+            HIPCHK(hipMemcpyAsync(&after, s->scal.p + SC_TMP, 8, hipMemcpyDeviceToHost, s->stream)); HIPCHK(hipStreamSynchronize(s->stream));
+            if (after >= 0.5 * t2) { tn = std::sqrt(after > 0.0 ? after : 0.0); done_orth = true; }
+        }
+        if (!done_orth) {
+            std::vector<double *> bas(m); for (int i = 0; i < m; i++) bas[i] = Vp(i);
+            std::vector<double> hj;
+            CHK(orthogonalise_cgs(s, bas.data(), m, 0, t, n, nb, hj, tn));
+        }
         if (!(tn > 1e-14)) break;                              // no new direction: the space is invariant
         hipLaunchKernelGGL(k_scale_copy, dim3(gs), dim3(256), 0, s->stream, Vp(m), (const double *)t, 1.0 / tn, n);
         HIPCHK(hipGetLastError());

@@ -167,6 +167,7 @@ template <class T> struct DevBuf {
     {
         release(); n = count; if (!count) return EDGPU_OK;
         const size_t bytes = count * sizeof(T);
+#ifndef EDGPU_NO_POOL
         if (bytes <= SmallPool::kMaxBlock) {
             int dev = 0; (void)hipGetDevice(&dev);
             const size_t c = SmallPool::cls(bytes);
@@ -180,6 +181,7 @@ template <class T> struct DevBuf {
             p = static_cast<T *>(q); pooled = c; pdev = dev;
             return EDGPU_OK;
         }
+#endif
         hipError_t e = hipMalloc((void **)&p, bytes);
         if (e == hipErrorOutOfMemory) { (void)hipGetLastError(); kpool_release(); e = hipMalloc((void **)&p, bytes); }
         if (e != hipSuccess) { p = nullptr; n = 0; }
@@ -252,6 +254,7 @@ struct edgpu_sector_s {
     bool csr_il_loc = false, csr_il_dw = false; bool csrL_nt = false;
     int csr_loc_cnt = 0;      // entries per row of the local block when every row has the same number (half-filled up sector: 1 + Ns/2), else 0
     bool x_own_in_v = false;  // several ranks, stored-factor / on-the-fly forms with the needed-rows exchange: the dw pass reads the rank's own rows from the input vector, the x-space only holds received rows
+    bool dvd_fused_on = true; // EDGPU_DVD_FUSED: Davidson step with residual, correction and Gram-Schmidt dots in one pass (k_dvd_step)
     bool lz_wg_on = true;     // EDGPU_LZ_WG: sectors that fit LDS run their Lanczos loops in one workgroup (k_lanczos_wg)
     DevBuf<int32_t> wg_done; DevBuf<double> wg_slab;      // iteration count written by that kernel; its Krylov slab
     bool csr_fused_on = true; // EDGPU_CSR_FUSED: fused Lanczos iteration on the explicit CSR (k_csr_loc_ax)
@@ -394,6 +397,7 @@ static const KnobDef kKnobs[] = {
     {"EDGPU_EIGSH_FUSED", 1, "fallback", "fused two-pass products inside edgpu_eigsh", "test_eigsh.py::test_eigsh_alternative_forms"},
     {"EDGPU_EIGSH_OMEGA_PCT", 100, "test hook", "re-orthogonalisation trigger in % of sqrt(eps) (tests: always / never)", "test_eigsh.py::test_eigsh_alternative_forms"},
     {"EDGPU_EIGSH_MEM_MB", 0, "test hook", "pretend only this much device memory is free for the basis", "test_eigsh.py::test_eigsh_runs_with_the_basis_that_fits"},
+    {"EDGPU_DVD_FUSED", 1, "fallback", "Davidson: residual, correction and the first Gram-Schmidt dots in one pass over the search space; 0: separate passes", "test_eigsh.py::test_davidson_matches_dense"},
     {"EDGPU_ROT2", 1, "fallback", "restart rotation with 16-byte accesses on contiguous pieces", "test_eigsh.py::test_eigsh_alternative_forms"},
     {"EDGPU_ROT_MFMA", 1, "fallback", "restart rotation on the f64 matrix cores; 0: register-resident kernels", "test_eigsh.py::test_eigsh_alternative_forms"},
     // several ranks: forms awaiting a measurement on xGMI

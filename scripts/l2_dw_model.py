@@ -57,6 +57,29 @@ def sim_block(capseg, t, inflight=32, order="asc"):
                     if not (a<=j<b): L.touch(('x',j))
         maxrows=max(maxrows,maxlen)
     return L.miss/D, maxrows, len(blocks)
+def sim_order(capseg, chunk_order, R=16, inflight=256, pollute=2):
+    """the shipped walk with the 16-row chunks taken in a given ORDER (round 4: does a Gray-code walk over the top-bit segments help?)"""
+    L=LRU(capseg); uid=0
+    for g0 in range(0,len(chunk_order),inflight):
+        chs=chunk_order[g0:g0+inflight]
+        for r in range(R):
+            for c in chs:
+                i=c*R+r
+                if i>=D: continue
+                for j in hops[i]: L.touch(('x',j))
+                for p in range(pollute): uid+=1; L.touch(('o',uid))
+    return (L.miss-uid)/D
+def gray_orders(cap, R=16):
+    nch=(D+R-1)//R
+    print("chunk order natural: gather misses per row %.2f"%sim_order(cap,list(range(nch))))
+    for t in (3,4,5,6,7):
+        top=(states>>(Ns-t)); pat=np.array([int(top[min(c*R,D-1)]) for c in range(nch)])
+        gray=[i^(i>>1) for i in range(1<<t)]; pos={g:i for i,g in enumerate(gray)}
+        order=sorted(range(nch), key=lambda c:(pos[pat[c]], c))
+        snake=[]
+        for k,g in enumerate(gray):
+            cs=[c for c in range(nch) if pat[c]==g]; snake+= cs if k%2==0 else cs[::-1]
+        print("chunk order gray over top-%d bits: %.2f   as a snake: %.2f"%(t,sim_order(cap,order),sim_order(cap,snake)))
 if __name__=="__main__":
     w=int(sys.argv[1]); segB=w*8; cap=4*1024*1024//segB
     print("tile width",w,"L2 capacity in row segments",cap)
@@ -66,3 +89,4 @@ if __name__=="__main__":
         for infl in (32,16):
             m,mr,nb=sim_block(cap,t,infl)
             print("block t=%d inflight=%d: misses per row %.2f  max rows/block %d (LDS %.0f KB) blocks %d"%(t,infl,m,mr,mr*segB/1024,nb))
+    gray_orders(cap)

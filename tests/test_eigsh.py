@@ -154,12 +154,17 @@ def test_eigsh_argument_errors(edgpu_mod):
 
 
 @pytest.mark.parametrize("name,m,nu,nd", SEL, ids=[z[0] for z in SEL])
-def test_davidson_matches_dense(edgpu_mod, name, m, nu, nd):
+def test_davidson_matches_dense(edgpu_mod, monkeypatch, name, m, nu, nd):
     """lanc_method="dvdson" (sp_dvdson_eigh, ED_DIAG.f90:189-203): Davidson with the diagonal preconditioner.
-    The routine itself lives in SciFortran (parity unpinned): checked against dense diagonalisation."""
+    The routine itself lives in SciFortran (parity unpinned): checked against dense diagonalisation.  Search spaces of up to 12
+    vectors (1-3 pairs) take the fused step (k_dvd_step; EDGPU_DVD_FUSED=0: separate passes), larger ones the separate passes;
+    every space restarts with the previous iterate kept (GD+1)."""
     S = oracle.Sector(m, nu, nd)
     w = np.linalg.eigvalsh(S.hmat())
-    for neigen, st in ((1, "kron"), (3, "direct")):
+    for neigen, st, fused in ((1, "kron", "1"), (3, "direct", "1"), (2, "kron", "0"), (4, "kron", "1")):
+        if neigen >= S.Dim:
+            continue
+        monkeypatch.setenv("EDGPU_DVD_FUSED", fused)
         G = edgpu_mod.HvSector(m, nu, nd, storage=st)
         ev, X, info = G.sp_dvdson_eigh(neigen, nitermax=600, tol=1e-11)
         assert info["nconv"] == neigen, info
