@@ -55,6 +55,22 @@ static int gather_full(S *s, const double *v_local, double *dst, hipStream_t st)
     }
     return EDGPU_OK;
 }
+// The rows the peers need, packed on the COMPUTE stream in front of the local pass (hxv): beside the local pass the pack kernel is
+// starved of workgroup slots and takes 0.6 ms where it takes 0.12 ms alone (Ns=16 explicit CSR, one rank of eight), and everything
+// on the comm stream waits behind it.  (A high-priority comm stream has the same effect on one process per GPU, but with several
+// processes sharing one device -- the test layout -- it could starve another process's compute queue for good: a rank hung inside
+// its product while its peers waited in the next collective; profiles/r04/README.md.)
+static int halo_pack(S *s, const double *v_local, hipStream_t st)
+{
+    const SectorHost &H = s->H;
+    int64_t nsend_rows = 0; for (int r = 0; r < s->comm.size; r++) nsend_rows += s->send_rows_cnt[r];
+    if (nsend_rows <= 0) return EDGPU_OK;
+    const int64_t rowlen = xspace_ld(s);
+    PackArgs K{}; K.DimUp = (int32_t)H.DimUp; K.DimPh = H.DimPh; K.Qdw = H.Qdw; K.nrows = nsend_rows; K.list = s->send_list.p; K.v = v_local; K.out = s->sendbuf.p; K.ld = rowlen;
+    hipLaunchKernelGGL(k_pack_rows, dim3((unsigned)std::min<int64_t>(nsend_rows * H.DimPh, 8192)), dim3(256), 0, st, K);
+    HIPCHK(hipGetLastError());
+    return EDGPU_OK;
+}
 static int gather_vector(S *s, const double *v_local, hipStream_t st)
 {
     if (s->halo) return halo_exchange(s, v_local, st);
@@ -69,7 +85,7 @@ static int halo_exchange(S *s, const double *v_local, hipStream_t st)
     int64_t nsend_rows = 0; for (int r = 0; r < P; r++) nsend_rows += s->send_rows_cnt[r];
     // rows travel with the pitch of the x-space they land in: DimUp, or the line-aligned pitch of the explicit CSR (v_local has it too)
     const int64_t rowlen = xspace_ld(s);
-    if (nsend_rows > 0) {
+    if (nsend_rows > 0 && !s->packed_ahead) {
         PackArgs K{}; K.DimUp = (int32_t)H.DimUp; K.DimPh = H.DimPh; K.Qdw = H.Qdw; K.nrows = nsend_rows; K.list = s->send_list.p; K.v = v_local; K.out = s->sendbuf.p; K.ld = rowlen;
         hipLaunchKernelGGL(k_pack_rows, dim3((unsigned)std::min<int64_t>(nsend_rows * H.DimPh, 8192)), dim3(256), 0, st, K);
         HIPCHK(hipGetLastError());

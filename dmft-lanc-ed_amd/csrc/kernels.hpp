@@ -2311,7 +2311,7 @@ struct LzWgArgs {
 };
 // VPREG: v_{k-1} stays in registers (EMAX <= 8); otherwise it lives in A.vprev (L2-resident, 8 bytes read and written per element
 // and iteration) -- with 16-20 elements per lane two register arrays do not fit 128 registers
-template <int EMAX, int WA, bool VPREG>
+template <int EMAX, int WA, int WB, bool VPREG>
 __global__ void __launch_bounds__(1024) k_lanczos_wg(LzWgArgs A)
 {
     extern __shared__ double lds[];
@@ -2370,20 +2370,31 @@ __global__ void __launch_bounds__(1024) k_lanczos_wg(LzWgArgs A)
             const int b = __builtin_amdgcn_readfirstlane(b0v + TB * j);
             if (j < A.E && b < A.DimB) {
                 const int ib = b * A.sB, ia = a * A.sA;
+                // the hop list of row b: wave-uniform, i.e. scalar loads -- all WB of them requested before the first is used (one
+                // after the other inside the hop loop they were a chain of ~300-cycle round trips: 42 us per iteration at N = 14 520);
+                // slots beyond the row's width re-read the last entry with amplitude 0
+                int cb[WB]; double vb[WB];
+#pragma unroll
+                for (int q = 0; q < WB; q++) {
+                    const int qc = q < A.wB ? q : A.wB - 1;
+                    cb[q] = A.cB[(int64_t)qc * A.ksB + (int64_t)b * A.bsB] * A.sB;
+                    vb[q] = A.vB[(int64_t)qc * A.ksB + (int64_t)b * A.bsB];
+                }
                 const int impB = (A.mapB[b] & A.impmask) * A.multB;
+                const double eB = A.EB[b];
                 double acc = 0.0;
                 if (aok) {
                     const double x = lds[ia + ib];
-                    acc = (eA + A.EB[b] + A.cross[impA + impB]) * x;
+                    acc = (eA + eB + A.cross[impA + impB]) * x;
 #pragma unroll
                     for (int q = 0; q < WA; q++) acc += valA[q] * lds[colA[q] + ib];
-                    for (int q = 0; q < A.wB; q++) acc += A.vB[(int64_t)q * A.ksB + (int64_t)b * A.bsB] * lds[ia + A.cB[(int64_t)q * A.ksB + (int64_t)b * A.bsB] * A.sB];
+#pragma unroll
+                    for (int q = 0; q < WB; q++) acc += (q < A.wB ? vb[q] : 0.0) * lds[ia + cb[q]];
                     acc -= beta * (VPREG ? vp[j] : A.vprev[ia + ib]);
                     asum += x * acc;
                 }
                 w[j] = acc;
             }
-            __builtin_amdgcn_sched_barrier(0);      // one element at a time: hoisting the loads of all E elements to the top costs more registers than a lane has
         }
         const double alpha = bsum(asum);
         double nsum = 0.0;

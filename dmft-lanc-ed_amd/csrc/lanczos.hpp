@@ -147,6 +147,7 @@ static int lz_iter_deferred(S *s, LzVecs &V, int k, double *acc)
         hipLaunchKernelGGL(k_scalar_step, dim3(1), dim3(1), 0, s->stream, s->scal.p, s->alphas.p, s->betas.p, (const double *)nullptr, k, 0);
         if (acc) hipLaunchKernelGGL(k_scalar_step, dim3(1), dim3(1), 0, s->stream, s->scal.p, s->alphas.p, s->betas.p, (const double *)s->zvec.p, k, 3);
         hipLaunchKernelGGL(k_axpy_norm, dim3(nb), dim3(256), 0, s->stream, V.w, V.ucur, acc, s->scal.p, s->vlen, s->partial.p);
+        HIPCHK(hipGetLastError());
     } else {
         hipLaunchKernelGGL(k_scalar_step, dim3(1), dim3(1), 0, s->stream, s->scal.p, s->alphas.p, s->betas.p, (const double *)nullptr, k, 10);
         HIPCHK(hipGetLastError());
@@ -159,6 +160,7 @@ static int lz_iter_deferred(S *s, LzVecs &V, int k, double *acc)
         CHK(allreduce_dev(s, s->scal.p + SC_PAIR, 2));
         hipLaunchKernelGGL(k_scalar_step, dim3(1), dim3(1), 0, s->stream, s->scal.p, s->alphas.p, s->betas.p, (const double *)(acc ? s->zvec.p : nullptr), k, 11);
         hipLaunchKernelGGL(k_axpy3_norm, dim3(nb), dim3(256), 0, s->stream, V.w, V.ucur, V.uprev, acc, s->scal.p, s->vlen, s->partial.p);
+        HIPCHK(hipGetLastError());
     }
     hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(1024), 0, s->stream, s->partial.p, (int64_t)nb, s->scal.p + SC_NPEND);
     HIPCHK(hipGetLastError());
@@ -260,7 +262,7 @@ static int fetch_coeffs(S *s, int k, std::vector<double> &al, std::vector<double
 }
 
 // ---- whole Lanczos loop in one workgroup (k_lanczos_wg): sectors of up to ~19 000 states -----------------------------------
-struct WgPlan { bool ok = false; bool a_is_up = true; int nC = 1, E = 1, emax = 8, wa = 6; };
+struct WgPlan { bool ok = false; bool a_is_up = true; int nC = 1, E = 1, emax = 8, wa = 6, wb = 6; };
 static WgPlan wg_plan(const S *s)
 {
     WgPlan P;
@@ -270,12 +272,12 @@ static WgPlan wg_plan(const S *s)
     if (N < 2 || N * 8 > 150 * 1024) return P;
     P.a_is_up = H.DimUp >= H.DimDw;
     const int64_t DimA = P.a_is_up ? H.DimUp : H.DimDw, DimB = P.a_is_up ? H.DimDw : H.DimUp;
-    const int wA = P.a_is_up ? s->upf->width : s->dwf->width;
-    if (DimA > 1024 || wA > 12) return P;
+    const int wA = P.a_is_up ? s->upf->width : s->dwf->width, wB = P.a_is_up ? s->dwf->width : s->upf->width;
+    if (DimA > 1024 || wA > 12 || wB > 12 || wB < 1) return P;
     int nC = 1; while (nC * 64 < DimA) nC *= 2;
     P.nC = nC; P.E = (int)cdiv(DimB, 16 / nC);
     if (P.E > 20) return P;
-    P.emax = P.E <= 8 ? 8 : (P.E <= 16 ? 16 : 20); P.wa = wA <= 6 ? 6 : 12;
+    P.emax = P.E <= 8 ? 8 : (P.E <= 16 ? 16 : 20); P.wa = wA <= 6 ? 6 : 12; P.wb = wB <= 6 ? 6 : 12;
     P.ok = true;
     return P;
 }
@@ -300,14 +302,15 @@ static int lanczos_wg_steps(S *s, const WgPlan &P, double *v, double *vprev, int
     A.v = v; A.vprev = vprev; A.alphas = s->alphas.p; A.betas = s->betas.p; A.k0 = k0; A.nsteps = nsteps; A.threshold = threshold;
     A.krylov = krylov; A.kstride = kstride; A.done = s->wg_done.p;
     const size_t lds = (size_t)(H.DimUp * H.DimDw) * 8;
-#define WG_LAUNCH(E_, W_, R_)                                                                                                   \
+#define WG_LAUNCH(E_, W_, B_, R_)                                                                                               \
     do {                                                                                                                            \
         static OncePerDevice once_;                                                                                                 \
-        if (once_.first(s->device)) (void)hipFuncSetAttribute((const void *)k_lanczos_wg<E_, W_, R_>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024); \
-        hipLaunchKernelGGL((k_lanczos_wg<E_, W_, R_>), dim3(1), dim3(1024), lds, s->stream, A);                                     \
+        if (once_.first(s->device)) (void)hipFuncSetAttribute((const void *)k_lanczos_wg<E_, W_, B_, R_>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024); \
+        hipLaunchKernelGGL((k_lanczos_wg<E_, W_, B_, R_>), dim3(1), dim3(1024), lds, s->stream, A);                                 \
     } while (0)
-    if (P.wa == 6) { if (P.emax == 8) WG_LAUNCH(8, 6, true); else if (P.emax == 16) WG_LAUNCH(16, 6, false); else WG_LAUNCH(20, 6, false); }
-    else { if (P.emax == 8) WG_LAUNCH(8, 12, true); else if (P.emax == 16) WG_LAUNCH(16, 12, false); else WG_LAUNCH(20, 12, false); }
+#define WG_E(W_, B_) do { if (P.emax == 8) WG_LAUNCH(8, W_, B_, true); else if (P.emax == 16) WG_LAUNCH(16, W_, B_, false); else WG_LAUNCH(20, W_, B_, false); } while (0)
+    if (P.wa == 6) { if (P.wb == 6) WG_E(6, 6); else WG_E(6, 12); } else { if (P.wb == 6) WG_E(12, 6); else WG_E(12, 12); }
+#undef WG_E
 #undef WG_LAUNCH
     HIPCHK(hipGetLastError());
     if (done) { HIPCHK(hipMemcpyAsync(done, s->wg_done.p, 4, hipMemcpyDeviceToHost, s->stream)); HIPCHK(hipStreamSynchronize(s->stream)); }
@@ -1240,6 +1243,7 @@ static int dvdson(S *s, int nev, int maxiter, double tol, double *evals, double 
     // restarted method then converges like the unrestarted one), so a small space loses no products while every pass over the
     // space is half as long as with the 16 vectors of rounds 2-3 (c3: 3.0 s -> profiles/r04/dvdson_c3.txt).
     int mmax = std::min<int64_t>(std::min<int64_t>(kMaxBasis, Dim), std::max(2 * nev + 6, 10));
+    { const int mx = XKNOB("EDGPU_DVD_MMAX", 0); if (mx > nev + 2) mmax = (int)std::min<int64_t>(std::min<int64_t>(kMaxBasis, Dim), mx); }      // experiments build: size of the search space
     const bool small = mmax <= 12 && s->dvd_fused_on;      // k_dvd_step: residual, correction and the Gram-Schmidt dots in one pass
     if (mmax <= nev) return fail(EDGPU_EINVAL, "edgpu_dvdson: too many eigenpairs requested for the search space");
     if (maxiter < 1) maxiter = 1;
@@ -1327,7 +1331,7 @@ static int dvdson(S *s, int nev, int maxiter, double tol, double *evals, double 
         }
         bool restarted = false;
         if (m == mmax) {     // thick restart (GD+1): lowest `keep` Ritz vectors + the previous iterate of the target pair, V and W rotated alike
-            int keep = std::min(mmax - 2, nev + 2);
+            int keep = std::min(mmax - 2, nev + XKNOB("EDGPU_DVD_KEEP", 2));
             std::vector<double> Cm((size_t)m * (keep + 1), 0.0);
             for (int j = 0; j < keep; j++) for (int i = 0; i < m; i++) Cm[(size_t)m * j + i] = Y[(size_t)m * j + i];
             double gpp = 0.0; bool plus = false;

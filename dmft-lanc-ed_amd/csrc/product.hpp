@@ -427,12 +427,15 @@ static int hxv(S *s, const double *v, double *out, bool epi, const double *uprev
         v = s->csr_xs.p; out = s->csr_ys.p;
     }
     if (multi) {  // start the exchange on the comm stream; local work overlaps it
+        s->packed_ahead = false;
+        if (s->halo && !s->tr_on) { CHK(halo_pack(s, v, s->stream)); s->packed_ahead = true; }      // the pack kernel first, alone, on the compute stream
         HIPCHK(hipEventRecord(s->ev_ready, s->stream));
         HIPCHK(hipStreamWaitEvent(s->cstream, s->ev_ready, 0));
         const bool timed = s->comm_slot >= 0 && 2 * s->comm_slot + 1 < (int)s->comm_ev.size();
         if (timed) HIPCHK(hipEventRecord(s->comm_ev[2 * s->comm_slot], s->cstream));
         if (s->tr_on) CHK(transposed_dw_pass(s, v, s->cstream));      // whole dw part, on the comm stream
         else CHK(gather_vector(s, v, s->cstream));
+        s->packed_ahead = false;
         if (timed) HIPCHK(hipEventRecord(s->comm_ev[2 * s->comm_slot + 1], s->cstream));
         HIPCHK(hipEventRecord(s->ev_gather, s->cstream));
     }

@@ -43,25 +43,28 @@ static int fail(int code, const std::string &msg) { g_err = msg; return code; }
 // /proc/self/maps (≈0.2 ms; entries that create sectors / communicators / device memory only).
 static int single_hip_runtime()
 {
-    std::vector<std::string> seen;
+    // one entry per FILE (device:inode column of /proc/self/maps): the same library reached through two mounts, or unlinked
+    // after it was mapped ("(deleted)"), is still one runtime
+    std::vector<std::string> ids, paths;
     if (FILE *f = fopen("/proc/self/maps", "r")) {
         char line[4096];
         while (fgets(line, sizeof(line), f)) {
             if (!strstr(line, "libamdhip64")) continue;
-            char *path = strchr(line, '/');
-            if (!path) continue;
-            path[strcspn(path, "\n")] = 0;
+            char dev[64] = "", path[4000] = ""; unsigned long long ino = 0;
+            if (sscanf(line, "%*s %*s %*s %63s %llu %3999[^\n]", dev, &ino, path) < 2) continue;
+            const std::string id = std::string(dev) + ":" + std::to_string(ino);
             bool dup = false;
-            for (auto &s : seen) dup = dup || s == path;
-            if (!dup) seen.push_back(path);
+            for (auto &s : ids) dup = dup || s == id;
+            if (!dup) { ids.push_back(id); paths.push_back(path); }
         }
         fclose(f);
     }
-    if (seen.size() <= 1) return EDGPU_OK;
-    std::string msg = "edgpu: " + std::to_string(seen.size()) + " copies of the HIP runtime are mapped in this process (";
-    for (size_t i = 0; i < seen.size(); i++) msg += (i ? ", " : "") + seen[i];
-    msg += "): load the embedding framework (e.g. `import torch`) BEFORE libedgpu.so so that both bind to one runtime, "
-           "or preload that runtime (LD_PRELOAD); continuing would end in heap corruption at process exit";
+    if (ids.size() <= 1) return EDGPU_OK;
+    std::string msg = "edgpu: " + std::to_string(ids.size()) + " copies of the HIP runtime are mapped in this process (";
+    for (size_t i = 0; i < paths.size(); i++) msg += (i ? ", " : "") + paths[i];
+    msg += "): load the embedding framework (e.g. `import torch`) BEFORE libedgpu.so so that both bind to one runtime, or preload that "
+           "runtime (LD_PRELOAD); a process that never loads such a framework sets EDGPU_HIP_RUNTIME=system in the Python binding; "
+           "continuing would end in heap corruption at process exit";
     return fail(EDGPU_EHIP, msg);
 }
 
@@ -253,6 +256,7 @@ struct edgpu_sector_s {
     // hops, the dw-type blocks always (their rows are uniform per idw row)
     bool csr_il_loc = false, csr_il_dw = false; bool csrL_nt = false;
     int csr_loc_cnt = 0;      // entries per row of the local block when every row has the same number (half-filled up sector: 1 + Ns/2), else 0
+    bool packed_ahead = false;      // hxv has packed the send rows on the compute stream already (halo_pack): halo_exchange does not pack again
     bool x_own_in_v = false;  // several ranks, stored-factor / on-the-fly forms with the needed-rows exchange: the dw pass reads the rank's own rows from the input vector, the x-space only holds received rows
     bool dvd_fused_on = true; // EDGPU_DVD_FUSED: Davidson step with residual, correction and Gram-Schmidt dots in one pass (k_dvd_step)
     bool lz_wg_on = true;     // EDGPU_LZ_WG: sectors that fit LDS run their Lanczos loops in one workgroup (k_lanczos_wg)

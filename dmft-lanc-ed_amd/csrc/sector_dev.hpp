@@ -501,16 +501,7 @@ static int create(const edgpu_desc *desc, S **out)
     if (desc->device >= 0) HIPCHK(hipSetDevice(desc->device));
     HIPCHK(hipGetDevice(&s->device));
     HIPCHK(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
-    {   // the comm stream carries the packing kernel and the exchange, which the dw pass waits for: highest priority, so that its
-        // workgroups are dispatched ahead of the local pass that runs beside it (emulated rank of eight: k_pack_rows took 0.62 ms
-        // next to the local block where it takes 0.12 ms alone, profiles/r04/rank_of_8_ns16csr.txt)
-        int lo = 0, hi = 0;
-        if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) { (void)hipGetLastError(); hi = 0; }
-#ifdef EDGPU_NO_PRIO
-        hi = 0;
-#endif
-        HIPCHK(hipStreamCreateWithPriority(&s->cstream, hipStreamNonBlocking, hi));
-    }
+    HIPCHK(hipStreamCreateWithFlags(&s->cstream, hipStreamNonBlocking));
     HIPCHK(hipEventCreate(&s->ev_a)); HIPCHK(hipEventCreate(&s->ev_b));
     HIPCHK(hipEventCreateWithFlags(&s->ev_gather, hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&s->ev_ready, hipEventDisableTiming));
     SectorHost &H = s->H;

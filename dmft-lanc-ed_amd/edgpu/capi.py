@@ -69,18 +69,23 @@ class EdgpuError(RuntimeError):
 
 
 def mapped_hip_runtimes():
-    """distinct libamdhip64 files mapped into this process (/proc/self/maps)"""
-    seen = []
+    """distinct libamdhip64 FILES mapped into this process (/proc/self/maps, one entry per device:inode -- the same library seen
+    through two mounts or marked '(deleted)' is one runtime); returns their paths"""
+    seen, paths = set(), []
     try:
         with open("/proc/self/maps") as f:
             for line in f:
-                if "libamdhip64" in line:
-                    path = line[line.index("/"):].strip()
-                    if path not in seen:
-                        seen.append(path)
+                if "libamdhip64" not in line:
+                    continue
+                parts = line.split(None, 5)
+                if len(parts) < 6:
+                    continue
+                key = (parts[3], parts[4])
+                if key not in seen:
+                    seen.add(key); paths.append(parts[5].strip())
     except OSError:
         pass
-    return seen
+    return paths
 
 
 def _preload_embedding_hip_runtime():
@@ -109,9 +114,10 @@ def _preload_embedding_hip_runtime():
 def assert_single_hip_runtime():
     rt = mapped_hip_runtimes()
     if len(rt) > 1:
-        raise ImportError("%d copies of the HIP runtime are mapped in this process (%s): import torch BEFORE edgpu, or leave "
-                          "EDGPU_HIP_RUNTIME unset so that edgpu binds to PyTorch's copy; continuing would corrupt the heap at exit"
-                          % (len(rt), ", ".join(rt)))
+        raise ImportError("%d copies of the HIP runtime are mapped in this process (%s): import torch BEFORE edgpu; or, in a process that "
+                          "imports edgpu first, leave EDGPU_HIP_RUNTIME unset so that edgpu binds to the installed PyTorch's copy; or, when the "
+                          "preloaded copy is not the one libedgpu.so resolves to (different SONAME), set EDGPU_HIP_RUNTIME=system and do not "
+                          "import torch in that process; continuing would corrupt the heap at exit" % (len(rt), ", ".join(rt)))
 
 
 def lib():

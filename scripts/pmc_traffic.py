@@ -18,7 +18,7 @@ def source_stamp():      # same digest as bench.py: the summary is only quoted w
 
 
 STAMP = source_stamp()
-PRODUCT = {"csr": ("k_csr_spmv2", "k_csr_il"), "kron": ("k_uppass", "k_dwpass"), "direct": ("k_uppass", "k_dwpass", "k_direct_tables")}
+PRODUCT = {"csr": ("k_csr_spmv2", "k_csr_il", "k_csr_loc_ax"), "kron": ("k_uppass", "k_dwpass"), "direct": ("k_uppass", "k_dwpass")}      # the on-the-fly tables are derived once per sector (first product), not per product
 out = []
 for st, prefixes in PRODUCT.items():
     per = {}
@@ -34,12 +34,12 @@ for st, prefixes in PRODUCT.items():
         per[cn] = {k: (s / n, n) for k, (s, n) in acc.items()}
     if not per["FETCH_SIZE"]:
         continue
-    # a product launches each kernel name once, except the tables kernel (twice: up and dw factor)
+    # a product (or fused iteration) launches each kernel name once
     tot = 0.0
     print("== storage=%s" % st)
     for kn in sorted(per["FETCH_SIZE"]):
         fs, n = per["FETCH_SIZE"][kn]; ws = per["WRITE_SIZE"].get(kn, (0.0, 0))[0]
-        mult = 2 if "k_direct_tables" in kn else 1
+        mult = 1
         b = (2 * fs + ws) * 1024 * mult
         # only the Lanczos-fused (epilogue) instantiations belong to the timed loop
         print("  %-50s FETCH_SIZE %.4g KiB  WRITE_SIZE %.4g KiB  -> %.3f GB per product (n=%d)" % (kn, fs, ws, b / 1e9, n))
@@ -53,10 +53,10 @@ for st, prefixes in PRODUCT.items():
         for r in csv.DictReader(open(stats)):
             kn = r["Name"].split("(")[0].replace("void edgpu::", "").replace("edgpu::", "")
             if kn in per["FETCH_SIZE"]:
-                rp_ms += float(r["AverageNs"]) * 1e-6 * (2 if "k_direct_tables" in kn else 1)
+                rp_ms += float(r["AverageNs"]) * 1e-6
         print("  kernel time per product under rocprofv3: %.3f ms" % rp_ms)
     out.append({"storage": st, "nbath": 15, "n_gpus": 1, "hbm_bytes_per_launch": tot, "source_stamp": STAMP, "kernels": sorted(per["FETCH_SIZE"]),
                 "rocprof_kernel_ms_per_product": rp_ms,
-                "file": "profiles/%s/pmc_traffic_summary.txt" % os.environ.get("EDGPU_PROFILE_ROUND", "r03"),
+                "file": "profiles/%s/pmc_traffic_summary.txt" % os.environ.get("EDGPU_PROFILE_ROUND", "r04"),
                 "source": "profiles: (2*FETCH_SIZE + WRITE_SIZE)*1024 per dispatch, summed over the kernels of one product (%s); FETCH_SIZE doubled per MI355X_MICROARCH.md (64 B tallied per 128-B request); fabric-side count, Infinity-Cache hits included" % ", ".join(sorted(per["FETCH_SIZE"]))})
 json.dump(out, open(os.path.join(root, "pmc_traffic.json"), "w"), indent=1)

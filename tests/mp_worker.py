@@ -12,6 +12,8 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "dmft-lanc-ed_am
 
 def main():
     mode, case, outdir = sys.argv[1], sys.argv[2], sys.argv[3]
+    import faulthandler
+    faulthandler.dump_traceback_later(110, exit=False)      # a rank that is stuck says where (the launcher gives up after 150 s)
     import torch.distributed as dist
     rank, size = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%s" % os.environ["MASTER_PORT"], rank=rank, world_size=size)
