@@ -31,7 +31,6 @@ sys.path.insert(0, os.path.join(ROOT, "dmft-lanc-ed_amd"))
 
 HBM_PEAK_GBPS = 8000.0  # MI355X spec, /opt/skills/guides/MI355X_MICROARCH.md
 KERNELS = {"csr": "k_csr_il<false,0> (local block) + k_csr_il<true,1> (dw block): one product of the split explicit CSR, 64-row blocks stored lane-major",
-           "csr_fused": "k_csr_loc_ax (LDS-row local block carrying the axpy+norm of the previous iteration) + k_csr_il<true,1> (dw block carrying scale, -beta*u_prev and the alpha dot): one fused Lanczos iteration on the split explicit CSR",
            "kron": "k_uppass2_ax + k_dwpass2 (fused Lanczos iteration over the stored factors: axpy+norm+local pass, dw pass+scale+dot)",
            "direct": "k_uppass2_ax<DIRECT> + k_dwpass2 (fused Lanczos iteration, on-the-fly operator; the hop tables are derived from the bit patterns once per sector, k_direct_tables_wave)"}
 
@@ -39,7 +38,7 @@ KERNELS = {"csr": "k_csr_il<false,0> (local block) + k_csr_il<true,1> (dw block)
 BOUND_NOTE = {"csr": "explicit CSR inside the Lanczos loop is bounded at 0.57-0.60 of the 8 TB/s peak on this device: the split form moves 43.1 GB per product "
                      "(37.8 algorithmic + 4.0 second read of x and read-modify-write of the result + 1.3 u_prev) and every read/write mix measured here runs at "
                      "5.3-6.1 TB/s depending on the box (pure reads 7.07): floor 7.1-7.4 ms, measured 7.9-8.3 ms (HIP events) / +3-4 % under rocprofv3; "
-                     "DESIGN.md section 4.  Round 4: the axpy+norm pass rides in an LDS-row form of the local block (fused iteration, 8.7 ms against 9.0 ms per step on the same box)"}
+                     "DESIGN.md section 4.  Round 4: a fused iteration (axpy+norm pass inside an LDS-row form of the local block) was built and measured on four boxes: -3.4 %, +1 %, +5 % per step -- not shipped (profiles/r04/csr_fused_iteration.txt)"}
 
 
 def b_csr(N, nnz):
@@ -358,12 +357,8 @@ def main():
     Nloc = int(G.vecDim); nnz_loc = int(G.info.nnz_total)
     ms_step = dt / K * 1e3
     bytes_fmt = {"csr": b_csr(Nloc, nnz_loc), "kron": 24 * Nloc, "direct": 16 * Nloc}[a.storage]
-    # The timed bracket (HIP events around the product kernels of every step).  In the fused iteration those two kernels ARE the
-    # Lanczos iteration: they also carry the vector updates, whose algorithmic bytes SURVEY 8(d) states next to the product's
-    # ("full Lanczos iteration = 1 HxV + fused vector updates; algorithmic extra bytes ~ 40*N": read w, v, v_prev; write w, v_next).
-    fused_csr = a.storage == "csr" and bool(G.lanczos_fused)
-    kernel_key = "csr_fused" if fused_csr else a.storage
-    bytes_bracket = bytes_fmt + (40 * Nloc if fused_csr else 0)
+    kernel_key = a.storage
+    bytes_bracket = bytes_fmt
     par = "single GPU"
     if multi:
         par = "dw-column split x%d (ED_HAMILTONIAN.f90:96-110), %s exchange per product over %s" % (
@@ -382,11 +377,7 @@ def main():
                      "achieved": bytes_bracket / (hxv_ms * 1e-3) / 1e9 if hxv_ms > 0 else None, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": (bytes_bracket / (hxv_ms * 1e-3) / 1e9) / HBM_PEAK_GBPS if hxv_ms > 0 else None,
                      "algorithmic_bytes_per_launch": bytes_bracket, "kernel_ms": hxv_ms, "traffic": None,
-                     "algorithmic_bytes_are": ("B_csr + 40*N: the two kernels of the bracket are one fused Lanczos iteration = one product of the explicit CSR (B_csr = 12*nnz + 8*(N+1) + 16*N) "
-                                               "plus the vector updates it carries (SURVEY 8d: 40 B per row)" if fused_csr else
-                                               "algorithmic bytes of one product in the storage that is streamed (SURVEY 8d)"),
-                     "product_bytes_only": bytes_fmt,
-                     "frac_counting_product_bytes_only": (bytes_fmt / (hxv_ms * 1e-3) / 1e9) / HBM_PEAK_GBPS if hxv_ms > 0 else None,
+                     "algorithmic_bytes_are": "algorithmic bytes of one product in the storage that is streamed (SURVEY 8d); for storage=csr: B_csr = 12*nnz + 8*(N+1) + 16*N",
                      "bound_note": BOUND_NOTE.get(a.storage)},
         "time_split_ms": dict({"hxv_product": hxv_ms, "axpy_norm_reductions_scalars": ms_step - hxv_ms},
                               **({"exchange_on_comm_stream_overlapped_with_local_blocks": comm_ms} if multi else {})),

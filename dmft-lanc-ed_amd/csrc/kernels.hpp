@@ -103,6 +103,27 @@ __device__ __forceinline__ double wave_sum(double x)
     for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
     return x;
 }
+// the same sum through the DPP network (no LDS crossbar round trips): quad permutes, row shifts, row broadcasts; the total ends up
+// in lane 63 and is broadcast from there.  Every lane of the wave must be active.
+template <int CTRL, int ROW_MASK = 0xf>
+__device__ __forceinline__ double dpp_mov_f64(double x)
+{
+    int lo = __double2loint(x), hi = __double2hiint(x);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wave_sum_dpp(double x)
+{
+    x += dpp_mov_f64<0xb1>(x);             // quad_perm [1,0,3,2]
+    x += dpp_mov_f64<0x4e>(x);             // quad_perm [2,3,0,1]
+    x += dpp_mov_f64<0x114>(x);            // row_shr 4   (lanes 4.. of a row; lanes 0-3 add 0: old value 0, bound_ctrl off -> keeps old = 0)
+    x += dpp_mov_f64<0x118>(x);            // row_shr 8
+    x += dpp_mov_f64<0x142, 0xa>(x);       // row_bcast 15 -> rows 1 and 3
+    x += dpp_mov_f64<0x143, 0xc>(x);       // row_bcast 31 -> rows 2 and 3
+    const int lo = __builtin_amdgcn_readlane(__double2loint(x), 63), hi = __builtin_amdgcn_readlane(__double2hiint(x), 63);
+    return __hiloint2double(hi, lo);
+}
 __device__ __forceinline__ double block_sum(double x, double *scratch /* >= blockDim/64 doubles */)
 {
     x = wave_sum(x);
@@ -1731,7 +1752,6 @@ struct CsrArgs {
     const int64_t *rowbase; const int32_t *rowcnt;
     int64_t ld;             // row pitch of x / y / uprev / v_local in doubles (the stored columns index that space); rowptr stays dense
     const int64_t *cpre;    // lane-major dw-type blocks stored tile-major (k_csr_il only): block (jb, idw) starts at jb*64*cpre[Qdw] + rows(jb)*cpre[idw]
-    const double *uprev2;   // fused Lanczos iteration (last block, epi): y holds the UNSCALED local part; y = s_cur*(y + this block) - beta*s_prev*uprev2
 };
 
 // Row-block CSR product.  A workgroup owns `rows_per_block` consecutive rows of one idw row.  Their
@@ -1820,12 +1840,11 @@ __global__ void __launch_bounds__(64) k_csr_il(CsrArgs A)
         p0 = ((int64_t)__builtin_amdgcn_readfirstlane((int)(ra >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(ra & 0xffffffffll));
         cnt = __builtin_amdgcn_readfirstlane((int)(re - ra)); len = act ? (int)(re - ra) : 0;
     }
-    double up_i = 0.0, xl_i = 0.0, up2_i = 0.0;
+    double up_i = 0.0, xl_i = 0.0;
     if (act) {
         if (A.epi && A.pass < 2) up_i = A.uprev[vrow0 + tid];
         if (A.epi && (A.pass == 0 || A.pass == 2)) xl_i = A.v_local[vrow0 + tid];
         if (A.pass >= 2) up_i = A.y[vrow0 + tid];        // running value of the earlier blocks
-        if (A.uprev2) up2_i = A.uprev2[vrow0 + tid];
     }
     double s_cur = 1.0, c_prev = 0.0, asum = 0.0;
     if (A.epi) { s_cur = A.scal[SC_SCUR]; c_prev = A.scal[SC_BETA] * A.scal[SC_SPREV]; }
@@ -1870,112 +1889,11 @@ __global__ void __launch_bounds__(64) k_csr_il(CsrArgs A)
         }
         const int64_t row = vrow0 + tid;
         if (A.epi) {
-            const double w = A.uprev2 ? s_cur * (up_i + acc) - c_prev * up2_i : (A.pass >= 2 ? up_i + s_cur * acc : s_cur * acc - c_prev * up_i);
+            const double w = A.pass >= 2 ? up_i + s_cur * acc : s_cur * acc - c_prev * up_i;
             A.y[row] = w; asum = (s_cur * xl_i) * w;
         } else A.y[row] = A.pass >= 2 ? up_i + acc : acc;
     }
     if (A.epi && (A.pass == 0 || A.pass == 2)) { double r = block_sum(asum, red); if (tid == 0) A.partial[blockIdx.x] = r; }
-}
-
-// Local half of the FUSED Lanczos iteration on the explicit CSR (round 4; the stored-factor form is k_uppass2_ax).  The three-pass
-// loop of the explicit storage ends every iteration with w -= alpha v, beta^2 = w.w over three vectors (k_axpy_norm, 0.75 ms of a
-// 9 ms iteration at c3); that pass has the operands of the NEXT iteration's local block, whose gathers stay inside one idw row.
-// A persistent 1024-thread workgroup per idw row forms u_k = r_{k-1} - (alpha s) u_{k-1} on its way into LDS (written back over
-// r, |u_k|^2 summed), then its 16 waves stream the lane-major 64-row blocks of the row's local block (diagonal + up hops, 12 B
-// per entry, row pointer read as before) and gather x from the LDS image (column - idw*ld) instead of from L2; T = unscaled
-// local part.  The dw block (k_csr_il with uprev2) applies the scale, subtracts beta u_{k-1} and takes the alpha dot.
-// The next row's r / u_prev pairs are requested one block step ahead and combined there (as k_uppass2_ax does).
-// Per wave a three-deep pipeline over its blocks: row pointer of block it+2, entries of block it+1 (18 coalesced loads in flight
-// while block it gathers), gathers + result of block it; the next row's r / u_prev pair of the step is requested one step ahead
-// and combined there, so the row switch only re-reads the finished u (written by the same lane, L2-hot) into LDS.
-struct CsrAxArgs {
-    int32_t DimUp; int64_t Qdw, ld;
-    const int64_t *rowptr; const int32_t *cols; const double *vals;
-    double *r; const double *vprev; double *t_out;
-    const double *scal; double *partial; double *acc; const double *zvec;
-};
-template <int C, bool ACC>
-__global__ void __launch_bounds__(1024) k_csr_loc_ax(CsrAxArgs A)
-{
-    extern __shared__ double lds[];
-    constexpr int NT = 1024;
-    const int DimUp = A.DimUp, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int npair = (DimUp + 1) >> 1;                  // the last pair of an odd row ends in the (zero) padding column of the pitched vectors
-    const int64_t ld = A.ld;
-    double *red = lds + ((DimUp + 2) & ~1);
-    const int nq = (npair + NT - 1) / NT;
-    const int nblk = (DimUp + 63) >> 6, nit = (nblk + 15) >> 4;      // 64-row blocks of a row; block steps of a wave (nit >= nq)
-    const double c_ax = A.scal[SC_ALPHA] * A.scal[SC_SCUR];          // alpha_{k-1} * s_{k-1}  (0 at k = 0)
-    const double zk = ACC ? A.zvec[(int)A.scal[SC_K]] : 0.0;
-    double bsum = 0.0;
-    auto combine = [&](int64_t rw, int p, const dbl2v &r, const dbl2v &v) -> dbl2v {
-        const dbl2v u = r - c_ax * v;
-        *reinterpret_cast<dbl2v *>(A.r + rw * ld + 2 * p) = u;
-        bsum += u.x * u.x + u.y * u.y;
-        if (ACC) { dbl2v *pa = reinterpret_cast<dbl2v *>(A.acc + rw * ld + 2 * p); *pa = *pa + zk * u; }
-        return u;
-    };
-    const int pmax = npair - 1;
-    struct Ent { double v[C]; int32_t c[C]; };
-    struct Rp { int64_t ra; int nr, iup0, len; bool valid; };
-    // the block sequence of a wave runs on across rows: (row, wv), (row, wv+16), ..., (row + grid, wv), ...; step t of the pipeline
-    // requests the row pointer of block t+2 and the entries of block t+1 while block t gathers, also across a row switch
-    auto blk_ptr = [&](int64_t rw, int it) -> Rp {
-        Rp R; const int jb = wv + 16 * it; R.valid = jb < nblk && rw < A.Qdw;
-        const int jc = jb < nblk ? jb : nblk - 1; const int64_t rc = rw < A.Qdw ? rw : A.Qdw - 1;
-        R.iup0 = jc * 64; R.nr = DimUp - R.iup0; R.nr = R.nr > 64 ? 64 : R.nr;
-        // the row pointer is streamed as by k_csr_il: lane l reads rowptr[l] and rowptr[l+1] of its row; block start = first lane's
-        const int l = lane < R.nr ? lane : 0;
-        const int64_t ra = A.rowptr[rc * DimUp + R.iup0 + l], re = A.rowptr[rc * DimUp + R.iup0 + l + 1];
-        R.ra = ra - (int64_t)l * C; R.len = (int)(re - ra);      // rows of a block have C entries each (the host selects this kernel only then): start of the block
-        return R;
-    };
-    auto load_ent = [&](const Rp &R, Ent &E) {
-        const int l = lane < R.nr ? lane : 0;
-        const double *pv = A.vals + R.ra + l; const int32_t *pc = A.cols + R.ra + l;
-#pragma unroll
-        for (int e = 0; e < C; e++) { E.v[e] = pv[(int64_t)e * R.nr]; E.c[e] = pc[(int64_t)e * R.nr]; }
-    };
-    auto advance = [&](int64_t &rw, int &it) { if (++it == nit) { it = 0; rw += gridDim.x; } };
-    int64_t prow = blockIdx.x; int pit = 0;              // position of the row-pointer prefetch: two blocks ahead of the one that gathers
-    Rp r0 = blk_ptr(prow, pit); advance(prow, pit);
-    Rp r1 = blk_ptr(prow, pit); advance(prow, pit);
-    Ent cur, nxt;
-    if (r0.valid) load_ent(r0, cur);
-    bool first = true;
-    for (int64_t row = blockIdx.x; row < A.Qdw; row += gridDim.x) {
-        const int64_t next = row + gridDim.x; const bool more = next < A.Qdw;
-        const int64_t nrow = more ? next : row;          // no branch around a prefetch load: the last row loads itself again
-        for (int q = 0; q < nq; q++) {
-            const int p = tid + q * NT;
-            if (p < npair) {
-                dbl2v u;
-                if (first) u = combine(row, p, *reinterpret_cast<const dbl2v *>(A.r + row * ld + 2 * p), *reinterpret_cast<const dbl2v *>(A.vprev + row * ld + 2 * p));
-                else u = *reinterpret_cast<const dbl2v *>(A.r + row * ld + 2 * p);      // formed during the previous row's block steps, by this lane
-                *reinterpret_cast<dbl2v *>(lds + 2 * p) = u;
-            }
-        }
-        first = false;
-        __syncthreads();
-        const int64_t xoff = row * ld;                   // stored columns index the pitched vector space: LDS index = column - row*ld
-        for (int it = 0; it < nit; it++) {
-            const Rp r2 = blk_ptr(prow, pit); advance(prow, pit);
-            dbl2v pr, pvv;                               // pair `it` of the next row: requested here, combined at the end of the step
-            { int p = tid + it * NT; p = p < npair ? p : pmax; pr = *reinterpret_cast<const dbl2v *>(A.r + nrow * ld + 2 * p); pvv = *reinterpret_cast<const dbl2v *>(A.vprev + nrow * ld + 2 * p); }
-            if (r1.valid) load_ent(r1, nxt);             // wave-uniform
-            if (r0.valid && lane < r0.nr && r0.len == C) {
-                double a0 = 0.0, a1 = 0.0;
-#pragma unroll
-                for (int e = 0; e < C; e++) { const double xv = lds[cur.c[e] - xoff]; if (e & 1) a1 += cur.v[e] * xv; else a0 += cur.v[e] * xv; }
-                A.t_out[row * ld + r0.iup0 + lane] = a0 + a1;
-            }
-            if (more && it < nq) { const int p = tid + it * NT; if (p < npair) combine(next, p, pr, pvv); }
-            r0 = r1; r1 = r2; cur = nxt;
-        }
-        __syncthreads();
-    }
-    const double rr = block_sum(bsum, red);
-    if (tid == 0) A.partial[blockIdx.x] = rr;
 }
 
 template <int ROWS, int CAPN, bool NT>
@@ -1997,14 +1915,13 @@ __global__ void __launch_bounds__(ROWS) k_csr_spmv2(CsrArgs A)
     else { p0 = A.rowptr[row0]; n = (int)(A.rowptr[row0 + nr] - p0); }
     const int sh = (int)(p0 & 3);
     int ra = 0, re = 0;
-    double up_i = 0.0, xl_i = 0.0, up2_i = 0.0;   // epilogue operands, requested before the stream so their latency hides under it
+    double up_i = 0.0, xl_i = 0.0;   // epilogue operands, requested before the stream so their latency hides under it
     if (tid < nr) {
         if (A.rowbase) { ra = tid * ucnt + sh; re = ra + ucnt; }
         else { ra = (int)(A.rowptr[row0 + tid] - p0) + sh; re = (int)(A.rowptr[row0 + tid + 1] - p0) + sh; }
         if (A.epi && A.pass < 2) up_i = A.uprev[vrow0 + tid];
         if (A.epi && (A.pass == 0 || A.pass == 2)) xl_i = A.v_local[vrow0 + tid];
         if (A.pass >= 2) up_i = A.y[vrow0 + tid];        // running value of the earlier blocks
-        if (A.uprev2) up2_i = A.uprev2[vrow0 + tid];
     }
     {
         const double *gv = A.vals + (p0 - sh); const int32_t *gc = A.cols + (p0 - sh);   // 4-aligned base
@@ -2039,7 +1956,7 @@ __global__ void __launch_bounds__(ROWS) k_csr_spmv2(CsrArgs A)
         for (; k < re; k++) acc0 += sval[k] * A.x[scol[k]];
         const double acc = acc0 + acc1;
         if (A.epi) {
-            const double w = A.uprev2 ? s_cur * (up_i + acc) - c_prev * up2_i : (A.pass >= 2 ? up_i + s_cur * acc : s_cur * acc - c_prev * up_i);
+            const double w = A.pass >= 2 ? up_i + s_cur * acc : s_cur * acc - c_prev * up_i;
             A.y[row] = w; asum = (s_cur * xl_i) * w;
         } else A.y[row] = A.pass >= 2 ? up_i + acc : acc;
     }
@@ -2286,7 +2203,7 @@ __global__ void __launch_bounds__(1024) k_reduce_final_step(const double *__rest
 }
 
 // ---------------------------------------------------------------------------------------------
-// Whole Lanczos loop of a SMALL sector in ONE workgroup (round 4).  A sector of N <= 16 384 states is launch bound: an
+// Whole Lanczos loop of a SMALL sector in ONE workgroup (round 4).  A sector of N <= ~8 000 states (8 elements per lane) is launch bound: an
 // iteration of the device loop above is four kernels of a few microseconds of work each, 24-30 us in all (profiles/r03/
 // small_sectors.txt), and the reference's everyday sectors (Ns <= 12, O(Ns^2) of them per DMFT iteration, 200-step legs per
 // state: ED_DIAG.f90:83-276, ED_GF_NORMAL.f90:224-239) are of that size.  Here 1024 threads keep v_k in LDS (the gathers of
@@ -2303,12 +2220,31 @@ struct LzWgArgs {
     int32_t nC, E;                         // chunks of A (power of two, <= 16); B rows per wave
     const int32_t *cA; const double *vA; int32_t wA, ksA, asA;      // hop entry k of configuration a: cA[k*ksA + a*asA]
     const int32_t *cB; const double *vB; int32_t wB, ksB, bsB;
+    const uint32_t *brec;                  // per row b of the uniform dimension ONE record (k_wg_pack_b): WB pre-scaled columns | WB amplitudes | E_b | impurity word * multB
     const double *EA, *EB; const int32_t *mapA, *mapB; const double *cross; int32_t multA, multB, impmask; double econst;
     double *v, *vprev;                     // v_k (any norm on entry when k0 == 0), v_{k-1}; both updated for a following launch
     double *alphas, *betas; int32_t k0, nsteps; double threshold;
     double *krylov; int64_t kstride;       // optional: v_k stored at krylov + k*kstride
     int32_t *done;                         // out: iterations completed (k0 + nsteps, or fewer when beta fell below the threshold)
 };
+// record of row b: dwords [0, WB): column * sB (slots beyond the row's width: 0 with amplitude 0.0) | [WB, 3*WB): amplitudes | E_b | imp * multB | pad
+template <int WB> struct WgRec { static constexpr int kDwords = (3 * WB + 3 + 3) & ~3; };
+template <int WB>
+__global__ void __launch_bounds__(64) k_wg_pack_b(LzWgArgs A, uint32_t *rec)
+{
+    const int b = blockIdx.x * 64 + threadIdx.x;
+    if (b >= A.DimB) return;
+    uint32_t *r = rec + (int64_t)b * WgRec<WB>::kDwords;
+    for (int q = 0; q < WB; q++) {
+        const bool h = q < A.wB;
+        const int32_t c = h ? A.cB[(int64_t)q * A.ksB + (int64_t)b * A.bsB] * A.sB : 0;
+        const double v = h ? A.vB[(int64_t)q * A.ksB + (int64_t)b * A.bsB] : 0.0;
+        r[q] = (uint32_t)c; r[WB + 2 * q] = (uint32_t)__double2loint(v); r[WB + 2 * q + 1] = (uint32_t)__double2hiint(v);
+    }
+    const double e = A.EB[b];
+    r[3 * WB] = (uint32_t)__double2loint(e); r[3 * WB + 1] = (uint32_t)__double2hiint(e);
+    r[3 * WB + 2] = (uint32_t)((A.mapB[b] & A.impmask) * A.multB);
+}
 // VPREG: v_{k-1} stays in registers (EMAX <= 8); otherwise it lives in A.vprev (L2-resident, 8 bytes read and written per element
 // and iteration) -- with 16-20 elements per lane two register arrays do not fit 128 registers
 template <int EMAX, int WA, int WB, bool VPREG>
@@ -2327,7 +2263,7 @@ __global__ void __launch_bounds__(1024) k_lanczos_wg(LzWgArgs A)
     for (int k = 0; k < WA; k++) { const bool h = k < A.wA; colA[k] = h ? A.cA[(int64_t)k * A.ksA + (int64_t)ac * A.asA] * A.sA : 0; valA[k] = (h && aok) ? A.vA[(int64_t)k * A.ksA + (int64_t)ac * A.asA] : 0.0; }
     const double eA = A.EA[ac] + A.econst; const int impA = (A.mapA[ac] & A.impmask) * A.multA;
     auto bsum = [&](double x) -> double {      // sum over the workgroup, same value on every thread
-        x = wave_sum(x);
+        x = wave_sum_dpp(x);
         __syncthreads();
         if (lane == 0) red[wv] = x;
         __syncthreads();
@@ -2370,18 +2306,17 @@ __global__ void __launch_bounds__(1024) k_lanczos_wg(LzWgArgs A)
             const int b = __builtin_amdgcn_readfirstlane(b0v + TB * j);
             if (j < A.E && b < A.DimB) {
                 const int ib = b * A.sB, ia = a * A.sA;
-                // the hop list of row b: wave-uniform, i.e. scalar loads -- all WB of them requested before the first is used (one
-                // after the other inside the hop loop they were a chain of ~300-cycle round trips: 42 us per iteration at N = 14 520);
-                // slots beyond the row's width re-read the last entry with amplitude 0
+                // the hop list of row b is wave-uniform: ONE record per row (k_wg_pack_b), read with a few wide scalar loads through
+                // the constant address space (the tables are not written while the kernel runs; only a load the compiler knows to be
+                // invariant becomes a scalar load).  Entry by entry out of the ELL images it was 2*WB loads with 64-bit index
+                // arithmetic and a wait each: 178 instructions and ~14 serial round trips per element.
+                typedef const __attribute__((address_space(4))) uint32_t *cu32;
+                const cu32 rb = (cu32)(uintptr_t)A.brec + (int64_t)b * WgRec<WB>::kDwords;
                 int cb[WB]; double vb[WB];
 #pragma unroll
-                for (int q = 0; q < WB; q++) {
-                    const int qc = q < A.wB ? q : A.wB - 1;
-                    cb[q] = A.cB[(int64_t)qc * A.ksB + (int64_t)b * A.bsB] * A.sB;
-                    vb[q] = A.vB[(int64_t)qc * A.ksB + (int64_t)b * A.bsB];
-                }
-                const int impB = (A.mapB[b] & A.impmask) * A.multB;
-                const double eB = A.EB[b];
+                for (int q = 0; q < WB; q++) { cb[q] = (int)rb[q]; vb[q] = __hiloint2double((int)rb[WB + 2 * q + 1], (int)rb[WB + 2 * q]); }
+                const double eB = __hiloint2double((int)rb[3 * WB + 1], (int)rb[3 * WB]);
+                const int impB = (int)rb[3 * WB + 2];
                 double acc = 0.0;
                 if (aok) {
                     const double x = lds[ia + ib];
@@ -2389,12 +2324,19 @@ __global__ void __launch_bounds__(1024) k_lanczos_wg(LzWgArgs A)
 #pragma unroll
                     for (int q = 0; q < WA; q++) acc += valA[q] * lds[colA[q] + ib];
 #pragma unroll
-                    for (int q = 0; q < WB; q++) acc += (q < A.wB ? vb[q] : 0.0) * lds[ia + cb[q]];
-                    acc -= beta * (VPREG ? vp[j] : A.vprev[ia + ib]);
-                    asum += x * acc;
+                    for (int q = 0; q < WB; q++) acc += vb[q] * lds[ia + cb[q]];
+                    if (VPREG) { acc -= beta * vp[j]; asum += x * acc; }
                 }
                 w[j] = acc;
             }
+            __builtin_amdgcn_sched_barrier(0);      // one element's scalar loads at a time: hoisted across elements they spill the scalar registers into lanes
+        }
+        if (!VPREG) {      // v_{k-1} from L2: every element's value requested before the first is used (one exposed round trip per iteration, not E)
+            double t[EMAX];
+#pragma unroll
+            for (int j = 0; j < EMAX; j++) { const int b = b0v + TB * j; t[j] = (j < A.E && aok && b < A.DimB) ? A.vprev[a * A.sA + b * A.sB] : 0.0; }
+#pragma unroll
+            for (int j = 0; j < EMAX; j++) { const int b = b0v + TB * j; if (j < A.E && aok && b < A.DimB) { w[j] -= beta * t[j]; asum += lds[a * A.sA + b * A.sB] * w[j]; } }
         }
         const double alpha = bsum(asum);
         double nsum = 0.0;

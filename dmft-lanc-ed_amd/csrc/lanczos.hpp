@@ -261,7 +261,7 @@ static int fetch_coeffs(S *s, int k, std::vector<double> &al, std::vector<double
     return EDGPU_OK;
 }
 
-// ---- whole Lanczos loop in one workgroup (k_lanczos_wg): sectors of up to ~19 000 states -----------------------------------
+// ---- whole Lanczos loop in one workgroup (k_lanczos_wg): sectors of up to ~8 000 states -----------------------------------
 struct WgPlan { bool ok = false; bool a_is_up = true; int nC = 1, E = 1, emax = 8, wa = 6, wb = 6; };
 static WgPlan wg_plan(const S *s)
 {
@@ -276,8 +276,8 @@ static WgPlan wg_plan(const S *s)
     if (DimA > 1024 || wA > 12 || wB > 12 || wB < 1) return P;
     int nC = 1; while (nC * 64 < DimA) nC *= 2;
     P.nC = nC; P.E = (int)cdiv(DimB, 16 / nC);
-    if (P.E > 20) return P;
-    P.emax = P.E <= 8 ? 8 : (P.E <= 16 ? 16 : 20); P.wa = wA <= 6 ? 6 : 12; P.wb = wB <= 6 ? 6 : 12;
+    if (P.E > 8) return P;      // up to 8 elements per lane: w and v_{k-1} both stay in registers; with 16-20 the loop measured SLOWER than the per-iteration launches (33 vs 22 us per step at N = 14 400: v_{k-1} through L2, scalar registers spilled into lanes)
+    P.emax = 8; P.wa = wA <= 6 ? 6 : 12; P.wb = wB <= 6 ? 6 : 12;
     P.ok = true;
     return P;
 }
@@ -301,6 +301,16 @@ static int lanczos_wg_steps(S *s, const WgPlan &P, double *v, double *vprev, int
     A.multA = P.a_is_up ? nI : 1; A.multB = P.a_is_up ? 1 : nI; A.impmask = nI - 1; A.econst = H.econst;
     A.v = v; A.vprev = vprev; A.alphas = s->alphas.p; A.betas = s->betas.p; A.k0 = k0; A.nsteps = nsteps; A.threshold = threshold;
     A.krylov = krylov; A.kstride = kstride; A.done = s->wg_done.p;
+    // the record table of the wave-uniform dimension, derived on the device from the ELL images (once per sector; storage=DIRECT:
+    // after the on-the-fly tables exist)
+    if (!s->wg_brec.p) {
+        const int recd = P.wb == 6 ? WgRec<6>::kDwords : WgRec<12>::kDwords;
+        CHK(s->wg_brec.alloc((size_t)A.DimB * recd));
+        if (P.wb == 6) hipLaunchKernelGGL(k_wg_pack_b<6>, dim3((unsigned)cdiv(A.DimB, 64)), dim3(64), 0, s->stream, A, s->wg_brec.p);
+        else hipLaunchKernelGGL(k_wg_pack_b<12>, dim3((unsigned)cdiv(A.DimB, 64)), dim3(64), 0, s->stream, A, s->wg_brec.p);
+        HIPCHK(hipGetLastError());
+    }
+    A.brec = s->wg_brec.p;
     const size_t lds = (size_t)(H.DimUp * H.DimDw) * 8;
 #define WG_LAUNCH(E_, W_, B_, R_)                                                                                               \
     do {                                                                                                                            \
@@ -308,7 +318,7 @@ static int lanczos_wg_steps(S *s, const WgPlan &P, double *v, double *vprev, int
         if (once_.first(s->device)) (void)hipFuncSetAttribute((const void *)k_lanczos_wg<E_, W_, B_, R_>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024); \
         hipLaunchKernelGGL((k_lanczos_wg<E_, W_, B_, R_>), dim3(1), dim3(1024), lds, s->stream, A);                                 \
     } while (0)
-#define WG_E(W_, B_) do { if (P.emax == 8) WG_LAUNCH(8, W_, B_, true); else if (P.emax == 16) WG_LAUNCH(16, W_, B_, false); else WG_LAUNCH(20, W_, B_, false); } while (0)
+#define WG_E(W_, B_) do { WG_LAUNCH(8, W_, B_, true); } while (0)
     if (P.wa == 6) { if (P.wb == 6) WG_E(6, 6); else WG_E(6, 12); } else { if (P.wb == 6) WG_E(12, 6); else WG_E(12, 12); }
 #undef WG_E
 #undef WG_LAUNCH

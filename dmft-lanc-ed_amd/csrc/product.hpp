@@ -251,19 +251,9 @@ static int fused_form(const S *s)
     if (s->up_pairs && s->up_pairs10 && s->upf->packed_elem8 && s->upf->width <= 10 && odd_cols_ok(s)) return 3;      // pair form with 10 hop slots (8-dword element image)
     return (s->upf->packed && s->upf->width <= 16) ? 1 : 0;
 }
-// explicit CSR: the LDS-row local block (k_csr_loc_ax) needs the split lane-major form with equal row lengths in the local block
-// (a half-filled up sector), the factored tile-major dw block, one rank, no Jx/Jp or phonon blocks, and a row that fits LDS
-static bool csr_fused_ok(const S *s)
-{
-    const SectorHost &H = s->H;
-    return H.desc.storage == EDGPU_STORE_CSR && s->lz_fused_on && s->csr_fused_on && !s->multi && !s->extra && H.DimPh == 1 && s->csr_split &&
-           s->csr_il_loc && s->csr_il_dw && s->csr_uni && s->csr_loc_cnt >= 4 && s->csr_loc_cnt <= 9 && H.DimUp <= 13312 && H.DimUp >= 64 &&
-           (s->csr_ld == H.DimUp || s->csr_ld == ((H.DimUp + 15) & ~(int64_t)15)) && (H.DimUp % 2 == 0 || s->csr_ld > H.DimUp);
-}
 static bool fused_ok(const S *s)
 {
     const SectorHost &H = s->H;
-    if (H.desc.storage == EDGPU_STORE_CSR) return csr_fused_ok(s);
     // Jx/Jp sectors run their non-local pass between the two halves; phonon terms live in the row-wise kernel only
     const bool terms_ok = !s->extra || (s->has_nd && !s->has_ph && s->nd_split);
     return s->lz_fused_on && !s->multi && s->kron2 && terms_ok && s->kron_split && H.desc.storage != EDGPU_STORE_CSR && fused_form(s) != 0 &&
@@ -276,32 +266,6 @@ static int fused_local(S *s, double *r, const double *uprev, double *t, double *
 {
     if (redo) { hipLaunchKernelGGL(k_scalar_step, dim3(1), dim3(1), 0, s->stream, s->scal.p, s->alphas.p, s->betas.p, (const double *)nullptr, -1, 9); HIPCHK(hipGetLastError()); }
     const SectorHost &H = s->H; const edgpu_desc &d = H.desc;
-    if (d.storage == EDGPU_STORE_CSR) {
-        CsrAxArgs U{};
-        U.DimUp = (int32_t)H.DimUp; U.Qdw = H.Qdw; U.ld = s->vld;
-        U.rowptr = s->csr_rowptr.p; U.cols = s->csr_cols.p; U.vals = s->csr_vals.p;
-        U.r = r; U.vprev = uprev; U.t_out = t; U.scal = s->scal.p; U.partial = s->partial.p; U.acc = acc; U.zvec = s->zvec.p;
-        if (s->vld != s->csr_ld) return fail(EDGPU_EINVAL, "edgpu: internal: Lanczos vectors and CSR columns disagree on the row pitch");
-        const size_t lds = (size_t)((H.DimUp + 2) & ~(int64_t)1) * 8 + 32 * 8;
-        const int grid = (int)std::min<int64_t>(H.Qdw, s->up_grid > 0 ? s->up_grid : 256);
-#define CSRAX(C_)                                                                                                               \
-    case C_: {                                                                                                                      \
-        static OncePerDevice once_;                                                                                                 \
-        if (once_.first(s->device)) { (void)hipFuncSetAttribute((const void *)k_csr_loc_ax<C_, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); (void)hipFuncSetAttribute((const void *)k_csr_loc_ax<C_, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); } \
-        if (acc) hipLaunchKernelGGL((k_csr_loc_ax<C_, true>), dim3(grid), dim3(1024), lds, s->stream, U);                           \
-        else hipLaunchKernelGGL((k_csr_loc_ax<C_, false>), dim3(grid), dim3(1024), lds, s->stream, U);                              \
-    } break
-        switch (s->csr_loc_cnt) {
-        CSRAX(4); CSRAX(5); CSRAX(6); CSRAX(7); CSRAX(8); CSRAX(9);
-        default: return fail(EDGPU_EINVAL, "edgpu: internal: fused CSR iteration without a kernel for this row length");
-        }
-#undef CSRAX
-        HIPCHK(hipGetLastError());
-        s->fuse_mode = redo ? 8 : 4; s->fuse_zvec = nullptr;
-        const int rc = reduce_partials(s, grid);
-        s->fuse_mode = -1;
-        return rc;
-    }
     const bool direct = d.storage == EDGPU_STORE_DIRECT;
     if (direct) CHK(direct_tables(s));
     UpAxArgs U{};
@@ -361,22 +325,6 @@ static int fused_local(S *s, double *r, const double *uprev, double *t, double *
 static int fused_dw(S *s, const double *u, double *t, const double *uprev)
 {
     const SectorHost &H = s->H;
-    if (H.desc.storage == EDGPU_STORE_CSR) {      // dw block of the split explicit CSR with the fused epilogue (k_csr_il, uprev2)
-        CsrArgs A{};
-        A.ld = s->csr_ld; A.nrows = s->nloc_el; A.DimUp = (int32_t)H.DimUp; A.Qdw = H.Qdw; A.tile = s->csr_tile;
-        A.rows_per_block = s->csrD_rpb; A.blocks_per_row = s->csrD_bpr; A.coltiles = 1; A.xcd_rows = 0;
-        A.rowptr = s->csrD_rowptr.p; A.cols = s->csrD_cols.p; A.vals = s->csrD_vals.p;
-        A.rowbase = s->csrD_base.p; A.rowcnt = s->csrD_cnt.p; A.cpre = s->csr_tm ? s->csrD_cpre.p : nullptr;
-        A.x = u; A.y = t; A.v_local = u; A.uprev = nullptr; A.uprev2 = uprev; A.scal = s->scal.p; A.partial = s->partial.p; A.epi = 1; A.pass = 2;
-        const int64_t nb = (int64_t)s->csrD_bpr * H.Qdw;
-        if (s->csrD_nt != 0) hipLaunchKernelGGL((k_csr_il<true, 1>), dim3((unsigned)nb), dim3(64), 0, s->stream, A);
-        else hipLaunchKernelGGL((k_csr_il<false, 1>), dim3((unsigned)nb), dim3(64), 0, s->stream, A);
-        HIPCHK(hipGetLastError());
-        s->fuse_mode = 5; s->fuse_zvec = nullptr;
-        const int rc = reduce_partials(s, nb);
-        s->fuse_mode = -1;
-        return rc;
-    }
     DwArgs D{};
     D.DimUp = dw_cols(s, s->vld); D.DimDw = (int32_t)H.DimDw; D.DimPh = H.DimPh; D.Qdw = H.Qdw; D.dw0 = H.dw0;
     D.dwc = s->dwf->ellc.p; D.dwv = s->dwf->ellv.p; D.dww = s->dwf->width; D.v = u; D.vfull = u; D.out = t; D.scal = s->scal.p; D.partial = s->partial.p;

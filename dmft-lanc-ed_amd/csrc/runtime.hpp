@@ -255,13 +255,11 @@ struct edgpu_sector_s {
     // lane-major image of the 64-row blocks (k_csr_il): the local block when every up configuration has the same number of
     // hops, the dw-type blocks always (their rows are uniform per idw row)
     bool csr_il_loc = false, csr_il_dw = false; bool csrL_nt = false;
-    int csr_loc_cnt = 0;      // entries per row of the local block when every row has the same number (half-filled up sector: 1 + Ns/2), else 0
     bool packed_ahead = false;      // hxv has packed the send rows on the compute stream already (halo_pack): halo_exchange does not pack again
     bool x_own_in_v = false;  // several ranks, stored-factor / on-the-fly forms with the needed-rows exchange: the dw pass reads the rank's own rows from the input vector, the x-space only holds received rows
     bool dvd_fused_on = true; // EDGPU_DVD_FUSED: Davidson step with residual, correction and Gram-Schmidt dots in one pass (k_dvd_step)
     bool lz_wg_on = true;     // EDGPU_LZ_WG: sectors that fit LDS run their Lanczos loops in one workgroup (k_lanczos_wg)
-    DevBuf<int32_t> wg_done; DevBuf<double> wg_slab;      // iteration count written by that kernel; its Krylov slab
-    bool csr_fused_on = true; // EDGPU_CSR_FUSED: fused Lanczos iteration on the explicit CSR (k_csr_loc_ax)
+    DevBuf<int32_t> wg_done; DevBuf<double> wg_slab; DevBuf<uint32_t> wg_brec;      // iteration count written by that kernel; its Krylov slab
     // single rank: the stored columns index vectors whose rows are padded to the 128-B line (csr_ld doubles per row; == DimUp
     // when off); the Lanczos loops then run on pitched vectors, a caller's dense vectors go through csr_xs / csr_ys
     int axpy_nb = 512;      // workgroups of the axpy+norm pass of the three-pass iteration
@@ -393,10 +391,9 @@ static const KnobDef kKnobs[] = {
     {"EDGPU_CSRD_ROWS", 64, "test hook", "rows per block of the row-major dw block", "test_gpu_parity.py::test_large_sector_code_paths_on_small_sectors"},
     {"EDGPU_CSRD_NT", 1, "fallback", "non-temporal entry loads of the dw block", "test_gpu_parity.py::test_large_sector_code_paths_on_small_sectors"},
     // Lanczos loops and eigensolvers
-    {"EDGPU_CSR_FUSED", 1, "fallback", "fused Lanczos iteration on the explicit CSR (LDS-row local block carrying the axpy+norm pass); 0: product + axpy/norm pass", "test_gpu_parity.py::test_fused_iteration_on_the_explicit_csr"},
     {"EDGPU_LZ_STORE", 1, "fallback", "keep the Krylov vectors of a ground-state search in HBM; 0: second Lanczos pass", "test_gpu_parity.py::test_ground_state_with_stored_krylov_vectors"},
     {"EDGPU_LZ_STORE_MAX", 1 << 30, "test hook", "cap on the stored Krylov vectors (tests: running out mid-search)", "test_gpu_parity.py::test_ground_state_with_stored_krylov_vectors"},
-    {"EDGPU_LZ_WG", 1, "fallback", "sectors of up to ~19 000 states run their Lanczos loops (sp_lanc_eigh, sp_lanc_tridiag and the legs built on it) in one workgroup; 0: per-iteration launches", "test_small_sector_lanczos.py::test_workgroup_lanczos_equals_the_launch_per_iteration_loop"},
+    {"EDGPU_LZ_WG", 1, "fallback", "sectors of up to ~8 000 states run their Lanczos loops (sp_lanc_eigh, sp_lanc_tridiag and the legs built on it) in one workgroup; 0: per-iteration launches", "test_small_sector_lanczos.py::test_workgroup_lanczos_equals_the_launch_per_iteration_loop"},
     {"EDGPU_EIGSH_PRO", 1, "fallback", "thick-restart Lanczos with partial re-orthogonalisation; 0: whole-basis form", "test_eigsh.py::test_eigsh_alternative_forms"},
     {"EDGPU_EIGSH_FUSED", 1, "fallback", "fused two-pass products inside edgpu_eigsh", "test_eigsh.py::test_eigsh_alternative_forms"},
     {"EDGPU_EIGSH_OMEGA_PCT", 100, "test hook", "re-orthogonalisation trigger in % of sqrt(eps) (tests: always / never)", "test_eigsh.py::test_eigsh_alternative_forms"},

@@ -410,7 +410,6 @@ static int build_csr(S *s)
             const int il = knob("EDGPU_CSR_IL");      // bit 0: local block, bit 1: dw-type blocks
             s->csr_il_loc = (il & 1) && (up_uniform || knob("EDGPU_CSR_JAG") != 0);      // rows of different lengths: packed level by level (k_csr_il, jagged path)
             s->csr_il_dw = (il & 2) != 0;
-            s->csr_loc_cnt = up_uniform ? (int)(1 + up.rowptr[1] - up.rowptr[0]) : 0;
         }
         A.rpb = 64;
         s->csr_three = s->halo && !H.Jhflag && knob("EDGPU_CSR_THREE") != 0;      // the stored non-local block reads own and received rows from one x buffer: keep the own-row copy
@@ -510,7 +509,7 @@ static int create(const edgpu_desc *desc, S **out)
     s->extra = H.DimPh > 1 || H.Jhflag; s->has_ph = H.DimPh > 1; s->has_nd = H.Jhflag;
     s->nloc_el = H.DimUp * H.Qdw; s->nloc = s->nloc_el * H.DimPh; s->vecdim = s->nloc;
     s->multi = desc->mpi_size > 1 || (desc->reserved & 1);   // reserved bit 0: run the exchange path even on one rank (tests)
-    s->lz_fused_on = knob("EDGPU_LZ_FUSED") != 0; s->csr_fused_on = knob("EDGPU_CSR_FUSED") != 0; s->lz_wg_on = knob("EDGPU_LZ_WG") != 0; s->dvd_fused_on = knob("EDGPU_DVD_FUSED") != 0;
+    s->lz_fused_on = knob("EDGPU_LZ_FUSED") != 0; s->lz_wg_on = knob("EDGPU_LZ_WG") != 0; s->dvd_fused_on = knob("EDGPU_DVD_FUSED") != 0;
     s->dbg = dbg_flags(); s->one_ar = knob("EDGPU_ONE_ALLREDUCE") != 0; s->up_pairs10 = knob("EDGPU_UP_PAIRS10") != 0; s->direct_cache = XKNOB("EDGPU_DIRECT_CACHE", 1) != 0; s->up_elem16 = XKNOB("EDGPU_UP_ELEM16", 1) != 0; s->pad_allowed = knob("EDGPU_PAD") != 0 && knob("EDGPU_ODD_PAIRS") != 0; s->tables_wave = XKNOB("EDGPU_TABLES_WAVE", 1) != 0; s->dw_lds_kb = std::min(XKNOB("EDGPU_DW_LDS_KB", 0), 150);
     // distributed-transpose dw pass: opt-in (EDGPU_DW_TRANSPOSE=1) until an 8-GPU run has shown it correct and faster than the
     // needed-rows exchange; at most 64 ranks (larger jobs use the needed-rows exchange)

@@ -18,7 +18,7 @@ def source_stamp():      # same digest as bench.py: the summary is only quoted w
 
 
 STAMP = source_stamp()
-PRODUCT = {"csr": ("k_csr_spmv2", "k_csr_il", "k_csr_loc_ax"), "kron": ("k_uppass", "k_dwpass"), "direct": ("k_uppass", "k_dwpass")}      # the on-the-fly tables are derived once per sector (first product), not per product
+PRODUCT = {"csr": ("k_csr_spmv2", "k_csr_il"), "kron": ("k_uppass", "k_dwpass"), "direct": ("k_uppass", "k_dwpass")}      # the on-the-fly tables are derived once per sector (first product), not per product
 out = []
 for st, prefixes in PRODUCT.items():
     per = {}

@@ -1,5 +1,5 @@
 # Round evidence for profiles/rNN: bench line, rocprofv3 kernel stats and HBM-traffic counters for the three storages of BASELINE
-# config 3 (the explicit CSR in its fused and three-pass forms), the Ns=18 product, one rank of eight emulated on this GPU
+# config 3, the Ns=18 product, one rank of eight emulated on this GPU
 # (Ns=18 on-the-fly, Ns=16 explicit CSR), config 5, ed_total_ud=F, the solvers, the sector sweeps.
 # Usage (on the GPU box): bash scripts/profile_round.sh [part]   part: all (default) | bench | ns18 | emu | rest ; outputs under gpurun_out/prof_round/
 cd $GRAFT_REPO_ROOT
@@ -21,7 +21,6 @@ if [ $PART = all ] || [ $PART = bench ]; then
   python3 scripts/pmc_traffic.py $OUT > $OUT/pmc_traffic_summary.txt
   cat $OUT/pmc_traffic_summary.txt
   # the forms the fused iterations replace
-  EDGPU_CSR_FUSED=0 trace bench_c3_csr_unfused python3 bench.py --steps 20 --warmup 3 --no-extra --no-cpu --storage csr > $OUT/bench_c3_csr_unfused_traced.json 2> $OUT/trace_csr_unfused.err
   EDGPU_LZ_FUSED=0 trace bench_c3_kron_unfused python3 bench.py --steps 20 --warmup 3 --no-extra --no-cpu --storage kron > $OUT/bench_c3_kron_unfused_traced.json 2> $OUT/trace_kron_unfused.err
 fi
 if [ $PART = all ] || [ $PART = ns18 ]; then

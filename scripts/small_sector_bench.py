@@ -28,7 +28,7 @@ for nbath, nup, ndw in SECT:
         (e_a, nl_a, t1a, ua, t2a, aa), (e_b, nl_b, t1b, ub, t2b, ab) = row
         assert abs(nl_a - nl_b) <= 1 and abs(e_a - e_b) < 1e-10 and np.allclose(aa, ab, rtol=1e-9, atol=1e-9), (nl_a, nl_b, e_a, e_b)
         print("Ns=%d (%d,%d) N=%d %s: lanc_eigh nlanc=%d  launch per iteration %.2f ms  one workgroup %.2f ms | tridiag200: %.2f ms (%.1f us/step) -> %.2f ms (%.1f us/step)%s"
-              % (nbath + 1, nup, ndw, G.Dim, st, nl_a, t1a * 1e3, t1b * 1e3, t2a * 1e3, t2a / max(ua, 1) * 1e3, t2b * 1e3, t2b / max(ub, 1) * 1e3,
+              % (nbath + 1, nup, ndw, G.Dim, st, nl_a, t1a * 1e3, t1b * 1e3, t2a * 1e3, t2a / max(ua, 1) * 1e6, t2b * 1e3, t2b / max(ub, 1) * 1e6,
                  "" if G.Dim * 8 <= 150 * 1024 else "   [vector beyond LDS: same loop in both columns]"), flush=True)
 os.environ.pop("EDGPU_LZ_WG", None)
 

@@ -506,49 +506,6 @@ def test_fused_iteration_equals_three_pass_iteration(edgpu_mod, monkeypatch):
             assert min(np.abs(x - res["plain"][4]).max(), np.abs(x + res["plain"][4]).max()) < 1e-8, tag
 
 
-def test_fused_iteration_on_the_explicit_csr(edgpu_mod, monkeypatch):
-    """Round 4: the explicit CSR has a fused Lanczos iteration as well -- the axpy+norm pass rides in an LDS-row form of the local
-    block (k_csr_loc_ax), the dw block applies scale, -beta*u_prev and the alpha dot (k_csr_il with uprev2).  Against the
-    product + axpy/norm loop (EDGPU_CSR_FUSED=0) and the oracle's restatement of sp_lanc_tridiag; half-filled up sectors
-    (equal row lengths: 5, 6, 7 entries per row of the local block), odd and even row lengths, rows shorter and longer than a
-    64-row block, pitched and dense vectors; away from half filling the sector keeps the three-pass loop."""
-    from edgpu import model
-    monkeypatch.setenv("EDGPU_CSR_SPLIT", "1")
-    for nb, nud in ((7, None), (9, None), (11, None), (8, (4, 3)), (9, (5, 4)), (9, (4, 5))):
-        m, nu, nd = model.half_filled_c(nb)
-        if nud:
-            nu, nd = [nud[0]], [nud[1]]
-        S = oracle.Sector(m, nu, nd)
-        v0 = np.random.RandomState(5).uniform(0, 1, S.Dim)
-        n = 40 if S.Dim > 2000 else 16
-        a_ref, b_ref, used_ref = oracle.sp_lanc_tridiag(S.spmatvec, v0, n)
-        w0 = np.linalg.eigvalsh(S.hmat())[0] if S.Dim <= 5000 else None
-        uniform_up = 2 * nu[0] == m["Ns"]
-        res = {}
-        for tag, env in (("fused", {}), ("fused_dense", {"EDGPU_PAD": "0"}), ("fused_twopass", {"EDGPU_LZ_STORE": "0"}), ("plain", {"EDGPU_CSR_FUSED": "0"})):
-            for k, v in env.items():
-                monkeypatch.setenv(k, v)
-            G = edgpu_mod.HvSector(m, nu, nd, storage="csr")
-            want = uniform_up and tag != "plain" and G.DimUp >= 64 and not (tag == "fused_dense" and G.DimUp % 2)
-            assert G.lanczos_fused == want, (nb, nu, nd, tag, G.describe())
-            a, b, used = G.sp_lanc_tridiag(v0, n)
-            e0, x, nl = G.sp_lanc_eigh(v0, nitermax=300, threshold=1e-13)
-            res[tag] = (a, b, used, e0, x, nl, np.linalg.norm(G.spHtimesV(x) - e0 * x))
-            ev, _xx, info = G.sp_eigh(2, nblock=12, nitermax=400, tol=1e-11, vectors=False)      # the multi-eigenpair solver runs on the same halves
-            assert abs(ev[0] - e0) < 1e-9, (tag, ev, e0)
-            G.close()
-            for k in env:
-                monkeypatch.delenv(k)
-        for tag, (a, b, used, e0, x, nl, r) in res.items():
-            assert used == used_ref and b[0] == 0.0
-            np.testing.assert_allclose(a[:used], a_ref[:used], rtol=1e-9, atol=1e-9)
-            np.testing.assert_allclose(b[1:used], b_ref[1:used], rtol=1e-9, atol=1e-9)
-            assert abs(e0 - res["plain"][3]) <= 1e-10 and abs(nl - res["plain"][5]) <= 1 and r < 1e-6, (tag, e0, nl, r)
-            if w0 is not None:
-                assert abs(e0 - w0) <= 1e-10
-            assert min(np.abs(x - res["plain"][4]).max(), np.abs(x + res["plain"][4]).max()) < 1e-8, tag
-
-
 @pytest.mark.parametrize("nup,ndw", [(3, 6), (10, 6), (9, 5), (2, 7)])
 def test_pair_form_with_ten_hop_slots(edgpu_mod, monkeypatch, nup, ndw):
     """Sectors one or two electrons off half filling have 9-10 up hops per configuration (max(Nup, Ns-Nup)): the Green's-function

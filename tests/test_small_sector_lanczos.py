@@ -81,6 +81,15 @@ def test_workgroup_green_function_leg(edgpu_mod, monkeypatch):
     assert abs(out["wg"][0] - out["plain"][0]) < 1e-10 and abs(out["wg"][1] - out["plain"][1]) < 1e-10
     for (n2a, aa, ba, ua), (n2b, ab, bb, ub) in zip(out["wg"][2], out["plain"][2]):
         assert abs(n2a - n2b) < 1e-10 and ua == ub
-        k = min(ua, 25)
-        np.testing.assert_allclose(aa[:k], ab[:k], rtol=1e-8, atol=1e-8)
-        np.testing.assert_allclose(ba[1:k], bb[1:k], rtol=1e-8, atol=1e-8)
+        k = min(ua, 6)       # two different recurrences (normalised / scale-carrying): in a target sector of a few hundred states the Krylov space
+        # closes on near-invariant subspaces within ~10 steps (small beta) and rounding differences of the two grow by 1/beta per step
+        np.testing.assert_allclose(aa[:k], ab[:k], rtol=1e-9, atol=1e-9)
+        np.testing.assert_allclose(ba[1:k], bb[1:k], rtol=1e-9, atol=1e-9)
+        # ... what the host builds from them agrees far beyond that: the continued fraction of the leg at a few frequencies
+        for z in (0.3j, 1.0j, -1.5 + 0.2j):
+            def cf(a, b, n):
+                g = 0.0
+                for i in range(n - 1, -1, -1):
+                    g = 1.0 / (z - a[i] - (b[i + 1] ** 2 * g if i + 1 < n else 0.0))
+                return g
+            assert abs(cf(aa, ba, ua) - cf(ab, bb, ub)) < 1e-8 * max(1.0, abs(cf(ab, bb, ub)))
