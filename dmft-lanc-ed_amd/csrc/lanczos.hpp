@@ -276,8 +276,10 @@ static WgPlan wg_plan(const S *s)
     if (DimA > 1024 || wA > 12 || wB > 12 || wB < 1) return P;
     int nC = 1; while (nC * 64 < DimA) nC *= 2;
     P.nC = nC; P.E = (int)cdiv(DimB, 16 / nC);
-    if (P.E > 8) return P;      // up to 8 elements per lane: w and v_{k-1} both stay in registers; with 16-20 the loop measured SLOWER than the per-iteration launches (33 vs 22 us per step at N = 14 400: v_{k-1} through L2, scalar registers spilled into lanes)
-    P.emax = 8; P.wa = wA <= 6 ? 6 : 12; P.wb = wB <= 6 ? 6 : 12;
+    if (P.E > 12) return P;     // up to 12 elements per lane: w and v_{k-1} both stay in registers; with 16-20 the loop measured SLOWER than the per-iteration launches (33 vs 22 us per step at N = 14 400: v_{k-1} through L2, scalar registers spilled into lanes)
+    P.emax = P.E <= 8 ? 8 : 12;
+    if (P.emax == 12 && wA > 6) return P;      // 12 elements per lane AND 12 register-resident hop entries do not fit 128 registers
+    P.wa = wA <= 6 ? 6 : 12; P.wb = wB <= 6 ? 6 : 12;
     P.ok = true;
     return P;
 }
@@ -318,9 +320,9 @@ static int lanczos_wg_steps(S *s, const WgPlan &P, double *v, double *vprev, int
         if (once_.first(s->device)) (void)hipFuncSetAttribute((const void *)k_lanczos_wg<E_, W_, B_, R_>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024); \
         hipLaunchKernelGGL((k_lanczos_wg<E_, W_, B_, R_>), dim3(1), dim3(1024), lds, s->stream, A);                                 \
     } while (0)
-#define WG_E(W_, B_) do { WG_LAUNCH(8, W_, B_, true); } while (0)
-    if (P.wa == 6) { if (P.wb == 6) WG_E(6, 6); else WG_E(6, 12); } else { if (P.wb == 6) WG_E(12, 6); else WG_E(12, 12); }
-#undef WG_E
+    if (P.emax == 12) { if (P.wb == 6) WG_LAUNCH(12, 6, 6, true); else WG_LAUNCH(12, 6, 12, true); }
+    else if (P.wa == 6) { if (P.wb == 6) WG_LAUNCH(8, 6, 6, true); else WG_LAUNCH(8, 6, 12, true); }
+    else { if (P.wb == 6) WG_LAUNCH(8, 12, 6, true); else WG_LAUNCH(8, 12, 12, true); }
 #undef WG_LAUNCH
     HIPCHK(hipGetLastError());
     if (done) { HIPCHK(hipMemcpyAsync(done, s->wg_done.p, 4, hipMemcpyDeviceToHost, s->stream)); HIPCHK(hipStreamSynchronize(s->stream)); }
