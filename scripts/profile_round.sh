@@ -4,7 +4,7 @@
 # Usage (on the GPU box): bash scripts/profile_round.sh [part]   part: all (default) | bench | ns18 | emu | rest ; outputs under gpurun_out/prof_round/
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
-export EDGPU_PROFILE_ROUND=r04
+export PROFILE_ROUND_NAME=r04
 PART=${1:-all}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_round
 mkdir -p $OUT

@@ -11,6 +11,8 @@ import tempfile
 import numpy as np
 import pytest
 
+from oracle import oracle
+
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
@@ -226,6 +228,43 @@ def test_multirank_legs_observables_twin(edgpu_mod, case, size):
     state split over ranks: same numbers as the single-rank library and the oracle's apply_op."""
     res = _launch("legs", case, size)
     assert all(r["ok"] for r in res) and res[0]["nlegs"] >= 2
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("st", ["kron", "direct", "csr"])
+def test_emulated_rank_of_p_runs_the_multi_rank_forms_alone(edgpu_mod, monkeypatch, st):
+    """edgpu_comm_create_emulated (bench.py --emulate-rank): one rank of P alone on the GPU, exchanges replaced by device copies of the same
+    byte count, all-reduces local.  A measurement aid -- its numbers are not a result -- so the test checks what it must guarantee:
+    the sector has the partition and exchange lists of the P-rank job (same byte matrix as the callback job of the relay test would
+    report for that rank), products and Lanczos steps run to completion on finite numbers, and rank 0 of 1 reproduces the real product."""
+    import edgpu
+    from edgpu import model
+    monkeypatch.setenv("EDGPU_KRON_SPLIT", "1"); monkeypatch.setenv("EDGPU_CSR_SPLIT", "1")
+    m, nu, nd = model.half_filled_c(9)
+    P = 4
+    for r in (0, 2, 3):
+        G = edgpu_mod.HvSector(m, nu, nd, storage=st, rank=r, size=P)
+        c = edgpu.Communicator.emulated(r, P)
+        G.attach_comm(c)
+        q, d0 = model.dw_partition(G.DimDw, P, r)
+        assert G.vecDim == G.DimUp * q
+        mode, sb, rb = G.exchange_info()
+        assert mode == "needed-rows" and sb[r] == 0 and rb[r] == 0 and rb.sum() > 0 and rb.sum() % (8 * G.DimUp) == 0
+        v = np.random.RandomState(r).uniform(-0.5, 0.5, G.vecDim)
+        hv = G.spHtimesV(v)
+        assert np.all(np.isfinite(hv)) and np.abs(hv).max() > 0
+        G.bench_begin(8); G.bench_steps(2); G.bench_steps(4, timed=True)
+        ms, a, b = G.bench_result(4, ncoef=6)
+        assert ms > 0 and np.all(np.isfinite(a)) and np.all(np.isfinite(b))
+        G.close(); c.close()
+    # one rank of one: nothing is emulated, the product is the real one
+    S = oracle.Sector(m, nu, nd)
+    G = edgpu_mod.HvSector(m, nu, nd, storage=st, rank=0, size=1, force_exchange=True)
+    c = edgpu.Communicator.emulated(0, 1); G.attach_comm(c)
+    v = np.random.RandomState(9).uniform(-0.5, 0.5, S.Dim)
+    ref = S.spmatvec(v)
+    assert np.abs(G.spHtimesV(v) - ref).max() <= 1e-12 * np.abs(ref).max()
+    G.close(); c.close()
 
 
 @pytest.mark.gpu
