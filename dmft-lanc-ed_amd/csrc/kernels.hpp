@@ -17,7 +17,8 @@ constexpr int kMaxTerms = 256;
 
 // scalars of the Lanczos recurrence, resident in HBM so the loop needs no host round trip
 enum { SC_SCUR = 0, SC_SPREV = 1, SC_BETA = 2, SC_ALPHA = 3, SC_TMP = 4, SC_ZK = 5, SC_K = 6,
-       SC_NPEND = 7, SC_SV_SCUR = 8, SC_SV_BETA = 9, SC_PAIR = 10 /* and 11 */, SC_COUNT = 16 };      // 7-11: deferred-norm form of the loop for several ranks (one all-reduce per iteration)   // SC_K: iteration counter kept on the device (fused reduce+step kernels)
+       SC_NPEND = 7, SC_SV_SCUR = 8, SC_SV_BETA = 9, SC_PAIR = 10 /* and 11 */,
+       SC_N_SCUR = 12, SC_N_SPREV = 13, SC_N_BETA = 14, SC_N_K = 15 /* self-reducing iteration: scales as the running kernel pair sees them */, SC_COUNT = 16 };      // 7-11: deferred-norm form of the loop for several ranks (one all-reduce per iteration)   // SC_K: iteration counter kept on the device (fused reduce+step kernels)
 
 struct DiagArgs {  // bit-exact diagonal (stored/H_local.f90:13-71, stored/Orbs/H_local.f90:1-80)
     int32_t Norb, Nspin, Nbath, Nfoo, hfmode, total_ud, Ns_Ud;
@@ -159,9 +160,33 @@ struct Kron2Args {
     double *out;
     const double *uprev; const double *scal; double *partial;  // Lanczos epilogue
     int32_t rsplit;   // >1 (rows too long for LDS, local-only pass): `rsplit` workgroups of one XCD share a row
+    // KF_SR (self-reducing Lanczos iteration, launch-bound sectors): the beta^2 partial sums the previous axpy pass left behind
+    const double *sr_part; int32_t sr_n; double *scal_w; double *betas_w;
 };
 
-enum { KF_DIRECT = 1, KF_LDS = 2, KF_EPI = 4, KF_PH = 8, KF_ND = 16, KF_NOLOCAL = 32, KF_NODW = 64 };
+enum { KF_DIRECT = 1, KF_LDS = 2, KF_EPI = 4, KF_PH = 8, KF_ND = 16, KF_NOLOCAL = 32, KF_NODW = 64, KF_SR = 128 };
+
+// Self-reducing Lanczos iteration (round 4).  A launch-bound sector spends an iteration in four launches: product (alpha partial sums),
+// a one-workgroup reduction + scalar step, the axpy/norm pass (beta^2 partial sums), another reduction + step -- ~4.5 us each on the
+// device side whatever they do.  Here EVERY workgroup of the consuming kernel sums the partials of the producing one itself (a few
+// hundred numbers, the same fixed order everywhere, so every workgroup holds the same bits) and applies the scalar step in registers;
+// workgroup 0 also writes the coefficient and the scales for whoever reads them later.  Scales come in two sets: the committed ones
+// (SC_SCUR, SC_SPREV, SC_BETA, SC_K: what the host-side loops and the other kernels read) and the ones of the iteration in flight
+// (SC_N_*): the product kernel reads the committed set and writes the in-flight one, the axpy kernel reads the in-flight set and
+// commits it -- no workgroup reads a slot that another workgroup of the same launch writes.  Two launches per iteration.
+__device__ __forceinline__ double sr_sum(const double *__restrict__ part, int n, double *red /* >= 17 doubles */)
+{
+    double x = 0.0;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) x += part[i];
+    x = wave_sum(x);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    __syncthreads();
+    if (lane == 0) red[w] = x;
+    __syncthreads();
+    if (threadIdx.x == 0) { double r = 0.0; for (int i = 0; i < nw; i++) r += red[i]; red[16] = r; }
+    __syncthreads();
+    return red[16];
+}
 
 template <int F>
 __global__ void __launch_bounds__(1024) k_kron2(Kron2Args A)
@@ -195,6 +220,15 @@ __global__ void __launch_bounds__(1024) k_kron2(Kron2Args A)
     if (F & KF_DIRECT) edw = A.Edw[idw] + A.econst;
     double s_cur = 1.0, c_prev = 0.0, asum = 0.0;
     if (F & KF_EPI) { s_cur = A.scal[SC_SCUR]; c_prev = A.scal[SC_BETA] * A.scal[SC_SPREV]; }
+    if ((F & KF_EPI) && (F & KF_SR)) {      // the beta step of the previous iteration, taken here by every workgroup (see sr_sum)
+        double scur = A.scal[SC_SCUR], sprev = A.scal[SC_SPREV], beta = A.scal[SC_BETA], K = A.scal[SC_K];
+        if (A.sr_n > 0) { const double b = sqrt(sr_sum(A.sr_part, A.sr_n, red)); beta = b; sprev = scur; scur = b > 0.0 ? 1.0 / b : 0.0; K += 1.0; }
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            A.scal_w[SC_N_SCUR] = scur; A.scal_w[SC_N_SPREV] = sprev; A.scal_w[SC_N_BETA] = beta; A.scal_w[SC_N_K] = K;
+            if (A.sr_n > 0) A.betas_w[(int)K] = beta;
+        }
+        s_cur = scur; c_prev = beta * sprev;
+    }
 
     int iup_lo = 0, iup_hi = DimUp;
     if (A.rsplit > 1) { const int chunk = (DimUp + A.rsplit - 1) / A.rsplit; iup_lo = part * chunk; iup_hi = iup_lo + chunk < DimUp ? iup_lo + chunk : DimUp; }
@@ -2104,6 +2138,34 @@ __global__ void __launch_bounds__(256) k_axpy_norm(double *__restrict__ w, const
 
 // Deferred-norm form (several ranks, one all-reduce per iteration): w holds H u_k of the UNNORMALISED u_k, the scales are known
 // only now:  r_k = s_cur*w - alpha*s_cur*u - beta*s_prev*u_prev  (in place over w), partial |r_k|^2, optionally acc += zk*s_cur*u.
+// the axpy/norm pass of the self-reducing iteration: alpha = sum of the product kernel's partial sums, taken by every workgroup;
+// reads the in-flight scales (SC_N_*), commits them, writes alpha_k
+__global__ void __launch_bounds__(256) k_axpy_norm_sr(double *__restrict__ w, const double *__restrict__ u, const double *__restrict__ scal, double *__restrict__ scal_w,
+                                                      const double *__restrict__ part_a, int n_a, double *__restrict__ alphas, int64_t n, double *__restrict__ partial)
+{
+    __shared__ double red[17];
+    const double s_cur = scal[SC_N_SCUR], sprev = scal[SC_N_SPREV], beta = scal[SC_N_BETA], K = scal[SC_N_K];
+    const double alpha = sr_sum(part_a, n_a, red);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        alphas[(int)K] = alpha; scal_w[SC_ALPHA] = alpha;
+        scal_w[SC_SCUR] = s_cur; scal_w[SC_SPREV] = sprev; scal_w[SC_BETA] = beta; scal_w[SC_K] = K;
+    }
+    double s = 0.0;
+    const int64_t n2 = n >> 1;
+    dbl2v *w2 = reinterpret_cast<dbl2v *>(w); const dbl2v *u2 = reinterpret_cast<const dbl2v *>(u);
+    const int64_t per = (n2 + gridDim.x - 1) / gridDim.x, stride = blockDim.x;
+    const int64_t n2b = (int64_t)(blockIdx.x + 1) * per < n2 ? (int64_t)(blockIdx.x + 1) * per : n2;
+    for (int64_t i = (int64_t)blockIdx.x * per + threadIdx.x; i < n2b; i += stride) {
+        const dbl2v vi = s_cur * u2[i];
+        const dbl2v wi = w2[i] - alpha * vi;
+        w2[i] = wi; s += wi.x * wi.x + wi.y * wi.y;
+    }
+    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) { const double vi = s_cur * u[n - 1], wi = w[n - 1] - alpha * vi; w[n - 1] = wi; s += wi * wi; }
+    __syncthreads();
+    const double r = block_sum(s, red);
+    if (threadIdx.x == 0) partial[blockIdx.x] = r;
+}
+
 __global__ void __launch_bounds__(256) k_axpy3_norm(double *__restrict__ w, const double *__restrict__ u, const double *__restrict__ up, double *__restrict__ acc,
                                                     const double *__restrict__ scal, int64_t n, double *__restrict__ partial)
 {

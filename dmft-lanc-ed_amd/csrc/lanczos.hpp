@@ -101,7 +101,7 @@ struct LzVecs { double *uprev, *ucur, *w; };
 // start: ucur holds the (unnormalised) start vector
 static int lz_start(S *s, LzVecs &V)
 {
-    s->npend = false;
+    s->npend = false; s->sr_pending = false;
     HIPCHK(hipMemsetAsync(V.uprev, 0, (size_t)s->vlen * 8, s->stream));
     CHK(reduce_dot(s, V.ucur, V.ucur, s->vlen));
     hipLaunchKernelGGL(k_scalar_step, dim3(1), dim3(1), 0, s->stream, s->scal.p, s->alphas.p, s->betas.p, (const double *)nullptr, 0, 2);
@@ -183,9 +183,42 @@ struct OneArScope {      // the deferred form is on between construction and des
     explicit OneArScope(S *s_) : s(s_), was(s_->one_ar_on) { s->one_ar_on = s->multi && s->one_ar; s->npend = false; }
     ~OneArScope() { s->one_ar_on = was; s->npend = false; }
 };
+// the pending beta step of the self-reducing iteration, taken by a reduction kernel (before anything but its own product kernel
+// looks at the scales or the coefficients)
+static int lz_sr_flush(S *s)
+{
+    if (!s->sr_pending) return EDGPU_OK;
+    hipLaunchKernelGGL(k_reduce_final_step, dim3(1), dim3(1024), 0, s->stream, (const double *)s->partial_b.p, (int64_t)s->sr_nb, s->scal.p, s->alphas.p, s->betas.p, (const double *)nullptr, 1);
+    HIPCHK(hipGetLastError());
+    s->sr_pending = false;
+    return EDGPU_OK;
+}
+static bool lz_sr_ok(const S *s)
+{
+    return s->sr_on && s->sr_allow && !s->multi && s->kron2 && !s->kron_split && s->H.desc.storage != EDGPU_STORE_CSR && !s->pad_on &&
+           s->nloc <= ((int64_t)1 << 22) && s->H.Qdw * s->H.DimPh <= 8192;
+}
+struct SrScope {      // the plain Lanczos loops allow the self-reducing iteration between construction and destruction of this object
+    S *s; explicit SrScope(S *s_) : s(s_) { s->sr_allow = true; s->sr_pending = false; }
+    ~SrScope() { s->sr_allow = false; s->sr_pending = false; s->sr_now = false; }
+};
 static int lz_iter(S *s, LzVecs &V, int k, double *acc)
 {
     if (s->multi && s->one_ar_on) return lz_iter_deferred(s, V, k, acc);
+    if (!acc && lz_sr_ok(s)) {      // two launches: product (takes the pending beta step, leaves alpha partials), axpy (takes alpha, leaves beta^2 partials)
+        const int nb = (int)std::max<int64_t>(1, std::min<int64_t>(cdiv(s->vlen, 256 * 4), 256));
+        if (s->partial_b.n < 512) CHK(s->partial_b.alloc(512));
+        s->sr_now = true;
+        const int rc = hxv(s, V.ucur, V.w, true, V.uprev, s->vld);
+        s->sr_now = false;
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_axpy_norm_sr, dim3(nb), dim3(256), 0, s->stream, V.w, (const double *)V.ucur, (const double *)s->scal.p, s->scal.p, (const double *)s->partial.p, s->sr_na, s->alphas.p, s->vlen, s->partial_b.p);
+        HIPCHK(hipGetLastError());
+        s->sr_pending = true; s->sr_nb = nb;
+        double *t = V.uprev; V.uprev = V.ucur; V.ucur = V.w; V.w = t;
+        return EDGPU_OK;
+    }
+    CHK(lz_sr_flush(s));
     if (!s->multi) {   // alpha step rides on the product's final reduction (device counter == k by construction)
         s->fuse_mode = 0; s->fuse_zvec = acc ? s->zvec.p : nullptr;
         int rc = hxv(s, V.ucur, V.w, true, V.uprev, s->vld);
@@ -254,6 +287,7 @@ static int lzf_iter(S *s, LzF &F, double *tnew, double *acc)
 
 static int fetch_coeffs(S *s, int k, std::vector<double> &al, std::vector<double> &be)
 {
+    CHK(lz_sr_flush(s));
     al.resize(k + 1); be.resize(k + 2);
     HIPCHK(hipMemcpyAsync(al.data(), s->alphas.p, (size_t)(k + 1) * 8, hipMemcpyDeviceToHost, s->stream));
     HIPCHK(hipMemcpyAsync(be.data(), s->betas.p, (size_t)(k + 2) * 8, hipMemcpyDeviceToHost, s->stream));
@@ -409,6 +443,7 @@ static int lanczos_gs_impl(S *s, int nitermax, double threshold, int ncheck, dou
     if ((int64_t)nitermax > s->H.Dim) nitermax = (int)s->H.Dim;   // ED_DIAG.f90:100 Nitermax=min(dim,lanc_niter)
     CHK(lz_prepare(s, nitermax));
     OneArScope one_ar_scope(s);
+    SrScope sr_scope(s);
     const bool fused = fused_ok(s);
     const int64_t vlen = s->vlen;      // length of a work vector (row pitch padded to the 128-B line where the product kernels take one)
     if (s->lz[3].n != (size_t)s->nloc) CHK(s->lz[3].alloc((size_t)s->nloc));
@@ -601,6 +636,7 @@ static int lanczos_tridiag(S *s, const double *vin_dev, int nlanc, double thresh
         }
     }
     OneArScope one_ar_scope(s);
+    SrScope sr_scope(s);
     const bool fused = fused_ok(s);
     LzVecs V{s->lz[0].p, s->lz[1].p, s->lz[2].p};
     LzF F{s->lz[0].p, s->lz[2].p, s->lz[1].p};

@@ -26,7 +26,7 @@ static int reduce_partials(S *s, int64_t n)
 
 template <int F> static void launch_kron2(S *s, const Kron2Args &A, int64_t rows)
 {
-    size_t lds = (F & KF_LDS) ? s->kron_lds : 16 * sizeof(double);
+    size_t lds = (F & KF_LDS) ? s->kron_lds : 24 * sizeof(double);
     static OncePerDevice once;
     if (lds > 64 * 1024 && once.first(s->device)) (void)hipFuncSetAttribute((const void *)k_kron2<F>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipLaunchKernelGGL(k_kron2<F>, dim3((unsigned)rows), dim3(s->kron_threads), lds, s->stream, A);
@@ -37,10 +37,13 @@ static int dispatch_kron2(S *s, int flags, const Kron2Args &A, int64_t rows)
 #define CASE(f) case (f): launch_kron2<(f)>(s, A, rows); break;
 #define CASE4(b) CASE(b) CASE((b) | KF_DIRECT) CASE((b) | KF_EPI) CASE((b) | KF_DIRECT | KF_EPI)
 #define CASE8(b) CASE4(b) CASE4((b) | KF_PH | KF_ND)
+#define CASESR(b) CASE((b) | KF_EPI | KF_SR) CASE((b) | KF_DIRECT | KF_EPI | KF_SR)
     switch (flags) {
         CASE8(0) CASE8(KF_LDS) CASE8(KF_NODW) CASE8(KF_NODW | KF_LDS) CASE8(KF_NOLOCAL)
+        CASESR(0) CASESR(KF_LDS) CASESR(KF_PH | KF_ND) CASESR(KF_LDS | KF_PH | KF_ND)      // self-reducing Lanczos iteration (whole product in one kernel only)
     default: return fail(EDGPU_EINVAL, "edgpu: internal kernel variant missing");
     }
+#undef CASESR
 #undef CASE8
 #undef CASE4
 #undef CASE
@@ -469,6 +472,7 @@ static int hxv(S *s, const double *v, double *out, bool epi, const double *uprev
         A.impmask = (1 << d.Norb) - 1; A.nI = 1 << d.Norb; A.econst = H.econst; A.w0 = d.w0_ph; A.gsum = H.gph_sum; A.Jx = d.Jx; A.Jp = d.Jp;
         A.gup = s->gup.p; A.gdw = s->gdw.p;
         A.v = v; A.vfull = multi ? s->vfull.p : v; A.out = out; A.uprev = uprev; A.scal = s->scal.p; A.partial = s->partial.p;
+        A.sr_part = s->sr_pending ? s->partial_b.p : nullptr; A.sr_n = s->sr_pending ? s->sr_nb : 0; A.scal_w = s->scal.p; A.betas_w = s->betas.p;
 #ifdef EDGPU_EXPERIMENTS
         if (s->dbg & 1) A.upw = 0;      // timing only: no up hops / no dw hops (wrong results)
         if (s->dbg & 2) A.dww = 0;
@@ -478,7 +482,7 @@ static int hxv(S *s, const double *v, double *out, bool epi, const double *uprev
         // phonon terms live in the fused kernel only; Jx/Jp (without phonons) have their own pass
         const bool nd_pass = s->has_nd && !s->has_ph && s->nd_split;
         const bool split = multi || (s->kron_split && (!s->extra || nd_pass));
-        if (!split) CHK(dispatch_kron2(s, base | (s->use_lds ? KF_LDS : 0), A, nblocks));
+        if (!split) CHK(dispatch_kron2(s, base | (s->use_lds ? KF_LDS : 0) | ((epi && s->sr_now) ? KF_SR : 0), A, nblocks));
         else {
             const bool plain = !s->extra || nd_pass;      // local pass = stored/on-the-fly diagonal + up hops only
             // k_uppass_halo writes the unscaled local part; under the Lanczos epilogue the vectorised dw pass finishes it (uprev2)
@@ -685,6 +689,7 @@ static int hxv(S *s, const double *v, double *out, bool epi, const double *uprev
         hipLaunchKernelGGL(k_generic, dim3((unsigned)nblocks), dim3(256), 0, s->stream, A);
         HIPCHK(hipGetLastError());
     }
+    if (epi && s->sr_now) { s->sr_na = (int)nblocks; return EDGPU_OK; }      // self-reducing iteration: the axpy kernel sums these partials itself
     if (epi) {
         CHK(reduce_partials(s, nblocks));
         if (!s->defer_ar) CHK(allreduce_tmp(s));      // deferred-norm loop: the caller sums this together with the pending norm

@@ -257,6 +257,12 @@ struct edgpu_sector_s {
     bool csr_il_loc = false, csr_il_dw = false; bool csrL_nt = false;
     bool packed_ahead = false;      // hxv has packed the send rows on the compute stream already (halo_pack): halo_exchange does not pack again
     bool x_own_in_v = false;  // several ranks, stored-factor / on-the-fly forms with the needed-rows exchange: the dw pass reads the rank's own rows from the input vector, the x-space only holds received rows
+    // self-reducing Lanczos iteration of launch-bound sectors (k_kron2<KF_SR> + k_axpy_norm_sr): two launches per iteration
+    bool sr_on = true;        // EDGPU_LZ_SR
+    bool sr_allow = false;    // set by the plain Lanczos loops around their iterations (the eigensolvers interleave scalar steps of their own)
+    bool sr_now = false;      // this product is the first half of such an iteration
+    bool sr_pending = false;  // beta^2 partial sums of the last axpy pass not reduced yet
+    int sr_nb = 0, sr_na = 0; DevBuf<double> partial_b;
     bool dvd_fused_on = true; // EDGPU_DVD_FUSED: Davidson step with residual, correction and Gram-Schmidt dots in one pass (k_dvd_step)
     bool lz_wg_on = true;     // EDGPU_LZ_WG: sectors that fit LDS run their Lanczos loops in one workgroup (k_lanczos_wg)
     DevBuf<int32_t> wg_done; DevBuf<double> wg_slab; DevBuf<uint32_t> wg_brec;      // iteration count written by that kernel; its Krylov slab
@@ -393,6 +399,7 @@ static const KnobDef kKnobs[] = {
     // Lanczos loops and eigensolvers
     {"EDGPU_LZ_STORE", 1, "fallback", "keep the Krylov vectors of a ground-state search in HBM; 0: second Lanczos pass", "test_gpu_parity.py::test_ground_state_with_stored_krylov_vectors"},
     {"EDGPU_LZ_STORE_MAX", 1 << 30, "test hook", "cap on the stored Krylov vectors (tests: running out mid-search)", "test_gpu_parity.py::test_ground_state_with_stored_krylov_vectors"},
+    {"EDGPU_LZ_SR", 1, "fallback", "launch-bound sectors (whole product in one kernel, up to 4 M states): two launches per Lanczos iteration, every workgroup sums the partial sums itself; 0: four launches", "test_small_sector_lanczos.py::test_self_reducing_iteration_equals_the_four_launch_loop"},
     {"EDGPU_LZ_WG", 1, "fallback", "sectors of up to ~8 000 states run their Lanczos loops (sp_lanc_eigh, sp_lanc_tridiag and the legs built on it) in one workgroup; 0: per-iteration launches", "test_small_sector_lanczos.py::test_workgroup_lanczos_equals_the_launch_per_iteration_loop"},
     {"EDGPU_EIGSH_PRO", 1, "fallback", "thick-restart Lanczos with partial re-orthogonalisation; 0: whole-basis form", "test_eigsh.py::test_eigsh_alternative_forms"},
     {"EDGPU_EIGSH_FUSED", 1, "fallback", "fused two-pass products inside edgpu_eigsh", "test_eigsh.py::test_eigsh_alternative_forms"},

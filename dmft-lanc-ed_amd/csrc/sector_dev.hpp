@@ -509,7 +509,7 @@ static int create(const edgpu_desc *desc, S **out)
     s->extra = H.DimPh > 1 || H.Jhflag; s->has_ph = H.DimPh > 1; s->has_nd = H.Jhflag;
     s->nloc_el = H.DimUp * H.Qdw; s->nloc = s->nloc_el * H.DimPh; s->vecdim = s->nloc;
     s->multi = desc->mpi_size > 1 || (desc->reserved & 1);   // reserved bit 0: run the exchange path even on one rank (tests)
-    s->lz_fused_on = knob("EDGPU_LZ_FUSED") != 0; s->lz_wg_on = knob("EDGPU_LZ_WG") != 0; s->dvd_fused_on = knob("EDGPU_DVD_FUSED") != 0;
+    s->lz_fused_on = knob("EDGPU_LZ_FUSED") != 0; s->lz_wg_on = knob("EDGPU_LZ_WG") != 0; s->sr_on = knob("EDGPU_LZ_SR") != 0; s->dvd_fused_on = knob("EDGPU_DVD_FUSED") != 0;
     s->dbg = dbg_flags(); s->one_ar = knob("EDGPU_ONE_ALLREDUCE") != 0; s->up_pairs10 = knob("EDGPU_UP_PAIRS10") != 0; s->direct_cache = XKNOB("EDGPU_DIRECT_CACHE", 1) != 0; s->up_elem16 = XKNOB("EDGPU_UP_ELEM16", 1) != 0; s->pad_allowed = knob("EDGPU_PAD") != 0 && knob("EDGPU_ODD_PAIRS") != 0; s->tables_wave = XKNOB("EDGPU_TABLES_WAVE", 1) != 0; s->dw_lds_kb = std::min(XKNOB("EDGPU_DW_LDS_KB", 0), 150);
     // distributed-transpose dw pass: opt-in (EDGPU_DW_TRANSPOSE=1) until an 8-GPU run has shown it correct and faster than the
     // needed-rows exchange; at most 64 ranks (larger jobs use the needed-rows exchange)
@@ -534,7 +534,7 @@ static int create(const edgpu_desc *desc, S **out)
         if (XKNOB("EDGPU_KRON_THREADS", 0)) s->kron_threads_override = XKNOB("EDGPU_KRON_THREADS", 0);
         s->kron_threads = H.DimUp >= 4096 ? 1024 : (H.DimUp >= 1024 ? 512 : 256);
         if (s->kron_threads_override) s->kron_threads = s->kron_threads_override;
-        s->kron_lds = (s->use_lds ? rowbytes : 0) + 16 * sizeof(double);
+        s->kron_lds = (s->use_lds ? rowbytes : 0) + 24 * sizeof(double);
         // two-pass product (local pass + column-tiled dw pass) once the vector no longer fits the caches
         { const int k = knob("EDGPU_KRON_SPLIT"); s->kron_split = k < 0 ? H.DimUp * H.DimDw * 8 > ((int64_t)48 << 20) : k != 0; }
         // tile width of the dw pass: 64 columns measured best at Ns=16 (slab 6.6 MB, half of the gathers hit

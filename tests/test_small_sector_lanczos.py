@@ -93,3 +93,46 @@ def test_workgroup_green_function_leg(edgpu_mod, monkeypatch):
                     g = 1.0 / (z - a[i] - (b[i + 1] ** 2 * g if i + 1 < n else 0.0))
                 return g
             assert abs(cf(aa, ba, ua) - cf(ab, bb, ub)) < 1e-8 * max(1.0, abs(cf(ab, bb, ub)))
+
+
+@pytest.mark.parametrize("st", ["kron", "direct"])
+def test_self_reducing_iteration_equals_the_four_launch_loop(edgpu_mod, monkeypatch, st):
+    """Launch-bound sectors beyond the one-workgroup form (whole product in one kernel, up to 4 M states) run two launches per Lanczos
+    iteration: every workgroup of the consuming kernel sums the producing kernel's partial sums itself (k_kron2<KF_SR>, k_axpy_norm_sr).
+    Against the four-launch loop (EDGPU_LZ_SR=0) and the oracle: 1-orbital sectors of 14 400 - 853 776 states, a phonon sector and a
+    Jx/Jp sector (the row-wise kernel with those terms), sp_lanc_tridiag and sp_lanc_eigh (chunked host checks, stored and regenerated vectors)."""
+    from edgpu import model
+    import cases
+    zoo = {z[0]: z[1:] for z in cases.zoo()}
+    m9, _, _ = model.half_filled_c(9)
+    m11, nu11, nd11 = model.half_filled_c(11)
+    todo = [(m9, [3], [3]), (m9, [5], [5]), (m11, [5], [2]), (m11, nu11, nd11), zoo["phonons_nb3_nph3"], zoo["norb2_normal_JxJp"], zoo["replica_sz_sx_JxJp"]]
+    for m, nu, nd in todo:
+        S = oracle.Sector(m, nu, nd)
+        v0 = np.random.RandomState(7).uniform(0, 1, S.Dim)
+        n = min(40, S.Dim)
+        res = {}
+        for tag, env in (("sr", {}), ("sr_twopass", {"EDGPU_LZ_STORE": "0"}), ("plain", {"EDGPU_LZ_SR": "0"})):
+            for k, v in env.items():
+                monkeypatch.setenv(k, v)
+            G = edgpu_mod.HvSector(m, nu, nd, storage=st)
+            a, b, used = G.sp_lanc_tridiag(v0, n)
+            e0, x, nl = G.sp_lanc_eigh(v0, nitermax=min(300, S.Dim), threshold=1e-13)
+            res[tag] = (a, b, used, e0, x, nl)
+            G.close()
+            for k in env:
+                monkeypatch.delenv(k)
+        for tag, (a, b, used, e0, x, nl) in res.items():
+            assert used == res["plain"][2] and b[0] == 0.0
+            k = min(used, 25)
+            np.testing.assert_allclose(a[:k], res["plain"][0][:k], rtol=1e-11, atol=1e-11)      # the same arithmetic up to the order in which the partial sums are added
+            np.testing.assert_allclose(b[1:k], res["plain"][1][1:k], rtol=1e-11, atol=1e-11)
+            assert abs(e0 - res["plain"][3]) <= 1e-11 and abs(nl - res["plain"][5]) <= 1, (tag, e0, res["plain"][3], nl, res["plain"][5])      # the partial sums are added in another order: the 1e-13 stopping rule may fire one step apart
+            assert abs(np.linalg.norm(x) - 1.0) < 1e-12
+            assert min(np.abs(x - res["plain"][4]).max(), np.abs(x + res["plain"][4]).max()) < 1e-6, tag      # one Lanczos step more or less: the vector is converged to ~sqrt of the energy threshold
+            assert np.linalg.norm(S.spmatvec(x) - e0 * x) < 1e-5, tag
+        if S.Dim <= 70000:
+            a_ref, b_ref, used_ref = oracle.sp_lanc_tridiag(S.spmatvec, v0, n)
+            k = min(used_ref, 16)
+            np.testing.assert_allclose(res["sr"][0][:k], a_ref[:k], rtol=1e-9, atol=1e-9)
+            np.testing.assert_allclose(res["sr"][1][1:k], b_ref[1:k], rtol=1e-9, atol=1e-9)
