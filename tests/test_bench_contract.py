@@ -52,6 +52,19 @@ def test_bench_line(extra):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("storage", ["csr", "direct"])
+def test_bench_emulated_rank_line(storage):
+    """`bench.py --emulate-rank r --of P`: one rank of P alone on the GPU (measurement aid): one JSON line that says so, with the rank's
+    share of the rows, its exchange volume and the time split; never a job throughput (n_gpus stays 1, no `scaling` claim)."""
+    d = _run(["--emulate-rank", "2", "--of", "4", "--storage", storage])
+    assert d["emulated"] == {"rank": 2, "of": 4, "exchange": d["emulated"]["exchange"]} and "EMULATED" in d["metric"]
+    assert d["n_gpus"] == 1 and "scaling" not in d and d["ms_per_step"] > 0
+    assert d["config"]["rows_of_rank"] * 4 <= d["config"]["N"] + 4 * 252 and d["config"]["rows_of_rank"] > 0
+    assert d["exchange"]["mode"] == "needed-rows" and d["exchange"]["received_MB_per_product"] > 0
+    assert d["time_split_ms"]["hxv_product_of_rank"] > 0 and d["time_split_ms"]["emulated_exchange_on_comm_stream"] >= 0
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("storage", ["csr", "kron"])
 def test_bench_starts_its_own_ranks(storage):
     """`python bench.py --gpus 2` with NO launcher around it: two rank processes come up (sharing the one GPU of the test
