@@ -959,8 +959,8 @@ int edgpu_lanczos_bench_result(edgpu_handle h, int32_t nsteps_timed, float *hxv_
     }
     if (alphas && betas && ncoef > 0) {
         if (ncoef > h->bench_k) ncoef = h->bench_k;
-        HIPCHK(hipMemcpy(alphas, h->alphas.p, (size_t)ncoef * 8, hipMemcpyDeviceToHost));
-        HIPCHK(hipMemcpy(betas, h->betas.p + 1, (size_t)ncoef * 8, hipMemcpyDeviceToHost));
+        std::memcpy(alphas, h->alphas.h, (size_t)ncoef * 8);      // host memory (CoefBuf), the stream was synchronised above
+        std::memcpy(betas, h->betas.h + 1, (size_t)ncoef * 8);
     }
     return EDGPU_OK;
 }
@@ -1221,7 +1221,7 @@ int edgpu_comm_init_callbacks(edgpu_handle h, edgpu_allgatherv_fn ag, edgpu_exch
     return EDGPU_OK;
 }
 
-int edgpu_cache_release(void) { kpool_release(); return EDGPU_OK; }
+int edgpu_cache_release(void) { kpool_release(); g_streams.drain(); g_pinned.drain(); return EDGPU_OK; }
 
 int edgpu_device_count(int32_t *n)
 {

@@ -80,8 +80,8 @@ static int lz_prepare(S *s, int nmax, int nvec = 3)
         CHK(s->alphas.alloc((size_t)nmax + 2)); CHK(s->betas.alloc((size_t)nmax + 2)); CHK(s->zvec.alloc((size_t)nmax + 2));
         s->nmax = nmax;
     }
-    HIPCHK(hipMemsetAsync(s->alphas.p, 0, ((size_t)nmax + 2) * 8, s->stream));
-    HIPCHK(hipMemsetAsync(s->betas.p, 0, ((size_t)nmax + 2) * 8, s->stream));
+    HIPCHK(hipStreamSynchronize(s->stream));      // an earlier loop's kernels may still be writing the coefficient arrays (host memory)
+    std::memset(s->alphas.h, 0, ((size_t)nmax + 2) * 8); std::memset(s->betas.h, 0, ((size_t)nmax + 2) * 8);
     return EDGPU_OK;
 }
 
@@ -289,9 +289,8 @@ static int fetch_coeffs(S *s, int k, std::vector<double> &al, std::vector<double
 {
     CHK(lz_sr_flush(s));
     al.resize(k + 1); be.resize(k + 2);
-    HIPCHK(hipMemcpyAsync(al.data(), s->alphas.p, (size_t)(k + 1) * 8, hipMemcpyDeviceToHost, s->stream));
-    HIPCHK(hipMemcpyAsync(be.data(), s->betas.p, (size_t)(k + 2) * 8, hipMemcpyDeviceToHost, s->stream));
-    HIPCHK(hipStreamSynchronize(s->stream));
+    HIPCHK(hipStreamSynchronize(s->stream));      // the coefficient arrays are host memory the kernels write (CoefBuf)
+    std::memcpy(al.data(), s->alphas.h, (size_t)(k + 1) * 8); std::memcpy(be.data(), s->betas.h, (size_t)(k + 2) * 8);
     return EDGPU_OK;
 }
 
@@ -982,10 +981,8 @@ static int eigsh_pro(S *s, int nev, int ncv, int maxiter, double tol, double *ev
             if (fused) { Fz.u = B(j); Fz.t = B(j + 1); CHK(lzf_iter(s, Fz, B(j + 2), nullptr)); }      // afterwards Fz.u = B(j+1), Fz.uprev = B(j), Fz.t = B(j+2)
             else { V.ucur = B(j); V.w = B(j + 1); CHK(lz_iter(s, V, kloc, nullptr)); }              // afterwards V.uprev = B(j), V.ucur = B(j+1)
             nmv++;
-            double ab[2];
-            HIPCHK(hipMemcpyAsync(&ab[0], s->alphas.p + kloc, 8, hipMemcpyDeviceToHost, s->stream));
-            HIPCHK(hipMemcpyAsync(&ab[1], s->betas.p + kloc + 1, 8, hipMemcpyDeviceToHost, s->stream));
             HIPCHK(hipStreamSynchronize(s->stream));
+            const double ab[2] = {s->alphas.h[kloc], s->betas.h[kloc + 1]};      // written by the step kernels into pinned host memory: no copy call
             kloc++;
             double alpha = ab[0], beta = ab[1];
             Tm(j, j) = alpha;

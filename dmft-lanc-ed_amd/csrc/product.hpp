@@ -166,7 +166,7 @@ static int transposed_dw_pass(S *s, const double *v, hipStream_t st)
             CHK(a2a(s->tVT.p, rc, rd, s->tA.p, sc, sd));                                              // tA: DimUp x Qdw again
             return EDGPU_OK;
         }
-        if (!s->tstream) HIPCHK(hipStreamCreateWithFlags(&s->tstream, hipStreamNonBlocking));
+        if (!s->tstream) CHK(g_streams.take(s->device, &s->tstream));
         while ((int)s->tr_ev.size() < 2 * C) { hipEvent_t e; HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming)); s->tr_ev.push_back(e); }
         auto cut = [&](int64_t q, int c) { return q * c / C; };                                       // chunk c of a block of q rows: [cut(q,c), cut(q,c+1))
         std::vector<int64_t> sc2(P), sd2(P), rc2(P), rd2(P);

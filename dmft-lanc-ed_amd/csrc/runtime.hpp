@@ -163,6 +163,29 @@ struct SmallPool {
 };
 static SmallPool g_spool;
 
+// Streams are recycled the same way: on this runtime creating one costs ~0.6 ms and destroying it ~0.5 ms, and now and then a creation
+// takes 70-160 ms (a new hardware queue) -- 0.37 s of a 1.2 s sweep over the 91 sectors of an Ns=12 model went into the two streams
+// per sector (profiles/r04/sector_sweep_hip_api.txt).  A stream goes back only after it has been synchronised.
+struct StreamPool {
+    static constexpr size_t kMaxHeld = 16;
+    std::map<int, std::vector<hipStream_t>> free_;
+    int take(int dev, hipStream_t *out)
+    {
+        auto &v = free_[dev];
+        if (!v.empty()) { *out = v.back(); v.pop_back(); return EDGPU_OK; }
+        HIPCHK(hipStreamCreateWithFlags(out, hipStreamNonBlocking));
+        return EDGPU_OK;
+    }
+    void give(int dev, hipStream_t st)
+    {
+        if (!st) return;
+        auto &v = free_[dev];
+        if (v.size() < kMaxHeld && hipStreamSynchronize(st) == hipSuccess) v.push_back(st); else { (void)hipGetLastError(); (void)hipStreamDestroy(st); }
+    }
+    void drain() { for (auto &kv : free_) for (hipStream_t st : kv.second) (void)hipStreamDestroy(st); free_.clear(); }
+};
+static StreamPool g_streams;
+
 template <class T> struct DevBuf {
     T *p = nullptr; size_t n = 0;
     size_t pooled = 0; int pdev = -1;      // size class and device of a pooled block (0: a driver allocation of its own)
@@ -198,6 +221,36 @@ template <class T> struct DevBuf {
         p = nullptr; n = 0; pooled = 0; pdev = -1;
     }
     ~DevBuf() { release(); }
+};
+
+// Lanczos coefficients (alphas, betas) live in pinned host memory that the device writes directly (fine-grained, mapped): a solver that
+// looks at alpha_k / beta_k on the host after every step (edgpu_eigsh: the orthogonality estimates are kept on the host) then needs a
+// stream synchronisation only.  Two 8-byte hipMemcpyAsync calls cost ~20 us each on the host side of this runtime -- as much as the four
+// kernels of a small sector's iteration (profiles/r04/eigsh_small_sector_trace.txt).  The kernels only WRITE these arrays (one lane,
+// once per step; k_lanczos_wg reads one beta per launch); blocks are recycled through a process-wide pool like the device blocks.
+struct PinnedPool {
+    std::map<size_t, std::vector<void *>> free_;
+    static size_t cls(size_t bytes) { size_t c = 4096; while (c < bytes) c <<= 1; return c; }
+    void *take(size_t c) { auto it = free_.find(c); if (it == free_.end() || it->second.empty()) return nullptr; void *q = it->second.back(); it->second.pop_back(); return q; }
+    void give(size_t c, void *q) { if (free_[c].size() < 64) free_[c].push_back(q); else (void)hipHostFree(q); }
+    void drain() { for (auto &kv : free_) for (void *q : kv.second) (void)hipHostFree(q); free_.clear(); }
+};
+static PinnedPool g_pinned;
+template <class T> struct CoefBuf {      // p: the device's view (kernel arguments), h: the host's view (read after a stream synchronisation)
+    T *p = nullptr, *h = nullptr; size_t n = 0, cls = 0;
+    int alloc(size_t count)
+    {
+        release(); if (!count) return EDGPU_OK;
+        const size_t c = PinnedPool::cls(count * sizeof(T));
+        void *q = g_pinned.take(c);
+        if (!q) HIPCHK(hipHostMalloc(&q, c, hipHostMallocMapped | hipHostMallocPortable));
+        void *d = nullptr;
+        if (hipHostGetDevicePointer(&d, q, 0) != hipSuccess || !d) { (void)hipGetLastError(); (void)hipHostFree(q); return fail(EDGPU_EHIP, "edgpu: pinned host memory is not mapped into the device address space"); }
+        h = static_cast<T *>(q); p = static_cast<T *>(d); n = count; cls = c;
+        return EDGPU_OK;
+    }
+    void release() { if (h) g_pinned.give(cls, h); p = h = nullptr; n = 0; cls = 0; }
+    ~CoefBuf() { release(); }
 };
 
 // Single host thread per process (one rank per GPU, as the reference): the pool is not synchronised.  `in_use` is set for
@@ -295,7 +348,8 @@ struct edgpu_sector_s {
     std::vector<int64_t> xch_rows, relay_link_rows;        // relay_link_rows[a*P+b]: rows on link a->b, both phases, under the plan
     std::vector<RelayPeer> relay; bool relay_on = false; int relay_chunks = 0; int64_t relay_before = 0, relay_after = 0; DevBuf<double> relay_stage;
     std::vector<std::unique_ptr<DevBuf<double>>> eigV; DevBuf<double> eig_h, eig_y, eig_partial;
-    DevBuf<double> vfull, tmp_in, tmp_out, lz[5], scal, alphas, betas, zvec, partial, partial2;
+    DevBuf<double> vfull, tmp_in, tmp_out, lz[5], scal, zvec, partial, partial2;
+    CoefBuf<double> alphas, betas;      // pinned host memory written by the device (see CoefBuf)
     int64_t nloc = 0, nloc_el = 0, vecdim = 0;
     int32_t nmax = 0;
     bool use_lds = false; int kron_threads = 256, kron_threads_override = 0; size_t kron_lds = 0;
@@ -346,9 +400,7 @@ inline edgpu_sector_s::~edgpu_sector_s()
     if (ev_gather) (void)hipEventDestroy(ev_gather);
     if (ev_ready) (void)hipEventDestroy(ev_ready);
     for (auto e : tr_ev) (void)hipEventDestroy(e);
-    if (tstream) (void)hipStreamDestroy(tstream);
-    if (stream) (void)hipStreamDestroy(stream);
-    if (cstream) (void)hipStreamDestroy(cstream);
+    g_streams.give(device, tstream); g_streams.give(device, stream); g_streams.give(device, cstream);
 }
 
 namespace edgpu {

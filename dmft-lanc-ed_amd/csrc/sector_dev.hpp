@@ -499,8 +499,8 @@ static int create(const edgpu_desc *desc, S **out)
     if (desc->storage < EDGPU_STORE_KRON || desc->storage > EDGPU_STORE_DIRECT) return fail(EDGPU_EINVAL, "edgpu: bad storage");
     if (desc->device >= 0) HIPCHK(hipSetDevice(desc->device));
     HIPCHK(hipGetDevice(&s->device));
-    HIPCHK(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
-    HIPCHK(hipStreamCreateWithFlags(&s->cstream, hipStreamNonBlocking));
+    CHK(g_streams.take(s->device, &s->stream));      // plain non-blocking streams, recycled across sectors (runtime.hpp)
+    CHK(g_streams.take(s->device, &s->cstream));
     HIPCHK(hipEventCreate(&s->ev_a)); HIPCHK(hipEventCreate(&s->ev_b));
     HIPCHK(hipEventCreateWithFlags(&s->ev_gather, hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&s->ev_ready, hipEventDisableTiming));
     SectorHost &H = s->H;
