@@ -2141,7 +2141,8 @@ __global__ void __launch_bounds__(256) k_axpy_norm(double *__restrict__ w, const
 // the axpy/norm pass of the self-reducing iteration: alpha = sum of the product kernel's partial sums, taken by every workgroup;
 // reads the in-flight scales (SC_N_*), commits them, writes alpha_k
 __global__ void __launch_bounds__(256) k_axpy_norm_sr(double *__restrict__ w, const double *__restrict__ u, const double *__restrict__ scal, double *__restrict__ scal_w,
-                                                      const double *__restrict__ part_a, int n_a, double *__restrict__ alphas, int64_t n, double *__restrict__ partial)
+                                                      const double *__restrict__ part_a, int n_a, double *__restrict__ alphas, int64_t n, double *__restrict__ partial,
+                                                      double *__restrict__ partial_host)      // pinned host copy of the beta^2 partial sums (null: none): edgpu_eigsh sums them itself
 {
     __shared__ double red[17];
     const double s_cur = scal[SC_N_SCUR], sprev = scal[SC_N_SPREV], beta = scal[SC_N_BETA], K = scal[SC_N_K];
@@ -2163,7 +2164,7 @@ __global__ void __launch_bounds__(256) k_axpy_norm_sr(double *__restrict__ w, co
     if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) { const double vi = s_cur * u[n - 1], wi = w[n - 1] - alpha * vi; w[n - 1] = wi; s += wi * wi; }
     __syncthreads();
     const double r = block_sum(s, red);
-    if (threadIdx.x == 0) partial[blockIdx.x] = r;
+    if (threadIdx.x == 0) { partial[blockIdx.x] = r; if (partial_host) partial_host[blockIdx.x] = r; }
 }
 
 __global__ void __launch_bounds__(256) k_axpy3_norm(double *__restrict__ w, const double *__restrict__ u, const double *__restrict__ up, double *__restrict__ acc,

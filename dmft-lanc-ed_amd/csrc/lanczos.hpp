@@ -200,7 +200,7 @@ static bool lz_sr_ok(const S *s)
 }
 struct SrScope {      // the plain Lanczos loops allow the self-reducing iteration between construction and destruction of this object
     S *s; explicit SrScope(S *s_) : s(s_) { s->sr_allow = true; s->sr_pending = false; }
-    ~SrScope() { s->sr_allow = false; s->sr_pending = false; s->sr_now = false; }
+    ~SrScope() { s->sr_allow = false; s->sr_pending = false; s->sr_now = false; s->sr_host_partials = false; }
 };
 static int lz_iter(S *s, LzVecs &V, int k, double *acc)
 {
@@ -212,7 +212,7 @@ static int lz_iter(S *s, LzVecs &V, int k, double *acc)
         const int rc = hxv(s, V.ucur, V.w, true, V.uprev, s->vld);
         s->sr_now = false;
         if (rc) return rc;
-        hipLaunchKernelGGL(k_axpy_norm_sr, dim3(nb), dim3(256), 0, s->stream, V.w, (const double *)V.ucur, (const double *)s->scal.p, s->scal.p, (const double *)s->partial.p, s->sr_na, s->alphas.p, s->vlen, s->partial_b.p);
+        hipLaunchKernelGGL(k_axpy_norm_sr, dim3(nb), dim3(256), 0, s->stream, V.w, (const double *)V.ucur, (const double *)s->scal.p, s->scal.p, (const double *)s->partial.p, s->sr_na, s->alphas.p, s->vlen, s->partial_b.p, s->sr_host_partials ? s->partial_bh.p : (double *)nullptr);
         HIPCHK(hipGetLastError());
         s->sr_pending = true; s->sr_nb = nb;
         double *t = V.uprev; V.uprev = V.ucur; V.ucur = V.w; V.w = t;
@@ -972,6 +972,9 @@ static int eigsh_pro(S *s, int nev, int ncv, int maxiter, double tol, double *ev
         return EDGPU_OK;
     };
     Wm(0, 0) = 1.0;
+    // launch-bound sectors: the two-launch (self-reducing) iteration, beta summed on the host from a pinned copy of the partial sums
+    SrScope sr_scope(s);
+    if (!fused && lz_sr_ok(s)) { if (s->partial_bh.n < 512) CHK(s->partial_bh.alloc(512)); s->sr_host_partials = true; } else s->sr_allow = false;
     int l = 0, j = 0, kloc = 0, nconv = 0, it = 0, nmv = 0, meff = m, n_full = 0, n_sel = 0; int64_t nreads = 0;
     bool exact = false; double normT = 0.0, beta_last = 0.0;
     uint64_t seed = 7654321;
@@ -982,9 +985,15 @@ static int eigsh_pro(S *s, int nev, int ncv, int maxiter, double tol, double *ev
             else { V.ucur = B(j); V.w = B(j + 1); CHK(lz_iter(s, V, kloc, nullptr)); }              // afterwards V.uprev = B(j), V.ucur = B(j+1)
             nmv++;
             HIPCHK(hipStreamSynchronize(s->stream));
-            const double ab[2] = {s->alphas.h[kloc], s->betas.h[kloc + 1]};      // written by the step kernels into pinned host memory: no copy call
+            double alpha = s->alphas.h[kloc], beta;          // written by the step kernels into pinned host memory: no copy call
+            if (s->sr_pending) {
+                // self-reducing iteration (two launches): the beta step is still pending on the device (the next product takes it);
+                // the host sums the partial sums of |w|^2 itself.  Whatever else touches the scales or the new vector commits it first.
+                double b2 = 0.0; for (int i = 0; i < s->sr_nb; i++) b2 += s->partial_bh.h[i];
+                beta = std::sqrt(std::max(b2, 0.0));
+                if ((l > 0 && j == l) || j == m - 1) CHK(lz_sr_flush(s));
+            } else beta = s->betas.h[kloc + 1];
             kloc++;
-            double alpha = ab[0], beta = ab[1];
             Tm(j, j) = alpha;
             normT = std::max(normT, std::fabs(alpha) + beta + (j > 0 ? std::fabs(Tm(j, j - 1)) : 0.0));
             const bool arrow = l > 0 && j == l;            // H v_l couples to every kept Ritz vector
@@ -1029,6 +1038,7 @@ static int eigsh_pro(S *s, int nev, int ncv, int maxiter, double tol, double *ev
             }
             if (!idx.empty() && beta > 0.0) {
                 double nrm2 = 0.0;
+                CHK(lz_sr_flush(s));
                 std::vector<double> scl(idx.size()); for (size_t t = 0; t < idx.size(); t++) scl[t] = sc[idx[t]];
                 CHK(project_out(idx, scl.data(), B(j + 1), nrm2)); nreads += 2 * (int64_t)idx.size();
                 CHK(renorm(j, beta));                      // beta_j and the scale of u_{j+1} follow the new norm
@@ -1043,6 +1053,7 @@ static int eigsh_pro(S *s, int nev, int ncv, int maxiter, double tol, double *ev
                 // invariant subspace: every Ritz pair of T(0..j) is exact.  Enough of them -> done; else continue with a fresh
                 // random direction orthogonal to the basis (finds further copies of degenerate levels in tiny sectors)
                 Tm(j + 1, j) = Tm(j, j + 1) = 0.0; beta_last = 0.0;
+                CHK(lz_sr_flush(s));
                 if (j + 1 >= nev || (int64_t)(j + 1) >= Dim) { meff = j + 1; exact = true; break; }
                 hipLaunchKernelGGL(k_random_start, dim3(2048), dim3(256), 0, s->stream, dense, H.DimUp, H.Qdw, H.dw0, H.DimDw, H.DimPh, seed++);
                 HIPCHK(hipGetLastError());

@@ -350,6 +350,7 @@ struct edgpu_sector_s {
     std::vector<std::unique_ptr<DevBuf<double>>> eigV; DevBuf<double> eig_h, eig_y, eig_partial;
     DevBuf<double> vfull, tmp_in, tmp_out, lz[5], scal, zvec, partial, partial2;
     CoefBuf<double> alphas, betas;      // pinned host memory written by the device (see CoefBuf)
+    CoefBuf<double> partial_bh; bool sr_host_partials = false;      // edgpu_eigsh: host copy of the pending beta^2 partial sums of the self-reducing iteration
     int64_t nloc = 0, nloc_el = 0, vecdim = 0;
     int32_t nmax = 0;
     bool use_lds = false; int kron_threads = 256, kron_threads_override = 0; size_t kron_lds = 0;
