@@ -226,7 +226,7 @@ template <class T> struct DevBuf {
 // Lanczos coefficients (alphas, betas) live in pinned host memory that the device writes directly (fine-grained, mapped): a solver that
 // looks at alpha_k / beta_k on the host after every step (edgpu_eigsh: the orthogonality estimates are kept on the host) then needs a
 // stream synchronisation only.  Two 8-byte hipMemcpyAsync calls cost ~20 us each on the host side of this runtime -- as much as the four
-// kernels of a small sector's iteration (profiles/r04/eigsh_small_sector_trace.txt).  The kernels only WRITE these arrays (one lane,
+// kernels of a small sector's iteration (profiles/r04/sector_sweep_hip_api.txt).  The kernels only WRITE these arrays (one lane,
 // once per step; k_lanczos_wg reads one beta per launch); blocks are recycled through a process-wide pool like the device blocks.
 struct PinnedPool {
     std::map<size_t, std::vector<void *>> free_;
