@@ -311,9 +311,10 @@ int edgpu_sp_matvec(edgpu_spmat m, const double *v_host, double *hv_host, int32_
  * Asynchronous on `hip_stream` (a hipStream_t, NULL = the default stream); the caller synchronises. */
 int edgpu_sp_matvec_device(edgpu_spmat m, const double *v_dev, double *hv_dev, int32_t accumulate, void *hip_stream);
 
-/* The library keeps large work vectors (the stored Krylov basis of edgpu_lanczos_gs) in a process-wide cache between
- * calls and sectors; it gives them back by itself when one of its allocations fails.  Call this to return the memory
- * to the device at once (e.g. before another library needs it). */
+/* The library keeps large work vectors (the stored Krylov basis of edgpu_lanczos_gs), small device blocks, the streams of
+ * deleted sectors and the pinned host blocks of the Lanczos coefficients in process-wide caches between calls and sectors
+ * (the host creates and deletes O(Ns^2) sectors per DMFT iteration); device memory is given back by itself when one of the
+ * library's allocations fails.  Call this to return everything at once (e.g. before another library needs it). */
 int edgpu_cache_release(void);
 
 /* ---- device memory helpers for hosts without a HIP binding (Fortran) ---------------------- */
