@@ -967,6 +967,9 @@ struct DwArgs {
     int32_t ld;                // row pitch of v / vfull / out / uprev2 in doubles (0: DimUp)
     const double *uprev2;      // fused Lanczos iteration (EPI only): out holds the UNSCALED local part; out = s_cur*(out + dw part) - beta*s_prev*uprev2
     int32_t own_in_v;          // several ranks, needed-rows exchange: x-space rows < Qdw (the rank's own rows) are read from v itself, only received rows from vfull (no own-row copy per product)
+#ifdef EDGPU_EXPERIMENTS
+    int32_t abl;               // experiments build, timing only (WRONG results): 1 every gather reads the row's own segment, 2 no result store, 4 gathers from rows (j & 15), 8 no running-result read
+#endif
 };
 
 // Column tiles dealt to the XCDs (workgroups go round-robin over the 8 XCDs): XCD x owns tiles x, x+8, ... and walks all row
@@ -1062,9 +1065,17 @@ __global__ void __launch_bounds__(256) k_dwpass2(DwArgs A)
                     }
                 } else
                 for (int k = 0; k < nk; k++) {
+#ifdef EDGPU_EXPERIMENTS
+                    const int64_t xr = (A.abl & 1) ? row % A.Qdw + A.dw0 : ((A.abl & 4) ? (int64_t)(tcr[k] & 15) : (int64_t)tcr[k]);
+                    const dbl2v x = *reinterpret_cast<const dbl2v *>(A.vfull + fbase + xr * ld);
+#else
                     const dbl2v x = *reinterpret_cast<const dbl2v *>(A.vfull + fbase + (int64_t)tcr[k] * ld);
+#endif
                     acc += tvr[k] * x;
                 }
+#ifdef EDGPU_EXPERIMENTS
+                if (!(A.abl & 8))
+#endif
                 o = NT ? __builtin_nontemporal_load(po) : *po;
                 if (EPI) { vl = *reinterpret_cast<const dbl2v *>(A.v + e); if (A.uprev2) up = *reinterpret_cast<const dbl2v *>(A.uprev2 + e); }
                 if (EPI) {
@@ -1072,6 +1083,9 @@ __global__ void __launch_bounds__(256) k_dwpass2(DwArgs A)
                     else o += s_cur * acc;
                     asum += (s_cur * vl.x) * o.x + (s_cur * vl.y) * o.y;
                 } else o += acc;
+#ifdef EDGPU_EXPERIMENTS
+                if ((A.abl & 2) && o.x != 1.2345e300) continue;
+#endif
                 if (NT) __builtin_nontemporal_store(o, po); else *po = o;
             }
     }

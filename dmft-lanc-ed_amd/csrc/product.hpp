@@ -496,6 +496,9 @@ static int hxv(S *s, const double *v, double *out, bool epi, const double *uprev
                 D.DimUp = A.DimUp; D.DimDw = A.DimDw; D.DimPh = A.DimPh; D.Qdw = A.Qdw; D.dw0 = A.dw0;
                 D.dwc = A.dwc; D.dwv = A.dwv; D.dww = A.dww; D.v = v; D.vfull = A.vfull; D.out = out; D.scal = s->scal.p; D.partial = s->partial.p;
                 D.uprev2 = uprev2; D.ld = (int32_t)ld; D.own_in_v = (multi && s->x_own_in_v) ? 1 : 0;
+#ifdef EDGPU_EXPERIMENTS
+                D.abl = XKNOB("EDGPU_DW_ABL", 0);
+#endif
                 D.w = s->dw_w; D.wshift = 0; while ((1 << D.wshift) < D.w) D.wshift++;
                 const int dv = s->dw_variant;
                 const bool vec2 = dv >= 2 && (H.DimUp % 2 == 0 || ld > H.DimUp) && D.w >= 4 && D.dww <= 64;
