@@ -136,3 +136,63 @@ def test_self_reducing_iteration_equals_the_four_launch_loop(edgpu_mod, monkeypa
             k = min(used_ref, 16)
             np.testing.assert_allclose(res["sr"][0][:k], a_ref[:k], rtol=1e-9, atol=1e-9)
             np.testing.assert_allclose(res["sr"][1][1:k], b_ref[1:k], rtol=1e-9, atol=1e-9)
+
+
+def test_eigsh_two_launch_iteration_equals_the_four_launch_one(edgpu_mod, monkeypatch):
+    """edgpu_eigsh on launch-bound sectors runs the self-reducing iteration too; beta_k reaches the host as the partial sums of |w|^2 in pinned
+    memory (summed there), alpha_k through the pinned coefficient array.  Same pairs, same number of products and restarts as with
+    EDGPU_LZ_SR=0 (four launches, the beta step taken by a reduction kernel), eigenvalues against the dense spectrum; a phonon sector and a
+    Jx/Jp sector ride along (re-orthogonalisations and restarts commit the pending step first)."""
+    from edgpu import model
+    import cases
+    zoo = {z[0]: z[1:] for z in cases.zoo()}
+    m9, _, _ = model.half_filled_c(9)
+    todo = [(m9, [3], [3]), (m9, [5], [4]), zoo["phonons_nb3_nph3"], zoo["norb2_normal_JxJp"]]
+    for m, nu, nd in todo:
+        S = oracle.Sector(m, nu, nd)
+        res = {}
+        for tag, env in (("sr", {}), ("plain", {"EDGPU_LZ_SR": "0"})):
+            for k, v in env.items():
+                monkeypatch.setenv(k, v)
+            G = edgpu_mod.HvSector(m, nu, nd, storage="kron")
+            nev = min(3, S.Dim - 1)
+            ev, X, info = G.sp_eigh(nev, nblock=min(S.Dim, 12), nitermax=400, tol=1e-11)
+            res[tag] = (ev, X, info)
+            G.close()
+            for k in env:
+                monkeypatch.delenv(k)
+        ev, X, info = res["sr"]
+        np.testing.assert_allclose(ev, res["plain"][0], rtol=0, atol=1e-10)
+        assert abs(info["matvecs"] - res["plain"][2]["matvecs"]) <= 12 and info["nconv"] == res["plain"][2]["nconv"], (info, res["plain"][2])
+        for i in range(len(ev)):
+            assert np.linalg.norm(S.spmatvec(X[:, i]) - ev[i] * X[:, i]) < 1e-7 * max(1.0, abs(ev[i]))
+        if S.Dim <= 5000:
+            w = np.linalg.eigvalsh(S.hmat())
+            assert abs(ev[0] - w[0]) <= 1e-9
+            for e in ev:      # a single-vector Krylov space holds one copy of a degenerate level
+                assert np.abs(w - e).min() <= 1e-9
+
+
+def test_sector_churn_recycles_streams_and_blocks(edgpu_mod):
+    """The host creates and deletes O(Ns^2) sectors per DMFT iteration: streams, small device blocks and the pinned coefficient blocks are
+    recycled through process-wide pools (runtime.hpp).  Many create / solve / leg / delete cycles, edgpu_cache_release in between, and the
+    answers stay the ones of the first cycle."""
+    import edgpu
+    from edgpu import model
+    m, _, _ = model.half_filled_c(7)
+    first = None
+    for cycle in range(40):
+        G = edgpu_mod.HvSector(m, [4], [3], storage=("kron", "direct", "csr")[cycle % 3])
+        T = edgpu_mod.HvSector(m, [5], [3], storage="kron")
+        ev, X, info = G.sp_eigh(2, nblock=20, nitermax=300, tol=1e-11)
+        n2, a, b, used = edgpu.gf_lanczos(G, T, 1, 1, True, np.ascontiguousarray(X[:, 0]), 30)
+        got = (ev.copy(), n2, a[:10].copy(), b[:10].copy())
+        T.close(); G.close()
+        if first is None:
+            first = got
+        np.testing.assert_allclose(got[0], first[0], rtol=0, atol=1e-10)
+        assert abs(got[1] - first[1]) < 1e-10
+        np.testing.assert_allclose(got[2], first[2], rtol=1e-8, atol=1e-8)
+        np.testing.assert_allclose(got[3], first[3], rtol=1e-8, atol=1e-8)
+        if cycle % 13 == 12:
+            edgpu_mod.cache_release()
