@@ -243,7 +243,7 @@ template <class T> struct CoefBuf {      // p: the device's view (kernel argumen
         release(); if (!count) return EDGPU_OK;
         const size_t c = PinnedPool::cls(count * sizeof(T));
         void *q = g_pinned.take(c);
-        if (!q) HIPCHK(hipHostMalloc(&q, c, hipHostMallocMapped | hipHostMallocPortable));
+        if (!q) HIPCHK(hipHostMalloc(&q, c, hipHostMallocMapped | hipHostMallocPortable | hipHostMallocCoherent));
         void *d = nullptr;
         if (hipHostGetDevicePointer(&d, q, 0) != hipSuccess || !d) { (void)hipGetLastError(); (void)hipHostFree(q); return fail(EDGPU_EHIP, "edgpu: pinned host memory is not mapped into the device address space"); }
         h = static_cast<T *>(q); p = static_cast<T *>(d); n = count; cls = c;

@@ -532,7 +532,10 @@ static int create(const edgpu_desc *desc, S **out)
         size_t rowbytes = (size_t)H.DimUp * sizeof(double);
         s->use_lds = rowbytes + 128 <= 150 * 1024 && !(dbg_flags() & 4);
         if (XKNOB("EDGPU_KRON_THREADS", 0)) s->kron_threads_override = XKNOB("EDGPU_KRON_THREADS", 0);
-        s->kron_threads = H.DimUp >= 4096 ? 1024 : (H.DimUp >= 1024 ? 512 : 256);
+        // threads of the one-workgroup-per-row product: a lane walks DimUp / threads elements one after the other, each with its dependent
+        // dw gathers; 512 threads from 384 columns on (Ns=12: 25.2 -> 18.9 us per Lanczos step at N = 174 240, 31 -> 27 at N = 853 776;
+        // 1 024 threads lose again on the largest of those sectors: profiles/r04/kron_threads_small_sectors.txt)
+        s->kron_threads = H.DimUp >= 4096 ? 1024 : (H.DimUp >= 384 ? 512 : 256);
         if (s->kron_threads_override) s->kron_threads = s->kron_threads_override;
         s->kron_lds = (s->use_lds ? rowbytes : 0) + 24 * sizeof(double);
         // two-pass product (local pass + column-tiled dw pass) once the vector no longer fits the caches
