@@ -422,8 +422,8 @@ struct OncePerDevice { bool done[64] = {}; bool first(int dev) { if (dev < 0 || 
 struct KnobDef { const char *name; int dflt; const char *kind; const char *doc; const char *test; };
 static const KnobDef kKnobs[] = {
     // product forms
-    {"EDGPU_KRON_SPLIT", -1, "form", "two-pass product (local pass + column-tiled dw pass) of the stored-factor / on-the-fly operator; -1: once a vector exceeds 48 MB", "test_gpu_parity.py::test_large_sector_code_paths_on_small_sectors"},
-    {"EDGPU_CSR_SPLIT", -1, "form", "explicit CSR stored as two blocks H_loc + H_dw; -1: once a vector exceeds 48 MB", "test_gpu_parity.py::test_large_sector_code_paths_on_small_sectors"},
+    {"EDGPU_KRON_SPLIT", -1, "form", "two-pass product (local pass + column-tiled dw pass) of the stored-factor / on-the-fly operator; -1: once a vector exceeds 12 MiB", "test_gpu_parity.py::test_large_sector_code_paths_on_small_sectors"},
+    {"EDGPU_CSR_SPLIT", -1, "form", "explicit CSR stored as two blocks H_loc + H_dw; -1: once a vector exceeds 12 MiB", "test_gpu_parity.py::test_large_sector_code_paths_on_small_sectors"},
     {"EDGPU_COMPOSITE", 1, "fallback", "ed_total_ud=F through composite up/dw blocks; 0: generic mixed-radix kernel", "test_gpu_parity.py::test_large_sector_code_paths_on_small_sectors"},
     {"EDGPU_ND_SPLIT", 1, "fallback", "Jx/Jp terms in a pass of their own; 0: inside the row-wise kernel", "test_gpu_parity.py::test_c5_full_size_properties"},
     {"EDGPU_LZ_FUSED", 1, "fallback", "fused two-pass Lanczos iteration; 0: product + axpy/norm pass", "test_gpu_parity.py::test_fused_iteration_equals_three_pass_iteration"},

@@ -382,7 +382,7 @@ static int build_csr(S *s)
     // Two storage forms of the same explicit matrix: one CSR, or (default for large sectors) two CSR
     // blocks H = H_loc + H_dw so that each block can be streamed in the order that keeps ITS gathers
     // cache resident (rows for the up hops, XCD-owned column tiles for the dw hops).
-    { const int k = knob("EDGPU_CSR_SPLIT"); s->csr_split = (k < 0 ? H.DimUp * H.DimDw * 8 > ((int64_t)48 << 20) : k != 0) || H.Jhflag || H.DimPh > 1; }      // the non-local / phonon passes go between the local and the dw block
+    { const int k = knob("EDGPU_CSR_SPLIT"); s->csr_split = (k < 0 ? H.DimUp * H.DimDw * 8 > ((int64_t)12 << 20) /* measured: 16 MB 130 -> 109 us per step, 32 MB 253 -> 218, 48 MB 362 -> 310, tie at 5-8 MB, the single block wins below (profiles/r04/kron_split_threshold.txt); 48 MiB until round 4 */ : k != 0) || H.Jhflag || H.DimPh > 1; }      // the non-local / phonon passes go between the local and the dw block
     s->csrL_nnz = H.Qdw * uppre[up.dim]; s->csrD_nnz = s->csr_nnz - s->csrL_nnz;
     s->csr_ld = H.DimUp;
     // several ranks: only with the needed-rows exchange, whose messages carry the pitch (EDGPU_CSR_PITCH_MULTI=0: dense rows as in round 2)
@@ -538,8 +538,11 @@ static int create(const edgpu_desc *desc, S **out)
         s->kron_threads = H.DimUp >= 4096 ? 1024 : (H.DimUp >= 384 ? 512 : 256);
         if (s->kron_threads_override) s->kron_threads = s->kron_threads_override;
         s->kron_lds = (s->use_lds ? rowbytes : 0) + 24 * sizeof(double);
-        // two-pass product (local pass + column-tiled dw pass) once the vector no longer fits the caches
-        { const int k = knob("EDGPU_KRON_SPLIT"); s->kron_split = k < 0 ? H.DimUp * H.DimDw * 8 > ((int64_t)48 << 20) : k != 0; }
+        // two-pass product (local pass + column-tiled dw pass, fused Lanczos iteration) from 12 MiB per vector on: measured per Lanczos step at
+        // Ns=14, single pass -> two passes: 8 MB 35 -> 36 us (on the fly 42 -> 37), 16 MB 56 -> 48 (68 -> 48), 32 MB 96 -> 75 (110 -> 72),
+        // 48 MB 133 -> 95 (150 -> 93); below, the single-pass kernel with its two-launch iteration wins (profiles/r04/kron_split_threshold.txt).
+        // Until round 4 the switch sat at 48 MiB.
+        { const int k = knob("EDGPU_KRON_SPLIT"); s->kron_split = k < 0 ? H.DimUp * H.DimDw * 8 > ((int64_t)12 << 20) : k != 0; }
         // tile width of the dw pass: 64 columns measured best at Ns=16 (slab 6.6 MB, half of the gathers hit
         // L2) and at Ns=18 (slab 25 MB: no re-use left, but narrower tiles lose more to short segments)
         s->dw_w = knob("EDGPU_DW_W");
