@@ -1,70 +1,9 @@
 // lanczos.hpp -- device-resident Lanczos (ground state, tridiagonalisation) and the thick-restart multi-eigenpair solver
 // Part of libedgpu.so (one translation unit: edgpu.hip includes these headers in order).
 #pragma once
+#include "tridiag_host.hpp"
 
 namespace edgpu {
-
-// ---------------------------------------------------------------------------------------
-// symmetric tridiagonal eigen-solver (implicit QL with Wilkinson shifts), host, n <= ~1000.
-// d: diagonal (n), e: sub-diagonal e[1..n-1] (e[0] unused).  On exit d = eigenvalues
-// (unsorted); if z != nullptr (n*n, row-major z[i*n+j], identity on entry) columns = vectors.
-// ---------------------------------------------------------------------------------------
-static bool tqli(std::vector<double> &d, std::vector<double> &e, int n, double *z)
-{
-    for (int i = 1; i < n; i++) e[i - 1] = e[i];
-    if (n > 0) e[n - 1] = 0.0;
-    for (int l = 0; l < n; l++) {
-        int iter = 0, m;
-        do {
-            for (m = l; m < n - 1; m++) {
-                double dd = std::fabs(d[m]) + std::fabs(d[m + 1]);
-                if (std::fabs(e[m]) <= 2.3e-16 * dd) break;
-            }
-            if (m != l) {
-                if (iter++ == 120) return false;
-                double g = (d[l + 1] - d[l]) / (2.0 * e[l]);
-                double r = std::hypot(g, 1.0);
-                g = d[m] - d[l] + e[l] / (g + (g >= 0.0 ? std::fabs(r) : -std::fabs(r)));
-                double sn = 1.0, c = 1.0, p = 0.0;
-                int i;
-                for (i = m - 1; i >= l; i--) {
-                    double f = sn * e[i], b = c * e[i];
-                    e[i + 1] = (r = std::hypot(f, g));
-                    if (r == 0.0) { d[i + 1] -= p; e[m] = 0.0; break; }
-                    sn = f / r; c = g / r;
-                    g = d[i + 1] - p;
-                    r = (d[i] - g) * sn + 2.0 * c * b;
-                    d[i + 1] = g + (p = sn * r);
-                    g = c * r - b;
-                    if (z)
-                        for (int k = 0; k < n; k++) {
-                            double f2 = z[(size_t)k * n + i + 1];
-                            z[(size_t)k * n + i + 1] = sn * z[(size_t)k * n + i] + c * f2;
-                            z[(size_t)k * n + i] = c * z[(size_t)k * n + i] - sn * f2;
-                        }
-                }
-                if (r == 0.0 && i >= l) continue;
-                d[l] -= p; e[l] = g; e[m] = 0.0;
-            }
-        } while (m != l);
-    }
-    return true;
-}
-
-// lowest eigenvalue (and optionally its eigenvector) of T_k = tridiag(alphas[0..k), betas[1..k))
-static bool tridiag_lowest(const double *al, const double *be, int k, double *e0, std::vector<double> *zcol)
-{
-    std::vector<double> d(al, al + k), e(k, 0.0);
-    for (int i = 1; i < k; i++) e[i] = be[i];
-    std::vector<double> z;
-    if (zcol) { z.assign((size_t)k * k, 0.0); for (int i = 0; i < k; i++) z[(size_t)i * k + i] = 1.0; }
-    if (!tqli(d, e, k, zcol ? z.data() : nullptr)) return false;
-    int im = 0;
-    for (int i = 1; i < k; i++) if (d[i] < d[im]) im = i;
-    *e0 = d[im];
-    if (zcol) { zcol->resize(k); for (int i = 0; i < k; i++) (*zcol)[i] = z[(size_t)i * k + im]; }
-    return true;
-}
 
 // ---------------------------------------------------------------------------------------
 // Lanczos loop, device resident.  Restates SciFortran's lanczos_iteration / sp_lanc_eigh /
@@ -384,7 +323,7 @@ static int lanczos_gs_wg(S *s, const WgPlan &P, int nitermax, double threshold, 
     const size_t want = (size_t)(nitermax + 1) * (size_t)kstride;
     if (s->wg_slab.n < want) CHK(s->wg_slab.alloc(want));
     std::vector<double> al, be;
-    int nlanc = 0, done = 0; double esave = 0.0, e0 = 0.0; bool stop = false;
+    int nlanc = 0, done = 0; double e0 = 0.0; bool stop = false; StopRule rule;
     const int chunk = 16;
     for (int k = 0; k < nitermax && !stop;) {
         const int n = std::min(chunk, nitermax - k);
@@ -394,9 +333,9 @@ static int lanczos_gs_wg(S *s, const WgPlan &P, int nitermax, double threshold, 
         for (; k < done; k++) {
             nlanc = k + 1;
             if (std::fabs(be[k + 1]) < threshold) { stop = true; break; }
-            if (!tridiag_lowest(al.data(), be.data(), nlanc, &e0, nullptr)) return fail(EDGPU_ENOTCONVERGED, "edgpu: tridiagonal QL did not converge");
-            if (nlanc >= ncheck && std::fabs(e0 - esave) <= threshold) { stop = true; break; }
-            esave = e0;
+            const int r = rule.check(al.data(), be.data(), nlanc, ncheck, threshold, &e0);
+            if (r < 0) return fail(EDGPU_ENOTCONVERGED, "edgpu: tridiagonal QL did not converge");
+            if (r > 0) { stop = true; break; }
         }
     }
     std::vector<double> z;
@@ -522,7 +461,9 @@ static int lanczos_gs_impl(S *s, int nitermax, double threshold, int ncheck, dou
     }
     HIPCHK(hipMemcpyAsync(&s0, s->scal.p + SC_SCUR, 8, hipMemcpyDeviceToHost, s->stream)); HIPCHK(hipStreamSynchronize(s->stream));
     std::vector<double> al, be;
-    int nlanc = 0; double esave = 0.0, e0 = 0.0;
+    int nlanc = 0; double e0 = 0.0; StopRule rule;
+    using clk = std::chrono::steady_clock; auto tsec = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double>(b - a).count() * 1e3; };
+    const clk::time_point t_begin = clk::now(); double ms_issue = 0.0, ms_wait = 0.0, ms_rule = 0.0;      // EDGPU_DEBUG bit 3: where the wall time of a search goes
     // The stopping rule of iteration i only involves alpha/beta up to i, so iterations can be issued ahead of
     // the host check: small (launch-bound) sectors run `chunk` iterations per host round trip and then apply
     // the rule to each of them in order -- same nlanc and E0, at most chunk-1 surplus iterations.
@@ -530,6 +471,7 @@ static int lanczos_gs_impl(S *s, int nitermax, double threshold, int ncheck, dou
     bool done = false;
     for (int k = 0; k < nitermax && !done;) {
         const int kend = std::min(nitermax, k + chunk);
+        const clk::time_point t0 = clk::now();
         for (int j = k; j < kend; j++) {
             if (fused) {                              // dw half of j + local half of j+1: alpha_j and beta_j
                 double *tnew = store ? ring_get(j + 2) : nullptr;
@@ -545,20 +487,27 @@ static int lanczos_gs_impl(S *s, int nitermax, double threshold, int ncheck, dou
                 if (nx) { V.w = nx; CHK(lzf_zero_pads(s, nx)); } else store = false; // out of memory: keep rotating through the last three
             }
         }
+        const clk::time_point t1 = clk::now();
         CHK(fetch_coeffs(s, kend - 1, al, be));
+        const clk::time_point t2 = clk::now();
+        ms_issue += tsec(t0, t1); ms_wait += tsec(t1, t2);
+        struct RuleTimer { double &acc; clk::time_point a; ~RuleTimer() { acc += std::chrono::duration<double>(clk::now() - a).count() * 1e3; } } rule_timer{ms_rule, t2};
         for (; k < kend; k++) {
             nlanc = k + 1;
             if (s->one_ar_on) {       // beta_{k+1} is still a pending partial sum: the invariant-subspace test looks at beta_k, one product late
                 if (k > 0 && std::fabs(be[k]) < threshold) { nlanc = k; done = true; break; }
             } else
             if (std::fabs(be[k + 1]) < threshold) { done = true; break; }       // invariant subspace reached
-            if (!tridiag_lowest(al.data(), be.data(), nlanc, &e0, nullptr)) return fail(EDGPU_ENOTCONVERGED, "edgpu: tridiagonal QL did not converge");
-            if (nlanc >= ncheck && std::fabs(e0 - esave) <= threshold) { done = true; break; }
-            esave = e0;
+            const int r = rule.check(al.data(), be.data(), nlanc, ncheck, threshold, &e0);
+            if (r < 0) return fail(EDGPU_ENOTCONVERGED, "edgpu: tridiagonal QL did not converge");
+            if (r > 0) { done = true; break; }
         }
     }
+    const clk::time_point t_loop = clk::now();
     std::vector<double> z;
     if (!tridiag_lowest(al.data(), be.data(), nlanc, &e0, &z)) return fail(EDGPU_ENOTCONVERGED, "edgpu: tridiagonal QL did not converge");
+    if (s->dbg & 8) fprintf(stderr, "edgpu_lanczos_gs: %d iterations; loop %.3f ms (issuing %.3f, waiting for the device %.3f, stopping rule %.3f), eigenvector of T %.3f ms\n",
+                            nlanc, tsec(t_begin, t_loop), ms_issue, ms_wait, ms_rule, tsec(t_loop, clk::now()));
     *egs = e0; *nlanc_out = nlanc;
     if (s->multi) {      // every rank must take the same branch below (the second pass contains collectives)
         DevBuf<double> f; std::vector<double> one(1, store ? 1.0 : 0.0);
