@@ -46,14 +46,18 @@ def b_csr(N, nnz):
     return 12 * nnz + 8 * (N + 1) + 16 * N
 
 
+PRODUCT_SOURCES = ("exchange.hpp", "kernels.hpp", "product.hpp", "sector_dev.hpp", "sector_host.hpp")
+
+
 def source_stamp():
-    """sha256 over the kernel sources: the PMC traffic summary under profiles/ is stamped with it, and bench.py only
-    reports that traffic while the stamp still matches the code that is running (there is no .git on the GPU box)."""
+    """sha256 over the sources that define the product kernels, their launches and the storage forms (PRODUCT_SOURCES; the solver
+    loops, the C-ABI file and the host runtime around them cannot change what one product moves): the PMC traffic summary under
+    profiles/ is stamped with it, and bench.py only reports that traffic while the stamp still matches the code that is running
+    (there is no .git on the GPU box)."""
     h = hashlib.sha256()
     d = os.path.join(ROOT, "dmft-lanc-ed_amd", "csrc")
-    for f in sorted(os.listdir(d)):
-        if f.endswith((".hip", ".hpp")):
-            h.update(f.encode()); h.update(open(os.path.join(d, f), "rb").read())
+    for f in PRODUCT_SOURCES:
+        h.update(f.encode()); h.update(open(os.path.join(d, f), "rb").read())
     return h.hexdigest()[:16]
 
 

@@ -2928,14 +2928,24 @@ __global__ void __launch_bounds__(256) k_dvd_resid(DvdArgs A, double *__restrict
 // Davidson step for SMALL search spaces (nv <= NV <= 12; round 4): residual, preconditioned correction AND the first Gram-Schmidt
 // dots in ONE pass over V and W.  The V values of an element stay in registers until its correction t is known, so that
 // h_i = V_i . t (and |t|^2, |r|^2) are summed on the way: the separate multi-dot pass over the basis (nv more vector reads per
-// iteration) is gone.  partial[b*(nv+2) + i]: i < nv: V_i.t ; nv: |t|^2 ; nv+1: |r|^2  (layout of k_multidot_final).
-template <int NV>
-__global__ void __launch_bounds__(256) k_dvd_step(DvdArgs A, double *__restrict__ t, int64_t n, double *__restrict__ partial)
+// iteration) is gone.  The W values are in registers as well, so g_i = W_i . t rides along: with H symmetric,
+// V_i . (H v_new) = W_i . v_new, and v_new is a known combination of t and the V_j -- the new column of the projected matrix
+// follows on the host without the pass over V that used to compute it (dvdson(), lanczos.hpp).
+// partial[b*(2nv+2) + i]: i < nv: V_i.t ; nv <= i < 2nv: W_(i-nv).t ; 2nv: |t|^2 ; 2nv+1: |r|^2  (layout of k_multidot_final).
+// ROT (a restart is due): every value of V and W at an element is in registers here, so the thick-restart rotation
+// V'_j = sum_i V_i C[i + nv*j], W'_j likewise (j < nout <= 6), is written from them in place -- the restart costs its 2*nout vector
+// writes instead of two more passes over both bases (k_basis_rotate* read 2*nv and write 2*nout vectors).  The dots come out
+// against the OLD basis; the host rotates them (V'^T t = C^T V^T t).
+constexpr int kDvdRotOut = 6;
+template <int NV, bool ROT>
+__global__ void __launch_bounds__(256) k_dvd_step(DvdArgs A, double *__restrict__ t, int64_t n, double *__restrict__ partial, const double *__restrict__ C, int nout)
 {
     __shared__ double red[4];
     __shared__ double cs[NV];
+    __shared__ double cr[ROT ? NV * kDvdRotOut : 1];
     const int nv = A.nv;
     for (int i = threadIdx.x; i < NV; i += blockDim.x) cs[i] = i < nv ? A.y[i] : 0.0;
+    if (ROT) for (int q = threadIdx.x; q < NV * kDvdRotOut; q += blockDim.x) { const int j = q / NV, i = q - j * NV; cr[q] = (i < nv && j < nout) ? C[i + nv * j] : 0.0; }
     __syncthreads();
     const double theta = A.theta;
     auto finish = [&](int64_t e, double r) -> double {
@@ -2944,9 +2954,9 @@ __global__ void __launch_bounds__(256) k_dvd_step(DvdArgs A, double *__restrict_
         if (fabs(den) < 1e-8) den = den < 0.0 ? -1e-8 : 1e-8;
         return r / den;
     };
-    double hs[NV], tt = 0.0, rr = 0.0;
+    double hs[NV], gw[NV], tt = 0.0, rr = 0.0;
 #pragma unroll
-    for (int i = 0; i < NV; i++) hs[i] = 0.0;
+    for (int i = 0; i < NV; i++) { hs[i] = 0.0; gw[i] = 0.0; }
     const int64_t n2 = n >> 1;
     for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < n2; p += (int64_t)gridDim.x * blockDim.x) {
         dbl2_t vv[NV], wv[NV];
@@ -2959,7 +2969,17 @@ __global__ void __launch_bounds__(256) k_dvd_step(DvdArgs A, double *__restrict_
         reinterpret_cast<dbl2_t *>(t)[p] = o;
         rr += r.x * r.x + r.y * r.y; tt += o.x * o.x + o.y * o.y;
 #pragma unroll
-        for (int i = 0; i < NV; i++) if (i < nv) hs[i] += vv[i].x * o.x + vv[i].y * o.y;
+        for (int i = 0; i < NV; i++) if (i < nv) { hs[i] += vv[i].x * o.x + vv[i].y * o.y; gw[i] += wv[i].x * o.x + wv[i].y * o.y; }
+        if (ROT) {
+#pragma unroll
+            for (int j = 0; j < kDvdRotOut; j++) if (j < nout) {
+                dbl2_t a, b; a.x = 0.0; a.y = 0.0; b.x = 0.0; b.y = 0.0;
+#pragma unroll
+                for (int i = 0; i < NV; i++) { const double c = cr[j * NV + i]; a.x += c * vv[i].x; a.y += c * vv[i].y; b.x += c * wv[i].x; b.y += c * wv[i].y; }
+                reinterpret_cast<dbl2_t *>(const_cast<double *>(A.V[j]))[p] = a;
+                reinterpret_cast<dbl2_t *>(const_cast<double *>(A.W[j]))[p] = b;
+            }
+        }
     }
     if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
         const int64_t e = n - 1; double r = 0.0;
@@ -2968,12 +2988,73 @@ __global__ void __launch_bounds__(256) k_dvd_step(DvdArgs A, double *__restrict_
         const double o = finish(e, r);
         t[e] = o; rr += r * r; tt += o * o;
 #pragma unroll
-        for (int i = 0; i < NV; i++) if (i < nv) hs[i] += A.V[i][e] * o;
-    }
+        for (int i = 0; i < NV; i++) if (i < nv) { hs[i] += A.V[i][e] * o; gw[i] += A.W[i][e] * o; }
+        if (ROT) {
+            double ve[NV], we[NV];
 #pragma unroll
-    for (int i = 0; i < NV; i++) { if (i < nv) { const double sI = block_sum(hs[i], red); if (threadIdx.x == 0) partial[(int64_t)blockIdx.x * (nv + 2) + i] = sI; } }
-    { const double sT = block_sum(tt, red); if (threadIdx.x == 0) partial[(int64_t)blockIdx.x * (nv + 2) + nv] = sT; }
-    { const double sR = block_sum(rr, red); if (threadIdx.x == 0) partial[(int64_t)blockIdx.x * (nv + 2) + nv + 1] = sR; }
+            for (int i = 0; i < NV; i++) { ve[i] = A.V[i < nv ? i : 0][e]; we[i] = A.W[i < nv ? i : 0][e]; }
+#pragma unroll
+            for (int j = 0; j < kDvdRotOut; j++) if (j < nout) {
+                double a = 0.0, b = 0.0;
+#pragma unroll
+                for (int i = 0; i < NV; i++) { a += cr[j * NV + i] * ve[i]; b += cr[j * NV + i] * we[i]; }
+                const_cast<double *>(A.V[j])[e] = a; const_cast<double *>(A.W[j])[e] = b;
+            }
+        }
+    }
+    const int64_t pb = (int64_t)blockIdx.x * (2 * nv + 2);
+#pragma unroll
+    for (int i = 0; i < NV; i++) { if (i < nv) { const double sI = block_sum(hs[i], red); if (threadIdx.x == 0) partial[pb + i] = sI; } }
+#pragma unroll
+    for (int i = 0; i < NV; i++) { if (i < nv) { const double sI = block_sum(gw[i], red); if (threadIdx.x == 0) partial[pb + nv + i] = sI; } }
+    { const double sT = block_sum(tt, red); if (threadIdx.x == 0) partial[pb + 2 * nv] = sT; }
+    { const double sR = block_sum(rr, red); if (threadIdx.x == 0) partial[pb + 2 * nv + 1] = sR; }
+}
+
+static inline void launch_dvd_step(hipStream_t st, int nb, const DvdArgs &D, double *t, int64_t n, double *partial, const double *C, int nout)
+{
+    const int m = D.nv;
+#define C_(NV) do { if (C) hipLaunchKernelGGL((k_dvd_step<NV, true>), dim3(nb), dim3(256), 0, st, D, t, n, partial, C, nout); \
+                    else hipLaunchKernelGGL((k_dvd_step<NV, false>), dim3(nb), dim3(256), 0, st, D, t, n, partial, C, nout); } while (0)
+    // the exact size for the spaces the default cycle runs through (4..8): an instance compiled for more vectors re-reads vector 0 in their place
+    switch (m) { case 1: case 2: case 3: case 4: C_(4); break; case 5: C_(5); break; case 6: C_(6); break; case 7: C_(7); break; case 8: C_(8); break;
+                 case 9: case 10: C_(10); break; default: C_(12); }
+#undef C_
+}
+
+// Second half of the small-space Davidson step: v_new = (t - sum_i h_i V_i) * scale written straight into the next basis slot
+// (the norm of the orthogonalised vector is known beforehand from |t|^2 - sum h_i^2 whenever that difference is not a
+// cancellation, which is also the DGKS condition for one Gram-Schmidt pass being enough), |t - sum h_i V_i|^2 summed on the
+// way so that the host can check both.  Replaces multiaxpy_norm in place + k_scale_copy (two vector reads and one write less).
+template <int NV>
+__global__ void __launch_bounds__(256) k_dvd_orth(BasisArgs B, const double *__restrict__ h, const double *__restrict__ t, double *__restrict__ out, double scale, int64_t n, double *__restrict__ partial)
+{
+    __shared__ double red[4];
+    __shared__ double cs[NV];
+    const int nv = B.nv;
+    for (int i = threadIdx.x; i < NV; i += blockDim.x) cs[i] = i < nv ? h[i] : 0.0;
+    __syncthreads();
+    double ss = 0.0;
+    const int64_t n2 = n >> 1;
+    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < n2; p += (int64_t)gridDim.x * blockDim.x) {
+        dbl2_t vv[NV];
+#pragma unroll
+        for (int i = 0; i < NV; i++) vv[i] = reinterpret_cast<const dbl2_t *>(B.V[i < nv ? i : 0])[p];
+        dbl2_t x = reinterpret_cast<const dbl2_t *>(t)[p];
+#pragma unroll
+        for (int i = 0; i < NV; i++) { const double c = cs[i]; x.x -= c * vv[i].x; x.y -= c * vv[i].y; }
+        ss += x.x * x.x + x.y * x.y;
+        x.x *= scale; x.y *= scale;
+        reinterpret_cast<dbl2_t *>(out)[p] = x;
+    }
+    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+        double x = t[n - 1];
+#pragma unroll
+        for (int i = 0; i < NV; i++) if (i < nv) x -= cs[i] * B.V[i][n - 1];
+        ss += x * x; out[n - 1] = x * scale;
+    }
+    const double r = block_sum(ss, red);
+    if (threadIdx.x == 0) partial[blockIdx.x] = r;
 }
 
 __global__ void __launch_bounds__(256) k_scale_copy(double *__restrict__ y, const double *__restrict__ x, double a, int64_t n)

@@ -1243,11 +1243,12 @@ static int dvdson(S *s, int nev, int maxiter, double tol, double *evals, double 
     const int64_t Dim = s->H.Dim, n = s->nloc;
     if (nev < 1) return fail(EDGPU_EINVAL, "edgpu_dvdson: nev < 1");
     if ((int64_t)nev >= Dim) return fail(EDGPU_EINVAL, "edgpu_dvdson: nev must be smaller than the sector dimension (the reference switches to LAPACK there, ED_DIAG.f90:105-107)");
-    // Search space: 2*nev + 6 vectors (10 for the two pairs ED_DIAG.f90:189-203 asks for) with GD+1 restarts -- the restarted space
-    // keeps the lowest nev + 2 Ritz vectors AND the previous iterate of the target pair (Stathopoulos & Saad's "+k" vectors: the
+    // Search space: 2*nev + 4 vectors (8 for the two pairs ED_DIAG.f90:189-203 asks for) with GD+1 restarts -- the restarted space
+    // keeps the lowest nev + 1 Ritz vectors AND the previous iterate of the target pair (Stathopoulos & Saad's "+k" vectors: the
     // restarted method then converges like the unrestarted one), so a small space loses no products while every pass over the
-    // space is half as long as with the 16 vectors of rounds 2-3 (c3: 3.0 s -> profiles/r04/dvdson_c3.txt).
-    int mmax = std::min<int64_t>(std::min<int64_t>(kMaxBasis, Dim), std::max(2 * nev + 6, 10));
+    // space is short: c3, two pairs, 162-165 products for every size between 8 and 12 and 1 or 2 extra Ritz vectors kept
+    // (profiles/r04/dvdson_c3.txt; rounds 2-3 ran 16 vectors, 3.0 s; 10 vectors 2.35 s; this form 1.49 s).
+    int mmax = std::min<int64_t>(std::min<int64_t>(kMaxBasis, Dim), std::max(2 * nev + 4, 8));
     { const int mx = XKNOB("EDGPU_DVD_MMAX", 0); if (mx > nev + 2) mmax = (int)std::min<int64_t>(std::min<int64_t>(kMaxBasis, Dim), mx); }      // experiments build: size of the search space
     const bool small = mmax <= 12 && s->dvd_fused_on;      // k_dvd_step: residual, correction and the Gram-Schmidt dots in one pass
     if (mmax <= nev) return fail(EDGPU_EINVAL, "edgpu_dvdson: too many eigenpairs requested for the search space");
@@ -1266,8 +1267,8 @@ static int dvdson(S *s, int nev, int maxiter, double tol, double *evals, double 
     double *t = s->eigV[2 * mmax]->p;
     const int nb = (int)std::max<int64_t>(1, std::min<int64_t>(cdiv(n, 256 * 8), 1024));
     const int gs = (int)std::max<int64_t>(1, std::min<int64_t>(cdiv(n, 256 * 4), 4096));
-    if (s->eig_h.n < (size_t)(mmax + 3)) CHK(s->eig_h.alloc((size_t)mmax + 3));
-    if (s->eig_partial.n < (size_t)nb * (mmax + 3)) CHK(s->eig_partial.alloc((size_t)nb * (mmax + 3)));
+    if (s->eig_h.n < (size_t)(2 * mmax + 3)) CHK(s->eig_h.alloc((size_t)2 * mmax + 3));
+    if (s->eig_partial.n < (size_t)nb * (2 * mmax + 3)) CHK(s->eig_partial.alloc((size_t)nb * (2 * mmax + 3)));
     if (s->eig_y.n < (size_t)mmax * mmax) CHK(s->eig_y.alloc((size_t)mmax * mmax));
     const SectorHost &H = s->H;
     const bool rot_mfma = knob("EDGPU_ROT_MFMA") != 0;
@@ -1295,14 +1296,71 @@ static int dvdson(S *s, int nev, int maxiter, double tol, double *evals, double 
     std::vector<double> G((size_t)mmax * mmax, 0.0), theta, Y, yprev;
     int m = 0, nmv = 0, nconv = 0, it = 0;
     // append V[m] (already orthonormal to the space): W[m] = H V[m], new column of G
-    auto extend = [&]() -> int {
+    // gcol: the off-diagonal part of that column when it is already known (V_i . H v_new = W_i . v_new, summed inside k_dvd_step):
+    // only the diagonal entry then needs the new image, one dot of two vectors instead of a pass over the whole space
+    auto extend = [&](const double *gcol) -> int {
         CHK(hxv(s, Vp(m), Wp(m), false, nullptr)); nmv++;
-        CHK(dots(m + 1, Wp(m), false));
-        for (int i = 0; i <= m; i++) { G[(size_t)i * mmax + m] = h2[i]; G[(size_t)m * mmax + i] = h2[i]; }
+        if (gcol) {
+            double gmm = 0.0;
+            CHK(reduce_dot(s, Vp(m), Wp(m), n));
+            HIPCHK(hipMemcpyAsync(&gmm, s->scal.p + SC_TMP, 8, hipMemcpyDeviceToHost, s->stream)); HIPCHK(hipStreamSynchronize(s->stream));
+            for (int i = 0; i < m; i++) { G[(size_t)i * mmax + m] = gcol[i]; G[(size_t)m * mmax + i] = gcol[i]; }
+            G[(size_t)m * mmax + m] = gmm;
+        } else {
+            CHK(dots(m + 1, Wp(m), false));
+            for (int i = 0; i <= m; i++) { G[(size_t)i * mmax + m] = h2[i]; G[(size_t)m * mmax + i] = h2[i]; }
+        }
         m++;
         return EDGPU_OK;
     };
-    CHK(extend());
+    const bool gcol_on = XKNOB("EDGPU_DVD_GCOL", 1) != 0;      // experiments build: 0 = every new column of the projected matrix by a pass over the space
+    int n_fast = 0, n_slow = 0;
+    const bool rot_fused = XKNOB("EDGPU_DVD_ROTFUSED", 1) != 0;      // experiments build: 0 = restarts by the rotation kernels
+    // Thick restart (GD+1): the lowest `keep` Ritz vectors + the previous iterate of the target pair, V and W rotated alike.
+    // plan_restart: the m x nout coefficient matrix from the current Ritz vectors Y (column major, ld m); adopt_restart: the host
+    // state after the bases have been rotated (by k_dvd_step<.., true> or by the rotation kernels).
+    struct RestartPlan { std::vector<double> Cm; int keep = 0, nout = 0; bool plus = false; double gpp = 0.0; };
+    auto plan_restart = [&]() -> RestartPlan {
+        RestartPlan R;
+        R.keep = std::min(mmax - 2, nev + XKNOB("EDGPU_DVD_KEEP", 1));
+        const int keep = R.keep;
+        R.Cm.assign((size_t)m * (keep + 1), 0.0);
+        for (int j = 0; j < keep; j++) for (int i = 0; i < m; i++) R.Cm[(size_t)m * j + i] = Y[(size_t)m * j + i];
+        if (!yprev.empty() && (int)yprev.size() <= m) {
+            std::vector<double> pv((size_t)m, 0.0);
+            for (size_t i = 0; i < yprev.size(); i++) pv[i] = yprev[i];
+            for (int pass = 0; pass < 2; pass++)
+                for (int j = 0; j < keep; j++) { double d = 0.0; for (int i = 0; i < m; i++) d += Y[(size_t)m * j + i] * pv[i]; for (int i = 0; i < m; i++) pv[i] -= d * Y[(size_t)m * j + i]; }
+            double nn = 0.0; for (int i = 0; i < m; i++) nn += pv[i] * pv[i];
+            if (nn > 1e-16) {
+                nn = 1.0 / std::sqrt(nn);
+                for (int i = 0; i < m; i++) { pv[i] *= nn; R.Cm[(size_t)m * keep + i] = pv[i]; }
+                for (int i = 0; i < m; i++) for (int j = 0; j < m; j++) R.gpp += pv[i] * G[(size_t)i * mmax + j] * pv[j];
+                R.plus = true;
+            }
+        }
+        R.nout = keep + (R.plus ? 1 : 0);
+        return R;
+    };
+    auto adopt_restart = [&](const RestartPlan &R, std::vector<double> &hfirst, double t2, double r2) -> int {
+        std::fill(G.begin(), G.end(), 0.0);
+        for (int i = 0; i < R.keep; i++) G[(size_t)i * mmax + i] = theta[i];
+        if (R.plus) G[(size_t)R.keep * mmax + R.keep] = R.gpp;     // the Ritz vectors are G-orthogonal to everything orthogonal to them
+        if (small && !hfirst.empty()) {
+            // the correction was computed against the old basis and is still a valid new direction; its dots with the
+            // rotated bases follow from the old ones (V' = V C, W' = W C  =>  V'^T t = C^T V^T t): no pass over the space
+            const int nout = R.nout;
+            std::vector<double> hr((size_t)2 * nout + 2, 0.0);
+            for (int j = 0; j < nout; j++) for (int i = 0; i < m; i++) { hr[j] += R.Cm[(size_t)m * j + i] * hfirst[i]; hr[nout + j] += R.Cm[(size_t)m * j + i] * hfirst[m + i]; }
+            hr[2 * nout] = t2; hr[2 * nout + 1] = r2;
+            hfirst.swap(hr);
+            HIPCHK(hipMemcpyAsync(s->eig_h.p, hfirst.data(), (size_t)nout * 8, hipMemcpyHostToDevice, s->stream)); HIPCHK(hipStreamSynchronize(s->stream));
+        }
+        m = R.nout;
+        yprev.clear();
+        return EDGPU_OK;
+    };
+    CHK(extend(nullptr));
     for (it = 0; it < maxiter; it++) {
         std::vector<double> Gs((size_t)m * m);
         for (int i = 0; i < m; i++) for (int j = 0; j < m; j++) Gs[(size_t)i * m + j] = G[(size_t)i * mmax + j];
@@ -1313,14 +1371,24 @@ static int dvdson(S *s, int nev, int maxiter, double tol, double *evals, double 
         DvdArgs D{}; D.nv = m; for (int i = 0; i < m; i++) { D.V[i] = Vp(i); D.W[i] = Wp(i); }
         D.y = s->eig_y.p; D.theta = theta[k]; D.diag = s->diag.p; D.nel = s->nloc_el; D.w0 = H.DimPh > 1 ? H.desc.w0_ph : 0.0;
         double r2 = 0.0, t2 = 0.0; std::vector<double> hfirst;
-        if (small) {      // ... and the dots V_i . t of the first Gram-Schmidt pass, |t|^2, |r|^2 on the way
-            hipLaunchKernelGGL(k_dvd_step<12>, dim3(nb), dim3(256), 0, s->stream, D, t, n, s->eig_partial.p);
-            hipLaunchKernelGGL(k_multidot_final, dim3(1), dim3(256), 0, s->stream, (const double *)s->eig_partial.p, nb, m + 2, s->eig_h.p);
+        bool restarted = false;
+        if (small) {      // ... and the dots V_i . t of the first Gram-Schmidt pass, W_i . t, |t|^2, |r|^2 on the way
+            // a full space is restarted by this very pass (k_dvd_step<.., true>): what the restart keeps depends on the Ritz
+            // vectors only, not on the residual that is about to be computed
+            RestartPlan R;
+            bool rot = false;
+            if (m == mmax && rot_fused) { R = plan_restart(); rot = R.nout <= kDvdRotOut; }
+            if (rot) {
+                HIPCHK(hipMemcpyAsync(s->eig_y.p + mmax, R.Cm.data(), (size_t)m * R.nout * 8, hipMemcpyHostToDevice, s->stream));
+            }
+            launch_dvd_step(s->stream, nb, D, t, n, s->eig_partial.p, rot ? (const double *)(s->eig_y.p + mmax) : nullptr, rot ? R.nout : 0);
+            hipLaunchKernelGGL(k_multidot_final, dim3(1), dim3(256), 0, s->stream, (const double *)s->eig_partial.p, nb, 2 * m + 2, s->eig_h.p);
             HIPCHK(hipGetLastError());
-            CHK(allreduce_dev(s, s->eig_h.p, m + 2));
-            hfirst.resize((size_t)m + 2);
-            HIPCHK(hipMemcpyAsync(hfirst.data(), s->eig_h.p, (size_t)(m + 2) * 8, hipMemcpyDeviceToHost, s->stream)); HIPCHK(hipStreamSynchronize(s->stream));
-            t2 = hfirst[m]; r2 = hfirst[m + 1];
+            CHK(allreduce_dev(s, s->eig_h.p, 2 * m + 2));
+            hfirst.resize((size_t)2 * m + 2);      // [0,m): V_i.t   [m,2m): W_i.t   2m: |t|^2   2m+1: |r|^2
+            HIPCHK(hipMemcpyAsync(hfirst.data(), s->eig_h.p, (size_t)(2 * m + 2) * 8, hipMemcpyDeviceToHost, s->stream)); HIPCHK(hipStreamSynchronize(s->stream));
+            t2 = hfirst[2 * m]; r2 = hfirst[2 * m + 1];
+            if (rot) { CHK(adopt_restart(R, hfirst, t2, r2)); restarted = true; }      // the bases are the rotated ones from here on, converged or not
         } else {
             hipLaunchKernelGGL(k_dvd_resid, dim3(nb), dim3(256), 0, s->stream, D, t, n, s->eig_partial.p);
             hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(1024), 0, s->stream, (const double *)s->eig_partial.p, (int64_t)nb, s->scal.p + SC_TMP);
@@ -1334,47 +1402,64 @@ static int dvdson(S *s, int nev, int maxiter, double tol, double *evals, double 
             if (nconv >= nev || nconv >= m) break;
             continue;                                          // next pair, same space
         }
-        bool restarted = false;
-        if (m == mmax) {     // thick restart (GD+1): lowest `keep` Ritz vectors + the previous iterate of the target pair, V and W rotated alike
-            int keep = std::min(mmax - 2, nev + XKNOB("EDGPU_DVD_KEEP", 2));
-            std::vector<double> Cm((size_t)m * (keep + 1), 0.0);
-            for (int j = 0; j < keep; j++) for (int i = 0; i < m; i++) Cm[(size_t)m * j + i] = Y[(size_t)m * j + i];
-            double gpp = 0.0; bool plus = false;
-            if (!yprev.empty() && (int)yprev.size() <= m) {
-                std::vector<double> pv((size_t)m, 0.0);
-                for (size_t i = 0; i < yprev.size(); i++) pv[i] = yprev[i];
-                for (int pass = 0; pass < 2; pass++)
-                    for (int j = 0; j < keep; j++) { double d = 0.0; for (int i = 0; i < m; i++) d += Y[(size_t)m * j + i] * pv[i]; for (int i = 0; i < m; i++) pv[i] -= d * Y[(size_t)m * j + i]; }
-                double nn = 0.0; for (int i = 0; i < m; i++) nn += pv[i] * pv[i];
-                if (nn > 1e-16) {
-                    nn = 1.0 / std::sqrt(nn);
-                    for (int i = 0; i < m; i++) { pv[i] *= nn; Cm[(size_t)m * keep + i] = pv[i]; }
-                    for (int i = 0; i < m; i++) for (int j = 0; j < m; j++) gpp += pv[i] * G[(size_t)i * mmax + j] * pv[j];
-                    plus = true;
-                }
-            }
-            const int nout = keep + (plus ? 1 : 0);
-            HIPCHK(hipMemcpyAsync(s->eig_y.p, Cm.data(), (size_t)m * nout * 8, hipMemcpyHostToDevice, s->stream));
+        if (m == mmax && !restarted) {     // thick restart by the rotation kernels (large spaces, or the fused form switched off)
+            RestartPlan R = plan_restart();
+            HIPCHK(hipMemcpyAsync(s->eig_y.p, R.Cm.data(), (size_t)m * R.nout * 8, hipMemcpyHostToDevice, s->stream));
             for (int half = 0; half < 2; half++) {
                 if (rot_mfma) { std::vector<double *> vb((size_t)m); for (int i = 0; i < m; i++) vb[i] = half ? Wp(i) : Vp(i);
-                    CHK(launch_basis_rotate_mfma(s->stream, s->device, vb.data(), m, nout, s->eig_y.p, n)); continue; }
-                RotArgs Rt{}; Rt.nv = m; Rt.nout = nout; Rt.Y = s->eig_y.p; for (int i = 0; i < m; i++) Rt.V[i] = half ? Wp(i) : Vp(i);
-                hipLaunchKernelGGL(k_basis_rotate<kMaxBasis>, dim3(gs), dim3(256), (size_t)m * nout * 8, s->stream, Rt, n);
+                    CHK(launch_basis_rotate_mfma(s->stream, s->device, vb.data(), m, R.nout, s->eig_y.p, n)); continue; }
+                RotArgs Rt{}; Rt.nv = m; Rt.nout = R.nout; Rt.Y = s->eig_y.p; for (int i = 0; i < m; i++) Rt.V[i] = half ? Wp(i) : Vp(i);
+                hipLaunchKernelGGL(k_basis_rotate<kMaxBasis>, dim3(gs), dim3(256), (size_t)m * R.nout * 8, s->stream, Rt, n);
             }
             HIPCHK(hipGetLastError());
-            HIPCHK(hipStreamSynchronize(s->stream));          // Cm lives on this frame
-            std::fill(G.begin(), G.end(), 0.0);
-            for (int i = 0; i < keep; i++) G[(size_t)i * mmax + i] = theta[i];
-            if (plus) G[(size_t)keep * mmax + keep] = gpp;     // the Ritz vectors are G-orthogonal to everything orthogonal to them
-            m = nout; restarted = true;
-            yprev.clear();
-            // the correction was computed against the old basis: still a valid new direction
-        } else {
+            HIPCHK(hipStreamSynchronize(s->stream));          // R.Cm lives on this frame
+            CHK(adopt_restart(R, hfirst, t2, r2));
+            restarted = true;
+        } else if (!restarted) {
             yprev.assign(Y.begin() + (size_t)m * k, Y.begin() + (size_t)m * (k + 1));      // this iterate, in the basis of this iteration (the next one has one vector more: coefficient 0)
         }
         // orthogonalise t against the space, normalise, append
         double tn = 0.0;
         bool done_orth = false;
+        if (small && gcol_on) {
+            // |t - sum h_i V_i|^2 = |t|^2 - sum h_i^2 for an orthonormal space; when that difference keeps at least half of |t|^2
+            // it is no cancellation (relative error a few ulp) AND one Gram-Schmidt pass is enough (DGKS): the new basis vector
+            // is written normalised in the same pass, and its row of the projected matrix follows from the W_i . t.
+            double sh = 0.0; for (int i = 0; i < m; i++) sh += hfirst[i] * hfirst[i];
+            const double est = t2 - sh;
+            if (est >= 0.5 * t2 && est > 1e-28) {
+                const double sc = 1.0 / std::sqrt(est);
+                BasisArgs Bu{}; Bu.nv = m; for (int i = 0; i < m; i++) Bu.V[i] = Vp(i);
+                if (m <= 6) hipLaunchKernelGGL(k_dvd_orth<6>, dim3(nb), dim3(256), 0, s->stream, Bu, (const double *)s->eig_h.p, (const double *)t, Vp(m), sc, n, s->eig_partial.p);
+                else if (m <= 8) hipLaunchKernelGGL(k_dvd_orth<8>, dim3(nb), dim3(256), 0, s->stream, Bu, (const double *)s->eig_h.p, (const double *)t, Vp(m), sc, n, s->eig_partial.p);
+                else if (m <= 10) hipLaunchKernelGGL(k_dvd_orth<10>, dim3(nb), dim3(256), 0, s->stream, Bu, (const double *)s->eig_h.p, (const double *)t, Vp(m), sc, n, s->eig_partial.p);
+                else hipLaunchKernelGGL(k_dvd_orth<12>, dim3(nb), dim3(256), 0, s->stream, Bu, (const double *)s->eig_h.p, (const double *)t, Vp(m), sc, n, s->eig_partial.p);
+                hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(1024), 0, s->stream, (const double *)s->eig_partial.p, (int64_t)nb, s->scal.p + SC_TMP);
+                HIPCHK(hipGetLastError());
+                CHK(allreduce_tmp(s));
+                double after = 0.0;
+                HIPCHK(hipMemcpyAsync(&after, s->scal.p + SC_TMP, 8, hipMemcpyDeviceToHost, s->stream)); HIPCHK(hipStreamSynchronize(s->stream));
+                if (after >= 0.5 * t2 && std::fabs(after - est) <= 1e-8 * t2) {      // what was summed agrees with what was predicted: |v_new| = 1 to rounding
+                    std::vector<double> gcol((size_t)m);
+                    for (int i = 0; i < m; i++) { double a = hfirst[m + i]; for (int j = 0; j < m; j++) a -= hfirst[j] * G[(size_t)i * mmax + j]; gcol[i] = a * sc; }
+                    n_fast++;
+                    CHK(extend(gcol.data()));
+                    continue;
+                }
+                // the space has lost orthogonality beyond what the prediction tolerates: orthogonalise v_new itself, the long way
+                std::vector<double *> bas(m); for (int i = 0; i < m; i++) bas[i] = Vp(i);
+                std::vector<double> hj; double vn = 0.0;
+                CHK(orthogonalise_cgs(s, bas.data(), m, 0, Vp(m), n, nb, hj, vn));
+                if (!(vn > 1e-14)) break;
+                hipLaunchKernelGGL(k_scale_copy, dim3(gs), dim3(256), 0, s->stream, t, (const double *)Vp(m), 1.0 / vn, n);
+                hipLaunchKernelGGL(k_scale_copy, dim3(gs), dim3(256), 0, s->stream, Vp(m), (const double *)t, 1.0, n);
+                HIPCHK(hipGetLastError());
+                n_slow++;
+                CHK(extend(nullptr));
+                continue;
+            }
+        }
+        n_slow++;
         if (small && !restarted) {      // first pass with the dots that came with the correction; DGKS: a second, full pass only when the vector shrank
             BasisArgs Bu{}; Bu.nv = m; for (int i = 0; i < m; i++) Bu.V[i] = Vp(i);
             launch_multiaxpy_norm(s->stream, nb, Bu, (const double *)s->eig_h.p, t, n, s->eig_partial.p);
@@ -1393,8 +1478,9 @@ static int dvdson(S *s, int nev, int maxiter, double tol, double *evals, double 
         if (!(tn > 1e-14)) break;                              // no new direction: the space is invariant
         hipLaunchKernelGGL(k_scale_copy, dim3(gs), dim3(256), 0, s->stream, Vp(m), (const double *)t, 1.0 / tn, n);
         HIPCHK(hipGetLastError());
-        CHK(extend());
+        CHK(extend(nullptr));
     }
+    if (knob("EDGPU_DEBUG") & 8) fprintf(stderr, "edgpu_dvdson: %d products, %d steps in two passes over the space (column of the projected matrix from W.t), %d the long way\n", nmv, n_fast, n_slow);
     // Ritz vectors of the lowest nev pairs
     {
         std::vector<double> Gs((size_t)m * m);

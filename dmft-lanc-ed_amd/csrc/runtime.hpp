@@ -317,7 +317,7 @@ struct edgpu_sector_s {
     bool sr_now = false;      // this product is the first half of such an iteration
     bool sr_pending = false;  // beta^2 partial sums of the last axpy pass not reduced yet
     int sr_nb = 0, sr_na = 0; DevBuf<double> partial_b;
-    bool dvd_fused_on = true; // EDGPU_DVD_FUSED: Davidson step with residual, correction and Gram-Schmidt dots in one pass (k_dvd_step)
+    bool dvd_fused_on = true; // EDGPU_DVD_FUSED: Davidson step in two passes over the space (k_dvd_step + k_dvd_orth)
     bool lz_wg_on = true;     // EDGPU_LZ_WG: sectors that fit LDS run their Lanczos loops in one workgroup (k_lanczos_wg)
     DevBuf<int32_t> wg_done; DevBuf<double> wg_slab; DevBuf<uint32_t> wg_brec;      // iteration count written by that kernel; its Krylov slab
     // single rank: the stored columns index vectors whose rows are padded to the 128-B line (csr_ld doubles per row; == DimUp
@@ -459,7 +459,7 @@ static const KnobDef kKnobs[] = {
     {"EDGPU_EIGSH_FUSED", 1, "fallback", "fused two-pass products inside edgpu_eigsh", "test_eigsh.py::test_eigsh_alternative_forms"},
     {"EDGPU_EIGSH_OMEGA_PCT", 100, "test hook", "re-orthogonalisation trigger in % of sqrt(eps) (tests: always / never)", "test_eigsh.py::test_eigsh_alternative_forms"},
     {"EDGPU_EIGSH_MEM_MB", 0, "test hook", "pretend only this much device memory is free for the basis", "test_eigsh.py::test_eigsh_runs_with_the_basis_that_fits"},
-    {"EDGPU_DVD_FUSED", 1, "fallback", "Davidson: residual, correction and the first Gram-Schmidt dots in one pass over the search space; 0: separate passes", "test_eigsh.py::test_davidson_matches_dense"},
+    {"EDGPU_DVD_FUSED", 1, "fallback", "Davidson, spaces of up to 12 vectors: two passes over the space per step (residual, correction, Gram-Schmidt dots, new column of the projected matrix and the restart rotation in one; normalised new basis vector in the other); 0: separate passes and rotation kernels", "test_eigsh.py::test_davidson_two_pass_step_against_separate_passes"},
     {"EDGPU_ROT2", 1, "fallback", "restart rotation with 16-byte accesses on contiguous pieces", "test_eigsh.py::test_eigsh_alternative_forms"},
     {"EDGPU_ROT_MFMA", 1, "fallback", "restart rotation on the f64 matrix cores; 0: register-resident kernels", "test_eigsh.py::test_eigsh_alternative_forms"},
     // several ranks: forms awaiting a measurement on xGMI

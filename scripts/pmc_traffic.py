@@ -8,12 +8,14 @@ root = sys.argv[1]
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def source_stamp():      # same digest as bench.py: the summary is only quoted while the kernel sources are the ones it was measured on
+PRODUCT_SOURCES = ("exchange.hpp", "kernels.hpp", "product.hpp", "sector_dev.hpp", "sector_host.hpp")
+
+
+def source_stamp():      # same digest as bench.py: the summary is only quoted while the product-kernel sources are the ones it was measured on
     h = hashlib.sha256()
     d = os.path.join(ROOT, "dmft-lanc-ed_amd", "csrc")
-    for f in sorted(os.listdir(d)):
-        if f.endswith((".hip", ".hpp")):
-            h.update(f.encode()); h.update(open(os.path.join(d, f), "rb").read())
+    for f in PRODUCT_SOURCES:
+        h.update(f.encode()); h.update(open(os.path.join(d, f), "rb").read())
     return h.hexdigest()[:16]
 
 

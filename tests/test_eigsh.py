@@ -186,3 +186,33 @@ def test_davidson_on_c2_needs_fewer_products_than_lanczos(edgpu_mod):
     assert info["nconv"] == 1 and abs(ev[0] - e0) < 1e-9
     assert info["matvecs"] < 2 * nl              # Lanczos regenerates the basis in a second pass
     G.close()
+
+
+def test_davidson_two_pass_step_against_separate_passes(edgpu_mod, monkeypatch):
+    """The small-space Davidson step (k_dvd_step + k_dvd_orth: new column of the projected matrix from the W_i.t summed inside the
+    step kernel, new basis vector written normalised by the orthogonalisation pass, thick-restart rotation written by the step
+    kernel itself) against the separate passes (EDGPU_DVD_FUSED=0: residual, multi-dot, update, scale, rotation kernels): same
+    pairs, about the same number of products.  Ns=7 (3,4): N = 1225 is odd (the kernels' last-element branch, rotation included);
+    c2: a space of 8 vectors restarts every fourth product over ~100 products."""
+    from edgpu import model
+    for nbath, neigen in ((6, 2), (6, 3), (11, 2)):
+        m, nu, nd = model.half_filled_c(nbath)
+        res = {}
+        for fused in ("1", "0"):
+            monkeypatch.setenv("EDGPU_DVD_FUSED", fused)
+            G = edgpu_mod.HvSector(m, nu, nd, storage="kron")
+            ev, X, info = G.sp_dvdson_eigh(neigen, nitermax=900, tol=1e-11)
+            assert info["nconv"] == neigen, (nbath, fused, info)
+            for i in range(neigen):
+                x = np.ascontiguousarray(X[:, i])
+                assert abs(np.linalg.norm(x) - 1.0) < 1e-9
+                assert np.linalg.norm(G.spHtimesV(x) - ev[i] * x) < 1e-7, (nbath, fused, i)
+            assert np.abs(X.T @ X - np.eye(neigen)).max() < 1e-9
+            res[fused] = (ev, info["matvecs"])
+            G.close()
+        assert np.abs(res["1"][0] - res["0"][0]).max() < 1e-9, (nbath, res)
+        assert res["1"][1] <= 1.2 * res["0"][1] + 8, (nbath, res)      # the search itself is the same method: product counts stay close
+        if nbath == 6:
+            S = oracle.Sector(m, nu, nd)
+            assert S.Dim % 2 == 1
+            np.testing.assert_allclose(res["1"][0], np.linalg.eigvalsh(S.hmat())[:neigen], rtol=0, atol=1e-9)
