@@ -1,7 +1,8 @@
 // edgpu.hip -- libedgpu.so: sector operator + Lanczos loops on MI355X behind the C ABI of include/edgpu.h.
 // This file holds the extern "C" entry points; the implementation is split over (included in this order)
 //   runtime.hpp     error channel, RCCL loader, device buffers, per-sector state (edgpu_sector_s)
-//   sector_host.hpp host-side sector/factor construction        kernels.hpp  gfx950 device kernels
+//   sector_host.hpp host-side sector/factor construction        kernels.hpp  gfx950 device kernels of the operator
+//   basis_kernels.hpp  kernels of the multi-eigenpair solvers (multi-dot / update / rotation / Davidson step)
 //   sector_dev.hpp  device images, halo lists, diagonal, explicit CSR, create/destroy
 //   exchange.hpp    per-product exchange between ranks          product.hpp  hxv(): one sector product
 //   lanczos.hpp     Lanczos ground state / tridiagonalisation / thick-restart eigensolver

@@ -19,6 +19,7 @@
 #include "../../include/edgpu.h"
 #include "sector_host.hpp"
 #include "kernels.hpp"
+#include "basis_kernels.hpp"
 
 namespace edgpu {
 

@@ -163,7 +163,8 @@ int32_t edgpu_lanczos_is_fused(edgpu_handle h);
  * (NUL-terminated, truncated to cap).  For logs and bench records; no reference counterpart. */
 int edgpu_sector_describe(edgpu_handle h, char *buf, int32_t cap);
 /* sp_dvdson_eigh(MatVec,eval,evec,nitermax,tol)   ED_DIAG.f90:189-203 (lanc_method="dvdson"): Davidson with the
- * diagonal of H as preconditioner; search space and its image under H in HBM.  `maxiter` products at most; a pair
+ * diagonal of H as preconditioner; search space (2*nev + 4 vectors, restarted with the previous iterate kept) and its
+ * image under H in HBM.  `maxiter` products at most; a pair
  * counts as converged when |H x - theta x| <= max(tol,1e-11)*max(1,|theta|).  Same outputs as edgpu_eigsh. */
 int edgpu_dvdson(edgpu_handle h, int32_t nev, int32_t maxiter, double tol, double *evals, double *evecs,
                  int32_t *nconv, int32_t *nmatvec);      /* EDGPU_ENOTCONVERGED as edgpu_eigsh */
