@@ -348,7 +348,7 @@ __global__ void __launch_bounds__(256) k_dvd_step(DvdArgs A, double *__restrict_
     __shared__ double red[4];
     __shared__ double cs[NV];
     __shared__ double cr[ROT ? NV * kDvdRotOut : 1];
-    const int nv = A.nv;
+    constexpr int nv = NV;      // instances are compiled for the exact size of the space (launch_dvd_step): no guards, base pointers stay scalar
     for (int i = threadIdx.x; i < NV; i += blockDim.x) cs[i] = i < nv ? A.y[i] : 0.0;
     if (ROT) for (int q = threadIdx.x; q < NV * kDvdRotOut; q += blockDim.x) { const int j = q / NV, i = q - j * NV; cr[q] = (i < nv && j < nout) ? C[i + nv * j] : 0.0; }
     __syncthreads();
@@ -421,9 +421,8 @@ static inline void launch_dvd_step(hipStream_t st, int nb, const DvdArgs &D, dou
     const int m = D.nv;
 #define C_(NV) do { if (C) hipLaunchKernelGGL((k_dvd_step<NV, true>), dim3(nb), dim3(256), 0, st, D, t, n, partial, C, nout); \
                     else hipLaunchKernelGGL((k_dvd_step<NV, false>), dim3(nb), dim3(256), 0, st, D, t, n, partial, C, nout); } while (0)
-    // the exact size for the spaces the default cycle runs through (4..8): an instance compiled for more vectors re-reads vector 0 in their place
-    switch (m) { case 1: case 2: case 3: case 4: C_(4); break; case 5: C_(5); break; case 6: C_(6); break; case 7: C_(7); break; case 8: C_(8); break;
-                 case 9: case 10: C_(10); break; default: C_(12); }
+    switch (m) { case 1: C_(1); break; case 2: C_(2); break; case 3: C_(3); break; case 4: C_(4); break; case 5: C_(5); break; case 6: C_(6); break;
+                 case 7: C_(7); break; case 8: C_(8); break; case 9: C_(9); break; case 10: C_(10); break; case 11: C_(11); break; default: C_(12); }
 #undef C_
 }
 
@@ -436,7 +435,7 @@ __global__ void __launch_bounds__(256) k_dvd_orth(BasisArgs B, const double *__r
 {
     __shared__ double red[4];
     __shared__ double cs[NV];
-    const int nv = B.nv;
+    constexpr int nv = NV;
     for (int i = threadIdx.x; i < NV; i += blockDim.x) cs[i] = i < nv ? h[i] : 0.0;
     __syncthreads();
     double ss = 0.0;
@@ -460,6 +459,14 @@ __global__ void __launch_bounds__(256) k_dvd_orth(BasisArgs B, const double *__r
     }
     const double r = block_sum(ss, red);
     if (threadIdx.x == 0) partial[blockIdx.x] = r;
+}
+
+static inline void launch_dvd_orth(hipStream_t st, int nb, const BasisArgs &B, const double *h, const double *t, double *out, double scale, int64_t n, double *partial)
+{
+#define C_(NV) hipLaunchKernelGGL((k_dvd_orth<NV>), dim3(nb), dim3(256), 0, st, B, h, t, out, scale, n, partial)
+    switch (B.nv) { case 1: C_(1); break; case 2: C_(2); break; case 3: C_(3); break; case 4: C_(4); break; case 5: C_(5); break; case 6: C_(6); break;
+                    case 7: C_(7); break; case 8: C_(8); break; case 9: C_(9); break; case 10: C_(10); break; case 11: C_(11); break; default: C_(12); }
+#undef C_
 }
 
 __global__ void __launch_bounds__(256) k_scale_copy(double *__restrict__ y, const double *__restrict__ x, double a, int64_t n)

@@ -1430,10 +1430,7 @@ static int dvdson(S *s, int nev, int maxiter, double tol, double *evals, double 
             if (est >= 0.5 * t2 && est > 1e-28) {
                 const double sc = 1.0 / std::sqrt(est);
                 BasisArgs Bu{}; Bu.nv = m; for (int i = 0; i < m; i++) Bu.V[i] = Vp(i);
-                if (m <= 6) hipLaunchKernelGGL(k_dvd_orth<6>, dim3(nb), dim3(256), 0, s->stream, Bu, (const double *)s->eig_h.p, (const double *)t, Vp(m), sc, n, s->eig_partial.p);
-                else if (m <= 8) hipLaunchKernelGGL(k_dvd_orth<8>, dim3(nb), dim3(256), 0, s->stream, Bu, (const double *)s->eig_h.p, (const double *)t, Vp(m), sc, n, s->eig_partial.p);
-                else if (m <= 10) hipLaunchKernelGGL(k_dvd_orth<10>, dim3(nb), dim3(256), 0, s->stream, Bu, (const double *)s->eig_h.p, (const double *)t, Vp(m), sc, n, s->eig_partial.p);
-                else hipLaunchKernelGGL(k_dvd_orth<12>, dim3(nb), dim3(256), 0, s->stream, Bu, (const double *)s->eig_h.p, (const double *)t, Vp(m), sc, n, s->eig_partial.p);
+                launch_dvd_orth(s->stream, nb, Bu, (const double *)s->eig_h.p, (const double *)t, Vp(m), sc, n, s->eig_partial.p);
                 hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(1024), 0, s->stream, (const double *)s->eig_partial.p, (int64_t)nb, s->scal.p + SC_TMP);
                 HIPCHK(hipGetLastError());
                 CHK(allreduce_tmp(s));
