@@ -121,3 +121,30 @@ def test_bench_launcher_needs_no_gpu_to_refuse():
     """CPU: with no device visible the launcher path exits non-zero without a line (it never reports n_gpus < --gpus)."""
     err = _run(["--gpus", "2", "--no-extra"], expect_fail=True)
     assert "GPU" in err or "device" in err
+
+
+def test_traffic_stamp_covers_the_product_kernel_sources():
+    """CPU: the digest that ties roofline.traffic to the committed counter summary is taken over the files that define the product
+    kernels, their launches and the storage forms -- every one of them exists, the solver files are not among them (a change to a
+    solver loop must not null a traffic figure that is still that of the running kernels), scripts/pmc_traffic.py stamps with the
+    same digest, and the committed summary carries one record per storage with the fields bench.py reads."""
+    sys.path.insert(0, ROOT)
+    import bench
+    import importlib.util
+    csrc = os.path.join(ROOT, "dmft-lanc-ed_amd", "csrc")
+    for f in bench.PRODUCT_SOURCES:
+        assert os.path.isfile(os.path.join(csrc, f)), f
+    assert "kernels.hpp" in bench.PRODUCT_SOURCES and "product.hpp" in bench.PRODUCT_SOURCES
+    assert not {"lanczos.hpp", "basis_kernels.hpp", "tridiag_host.hpp", "edgpu.hip"} & set(bench.PRODUCT_SOURCES)
+    src = open(os.path.join(ROOT, "scripts", "pmc_traffic.py")).read()
+    assert repr(tuple(bench.PRODUCT_SOURCES)).replace("'", '"') in src.replace("'", '"')
+    # no product kernel lives in the solver headers
+    for f in ("basis_kernels.hpp", "lanczos.hpp"):
+        text = open(os.path.join(csrc, f)).read()
+        for k in ("k_csr_il", "k_dwpass2", "k_uppass2", "k_uppass_halo"):
+            assert "void %s" % k not in text and "__launch_bounds__(64) %s" % k not in text, (f, k)
+    recs = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+    assert sorted(r["storage"] for r in recs) == ["csr", "direct", "kron"]
+    for r in recs:
+        assert r["hbm_bytes_per_launch"] > 0 and len(r["source_stamp"]) == 16 and r["kernels"]
+    assert len(bench.source_stamp()) == 16
