@@ -71,6 +71,16 @@ __global__ void __launch_bounds__(256) k_multidot_final(const double *__restrict
     }
 }
 // w -= sum_i h[i] V_i      (NORM: |w_new|^2 accumulated on the way, block partials in fixed order: saves the separate norm pass)
+// out[0] = out2[0] = sum(in[0..n)) in the order of k_reduce_final: the device keeps the value where its scalar steps read it, the host
+// gets it in pinned memory without a copy call (out2 may be null)
+__global__ void __launch_bounds__(1024) k_reduce_final2(const double *__restrict__ in, int64_t n, double *__restrict__ out, double *__restrict__ out2)
+{
+    __shared__ double red[16];
+    double s = 0.0;
+    for (int64_t i = threadIdx.x; i < n; i += blockDim.x) s += in[i];
+    double r = block_sum(s, red);
+    if (threadIdx.x == 0) { *out = r; if (out2) *out2 = r; }
+}
 // Same shape as k_multidot: two elements per lane, groups of four vectors loaded together; coefficients from LDS (a uniform
 // read is a broadcast) instead of ~100 scalar registers.
 template <bool NORM, int NG>

@@ -861,10 +861,26 @@ static int eigsh_pro(S *s, int nev, int ncv, int maxiter, double tol, double *ev
     // w <- w - sum_{i in idx} <v_i,w> v_i with v_i = sc[i]*B_i (classical Gram-Schmidt, a second pass when the first one
     // removed more than half of |w|^2); |w|^2 afterwards in scal[TMP] and in nrm2; removed[t] = coefficient of v_idx[t]
     std::vector<double> removed;
+    // One rank: what these passes hand to the host (dots, norms) and take from it (coefficients) goes through pinned host memory
+    // the kernels write and read themselves -- a synchronisation where there was a copy call and a synchronisation (a copy call is
+    // ~20 us of host time; a launch-bound sector pays ~30 such events per search: profiles/r04/eigsh_small_sector_where.txt).
+    // Layout of eig_hp: [0, kHp) results of k_multidot_final, [kHp, 2 kHp) coefficients for the update kernels, [2 kHp] the last norm.
+    constexpr int kHp = kMaxBasis + 8;
+    const bool pin = !s->multi && XKNOB("EDGPU_EIGSH_PINNED", 1) != 0;
+    if (pin && s->eig_hp.n < (size_t)(2 * kHp + 8)) CHK(s->eig_hp.alloc((size_t)2 * kHp + 8));
+    double *const res_dev = pin ? s->eig_hp.p : s->eig_h.p;                 // device view of where the dots land
+    double *const cf_dev = pin ? s->eig_hp.p + kHp : s->eig_h.p;            // ... and of where the coefficients are read from
+    double *const nrm_dev = pin ? s->eig_hp.p + 2 * kHp : nullptr;
+    auto fetch_norm = [&](double &out) -> int {      // after k_reduce_final2(..., scal + SC_TMP, nrm_dev)
+        if (pin) { HIPCHK(hipStreamSynchronize(s->stream)); out = s->eig_hp.h[2 * kHp]; }
+        else { HIPCHK(hipMemcpyAsync(&out, s->scal.p + SC_TMP, 8, hipMemcpyDeviceToHost, s->stream)); HIPCHK(hipStreamSynchronize(s->stream)); }
+        return EDGPU_OK;
+    };
     auto project_out = [&](const std::vector<int> &idx, const double *scl, double *w, double &nrm2) -> int {
         const int nv = (int)idx.size();
         removed.assign((size_t)nv, 0.0);
         double before = -1.0;
+        const bool pinp = pin && nv + 1 <= kHp;      // larger index sets (bases beyond one kernel argument block) keep the copies
         for (int pass = 0; pass < 2; pass++) {
             const int ngroups = std::max(1, (int)cdiv(nv, kMaxBasis));
             for (int g = 0; g < ngroups; g++) {
@@ -873,25 +889,30 @@ static int eigsh_pro(S *s, int nev, int ncv, int maxiter, double tol, double *ev
                 for (int i = 0; i < gc; i++) Ba.V[i] = B(idx[g0 + i]);
                 if (lastg) Ba.V[gc] = w;                      // |w|^2 before the update rides along
                 launch_multidot(s->stream, nb, Ba, (const double *)w, vlen, s->eig_partial.p);
-                hipLaunchKernelGGL(k_multidot_final, dim3(1), dim3(256), 0, s->stream, (const double *)s->eig_partial.p, nb, Ba.nv, s->eig_h.p + g0);
+                hipLaunchKernelGGL(k_multidot_final, dim3(1), dim3(256), 0, s->stream, (const double *)s->eig_partial.p, nb, Ba.nv, (pinp ? res_dev : s->eig_h.p) + g0);
                 HIPCHK(hipGetLastError());
             }
-            CHK(allreduce_dev(s, s->eig_h.p, nv + 1));
-            HIPCHK(hipMemcpyAsync(coef.data(), s->eig_h.p, (size_t)(nv + 1) * 8, hipMemcpyDeviceToHost, s->stream)); HIPCHK(hipStreamSynchronize(s->stream));
+            if (pinp) { HIPCHK(hipStreamSynchronize(s->stream)); std::memcpy(coef.data(), s->eig_hp.h, (size_t)(nv + 1) * 8); }
+            else {
+                CHK(allreduce_dev(s, s->eig_h.p, nv + 1));
+                HIPCHK(hipMemcpyAsync(coef.data(), s->eig_h.p, (size_t)(nv + 1) * 8, hipMemcpyDeviceToHost, s->stream)); HIPCHK(hipStreamSynchronize(s->stream));
+            }
             before = coef[nv];
             for (int i = 0; i < nv; i++) { removed[i] += coef[i] * scl[i]; coef[i] *= scl[i] * scl[i]; }
-            HIPCHK(hipMemcpyAsync(s->eig_h.p, coef.data(), (size_t)nv * 8, hipMemcpyHostToDevice, s->stream));
+            if (pinp) std::memcpy(s->eig_hp.h + kHp, coef.data(), (size_t)nv * 8);
+            else HIPCHK(hipMemcpyAsync(s->eig_h.p, coef.data(), (size_t)nv * 8, hipMemcpyHostToDevice, s->stream));
+            const double *cfp = pinp ? cf_dev : s->eig_h.p;
             for (int g = 0; g < ngroups; g++) {
                 const int g0 = g * kMaxBasis, gc = std::min(kMaxBasis, nv - g0);
                 BasisArgs Bu{}; Bu.nv = gc; for (int i = 0; i < gc; i++) Bu.V[i] = B(idx[g0 + i]);
-                if (g == ngroups - 1) launch_multiaxpy_norm(s->stream, nb, Bu, (const double *)(s->eig_h.p + g0), w, vlen, s->eig_partial.p);
-                else launch_multiaxpy(s->stream, nb, Bu, (const double *)(s->eig_h.p + g0), w, vlen);
+                if (g == ngroups - 1) launch_multiaxpy_norm(s->stream, nb, Bu, cfp + g0, w, vlen, s->eig_partial.p);
+                else launch_multiaxpy(s->stream, nb, Bu, cfp + g0, w, vlen);
                 HIPCHK(hipGetLastError());
             }
-            hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(1024), 0, s->stream, (const double *)s->eig_partial.p, (int64_t)nb, s->scal.p + SC_TMP);
+            hipLaunchKernelGGL(k_reduce_final2, dim3(1), dim3(1024), 0, s->stream, (const double *)s->eig_partial.p, (int64_t)nb, s->scal.p + SC_TMP, nrm_dev);
             HIPCHK(hipGetLastError());
             CHK(allreduce_tmp(s));
-            HIPCHK(hipMemcpyAsync(&nrm2, s->scal.p + SC_TMP, 8, hipMemcpyDeviceToHost, s->stream)); HIPCHK(hipStreamSynchronize(s->stream));
+            CHK(fetch_norm(nrm2));
             if (nrm2 >= 0.5 * before) break;
         }
         return EDGPU_OK;
@@ -912,11 +933,12 @@ static int eigsh_pro(S *s, int nev, int ncv, int maxiter, double tol, double *ev
     else CHK(lz_start(s, V));                             // zeroes the dummy previous vector, scale of u_0 -> scal[SCUR]
     HIPCHK(hipMemcpyAsync(&sc[0], s->scal.p + SC_SCUR, 8, hipMemcpyDeviceToHost, s->stream)); HIPCHK(hipStreamSynchronize(s->stream));
     // after u_{j+1} = B(j+1) was changed in place: its norm / scale / beta_j follow; the fused form also redoes the local half
-    auto renorm = [&](int j, double &beta) -> int {
+    // known_b2 >= 0: the caller already holds |u_{j+1}|^2 = scal[TMP] (project_out returned it): nothing to fetch on the plain path
+    auto renorm = [&](int j, double &beta, double known_b2 = -1.0) -> int {
         if (fused) CHK(fused_local(s, B(j + 1), B(j), B(j + 2), nullptr, true));
         else CHK(scalar_mode(6));
-        double b2 = 0.0;
-        HIPCHK(hipMemcpyAsync(&b2, s->scal.p + SC_TMP, 8, hipMemcpyDeviceToHost, s->stream)); HIPCHK(hipStreamSynchronize(s->stream));
+        double b2 = known_b2;
+        if (fused || !(known_b2 >= 0.0)) { HIPCHK(hipMemcpyAsync(&b2, s->scal.p + SC_TMP, 8, hipMemcpyDeviceToHost, s->stream)); HIPCHK(hipStreamSynchronize(s->stream)); }
         beta = std::sqrt(std::max(b2, 0.0));
         return EDGPU_OK;
     };
@@ -925,15 +947,23 @@ static int eigsh_pro(S *s, int nev, int ncv, int maxiter, double tol, double *ev
     SrScope sr_scope(s);
     if (!fused && lz_sr_ok(s)) { if (s->partial_bh.n < 512) CHK(s->partial_bh.alloc(512)); s->sr_host_partials = true; } else s->sr_allow = false;
     int l = 0, j = 0, kloc = 0, nconv = 0, it = 0, nmv = 0, meff = m, n_full = 0, n_sel = 0; int64_t nreads = 0;
+    using clk = std::chrono::steady_clock; auto tsec = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double>(b - a).count() * 1e3; };
+    const clk::time_point t_begin = clk::now();      // EDGPU_DEBUG bit 3: where the wall time of a search goes
+    double ms_issue = 0.0, ms_wait = 0.0, ms_step_host = 0.0, ms_eig = 0.0, ms_restart_host = 0.0, ms_restart_dev = 0.0;
     bool exact = false; double normT = 0.0, beta_last = 0.0;
     uint64_t seed = 7654321;
     for (it = 0; it < maxiter; it++) {
         meff = m; exact = false;
         for (; j < m; j++) {
+            const clk::time_point t0 = clk::now();
             if (fused) { Fz.u = B(j); Fz.t = B(j + 1); CHK(lzf_iter(s, Fz, B(j + 2), nullptr)); }      // afterwards Fz.u = B(j+1), Fz.uprev = B(j), Fz.t = B(j+2)
             else { V.ucur = B(j); V.w = B(j + 1); CHK(lz_iter(s, V, kloc, nullptr)); }              // afterwards V.uprev = B(j), V.ucur = B(j+1)
             nmv++;
+            const clk::time_point t1 = clk::now();
             HIPCHK(hipStreamSynchronize(s->stream));
+            const clk::time_point t2 = clk::now();
+            ms_issue += tsec(t0, t1); ms_wait += tsec(t1, t2);
+            struct StepTimer { const clk::time_point a; double &acc; ~StepTimer() { acc += std::chrono::duration<double>(clk::now() - a).count() * 1e3; } } step_timer{t2, ms_step_host};
             double alpha = s->alphas.h[kloc], beta;          // written by the step kernels into pinned host memory: no copy call
             if (s->sr_pending) {
                 // self-reducing iteration (two launches): the beta step is still pending on the device (the next product takes it);
@@ -952,23 +982,25 @@ static int eigsh_pro(S *s, int nev, int ncv, int maxiter, double tol, double *ev
                 // they are subtracted in one pass over the kept Ritz vectors (no dots); how orthogonal the result is to them is
                 // what the recurrence below estimates from the defects eta_i -- a pass with measured coefficients follows only
                 // if that estimate asks for it
-                double nrm2 = 0.0;
                 for (int i = 0; i < l; i++) coef[i] = Tm(i, l) * sc[i];
-                HIPCHK(hipMemcpyAsync(s->eig_h.p, coef.data(), (size_t)l * 8, hipMemcpyHostToDevice, s->stream));
-                HIPCHK(hipStreamSynchronize(s->stream));
+                const bool pina = pin && l <= kHp;
+                if (pina) std::memcpy(s->eig_hp.h + kHp, coef.data(), (size_t)l * 8);      // the device is idle: this step has been waited for
+                else { HIPCHK(hipMemcpyAsync(s->eig_h.p, coef.data(), (size_t)l * 8, hipMemcpyHostToDevice, s->stream)); HIPCHK(hipStreamSynchronize(s->stream)); }
+                const double *cfp = pina ? cf_dev : s->eig_h.p;
                 const int ngroups = std::max(1, (int)cdiv(l, kMaxBasis));
                 for (int g = 0; g < ngroups; g++) {
                     const int g0 = g * kMaxBasis, gc = std::min(kMaxBasis, l - g0);
                     BasisArgs Bu{}; Bu.nv = gc; for (int i = 0; i < gc; i++) Bu.V[i] = B(g0 + i);
-                    if (g == ngroups - 1) launch_multiaxpy_norm(s->stream, nb, Bu, (const double *)(s->eig_h.p + g0), B(j + 1), vlen, s->eig_partial.p);
-                    else launch_multiaxpy(s->stream, nb, Bu, (const double *)(s->eig_h.p + g0), B(j + 1), vlen);
+                    if (g == ngroups - 1) launch_multiaxpy_norm(s->stream, nb, Bu, cfp + g0, B(j + 1), vlen, s->eig_partial.p);
+                    else launch_multiaxpy(s->stream, nb, Bu, cfp + g0, B(j + 1), vlen);
                     HIPCHK(hipGetLastError());
                 }
-                hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(1024), 0, s->stream, (const double *)s->eig_partial.p, (int64_t)nb, s->scal.p + SC_TMP);
+                hipLaunchKernelGGL(k_reduce_final2, dim3(1), dim3(1024), 0, s->stream, (const double *)s->eig_partial.p, (int64_t)nb, s->scal.p + SC_TMP, nrm_dev);
                 HIPCHK(hipGetLastError());
                 CHK(allreduce_tmp(s));
-                (void)nrm2;
-                CHK(renorm(j, beta)); nreads += l;
+                if (pin && !fused) { CHK(scalar_mode(6)); double b2 = 0.0; CHK(fetch_norm(b2)); beta = std::sqrt(std::max(b2, 0.0)); }      // = renorm(), the norm read from pinned memory
+                else CHK(renorm(j, beta));
+                nreads += l;
             }
             {
                 // omega recurrence: estimates w(j+1,k), k < j
@@ -990,7 +1022,7 @@ static int eigsh_pro(S *s, int nev, int ncv, int maxiter, double tol, double *ev
                 CHK(lz_sr_flush(s));
                 std::vector<double> scl(idx.size()); for (size_t t = 0; t < idx.size(); t++) scl[t] = sc[idx[t]];
                 CHK(project_out(idx, scl.data(), B(j + 1), nrm2)); nreads += 2 * (int64_t)idx.size();
-                CHK(renorm(j, beta));                      // beta_j and the scale of u_{j+1} follow the new norm
+                CHK(renorm(j, beta, nrm2));                // beta_j and the scale of u_{j+1} follow the new norm
                 for (size_t t = 0; t < idx.size(); t++) {
                     Wm(j + 1, idx[t]) = Wm(idx[t], j + 1) = eps;
                     Fm(idx[t], j) += removed[t];                 // not part of T: feeds the defect of the Ritz vectors formed at the next restart
@@ -1021,7 +1053,7 @@ static int eigsh_pro(S *s, int nev, int ncv, int maxiter, double tol, double *ev
         }
         std::vector<double> Hs((size_t)meff * meff);
         for (int a = 0; a < meff; a++) for (int b = 0; b < meff; b++) Hs[(size_t)a * meff + b] = Tm(a, b);
-        jacobi_eig(Hs, meff, theta, Y);
+        { const clk::time_point a = clk::now(); jacobi_eig(Hs, meff, theta, Y); ms_eig += tsec(a, clk::now()); }
         nconv = 0;
         const int want = std::min(nev, meff);
         for (int i = 0; i < want; i++) {
@@ -1033,7 +1065,8 @@ static int eigsh_pro(S *s, int nev, int ncv, int maxiter, double tol, double *ev
         const int lnew = std::min(m - 1, nev + std::max(1, (m - nev) / 2));
         std::vector<double> Yc((size_t)m * lnew);
         for (int a = 0; a < lnew; a++) for (int k = 0; k < m; k++) Yc[k + (size_t)m * a] = sc[k] * Y[k + (size_t)m * a];
-        CHK(rotate(m, lnew, Yc)); nreads += m + lnew;
+        { const clk::time_point a = clk::now(); CHK(rotate(m, lnew, Yc)); nreads += m + lnew; ms_restart_dev += tsec(a, clk::now()); }
+        const clk::time_point t_rh = clk::now();
         std::swap(s->eigV[lnew], s->eigV[m]);            // B(lnew) <- u_m, no copy
         if (fused) std::swap(s->eigV[lnew + 1], s->eigV[m + 1]);      // ... and the local part of H u_m that is already there
         std::vector<double> Wn((size_t)M * M, 0.0), etan((size_t)M, 0.0);
@@ -1061,7 +1094,9 @@ static int eigsh_pro(S *s, int nev, int ncv, int maxiter, double tol, double *ev
         CHK(scalar_mode(7));                              // scal[SCUR] already is the scale of u_m
         l = lnew; j = l; kloc = 0;
         V.uprev = B(l - 1); Fz.uprev = B(l - 1);           // any finite vector: its coefficient is zero
+        ms_restart_host += tsec(t_rh, clk::now());
     }
+    const clk::time_point t_loop = clk::now();
     const int nout = std::min(nev, meff);
     {
         std::vector<double> Yc((size_t)meff * nout);
@@ -1113,6 +1148,8 @@ static int eigsh_pro(S *s, int nev, int ncv, int maxiter, double tol, double *ev
     HIPCHK(hipStreamSynchronize(s->stream));
     if (s->dbg & 8) fprintf(stderr, "edgpu_eigsh: %d products, %d restarts, basis %d; re-orthogonalisations: %d whole basis, %d kept Ritz vectors only; %.1f basis-vector reads per product\n",
                             nmv, it + 1, m, n_full, n_sel, nmv ? (double)nreads / nmv : 0.0);
+    if (s->dbg & 8) fprintf(stderr, "edgpu_eigsh: loop %.3f ms (issuing steps %.3f, waiting for the device %.3f, host work per step incl. re-orthogonalisation passes %.3f, eigenproblems of T %.3f, restart rotations %.3f, restart bookkeeping %.3f), Ritz vectors + checks %.3f ms\n",
+                            tsec(t_begin, t_loop), ms_issue, ms_wait, ms_step_host, ms_eig, ms_restart_dev, ms_restart_host, tsec(t_loop, clk::now()));
     if (nconv_out) *nconv_out = nconv;
     if (nrestart_out) *nrestart_out = it + 1;
     if (nmatvec_out) *nmatvec_out = nmv;

@@ -350,6 +350,7 @@ struct edgpu_sector_s {
     std::vector<int64_t> xch_rows, relay_link_rows;        // relay_link_rows[a*P+b]: rows on link a->b, both phases, under the plan
     std::vector<RelayPeer> relay; bool relay_on = false; int relay_chunks = 0; int64_t relay_before = 0, relay_after = 0; DevBuf<double> relay_stage;
     std::vector<std::unique_ptr<DevBuf<double>>> eigV; DevBuf<double> eig_h, eig_y, eig_partial;
+    CoefBuf<double> eig_hp;      // one rank: dots and coefficients of the re-orthogonalisation passes travel through pinned host memory the kernels read and write (no copy calls)
     DevBuf<double> vfull, tmp_in, tmp_out, lz[5], scal, zvec, partial, partial2;
     CoefBuf<double> alphas, betas;      // pinned host memory written by the device (see CoefBuf)
     CoefBuf<double> partial_bh; bool sr_host_partials = false;      // edgpu_eigsh: host copy of the pending beta^2 partial sums of the self-reducing iteration
