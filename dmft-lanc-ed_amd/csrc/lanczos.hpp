@@ -702,7 +702,10 @@ static int orthogonalise_cgs(S *s, double *const *basis, int nv, int first_from,
 // maxiter=Nitermax restarts, residual test |r_i| <= tol*max(eps^(2/3),|theta_i|)).
 // ---------------------------------------------------------------------------------------
 static void jacobi_eig(std::vector<double> &A, int m, std::vector<double> &w, std::vector<double> &Y)
-{   // cyclic Jacobi on the symmetric m x m matrix A (row-major); eigenvalues ascending in w, vectors = columns of Y (Y[i + m*j])
+{   // symmetric m x m matrix A (row-major); eigenvalues ascending in w, vectors = columns of Y (Y[i + m*j]).  From 6 rows on:
+    // Householder + QL (tridiag_host.hpp: 26 us against 73 at m = 20, 0.9 ms against 5.1 at m = 80); below that, and should QL
+    // ever fail to converge: cyclic Jacobi
+    if (m >= 6) { std::vector<double> A2(A); if (sym_eig_householder(A2, m, w, Y)) return; }
     std::vector<double> V((size_t)m * m, 0.0);
     for (int i = 0; i < m; i++) V[(size_t)i * m + i] = 1.0;
     for (int sweep = 0; sweep < 60; sweep++) {
@@ -1122,14 +1125,15 @@ static int eigsh_pro(S *s, int nev, int ncv, int maxiter, double tol, double *ev
             double *w = B(m);                              // stale basis vector: free after the final rotation
             CHK(hxv(s, B(i), w, false, nullptr, s->vld));
             coef[0] = theta[i];
-            HIPCHK(hipMemcpyAsync(s->eig_h.p, coef.data(), 8, hipMemcpyHostToDevice, s->stream)); HIPCHK(hipStreamSynchronize(s->stream));
+            if (pin) s->eig_hp.h[kHp] = theta[i];      // nothing on the device reads the coefficient area now: the last pass that did has been waited for
+            else { HIPCHK(hipMemcpyAsync(s->eig_h.p, coef.data(), 8, hipMemcpyHostToDevice, s->stream)); HIPCHK(hipStreamSynchronize(s->stream)); }
             BasisArgs Bu{}; Bu.nv = 1; Bu.V[0] = B(i);
-            launch_multiaxpy_norm(s->stream, nb, Bu, (const double *)s->eig_h.p, w, vlen, s->eig_partial.p);
-            hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(1024), 0, s->stream, (const double *)s->eig_partial.p, (int64_t)nb, s->scal.p + SC_TMP);
+            launch_multiaxpy_norm(s->stream, nb, Bu, (const double *)(pin ? cf_dev : s->eig_h.p), w, vlen, s->eig_partial.p);
+            hipLaunchKernelGGL(k_reduce_final2, dim3(1), dim3(1024), 0, s->stream, (const double *)s->eig_partial.p, (int64_t)nb, s->scal.p + SC_TMP, nrm_dev);
             HIPCHK(hipGetLastError());
             CHK(allreduce_tmp(s));
             double r2 = 0.0;
-            HIPCHK(hipMemcpyAsync(&r2, s->scal.p + SC_TMP, 8, hipMemcpyDeviceToHost, s->stream)); HIPCHK(hipStreamSynchronize(s->stream));
+            CHK(fetch_norm(r2));
             worst = std::max(worst, std::sqrt(std::max(r2, 0.0)) / std::max(1.0, std::fabs(theta[i])));
         }
         if (s->dbg & 8) fprintf(stderr, "edgpu_eigsh: largest true residual / max(1,|theta|) of the returned pairs: %.3e\n", worst);
