@@ -469,10 +469,9 @@ static int lanczos_gs_impl(S *s, int nitermax, double threshold, int ncheck, dou
     // the rule to each of them in order -- same nlanc and E0, at most chunk-1 surplus iterations.
     const int chunk = lz_small(s) ? std::max(1, XKNOB("EDGPU_LZ_CHUNK", 6)) : 1;
     bool done = false;
-    for (int k = 0; k < nitermax && !done;) {
-        const int kend = std::min(nitermax, k + chunk);
-        const clk::time_point t0 = clk::now();
-        for (int j = k; j < kend; j++) {
+    // iterations [k0, k1) queued on the stream (no host round trip)
+    auto issue = [&](int k0, int k1) -> int {
+        for (int j = k0; j < k1; j++) {
             if (fused) {                              // dw half of j + local half of j+1: alpha_j and beta_j
                 double *tnew = store ? ring_get(j + 2) : nullptr;
                 if (store && !tnew) store = false;    // out of memory: from here on the oldest of the three live vectors is recycled
@@ -487,11 +486,10 @@ static int lanczos_gs_impl(S *s, int nitermax, double threshold, int ncheck, dou
                 if (nx) { V.w = nx; CHK(lzf_zero_pads(s, nx)); } else store = false; // out of memory: keep rotating through the last three
             }
         }
-        const clk::time_point t1 = clk::now();
-        CHK(fetch_coeffs(s, kend - 1, al, be));
-        const clk::time_point t2 = clk::now();
-        ms_issue += tsec(t0, t1); ms_wait += tsec(t1, t2);
-        struct RuleTimer { double &acc; clk::time_point a; ~RuleTimer() { acc += std::chrono::duration<double>(clk::now() - a).count() * 1e3; } } rule_timer{ms_rule, t2};
+        return EDGPU_OK;
+    };
+    // the rule applied to iterations [k, kend) in order, coefficients up to kend-1 in al / be; advances k
+    auto judge = [&](int &k, int kend) -> int {
         for (; k < kend; k++) {
             nlanc = k + 1;
             if (s->one_ar_on) {       // beta_{k+1} is still a pending partial sum: the invariant-subspace test looks at beta_k, one product late
@@ -502,6 +500,43 @@ static int lanczos_gs_impl(S *s, int nitermax, double threshold, int ncheck, dou
             if (r < 0) return fail(EDGPU_ENOTCONVERGED, "edgpu: tridiagonal QL did not converge");
             if (r > 0) { done = true; break; }
         }
+        return EDGPU_OK;
+    };
+    // Launch-bound sectors, one rank: the next chunk is queued BEFORE the host waits for the one it is about to judge, so the device
+    // works through it while the host evaluates the rule (the rule of a chunk costs about what its kernels do: 0.76 ms of rule, 0.93 ms of
+    // waiting and 0.53 ms of issuing per 77-iteration search at 52 272 states, strictly one after the other before).  Same nlanc and E0 -- the rule
+    // sees the same coefficients in the same order; up to 2*chunk-1 surplus iterations instead of chunk-1.
+    const bool ahead = chunk > 1 && !fused && !s->multi && XKNOB("EDGPU_LZ_AHEAD", 1) != 0;
+    if (ahead) {
+        for (auto &e : s->lz_ev) if (!e) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        int issued = std::min(nitermax, chunk), c = 0;
+        { const clk::time_point t0 = clk::now(); CHK(issue(0, issued)); CHK(lz_sr_flush(s)); HIPCHK(hipEventRecord(s->lz_ev[0], s->stream)); ms_issue += tsec(t0, clk::now()); }
+        for (int k = 0; k < nitermax && !done; c++) {
+            const int kend = std::min(nitermax, k + chunk);      // the chunk to judge now; everything up to `issued` is queued
+            const clk::time_point t0 = clk::now();
+            if (issued < nitermax) {
+                const int k1 = std::min(nitermax, issued + chunk);
+                CHK(issue(issued, k1)); CHK(lz_sr_flush(s)); HIPCHK(hipEventRecord(s->lz_ev[(c + 1) & 1], s->stream));
+                issued = k1;
+            }
+            const clk::time_point t1 = clk::now();
+            HIPCHK(hipEventSynchronize(s->lz_ev[c & 1]));      // the coefficient arrays are host memory the kernels write (CoefBuf)
+            al.resize(kend); be.resize(kend + 1);
+            std::memcpy(al.data(), s->alphas.h, (size_t)kend * 8); std::memcpy(be.data(), s->betas.h, (size_t)(kend + 1) * 8);
+            const clk::time_point t2 = clk::now();
+            CHK(judge(k, kend));
+            ms_issue += tsec(t0, t1); ms_wait += tsec(t1, t2); ms_rule += tsec(t2, clk::now());
+        }
+    } else
+    for (int k = 0; k < nitermax && !done;) {
+        const int kend = std::min(nitermax, k + chunk);
+        const clk::time_point t0 = clk::now();
+        CHK(issue(k, kend));
+        const clk::time_point t1 = clk::now();
+        CHK(fetch_coeffs(s, kend - 1, al, be));
+        const clk::time_point t2 = clk::now();
+        CHK(judge(k, kend));
+        ms_issue += tsec(t0, t1); ms_wait += tsec(t1, t2); ms_rule += tsec(t2, clk::now());
     }
     const clk::time_point t_loop = clk::now();
     std::vector<double> z;

@@ -291,6 +291,7 @@ struct edgpu_sector_s {
     int device = 0;
     hipStream_t stream = nullptr, cstream = nullptr;
     hipEvent_t ev_a = nullptr, ev_b = nullptr, ev_gather = nullptr, ev_ready = nullptr;
+    hipEvent_t lz_ev[2] = {nullptr, nullptr};      // ground-state search on launch-bound sectors: end of the chunk of iterations being judged / of the one issued ahead
     std::vector<std::unique_ptr<DevFactor>> fac;
     // the two factors the product kernels run on: fac[0], fac[1] (ed_total_ud=T) or the composite blocks (ed_total_ud=F, cdev)
     std::unique_ptr<DevFactor> cdev[2]; DevFactor *upf = nullptr, *dwf = nullptr; const Factor *hup = nullptr, *hdw = nullptr;
@@ -403,6 +404,7 @@ inline edgpu_sector_s::~edgpu_sector_s()
     if (ev_b) (void)hipEventDestroy(ev_b);
     if (ev_gather) (void)hipEventDestroy(ev_gather);
     if (ev_ready) (void)hipEventDestroy(ev_ready);
+    for (auto e : lz_ev) if (e) (void)hipEventDestroy(e);
     for (auto e : tr_ev) (void)hipEventDestroy(e);
     g_streams.give(device, tstream); g_streams.give(device, stream); g_streams.give(device, cstream);
 }
