@@ -287,7 +287,8 @@ __global__ void __launch_bounds__(256) k_basis_rotate_mfma(RotMfmaArgs R, int64_
 // correction in one pass over the two bases:
 //   r_e = sum_j y_j (W_j[e] - theta V_j[e]) ,  t_e = r_e / (theta - d_e)  (|theta - d_e| kept away from zero),
 //   partial[b] = sum r_e^2 over the block.    d_e = diag[e mod nel] + w0 * (e div nel)  (phonon blocks share the electronic diagonal)
-struct DvdArgs { const double *V[kMaxBasis + 1]; const double *W[kMaxBasis + 1]; int32_t nv; const double *y; double theta; const double *diag; int64_t nel; double w0; };
+struct DvdArgs { double *V[kMaxBasis + 1]; double *W[kMaxBasis + 1]; int32_t nv;      /* V, W: read by every step, written in place by the restart rotation of k_dvd_step<.., true> */
+                  const double *y; double theta; const double *diag; int64_t nel; double w0; };
 __global__ void __launch_bounds__(256) k_dvd_resid(DvdArgs A, double *__restrict__ t, int64_t n, double *__restrict__ partial)
 {
     // two elements per lane, the two bases in groups of four vector pairs loaded together, coefficients from LDS (as k_multidot)
@@ -391,8 +392,8 @@ __global__ void __launch_bounds__(256) k_dvd_step(DvdArgs A, double *__restrict_
                 dbl2_t a, b; a.x = 0.0; a.y = 0.0; b.x = 0.0; b.y = 0.0;
 #pragma unroll
                 for (int i = 0; i < NV; i++) { const double c = cr[j * NV + i]; a.x += c * vv[i].x; a.y += c * vv[i].y; b.x += c * wv[i].x; b.y += c * wv[i].y; }
-                reinterpret_cast<dbl2_t *>(const_cast<double *>(A.V[j]))[p] = a;
-                reinterpret_cast<dbl2_t *>(const_cast<double *>(A.W[j]))[p] = b;
+                reinterpret_cast<dbl2_t *>(A.V[j])[p] = a;
+                reinterpret_cast<dbl2_t *>(A.W[j])[p] = b;
             }
         }
     }
@@ -413,7 +414,7 @@ __global__ void __launch_bounds__(256) k_dvd_step(DvdArgs A, double *__restrict_
                 double a = 0.0, b = 0.0;
 #pragma unroll
                 for (int i = 0; i < NV; i++) { a += cr[j * NV + i] * ve[i]; b += cr[j * NV + i] * we[i]; }
-                const_cast<double *>(A.V[j])[e] = a; const_cast<double *>(A.W[j])[e] = b;
+                A.V[j][e] = a; A.W[j][e] = b;
             }
         }
     }
