@@ -491,6 +491,15 @@ def main():
                 out["eigsh_c3_s"] = te
                 out["default_solver_path"] = {"call": "edgpu_eigsh(nev=2, ncv=20, tol=1e-10) = sp_eigh of ED_DIAG.f90:153-170 (the library may enlarge the basis when HBM is free: ncv_used)", "storage": "kron", "seconds": te,
                                               "E": [float(x) for x in ev], "products": info["matvecs"], "restarts": info["restarts"], "ncv_used": info["ncv_used"]}
+                # lanc_method=dvdson (ED_DIAG.f90:189-203) on the same sector: edgpu_dvdson, second call; never allowed to cost the line
+                try:
+                    for _ in range(2):
+                        t0 = time.perf_counter(); evd, _x, infd = g.sp_dvdson_eigh(2, nitermax=600, tol=1e-10, vectors=False); td = time.perf_counter() - t0
+                    out["dvdson_c3_s"] = td
+                    out["dvdson_path"] = {"call": "edgpu_dvdson(nev=2, tol=1e-10) = sp_dvdson_eigh of ED_DIAG.f90:189-203", "storage": "kron", "seconds": td,
+                                          "E": [float(x) for x in evd], "products": infd["matvecs"]}
+                except Exception as e:      # noqa: BLE001
+                    out["dvdson_c3_s"] = None; out["dvdson_path"] = {"error": str(e)[:200]}
             g.close()
         out["other_formats"] = extra
         # the configurations the driver never runs: BASELINE config 4 (Ns=18, on-the-fly, the whole sector on ONE GPU) and config 5
